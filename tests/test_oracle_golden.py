@@ -1,0 +1,166 @@
+"""Pin the CPU oracle (oracle/ggad_oracle.py) against outputs captured from the imported reference.
+
+The reference has no tests or vectors of its own; tests/golden/*.npz hold what its
+code returned on seeded synthetic inputs in the build container (tests/golden/make_golden.py).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from ggad_amd import synth
+from oracle import ggad_oracle as O
+
+TOL = 2e-6
+
+
+def _mini_params(g, prefix):
+    return O.MiniParams(torch.tensor(g[prefix + ".weight"], requires_grad=True),
+                        torch.tensor(g[prefix + ".enc.weight"], requires_grad=True),
+                        torch.tensor(g[prefix + ".enc.fc.weight"], requires_grad=True))
+
+
+@pytest.mark.parametrize("name", ["minibatch_small.npz", "minibatch_dense.npz"])
+def test_inputs_regenerate(name):
+    g = load_golden(name)
+    assert synth.crc_of(g["rowptr"], g["col"], g["feat_raw"]) == int(g["inputs_crc"])
+    np.testing.assert_allclose(O.normalize_rows(g["feat_raw"]).astype(np.float32), g["feat"], rtol=0, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", ["minibatch_small.npz", "minibatch_dense.npz"])
+def test_aggregator_closed_form(name):
+    g = load_golden(name)
+    nodes = g["batches"][0]
+    agg = O.aggregate_batch(g["rowptr"], g["col"], g["feat"], nodes, True)
+    np.testing.assert_allclose(agg.to_feats, g["agg_to_feats"], atol=TOL, rtol=0)
+    # the reference orders U by python-set iteration; map through the recorded list
+    ref_u = g["agg_unique"]
+    assert sorted(ref_u.tolist()) == agg.unique.tolist()
+    perm = np.searchsorted(agg.unique, ref_u)
+    np.testing.assert_allclose(agg.to_feats_neigh[perm], g["agg_to_feats_neigh"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(agg.mask_row_dense()[:, perm], g["agg_mask_row"], atol=1e-7, rtol=0)
+    # dense-faithful port agrees as well
+    adj = synth.csr_to_adj_lists(g["rowptr"], g["col"])
+    tf, tfn, mrow, ulist = O.aggregate_batch_dense(adj, torch.from_numpy(g["feat"]), nodes.tolist(), True)
+    assert ulist == ref_u.tolist()
+    np.testing.assert_allclose(tf.numpy(), g["agg_to_feats"], atol=1e-7, rtol=0)
+    np.testing.assert_allclose(tfn.numpy(), g["agg_to_feats_neigh"], atol=1e-7, rtol=0)
+    np.testing.assert_allclose(mrow.numpy(), g["agg_mask_row"], atol=0, rtol=0)
+
+
+@pytest.mark.parametrize("name", ["minibatch_small.npz", "minibatch_dense.npz"])
+def test_encoder_loss_grads_and_adam_trajectory(name):
+    g = load_golden(name)
+    p = _mini_params(g, "init")
+    opt = O.make_adam(p.tensors(), 1e-3, 0.007)
+    for step, (nodes, lab) in enumerate(zip(g["batches"], g["labels"])):
+        agg = O.aggregate_batch(g["rowptr"], g["col"], g["feat"], nodes, True)
+        if step == 0:
+            with torch.no_grad():
+                ca, nbar, af, afn = O.encoder_forward(p, agg, lab, True)
+            np.testing.assert_allclose(ca.numpy(), g["enc_combined_all"], atol=TOL, rtol=0)
+            np.testing.assert_allclose(nbar.numpy(), g["enc_to_feats_neigh"], atol=TOL, rtol=0)
+            np.testing.assert_allclose(af.numpy(), g["enc_anomaly_feat"], atol=TOL, rtol=0)
+            np.testing.assert_allclose(afn.numpy(), g["enc_anomaly_feat_new"], atol=TOL, rtol=0)
+        opt.zero_grad()
+        total, cls, margin, rec = O.batch_loss(p, agg, lab)
+        total.backward()
+        got = np.array([total.item(), cls.item(), margin.item(), rec.item()])
+        np.testing.assert_allclose(got, g["losses"][step], atol=5e-6, rtol=0)
+        if step == 0:
+            np.testing.assert_allclose(p.weight.grad.numpy(), g["grad.weight"], atol=TOL, rtol=1e-5)
+            np.testing.assert_allclose(p.enc_weight.grad.numpy(), g["grad.enc.weight"], atol=TOL, rtol=1e-5)
+            np.testing.assert_allclose(p.enc_fc_weight.grad.numpy(), g["grad.enc.fc.weight"], atol=TOL, rtol=1e-5)
+        opt.step()
+        if step == 0:
+            np.testing.assert_allclose(p.enc_weight.detach().numpy(), g["step1.enc.weight"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(p.weight.detach().numpy(), g["final.weight"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(p.enc_weight.detach().numpy(), g["final.enc.weight"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(p.enc_fc_weight.detach().numpy(), g["final.enc.fc.weight"], atol=2e-5, rtol=0)
+
+
+@pytest.mark.parametrize("name", ["minibatch_small.npz", "minibatch_dense.npz"])
+def test_to_prob_reference_batches(name):
+    g = load_golden(name)
+    p = _mini_params(g, "final")
+    bs = int(g["test_bs"])
+    nodes = g["test_nodes"]
+    got = []
+    for s in range(0, len(nodes), bs):
+        got.extend(O.to_prob(p, g["rowptr"], g["col"], g["feat"], nodes[s:s + bs]).tolist())
+    np.testing.assert_allclose(np.array(got, dtype=np.float32), g["test_probs"], atol=TOL, rtol=0)
+
+
+def test_mean_aggregator_and_encoder(g_mini_small):
+    g = g_mini_small
+    nodes = g["batches"][0]
+    mean = O.mean_aggregate(g["rowptr"], g["col"], g["feat"], nodes, gcn=False)
+    np.testing.assert_allclose(mean, g["sage_mean"], atol=TOL, rtol=0)
+    w = torch.from_numpy(g["sage_weight"])
+    comb = torch.cat((torch.from_numpy(g["feat"][nodes]), torch.from_numpy(mean)), 1)
+    np.testing.assert_allclose(torch.relu(w.mm(comb.t())).numpy(), g["sage_enc"], atol=TOL, rtol=0)
+    mean_g = O.mean_aggregate(g["rowptr"], g["col"], g["feat"], nodes, gcn=True)
+    w2 = torch.from_numpy(g["sage_gcn_weight"])
+    np.testing.assert_allclose(torch.relu(w2.mm(torch.from_numpy(mean_g).t())).numpy(), g["sage_gcn_enc"],
+                               atol=TOL, rtol=0)
+
+
+# ------------------------------------------------------------------ full graph
+def _full_setup(g):
+    adjn_rp, adjn_ci, adjn_va, raw_rp, raw_ci, raw_va = O.normalize_adj(g["rowptr"], g["col"])
+    return (adjn_rp, adjn_ci, adjn_va), (raw_rp, raw_ci, raw_va)
+
+
+@pytest.mark.parametrize("name", ["fullgraph_reddit_like.npz", "fullgraph_amazon_like.npz"])
+def test_full_preprocessing(name):
+    g = load_golden(name)
+    assert synth.crc_of(g["rowptr"], g["col"], g["feat_raw"], g["ano"]) == int(g["inputs_crc"])
+    np.testing.assert_allclose(O.preprocess_features(g["feat_raw"]).astype(np.float32), g["features"],
+                               atol=1e-7, rtol=0)
+    (rp, ci, va), _ = _full_setup(g)
+    n = int(g["n"])
+    import scipy.sparse as sp
+    ref = sp.coo_matrix((g["adjn_val"], (g["adjn_row"], g["adjn_col"])), shape=(n, n)).tocsr()
+    ref.sum_duplicates(); ref.sort_indices()
+    assert np.array_equal(ref.indptr, rp) and np.array_equal(ref.indices, ci)
+    np.testing.assert_allclose(va, ref.data, atol=1e-15, rtol=0)
+
+
+@pytest.mark.parametrize("name", ["fullgraph_reddit_like.npz", "fullgraph_amazon_like.npz"])
+def test_full_forward_loss_grads_trajectory(name):
+    g = load_golden(name)
+    adjn, raw = _full_setup(g)
+    P = {k: torch.tensor(g["init." + k], requires_grad=True) for k in O.FULL_PARAM_ORDER}
+    opt = O.make_adam(list(P.values()), 1e-3, 0.0)
+    feat = torch.from_numpy(g["features"])
+    abn, nrm = g["abn_idx"], g["normal_idx"]
+    mean, var, h = float(g["mean"]), float(g["var"]), int(g["n_h"])
+    for step in range(len(g["losses"])):
+        torch.manual_seed(1000 + step)
+        noise = torch.randn(1, len(abn), h)[0] * var + mean
+        opt.zero_grad()
+        emb, comb, logits, con, eab = O.full_forward(P, feat, adjn, abn, nrm, noise, True)
+        total, lm, lb, lr, aff = O.full_loss(emb, logits, con, eab, raw, abn, nrm)
+        total.backward()
+        np.testing.assert_allclose([total.item(), lm.item(), lb.item(), lr.item()], g["losses"][step], atol=1e-5)
+        if step == 0:
+            np.testing.assert_allclose(emb.detach().numpy(), g["emb"], atol=TOL)
+            np.testing.assert_allclose(comb.detach().numpy(), g["emb_combine"], atol=TOL)
+            np.testing.assert_allclose(logits.detach().numpy(), g["logits"], atol=TOL)
+            np.testing.assert_allclose(con.detach().numpy(), g["emb_con"], atol=TOL)
+            np.testing.assert_allclose(eab.detach().numpy(), g["emb_abnormal"], atol=TOL)
+            np.testing.assert_allclose(aff.detach().numpy(), g["affinity"], atol=TOL)
+            for k in O.FULL_PARAM_ORDER:
+                np.testing.assert_allclose(P[k].grad.numpy(), g["grad." + k], atol=3e-6, rtol=1e-4, err_msg=k)
+        opt.step()
+    for k in O.FULL_PARAM_ORDER:
+        np.testing.assert_allclose(P[k].detach().numpy(), g["final." + k], atol=3e-5, err_msg=k)
+    torch.manual_seed(5000)
+    noise = torch.randn(1, len(abn), h)[0] * var + mean
+    with torch.no_grad():
+        _, _, le, _, _ = O.full_forward(P, feat, adjn, abn, nrm, noise, False)
+    np.testing.assert_allclose(le.numpy(), g["eval_logits"], atol=3e-5)
+    from sklearn.metrics import roc_auc_score, average_precision_score
+    yt = g["ano"][g["idx_test"]]
+    assert abs(roc_auc_score(yt, le.numpy()[g["idx_test"]]) - float(g["eval_auc"])) < 1e-4
+    assert abs(average_precision_score(yt, le.numpy()[g["idx_test"]]) - float(g["eval_ap"])) < 1e-4
