@@ -1,0 +1,112 @@
+"""ctypes binding of libggad_hip.so (the C-ABI declared in include/ggad_hip.h).
+
+The product path has NO fallback: if the shared library is missing this module raises
+(``GgadLibraryError``) instead of routing to a CPU / PyTorch implementation.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int32, c_int64, c_uint32, c_uint64, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libggad_hip.so")
+
+
+class GgadLibraryError(RuntimeError):
+    pass
+
+
+class GgadKernelError(RuntimeError):
+    pass
+
+
+_P = c_void_p      # device (or host) pointer
+_I = c_int32
+_L = c_int64
+_F = c_float
+
+# name -> (restype, argtypes); MUST mirror include/ggad_hip.h (tests/test_abi.py checks the symbol list)
+SIGNATURES = {
+    "ggad_abi_version": (c_int32, []),
+    "ggad_last_error": (c_char_p, []),
+    "ggad_max_embed_dim": (c_int32, []),
+    "ggad_max_feat_dim": (c_int32, []),
+    "ggad_scan_workspace_elems": (c_int64, [_L]),
+    "ggad_exclusive_scan_i32": (c_int32, [_P, _P, _L, _P, _P]),
+    "ggad_mb_row_degree": (c_int32, [_P, _P, _P, _P, _I, _I, _P, _P, _P]),
+    "ggad_mb_expand1": (c_int32, [_P, _P, _P, _P, _P, _I, _L, _P, _P, _P, _P, _P]),
+    "ggad_mb_gather1": (c_int32, [_P, _I, _P, _P, _P, _I, _L, _P, _P, _P, _P, _P, _P]),
+    "ggad_mb_count2": (c_int32, [_P, _P, _P, _P, _P, _L, _L, _P, _P, _P]),
+    "ggad_mb_gather2": (c_int32, [_P, _P, _P, _I, _P, _P, _P, _P, _L, _L, _P, _P, _P]),
+    "ggad_mb_plan_reset": (c_int32, [_P, _P, _P, _P, _P, _P, _L, _L, _P, _P, _I, _P]),
+    "ggad_mb_param_count": (c_int64, [_I, _I]),
+    "ggad_mb_param_block_elems": (c_int64, [_I, _I]),
+    "ggad_mb_params_sync": (c_int32, [_P, _I, _I, _P]),
+    "ggad_mb_fwd_rows": (c_int32, [_P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
+    "ggad_mb_loss": (c_int32, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "ggad_mb_bwd_rows": (c_int32, [_P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "ggad_mb_grad_reduce": (c_int32, [_I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "ggad_mb_adam": (c_int32, [_P, _P, _P, _P, _I, _I, _F, _F, _F, _P, _P]),
+    "ggad_mb_score": (c_int32, [_P, _I, _I, _P, _I, _P, _P]),
+    "ggad_mt_new": (c_void_p, []),
+    "ggad_mt_free": (None, [c_void_p]),
+    "ggad_mt_seed_u64": (c_int32, [c_void_p, c_uint64]),
+    "ggad_mt_set_state": (c_int32, [c_void_p, POINTER(c_uint32), c_int32]),
+    "ggad_mt_get_state": (c_int32, [c_void_p, POINTER(c_uint32), POINTER(c_int32)]),
+    "ggad_mt_shuffle_i64": (c_int32, [c_void_p, POINTER(c_int64), c_int64]),
+    "ggad_mt_getrandbits32": (c_uint32, [c_void_p]),
+}
+
+_lib = None
+
+
+def load(path: str = LIB_PATH) -> ctypes.CDLL:
+    """Load the library (once) and attach argtypes.  Raises GgadLibraryError if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise GgadLibraryError(
+            f"{path} not found: build it with `python -m ggad_amd.build` (hipcc, gfx950). "
+            "There is no CPU fallback for the GGAD hot path.")
+    try:
+        lib = ctypes.CDLL(path)
+    except OSError as exc:  # missing ROCm runtime etc.
+        raise GgadLibraryError(f"cannot load {path}: {exc}") from exc
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as exc:
+            raise GgadLibraryError(f"{path} does not export {name}; rebuild it") from exc
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().ggad_last_error()
+        raise GgadKernelError(f"{what} failed with code {rc}: {msg.decode() if msg else ''}")
+
+
+def ptr(t) -> int:
+    """Device pointer of a torch tensor (must be contiguous)."""
+    if t is None:
+        return 0
+    if not t.is_contiguous():
+        raise ValueError("tensor handed to the C-ABI must be contiguous")
+    return t.data_ptr()
+
+
+def current_stream() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name: str, *args) -> None:
+    """Call an int-returning kernel entry point on torch's current stream and raise on error."""
+    lib = load()
+    rc = getattr(lib, name)(*args, current_stream())
+    check(rc, name)

@@ -1,0 +1,51 @@
+// Shared helpers for the gfx950 kernels of libggad_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/ggad_hip.h"
+
+#define GGAD_WAVE 64
+#define GGAD_MAX_D 64    // embedding width handled by one wave (lane = channel)
+#define GGAD_MAX_F 1024  // feature width limit of the gather kernels
+
+void ggad_set_error(hipError_t e, const char *where);
+
+#define GGAD_CHECK_LAUNCH(where)                 \
+  do {                                           \
+    hipError_t _e = hipGetLastError();           \
+    if (_e != hipSuccess) {                      \
+      ggad_set_error(_e, where);                 \
+      return GGAD_E_LAUNCH;                      \
+    }                                            \
+  } while (0)
+
+#define GGAD_REQUIRE(cond) \
+  do {                     \
+    if (!(cond)) return GGAD_E_INVALID; \
+  } while (0)
+
+static inline hipStream_t as_stream(ggad_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (GGAD_WAVE - 1); }
+
+// Sum over the 64 lanes of a wave; every lane gets the result.  Fixed butterfly order,
+// so the value is deterministic for given inputs.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, GGAD_WAVE);
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, GGAD_WAVE);
+  return v;
+}
+
+// first index in sorted a[lo,hi) with a[idx] >= key
+__device__ __forceinline__ int lower_bound_i32(const int32_t *__restrict__ a, int lo, int hi, int key) {
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (a[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}

@@ -1,0 +1,135 @@
+// Host-side runtime pieces of libggad_hip.so: error reporting and the batch sampler.
+//
+// The sampler is a bit-exact re-implementation of what CPython's `random` module does for
+// random.seed(int) / random.shuffle(list): the reference draws its batches with exactly these
+// calls inside its timed loop (src/model_handler.py:29-30 seed, :314 shuffle of the ~1.05 M train
+// list per epoch, :341 shuffle of the 55,275-element pseudo-anomaly pool PER BATCH = 28 ms/batch
+// in CPython).  Algorithms restated from their published descriptions:
+//   * MT19937 (Matsumoto & Nishimura 1998): init_genrand(19650218) + init_by_array(key), the key
+//     being the 32-bit little-endian limbs of |seed| (CPython Modules/_randommodule.c);
+//   * getrandbits(k), k <= 32: top k bits of one 32-bit output;
+//   * _randbelow(n): k = n.bit_length(); draw getrandbits(k) until < n;
+//   * shuffle: for i = len-1 .. 1: j = _randbelow(i+1); swap(x[i], x[j])  (CPython Lib/random.py).
+// Pinned by tests/golden/sampler_shuffle.npz (captured from CPython 3.10 itself).
+#include <cstring>
+#include <string>
+
+#include "common.h"
+
+static thread_local std::string g_last_error;
+
+void ggad_set_error(hipError_t e, const char *where) {
+  g_last_error = std::string(where) + ": " + hipGetErrorString(e);
+}
+
+struct ggad_mt19937 {
+  uint32_t mt[624];
+  int index;
+};
+
+namespace {
+constexpr int MT_N = 624, MT_M = 397;
+
+void mt_init_genrand(ggad_mt19937 *g, uint32_t s) {
+  g->mt[0] = s;
+  for (int i = 1; i < MT_N; ++i) g->mt[i] = 1812433253u * (g->mt[i - 1] ^ (g->mt[i - 1] >> 30)) + (uint32_t)i;
+  g->index = MT_N;
+}
+
+void mt_init_by_array(ggad_mt19937 *g, const uint32_t *key, int len) {
+  mt_init_genrand(g, 19650218u);
+  int i = 1, j = 0;
+  for (int k = (MT_N > len ? MT_N : len); k; --k) {
+    g->mt[i] = (g->mt[i] ^ ((g->mt[i - 1] ^ (g->mt[i - 1] >> 30)) * 1664525u)) + key[j] + (uint32_t)j;
+    if (++i >= MT_N) { g->mt[0] = g->mt[MT_N - 1]; i = 1; }
+    if (++j >= len) j = 0;
+  }
+  for (int k = MT_N - 1; k; --k) {
+    g->mt[i] = (g->mt[i] ^ ((g->mt[i - 1] ^ (g->mt[i - 1] >> 30)) * 1566083941u)) - (uint32_t)i;
+    if (++i >= MT_N) { g->mt[0] = g->mt[MT_N - 1]; i = 1; }
+  }
+  g->mt[0] = 0x80000000u;
+}
+
+inline uint32_t mt_next(ggad_mt19937 *g) {
+  if (g->index >= MT_N) {
+    uint32_t *mt = g->mt;
+    int kk = 0;
+    for (; kk < MT_N - MT_M; ++kk) {
+      uint32_t y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu);
+      mt[kk] = mt[kk + MT_M] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    for (; kk < MT_N - 1; ++kk) {
+      uint32_t y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu);
+      mt[kk] = mt[kk + (MT_M - MT_N)] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    uint32_t y = (mt[MT_N - 1] & 0x80000000u) | (mt[0] & 0x7fffffffu);
+    mt[MT_N - 1] = mt[MT_M - 1] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    g->index = 0;
+  }
+  uint32_t y = g->mt[g->index++];
+  y ^= (y >> 11);
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= (y >> 18);
+  return y;
+}
+
+inline int bit_length_u64(uint64_t n) {
+  int k = 0;
+  while (n) { ++k; n >>= 1; }
+  return k;
+}
+}  // namespace
+
+extern "C" {
+
+int ggad_abi_version(void) { return 1; }
+const char *ggad_last_error(void) { return g_last_error.c_str(); }
+
+ggad_mt19937 *ggad_mt_new(void) {
+  ggad_mt19937 *g = new ggad_mt19937;
+  uint32_t key = 0;
+  mt_init_by_array(g, &key, 1);
+  return g;
+}
+void ggad_mt_free(ggad_mt19937 *g) { delete g; }
+
+int ggad_mt_seed_u64(ggad_mt19937 *g, uint64_t seed) {
+  if (!g) return GGAD_E_INVALID;
+  uint32_t key[2] = {(uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32)};
+  mt_init_by_array(g, key, key[1] ? 2 : 1);
+  return GGAD_OK;
+}
+
+int ggad_mt_set_state(ggad_mt19937 *g, const uint32_t *mt624_host, int32_t index) {
+  if (!g || !mt624_host || index < 0 || index > MT_N) return GGAD_E_INVALID;
+  std::memcpy(g->mt, mt624_host, sizeof(g->mt));
+  g->index = index;
+  return GGAD_OK;
+}
+
+int ggad_mt_get_state(const ggad_mt19937 *g, uint32_t *mt624_host, int32_t *index_host) {
+  if (!g || !mt624_host || !index_host) return GGAD_E_INVALID;
+  std::memcpy(mt624_host, g->mt, sizeof(g->mt));
+  *index_host = g->index;
+  return GGAD_OK;
+}
+
+uint32_t ggad_mt_getrandbits32(ggad_mt19937 *g) { return mt_next(g); }
+
+int ggad_mt_shuffle_i64(ggad_mt19937 *g, int64_t *data, int64_t n) {
+  if (!g || (!data && n > 0) || n < 0 || n > 0x7fffffffLL) return GGAD_E_INVALID;
+  for (int64_t i = n - 1; i >= 1; --i) {
+    const uint64_t bound = (uint64_t)i + 1;
+    const int k = bit_length_u64(bound);
+    uint32_t r;
+    do { r = mt_next(g) >> (32 - k); } while (r >= bound);
+    const int64_t t = data[i];
+    data[i] = data[r];
+    data[r] = t;
+  }
+  return GGAD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,75 @@
+"""Device-resident CSR graph container used by both GGAD paths.
+
+The reference keeps the DGraph adjacency as a pickled ``defaultdict(set)`` (`src/utils.py:96-112`)
+and the full-graph adjacency as a dense (1,N,N) tensor (`run.py:98-110`).  Here the graph lives in
+HBM once, as int32 CSR with sorted, de-duplicated columns; the reference containers are accepted
+and converted once (`from_adj_lists`, `from_scipy`).
+"""
+from __future__ import annotations
+
+from typing import Mapping, Optional
+
+import numpy as np
+import torch
+
+
+def _check_i32(x: int, what: str) -> None:
+    if x >= 2 ** 31:
+        raise ValueError(f"{what} = {x} does not fit the int32 indices of the HIP kernels")
+
+
+class DeviceGraph:
+    """CSR adjacency on one GPU (replicated per rank in the data-parallel setting)."""
+
+    def __init__(self, rowptr: np.ndarray, col: np.ndarray, device, val: Optional[np.ndarray] = None):
+        rowptr = np.ascontiguousarray(rowptr)
+        col = np.ascontiguousarray(col)
+        self.n = int(len(rowptr) - 1)
+        self.nnz = int(rowptr[-1])
+        _check_i32(self.n + 1, "number of nodes")
+        _check_i32(self.nnz, "number of directed entries")
+        if len(col) != self.nnz:
+            raise ValueError("rowptr[-1] != len(col)")
+        self.rowptr_host = rowptr.astype(np.int32, copy=False)
+        self.col_host = col.astype(np.int32, copy=False)
+        self.deg_host = np.diff(self.rowptr_host.astype(np.int64))
+        self.device = torch.device(device)
+        self.rowptr = torch.from_numpy(self.rowptr_host).to(self.device)
+        self.col = torch.from_numpy(self.col_host).to(self.device)
+        self.val = None if val is None else torch.from_numpy(np.ascontiguousarray(val, dtype=np.float32)).to(self.device)
+
+    # ---- constructors from the reference's containers
+    @classmethod
+    def from_adj_lists(cls, adj_lists: Mapping[int, set], n: Optional[int] = None, device="cuda") -> "DeviceGraph":
+        """dict node -> set(neighbours), the reference's `adj_lists` (`src/model_handler.py:234-239`)."""
+        if n is None:
+            n = (max(adj_lists.keys()) + 1) if len(adj_lists) else 0
+        deg = np.zeros(n, dtype=np.int64)
+        for k, s in adj_lists.items():
+            deg[int(k)] = len(s)
+        rowptr = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(deg, out=rowptr[1:])
+        col = np.empty(int(rowptr[-1]), dtype=np.int32)
+        for k, s in adj_lists.items():
+            k = int(k)
+            if deg[k]:
+                col[rowptr[k]:rowptr[k + 1]] = np.sort(np.fromiter(s, dtype=np.int64, count=int(deg[k])))
+        _check_i32(int(rowptr[-1]), "number of directed entries")
+        return cls(rowptr.astype(np.int32), col, device)
+
+    @classmethod
+    def from_scipy(cls, mat, device="cuda", keep_values: bool = False) -> "DeviceGraph":
+        m = mat.tocsr().copy()
+        m.sum_duplicates()
+        m.sort_indices()
+        return cls(m.indptr.astype(np.int32), m.indices.astype(np.int32), device,
+                   val=m.data if keep_values else None)
+
+    def adj_lists(self):
+        """Back-conversion (tests / interchange only)."""
+        from .synth import csr_to_adj_lists
+        return csr_to_adj_lists(self.rowptr_host, self.col_host)
+
+    def closed_degree_bound(self, nodes: np.ndarray) -> int:
+        """sum(deg + 1): host-side upper bound of the number of 1-hop entries of a chunk."""
+        return int(self.deg_host[np.asarray(nodes, dtype=np.int64)].sum() + len(nodes))

@@ -1,0 +1,278 @@
+"""Host driver of the DGraph mini-batch hot path on one MI355X.
+
+Two objects:
+
+* ``BatchChunk`` -- the "plan" for G batches processed together: closed-neighbourhood entries,
+  per-batch column counts, owner election and the 1-hop / 2-hop gather-aggregates.  This is the
+  device replacement of ``GCNAggregator.forward`` (`src/graphsage.py:295-360`).  The aggregation
+  does not depend on the weights (the feature table is frozen, `src/model_handler.py:264`), so a
+  whole epoch's worth of batches is aggregated by a handful of large launches instead of 150 tiny
+  ones -- that is what makes the gather HBM-bound rather than launch-bound.
+* ``MiniBatchEngine`` -- parameters + Adam state in one packed fp32 block and the per-step kernel
+  chain (``GCNEncoder.forward`` + ``GCN.loss`` + backward + Adam, `src/graphsage.py:171-258,395-454`).
+
+PyTorch is used for device memory and streams only; all arithmetic happens in libggad_hip.so.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import call, ptr
+from .graph import DeviceGraph
+
+
+def _i32(n, device):
+    return torch.empty(int(max(n, 1)), dtype=torch.int32, device=device)
+
+
+def _f32(n, device):
+    return torch.empty(int(max(n, 1)), dtype=torch.float32, device=device)
+
+
+class BatchChunk:
+    """Device plan of up to ``max_batches`` batches (see module docstring).
+
+    Buffers have fixed capacity and fixed addresses (so that a captured hipGraph can be replayed
+    after a rebuild); ``build`` grows them only when a chunk does not fit.
+    """
+
+    def __init__(self, graph: DeviceGraph, feat: torch.Tensor, embed_dim: int, max_batches: int,
+                 rows_cap: int, ent_cap: int, train: bool = True):
+        self.lib = _lib.load()
+        self.g = graph
+        self.feat = feat
+        self.F = int(feat.shape[1])
+        self.D = int(embed_dim)
+        self.dev = feat.device
+        self.train = train
+        self.max_batches = int(max_batches)
+        # per-batch counter slots: int32[max_batches][n]; zero on entry, zeroed again by reset()
+        self.cnt1 = torch.zeros(self.max_batches * graph.n, dtype=torch.int32, device=self.dev)
+        self.own1 = torch.zeros(self.max_batches * graph.n, dtype=torch.int32, device=self.dev)
+        self.cnt2 = torch.zeros(self.max_batches * graph.n, dtype=torch.int32, device=self.dev) if train else None
+        self.rows_cap = 0
+        self.ent_cap = 0
+        self._alloc_rows(rows_cap)
+        self._alloc_ents(ent_cap)
+        self.n_batches = 0
+        self.n_rows = 0
+        self.ent_bound = 0
+        self.batch_ptr_host = np.zeros(1, dtype=np.int32)
+        self.dirty = False
+
+    # ---- allocation
+    def _alloc_rows(self, cap: int) -> None:
+        cap = int(cap)
+        d = self.dev
+        self.rows_cap = cap
+        # one int32 staging block uploaded per build: batch_ptr | nodes | labels | src_of_pos
+        self.stage_host = torch.empty(self.max_batches + 1 + 3 * cap, dtype=torch.int32).pin_memory() \
+            if torch.cuda.is_available() else torch.empty(self.max_batches + 1 + 3 * cap, dtype=torch.int32)
+        self.stage = _i32(self.max_batches + 1 + 3 * cap, d)
+        o = self.max_batches + 1
+        self.batch_ptr = self.stage[:o]
+        self.nodes = self.stage[o:o + cap]
+        self.labels = self.stage[o + cap:o + 2 * cap]
+        self.src_of_pos = self.stage[o + 2 * cap:o + 3 * cap]
+        self.row_r = _i32(cap, d)
+        self.row_slot = _i32(cap, d)
+        self.ent_ptr = _i32(cap + 1, d)
+        self.scan_ws = _i32(self.lib.ggad_scan_workspace_elems(cap), d)
+        self.x1 = _f32(cap * self.F, d)
+        if self.train:
+            n = cap * self.D
+            self.h1, self.nbar, self.gen = _f32(n, d), _f32(n, d), _f32(n, d)
+            self.d_comb, self.d_nbar_aff, self.dz = _f32(n, d), _f32(n, d), _f32(n, d)
+        else:
+            self.h1 = _f32(cap * self.D, d)
+
+    def _alloc_ents(self, cap: int) -> None:
+        cap = int(cap)
+        d = self.dev
+        self.ent_cap = cap
+        self.ent_col, self.ent_slot = _i32(cap, d), _i32(cap, d)
+        self.ent_own, self.ent_c1 = _i32(cap, d), _i32(cap, d)
+        self.x2 = _f32(cap * self.F, d) if self.train else None
+
+    # ---- build
+    def build(self, batches: Sequence[np.ndarray], labels: Optional[Sequence[np.ndarray]] = None) -> None:
+        """Upload the batches and run the plan + gather kernels on the current stream."""
+        if self.dirty:
+            self.reset()
+        nb = len(batches)
+        if nb > self.max_batches or nb == 0:
+            raise ValueError(f"chunk holds 1..{self.max_batches} batches, got {nb}")
+        sizes = np.fromiter((len(b) for b in batches), dtype=np.int64, count=nb)
+        if (sizes == 0).any():
+            raise ValueError("empty batch")
+        rows = int(sizes.sum())
+        nodes = np.concatenate([np.asarray(b, dtype=np.int64) for b in batches])
+        if nodes.min() < 0 or nodes.max() >= self.g.n:
+            raise ValueError("batch node id out of range")
+        bound = self.g.closed_degree_bound(nodes)
+        _lib_check_i32(bound)
+        if rows > self.rows_cap:
+            self._alloc_rows(int(rows * 1.25) + 64)
+        if bound > self.ent_cap:
+            self._alloc_ents(int(bound * 1.25) + 1024)
+        bp = np.zeros(nb + 1, dtype=np.int32)
+        np.cumsum(sizes, out=bp[1:])
+        st = self.stage_host.numpy()
+        o = self.max_batches + 1
+        st[:nb + 1] = bp
+        st[nb + 1:o] = bp[-1]
+        cap = self.rows_cap
+        st[o:o + rows] = nodes
+        if self.train:
+            if labels is None:
+                raise ValueError("training chunk needs labels")
+            lab = np.concatenate([np.asarray(l, dtype=np.int64) for l in labels])
+            if len(lab) != rows:
+                raise ValueError("labels / batches length mismatch")
+            st[o + cap:o + cap + rows] = lab
+            # column q of `combined_all` holds: label-0 rows in order, then label-1 rows (graphsage.py:450)
+            src = np.empty(rows, dtype=np.int32)
+            for b in range(nb):
+                r0, r1 = bp[b], bp[b + 1]
+                order = np.argsort(lab[r0:r1] != 0, kind="stable")
+                src[r0:r1] = order + r0
+            st[o + 2 * cap:o + 2 * cap + rows] = src
+        self.stage.copy_(self.stage_host, non_blocking=True)
+        self.n_batches, self.n_rows, self.ent_bound = nb, rows, bound
+        self.batch_ptr_host = bp
+        g = self.g
+        call("ggad_mb_row_degree", ptr(g.rowptr), ptr(g.col), ptr(self.nodes), ptr(self.batch_ptr), nb, rows,
+             ptr(self.row_r), ptr(self.row_slot))
+        call("ggad_exclusive_scan_i32", ptr(self.row_r), ptr(self.ent_ptr), rows, ptr(self.scan_ws))
+        call("ggad_mb_expand1", ptr(g.rowptr), ptr(g.col), ptr(self.nodes), ptr(self.row_slot), ptr(self.ent_ptr), rows,
+             g.n, ptr(self.ent_col), ptr(self.ent_slot), ptr(self.cnt1), ptr(self.own1))
+        self.dirty = True
+        call("ggad_mb_gather1", ptr(self.feat), self.F, ptr(self.row_slot), ptr(self.ent_ptr), ptr(self.ent_col), rows,
+             g.n, ptr(self.cnt1), ptr(self.own1), ptr(self.ent_own), ptr(self.ent_c1), ptr(self.x1))
+        if self.train:
+            tot = self.ent_total_ptr()
+            call("ggad_mb_count2", ptr(g.rowptr), ptr(g.col), ptr(self.ent_col), ptr(self.ent_slot), tot, bound, g.n,
+                 ptr(self.own1), ptr(self.cnt2))
+            call("ggad_mb_gather2", ptr(g.rowptr), ptr(g.col), ptr(self.feat), self.F, ptr(self.ent_col),
+                 ptr(self.ent_slot), ptr(self.ent_own), tot, bound, g.n, ptr(self.cnt2), ptr(self.x2))
+
+    def ent_total_ptr(self) -> int:
+        return self.ent_ptr.data_ptr() + 4 * self.n_rows
+
+    def reset(self) -> None:
+        """Zero the counter slots again (walks the entries of the last build)."""
+        if not self.dirty:
+            return
+        g = self.g
+        call("ggad_mb_plan_reset", ptr(g.rowptr), ptr(g.col), ptr(self.ent_col), ptr(self.ent_slot), ptr(self.ent_own),
+             self.ent_total_ptr(), self.ent_bound, g.n, ptr(self.cnt1), ptr(self.cnt2) if self.train else 0,
+             1 if self.train else 0)
+        self.dirty = False
+
+    def batch_rows(self, b: int):
+        return int(self.batch_ptr_host[b]), int(self.batch_ptr_host[b + 1])
+
+
+def _lib_check_i32(x: int) -> None:
+    if x >= 2 ** 31:
+        raise ValueError("chunk too large for int32 entry indices; use fewer batches per chunk")
+
+
+class MiniBatchEngine:
+    """Parameters, optimiser state and the per-batch kernel chain."""
+
+    def __init__(self, feat_dim: int, embed_dim: int, device, lr: float = 1e-3, weight_decay: float = 0.007):
+        self.lib = _lib.load()
+        self.F, self.D = int(feat_dim), int(embed_dim)
+        if self.D > self.lib.ggad_max_embed_dim():
+            raise ValueError(f"emb_size {self.D} > {self.lib.ggad_max_embed_dim()} is not supported by the HIP step kernels")
+        self.dev = torch.device(device)
+        self.lr, self.wd = float(lr), float(weight_decay)
+        self.n_train = int(self.lib.ggad_mb_param_count(self.D, self.F))
+        n_block = int(self.lib.ggad_mb_param_block_elems(self.D, self.F))
+        self.params = torch.zeros(n_block, dtype=torch.float32, device=self.dev)
+        self.exp_avg = torch.zeros(self.n_train, dtype=torch.float32, device=self.dev)
+        self.exp_avg_sq = torch.zeros(self.n_train, dtype=torch.float32, device=self.dev)
+        self.grads = torch.zeros(self.n_train, dtype=torch.float32, device=self.dev)
+        self.grad_w = torch.zeros(self.D, dtype=torch.float32, device=self.dev)
+        self.step_counter = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self.dw_part = None
+        self.loss_log = torch.zeros(8, dtype=torch.float32, device=self.dev)
+        D, F = self.D, self.F
+        # views with the reference's state_dict names/shapes
+        self.weight = self.params[0:D].view(1, D)
+        self.enc_weight = self.params[D:D + D * F].view(D, F)
+        self.enc_fc_weight = self.params[D + D * F:D + D * F + D * D].view(D, D)
+
+    # ---- parameters
+    def load_params(self, weight, enc_weight, enc_fc_weight) -> None:
+        with torch.no_grad():
+            self.weight.copy_(torch.as_tensor(weight, dtype=torch.float32).reshape(1, self.D))
+            self.enc_weight.copy_(torch.as_tensor(enc_weight, dtype=torch.float32).reshape(self.D, self.F))
+            self.enc_fc_weight.copy_(torch.as_tensor(enc_fc_weight, dtype=torch.float32).reshape(self.D, self.D))
+        self.sync_params()
+
+    def sync_params(self) -> None:
+        call("ggad_mb_params_sync", ptr(self.params), self.D, self.F)
+
+    def reset_optimizer(self) -> None:
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        self.step_counter.zero_()
+
+    def _ensure_loss_log(self, n: int) -> None:
+        if self.loss_log.numel() < 8 * n:
+            self.loss_log = torch.zeros(8 * n, dtype=torch.float32, device=self.dev)
+
+    def _ensure_dw(self, rows: int) -> None:
+        need = rows * self.F * self.D
+        if self.dw_part is None or self.dw_part.numel() < need:
+            self.dw_part = _f32(need, self.dev)
+
+    # ---- kernel chain
+    def forward_batch(self, ch: BatchChunk, b: int, train: bool = True) -> None:
+        r0, r1 = ch.batch_rows(b)
+        call("ggad_mb_fwd_rows", ptr(self.params), self.D, self.F, ptr(ch.x1), ptr(ch.x2) if train else 0,
+             ptr(ch.ent_ptr), ptr(ch.ent_own), ptr(ch.labels), r0, r1 - r0, 1 if train else 0,
+             ptr(ch.h1), ptr(ch.nbar) if train else 0, ptr(ch.gen) if train else 0)
+
+    def loss_and_grads(self, ch: BatchChunk, b: int, log_slot: int = 0) -> None:
+        """forward + loss + backward for batch b; gradients land in self.grads (packed w | W | fc)."""
+        r0, r1 = ch.batch_rows(b)
+        nb = r1 - r0
+        self._ensure_dw(nb)
+        self._ensure_loss_log(log_slot + 1)
+        losses = self.loss_log.data_ptr() + 32 * log_slot
+        self.forward_batch(ch, b, True)
+        call("ggad_mb_loss", ptr(self.params), self.D, ptr(ch.h1), ptr(ch.nbar), ptr(ch.gen), ptr(ch.labels),
+             ptr(ch.src_of_pos), r0, nb, losses, ptr(ch.d_comb), ptr(ch.d_nbar_aff), ptr(self.grad_w),
+             ptr(self.step_counter))
+        call("ggad_mb_bwd_rows", ptr(self.params), self.D, self.F, ptr(ch.x1), ptr(ch.x2), ptr(ch.ent_ptr), ptr(ch.ent_own),
+             ptr(ch.labels), r0, nb, ptr(ch.h1), ptr(ch.nbar), ptr(ch.gen), ptr(ch.d_comb), ptr(ch.d_nbar_aff), losses,
+             ptr(self.dw_part), ptr(ch.dz))
+        call("ggad_mb_grad_reduce", self.D, self.F, ptr(ch.labels), r0, nb, ptr(ch.nbar), ptr(self.dw_part), ptr(ch.dz),
+             ptr(self.grad_w), ptr(self.grads))
+
+    def adam_step(self, grad_scale: float = 1.0) -> None:
+        call("ggad_mb_adam", ptr(self.params), ptr(self.exp_avg), ptr(self.exp_avg_sq), ptr(self.grads), self.D, self.F,
+             self.lr, self.wd, float(grad_scale), ptr(self.step_counter))
+
+    def train_chunk(self, ch: BatchChunk, allreduce=None, world_size: int = 1, log_base: int = 0) -> None:
+        """One optimiser step per batch of the chunk (src/model_handler.py:330-364)."""
+        for b in range(ch.n_batches):
+            self.loss_and_grads(ch, b, log_base + b)
+            if allreduce is not None:
+                allreduce(self.grads)
+            self.adam_step(1.0 / world_size)
+
+    def score_chunk(self, ch: BatchChunk, out: torch.Tensor) -> None:
+        """to_prob for every row of an inference chunk (src/graphsage.py:178-181)."""
+        call("ggad_mb_score", ptr(self.params), self.D, self.F, ptr(ch.x1), ch.n_rows, ptr(out))
+
+    def losses(self, n: int) -> np.ndarray:
+        """(n, 4) array of {total, cls, margin, rec} for the last n logged steps (synchronises)."""
+        return self.loss_log[:8 * n].view(n, 8)[:, :4].cpu().numpy()

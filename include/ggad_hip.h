@@ -1,0 +1,185 @@
+/*
+ * ggad_hip.h -- C ABI of the MI355X-native GGAD hot path (libggad_hip.so).
+ *
+ * The reference (mala-lab/GGAD) has no FFI / plugin layer: its boundary is the Python
+ * class surface.  This header is the C-ABI that sits UNDER that surface:
+ * every entry point replaces a group of ATen call sites of the reference (cited per
+ * function as file:line relative to the reference tree) and is what a binding in the
+ * reference would call (ctypes stub: INTEGRATION.md).
+ *
+ * Conventions
+ *   - plain pointers + sizes only; every pointer is a DEVICE pointer unless the name
+ *     ends in _host; no ownership transfer: the caller (PyTorch allocator in the Python
+ *     host layer) allocates every input, output and workspace;
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*) and is
+ *     asynchronous; functions are re-entrant per stream and keep no global mutable
+ *     state: the only cross-call state is in buffers the caller passes (counter slots,
+ *     optimiser state);
+ *   - return value: 0 = success, negative = error (GGAD_E_*), never throws;
+ *   - indices are int32, values fp32; row-major;
+ *   - graph = CSR (rowptr[n+1], col[nnz]) with sorted, de-duplicated columns per row.
+ */
+#ifndef GGAD_HIP_H
+#define GGAD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GGAD_OK 0
+#define GGAD_E_INVALID (-1)   /* bad argument (null pointer, unsupported size)          */
+#define GGAD_E_LAUNCH (-2)    /* HIP launch / runtime error, see ggad_last_error()       */
+#define GGAD_E_CAPACITY (-3)  /* caller-provided workspace too small                     */
+
+typedef void *ggad_stream_t;  /* hipStream_t */
+
+/* ABI version of this header; bumped on any signature change. */
+int ggad_abi_version(void);
+/* Text of the last HIP error seen by this thread ("" if none). Host pointer, static storage. */
+const char *ggad_last_error(void);
+/* Upper limits compiled into the kernels (embedding width, feature width). */
+int ggad_max_embed_dim(void);
+int ggad_max_feat_dim(void);
+
+/* ------------------------------------------------------------------------------------
+ * Generic device primitives
+ * ---------------------------------------------------------------------------------- */
+
+/* out[0..n] = exclusive prefix sum of in[0..n-1] (out[n] = total).  n <= 4,194,304.
+ * workspace: int32[ggad_scan_workspace_elems(n)]. */
+int64_t ggad_scan_workspace_elems(int64_t n);
+int ggad_exclusive_scan_i32(const int32_t *in, int32_t *out, int64_t n, int32_t *workspace, ggad_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Mini-batch path (DGraph-Fin): batch sub-graph plan + gather-aggregate
+ * Replaces GCNAggregator.forward, src/graphsage.py:295-360 (python set unions, dense
+ * B x U and U x U2 masks, sum/sqrt/div normalisation, Embedding gather, mask.mm).
+ *
+ * A "chunk" is G batches processed together; rows = all batch nodes of the chunk
+ * (batch g owns rows [batch_ptr[g], batch_ptr[g+1])).  Batch g uses counter slot g:
+ * slot arrays are int32[G * n_nodes], must be all-zero on entry and are all-zero again
+ * after ggad_mb_plan_reset.
+ *
+ * Entry e (0 <= e < E) is one element j of the closed neighbourhood N(i)+{i} of row i
+ * (graphsage.py:305), rows in order, columns ascending.  The "owner" entry of (batch, j)
+ * is one entry of that batch with column j; 2-hop rows are stored at owner entries, so
+ * the deduplicated set U of graphsage.py:306 is { e : ent_own[e] == e }.
+ * ---------------------------------------------------------------------------------- */
+
+/* row_r[i] = |N(i) + {i}|, row_slot[i] = batch (slot) of row i.          graphsage.py:305 */
+int ggad_mb_row_degree(const int32_t *rowptr, const int32_t *col, const int32_t *nodes, const int32_t *batch_ptr,
+                       int32_t n_batches, int32_t n_rows, int32_t *row_r, int32_t *row_slot, ggad_stream_t stream);
+
+/* Materialise entries (ent_ptr = exclusive scan of row_r), count c_j = number of rows of the
+ * batch whose closed neighbourhood holds j (column sums of the dense mask, graphsage.py:315)
+ * into cnt1[slot][j], elect owners into own1[slot][j]; ent_slot[e] = slot.   graphsage.py:305-311 */
+int ggad_mb_expand1(const int32_t *rowptr, const int32_t *col, const int32_t *nodes, const int32_t *row_slot,
+                    const int32_t *ent_ptr, int32_t n_rows, int64_t n_nodes, int32_t *ent_col, int32_t *ent_slot,
+                    int32_t *cnt1, int32_t *own1, ggad_stream_t stream);
+
+/* ent_own[e], ent_c1[e] from the slot arrays, and the 1-hop aggregate
+ * x1[i] = sum_j feat[j] / (sqrt(r_i) sqrt(c_j)).                        graphsage.py:314-326 */
+int ggad_mb_gather1(const float *feat, int32_t feat_dim, const int32_t *row_slot, const int32_t *ent_ptr,
+                    const int32_t *ent_col, int32_t n_rows, int64_t n_nodes, const int32_t *cnt1,
+                    const int32_t *own1, int32_t *ent_own, int32_t *ent_c1, float *x1, ggad_stream_t stream);
+
+/* The per-entry kernels below launch one wave per entry for n_entries_cap entries (a host-side
+ * upper bound, e.g. sum(deg+1)) and read the true count from *ent_total (= ent_ptr[n_rows]).
+ *
+ * cnt2[slot][k] += 1 for every k in N(u), u an owner entry: column sums of the U x U2 mask
+ * (graphsage.py:335-348; rows are adj_list.get(u) WITHOUT self union).                     */
+int ggad_mb_count2(const int32_t *rowptr, const int32_t *col, const int32_t *ent_col, const int32_t *ent_slot,
+                   const int32_t *ent_total, int64_t n_entries_cap, int64_t n_nodes, const int32_t *own1,
+                   int32_t *cnt2, ggad_stream_t stream);
+
+/* 2-hop aggregate at owner entries:
+ * x2[e] = sum_{k in N(u)} feat[k] / (sqrt(|N(u)|) sqrt(c'_k)).          graphsage.py:346-355
+ * Dominant kernel of the path: HBM gather of feat rows, 4*F+8 algorithmic bytes per neighbour. */
+int ggad_mb_gather2(const int32_t *rowptr, const int32_t *col, const float *feat, int32_t feat_dim,
+                    const int32_t *ent_col, const int32_t *ent_slot, const int32_t *ent_own, const int32_t *ent_total,
+                    int64_t n_entries_cap, int64_t n_nodes, const int32_t *cnt2, float *x2, ggad_stream_t stream);
+
+/* Restore the counter slots to zero by re-walking the chunk (with_hop2 = 0 for inference plans). */
+int ggad_mb_plan_reset(const int32_t *rowptr, const int32_t *col, const int32_t *ent_col, const int32_t *ent_slot,
+                       const int32_t *ent_own, const int32_t *ent_total, int64_t n_entries_cap, int64_t n_nodes,
+                       int32_t *cnt1, int32_t *cnt2, int32_t with_hop2, ggad_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Mini-batch path: dense step = GCNEncoder.forward + GCN.loss + backward + Adam
+ * Replaces src/graphsage.py:395-454 (projection W, neighbour mean, outlier generation fc,
+ * permuted concat), :171-258 (score, BCE, cosine-affinity margin, recon, total),
+ * autograd backward and torch.optim.Adam.step (src/model_handler.py:363-364).
+ *
+ * Parameter block `params` (fp32): w[D] | W[D*F] | fc[D*D]  (= state_dict keys `weight`,
+ * `enc.weight`, `enc.fc.weight`), followed by kernel-private transposed copies
+ * Wt[F*D] | fcT[D*D]; total ggad_mb_param_block_elems(D,F).  Gradients are packed the same
+ * way (first D + D*F + D*D elements): this is the buffer the data-parallel layer
+ * all-reduces.
+ * ---------------------------------------------------------------------------------- */
+int64_t ggad_mb_param_count(int32_t D, int32_t F);       /* D + D*F + D*D               */
+int64_t ggad_mb_param_block_elems(int32_t D, int32_t F); /* + transposed copies         */
+/* Refresh the transposed copies after the host wrote w/W/fc (load_state_dict). */
+int ggad_mb_params_sync(float *params, int32_t D, int32_t F, ggad_stream_t stream);
+
+/* Per-row forward for rows [row0, row0+n_rows):  h1 = relu(W x1) (graphsage.py:412),
+ * nbar = mean over the closed neighbourhood of relu(W x2[owner]) (:419-421) and, on label-1
+ * rows, the generated outlier g = relu(fc nbar) (:428-430).  train = 0: h1 only. */
+int ggad_mb_fwd_rows(const float *params, int32_t D, int32_t F, const float *x1, const float *x2,
+                     const int32_t *ent_ptr, const int32_t *ent_own, const int32_t *labels, int32_t row0,
+                     int32_t n_rows, int32_t train, float *h1, float *nbar, float *gen, ggad_stream_t stream);
+
+/* Batch loss + gradients w.r.t. the per-position tensors (graphsage.py:174,192-258).
+ * src_of_pos[q] = row whose embedding sits at column q of `combined_all` (label-0 rows first,
+ * generated outliers last, :450); labels are paired in ORIGINAL order (quirk 1).
+ * losses8 = {total, cls, margin, rec, 0.1/n1, margin_active, n0, n1}.  Also bumps *step_counter
+ * (Adam step index). */
+int ggad_mb_loss(const float *params, int32_t D, const float *h1, const float *nbar, const float *gen,
+                 const int32_t *labels, const int32_t *src_of_pos, int32_t row0, int32_t n_rows, float *losses8,
+                 float *d_comb, float *d_nbar_aff, float *grad_w, int32_t *step_counter, ggad_stream_t stream);
+
+/* Per-row backward: recomputes the relu masks, produces per-row partial dW[F][D] and dZ (for dfc). */
+int ggad_mb_bwd_rows(const float *params, int32_t D, int32_t F, const float *x1, const float *x2,
+                     const int32_t *ent_ptr, const int32_t *ent_own, const int32_t *labels, int32_t row0,
+                     int32_t n_rows, const float *h1, const float *nbar, const float *gen, const float *d_comb,
+                     const float *d_nbar_aff, const float *losses8, float *dw_part, float *dz,
+                     ggad_stream_t stream);
+
+/* Reduce the per-row partials into the packed gradient buffer grads[D + D*F + D*D]. */
+int ggad_mb_grad_reduce(int32_t D, int32_t F, const int32_t *labels, int32_t row0, int32_t n_rows,
+                        const float *nbar, const float *dw_part, const float *dz, const float *grad_w,
+                        float *grads, ggad_stream_t stream);
+
+/* torch.optim.Adam.step (betas .9/.999, eps 1e-8, L2 weight decay added to the gradient) on the
+ * packed block; grad_scale multiplies the gradient first (1/world_size after an all-reduce sum).
+ * Step index is read from *step_counter.  Refreshes the transposed copies. */
+int ggad_mb_adam(float *params, float *exp_avg, float *exp_avg_sq, const float *grads, int32_t D, int32_t F,
+                 float lr, float weight_decay, float grad_scale, const int32_t *step_counter,
+                 ggad_stream_t stream);
+
+/* Inference: prob[i] = sigmoid(w . relu(W x1[i]))                   graphsage.py:178-181 */
+int ggad_mb_score(const float *params, int32_t D, int32_t F, const float *x1, int32_t n_rows, float *prob,
+                  ggad_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * Host-side sampler: bit-exact CPython random.shuffle (MT19937 + getrandbits rejection),
+ * replaces the python shuffles inside the reference's timed loop
+ * (src/model_handler.py:314,341; 28 ms / batch there).  HOST pointers.
+ * ---------------------------------------------------------------------------------- */
+typedef struct ggad_mt19937 ggad_mt19937;
+ggad_mt19937 *ggad_mt_new(void);
+void ggad_mt_free(ggad_mt19937 *);
+/* random.seed(int) for 0 <= seed < 2^64 (init_by_array over the 32-bit limbs). */
+int ggad_mt_seed_u64(ggad_mt19937 *, uint64_t seed);
+/* state exchange with random.getstate()[1]: 624 words + index. */
+int ggad_mt_set_state(ggad_mt19937 *, const uint32_t *mt624_host, int32_t index);
+int ggad_mt_get_state(const ggad_mt19937 *, uint32_t *mt624_host, int32_t *index_host);
+/* random.shuffle(list) in place on an int64 array. */
+int ggad_mt_shuffle_i64(ggad_mt19937 *, int64_t *data_host, int64_t n);
+uint32_t ggad_mt_getrandbits32(ggad_mt19937 *);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GGAD_HIP_H */

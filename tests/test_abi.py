@@ -1,0 +1,51 @@
+"""The C-ABI library loads on a CPU-only host and exports every symbol include/ggad_hip.h declares."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+from ggad_amd import _lib
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "ggad_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ggad_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_builds_and_loads():
+    from ggad_amd.build import build
+    path = build(verbose=False)
+    assert os.path.exists(path)
+    lib = _lib.load()
+    assert lib.ggad_abi_version() >= 1
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    declared = _declared_symbols()
+    assert len(declared) > 20
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in ggad_hip.h but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature in ggad_amd/_lib.py"
+    for name in _lib.SIGNATURES:
+        assert name in declared, f"{name} bound in _lib.py but not declared in ggad_hip.h"
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    with pytest.raises(_lib.GgadLibraryError):
+        _lib.load(str(tmp_path / "nope.so"))
+    monkeypatch.setattr(_lib, "_lib", None)
+    _lib.load()
+
+
+def test_argument_validation_without_gpu():
+    lib = _lib.load()
+    # null pointers are rejected before any launch
+    assert lib.ggad_exclusive_scan_i32(None, None, 4, None, None) == -1
+    assert lib.ggad_mb_params_sync(None, 64, 17, None) == -1
+    assert lib.ggad_mb_param_count(64, 17) == 5248
+    assert lib.ggad_max_embed_dim() == 64
