@@ -44,7 +44,7 @@ SIGNATURES = {
     "ggad_mb_param_block_elems": (c_int64, [_I, _I]),
     "ggad_mb_params_sync": (c_int32, [_P, _I, _I, _P]),
     "ggad_mb_fwd_rows": (c_int32, [_P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
-    "ggad_mb_loss": (c_int32, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "ggad_mb_loss": (c_int32, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "ggad_mb_bwd_rows": (c_int32, [_P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ggad_mb_grad_reduce": (c_int32, [_I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
     "ggad_mb_adam": (c_int32, [_P, _P, _P, _P, _I, _I, _F, _F, _F, _P, _P]),

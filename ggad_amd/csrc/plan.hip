@@ -146,8 +146,10 @@ __device__ __forceinline__ void gather_block(const float *__restrict__ feat, int
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int src = (t + u) * rpi + g;              // < 64 + rpi; shfl wraps modulo 64, weight 0 guards
+      // shuffles are executed by ALL lanes (a bpermute returns 0 from an inactive source lane)
       const int jj = __shfl(j, src & 63, GGAD_WAVE);
-      ww[u] = (src < count) ? __shfl(w, src & 63, GGAD_WAVE) : 0.0f;
+      const float ws = __shfl(w, src & 63, GGAD_WAVE);
+      ww[u] = (src < count) ? ws : 0.0f;
       x[u] = (lane_active && src < count) ? feat[(int64_t)jj * F + fbase + f] : 0.0f;
     }
 #pragma unroll
@@ -156,7 +158,8 @@ __device__ __forceinline__ void gather_block(const float *__restrict__ feat, int
   for (; t < iters; ++t) {
     const int src = t * rpi + g;
     const int jj = __shfl(j, src & 63, GGAD_WAVE);
-    const float ww = (src < count) ? __shfl(w, src & 63, GGAD_WAVE) : 0.0f;
+    const float ws = __shfl(w, src & 63, GGAD_WAVE);
+    const float ww = (src < count) ? ws : 0.0f;
     const float x = (lane_active && src < count) ? feat[(int64_t)jj * F + fbase + f] : 0.0f;
     acc = fmaf(ww, x, acc);
   }

@@ -130,9 +130,9 @@ __device__ __forceinline__ PosVals eval_position(const float *__restrict__ w, in
 __global__ void __launch_bounds__(LOSS_T) k_loss(const float *__restrict__ params, int D, const float *__restrict__ h1,
                                                  const float *__restrict__ nbar, const float *__restrict__ gen,
                                                  const int32_t *__restrict__ labels, const int32_t *__restrict__ src_of_pos,
-                                                 int row0, int B, float *__restrict__ losses8, float *__restrict__ d_comb,
-                                                 float *__restrict__ d_nbar_aff, float *__restrict__ grad_w,
-                                                 int32_t *__restrict__ step_counter) {
+                                                 int row0, int B, float *__restrict__ losses8, float *__restrict__ d_h1,
+                                                 float *__restrict__ d_gen, float *__restrict__ d_nbar,
+                                                 float *__restrict__ grad_w, int32_t *__restrict__ step_counter) {
   __shared__ float red[LOSS_W][6];
   __shared__ float bc[8];
   __shared__ float gw[LOSS_W][64];
@@ -168,11 +168,11 @@ __global__ void __launch_bounds__(LOSS_T) k_loss(const float *__restrict__ param
     const float active = (m >= 0.0f) ? 1.0f : 0.0f;                   // clamp_min backward: pass where x >= min
     losses8[4] = 0.1f / t[5];                                         // d total / d rec_i
     losses8[5] = active; losses8[6] = t[4]; losses8[7] = t[5];
-    bc[0] = active; bc[1] = t[4]; bc[2] = t[5];
-    *step_counter += 1;
+    bc[0] = active; bc[1] = t[4]; bc[2] = t[5]; bc[3] = 0.1f / t[5];
+    if (step_counter) *step_counter += 1;
   }
   __syncthreads();
-  const float active = bc[0], fn0 = bc[1], fn1 = bc[2];
+  const float active = bc[0], fn0 = bc[1], fn1 = bc[2], rec_coef = bc[3];
   float gacc = 0.0f;
   for (int q = wid; q < B; q += LOSS_W) {
     const PosVals v = eval_position(w, D, h1, nbar, gen, labels, src_of_pos, row0, q, lane);
@@ -184,9 +184,21 @@ __global__ void __launch_bounds__(LOSS_T) k_loss(const float *__restrict__ param
     const float cb = v.nbn > 0.0f ? v.nb / v.nbn : 0.0f;
     const float dC = ds * (lane < D ? w[lane] : 0.0f) + gq * ((v.nb / v.nbc) / v.nac - (v.aff / v.nac) * ca);
     const float dN = gq * ((v.c / v.nac) / v.nbc - (v.aff / v.nbc) * cb);
+    // column q of combined_all is h1[src] (label-0 source) or the generated outlier gen[src] (label-1 source);
+    // a label-1 source row also carries the recon term 0.1 * mean_i |h1_i - gen_i|      graphsage.py:197-198,258
+    float gH = dC, gG = 0.0f;
+    if (labels[v.src] == 1) {
+      const float hs = (lane < D) ? h1[(int64_t)v.src * D + lane] : 0.0f;
+      const float dl = hs - v.c;
+      const float nrm = sqrtf(wave_sum(dl * dl));
+      const float t = rec_coef * (dl / nrm);
+      gH = t;
+      gG = dC - t;
+    }
     if (lane < D) {
-      d_comb[(int64_t)v.src * D + lane] = dC;
-      d_nbar_aff[(int64_t)(row0 + q) * D + lane] = dN;
+      d_h1[(int64_t)v.src * D + lane] = gH;
+      d_gen[(int64_t)v.src * D + lane] = gG;
+      d_nbar[(int64_t)(row0 + q) * D + lane] = dN;
     }
     gacc = fmaf(ds, v.c, gacc);
   }
@@ -206,8 +218,8 @@ __global__ void __launch_bounds__(64) k_bwd_rows(const float *__restrict__ param
                                                  const int32_t *__restrict__ ent_ptr, const int32_t *__restrict__ ent_own,
                                                  const int32_t *__restrict__ labels, int row0,
                                                  const float *__restrict__ h1, const float *__restrict__ nbar,
-                                                 const float *__restrict__ gen, const float *__restrict__ d_comb,
-                                                 const float *__restrict__ d_nbar_aff, const float *__restrict__ losses8,
+                                                 const float *__restrict__ gen, const float *__restrict__ d_h1,
+                                                 const float *__restrict__ d_gen, const float *__restrict__ d_nbar,
                                                  float *__restrict__ dw_part, float *__restrict__ dz) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int D = L.D, F = (FT > 0) ? FT : L.F;
@@ -235,21 +247,17 @@ __global__ void __launch_bounds__(64) k_bwd_rows(const float *__restrict__ param
     if constexpr (FT > 0) {
 #pragma unroll
       for (int f = 0; f < FT; ++f) acc[f] = fmaf(coef, x[f], acc[f]);
-    } else {
+    } else if (on) {   // lanes >= D alias channel D-1: they must not touch its accumulator
       for (int f = 0; f < F; ++f) acc_lds[f * D + d] = fmaf(coef, x[f], acc_lds[f * D + d]);
     }
   };
   const int y = labels[row];
   const float H1 = on ? h1[(int64_t)row * D + lane] : 0.0f;
-  const float dC = on ? d_comb[(int64_t)row * D + lane] : 0.0f;
-  float dH1, dNb = on ? d_nbar_aff[(int64_t)row * D + lane] : 0.0f;
+  const float dH1 = on ? d_h1[(int64_t)row * D + lane] : 0.0f;
+  float dNb = on ? d_nbar[(int64_t)row * D + lane] : 0.0f;
   if (y == 1) {
     const float G = on ? gen[(int64_t)row * D + lane] : 0.0f;
-    const float dl = H1 - G;
-    const float nrm = sqrtf(wave_sum(dl * dl));
-    const float t = losses8[4] * (dl / nrm);                          // d(0.1 mean_i |h1_i - g_i|)
-    dH1 = t;
-    const float dG = dC - t;
+    const float dG = on ? d_gen[(int64_t)row * D + lane] : 0.0f;
     const float dZ = (G > 0.0f) ? dG : 0.0f;                          // relu(fc(.))
     if (on) { dz[(int64_t)row * D + lane] = dZ; zs[lane] = dZ; }
     __syncthreads();
@@ -257,8 +265,6 @@ __global__ void __launch_bounds__(64) k_bwd_rows(const float *__restrict__ param
     float a = 0.0f;
     for (int dd = 0; dd < D; ++dd) a = fmaf(fc[dd * D + d], zs[dd], a);   // fc^T dZ
     dNb += a;
-  } else {
-    dH1 = dC;
   }
   const float dA = (H1 > 0.0f) ? dH1 : 0.0f;
   accumulate(on ? dA : 0.0f, x1 + (int64_t)row * F);
@@ -428,30 +434,30 @@ int ggad_mb_fwd_rows(const float *params, int32_t D, int32_t F, const float *x1,
 
 int ggad_mb_loss(const float *params, int32_t D, const float *h1, const float *nbar, const float *gen,
                  const int32_t *labels, const int32_t *src_of_pos, int32_t row0, int32_t n_rows, float *losses8,
-                 float *d_comb, float *d_nbar_aff, float *grad_w, int32_t *step_counter, ggad_stream_t stream) {
-  GGAD_REQUIRE(params && h1 && nbar && gen && labels && src_of_pos && losses8 && d_comb && d_nbar_aff && grad_w && step_counter);
+                 float *d_h1, float *d_gen, float *d_nbar, float *grad_w, int32_t *step_counter, ggad_stream_t stream) {
+  GGAD_REQUIRE(params && h1 && nbar && gen && labels && src_of_pos && losses8 && d_h1 && d_gen && d_nbar && grad_w);
   GGAD_REQUIRE(D >= 1 && D <= GGAD_MAX_D && n_rows >= 1 && row0 >= 0);
   k_loss<<<dim3(1), dim3(LOSS_T), 0, as_stream(stream)>>>(params, D, h1, nbar, gen, labels, src_of_pos, row0, n_rows, losses8,
-                                                         d_comb, d_nbar_aff, grad_w, step_counter);
+                                                         d_h1, d_gen, d_nbar, grad_w, step_counter);
   GGAD_CHECK_LAUNCH("mb_loss");
   return GGAD_OK;
 }
 
 int ggad_mb_bwd_rows(const float *params, int32_t D, int32_t F, const float *x1, const float *x2,
                      const int32_t *ent_ptr, const int32_t *ent_own, const int32_t *labels, int32_t row0,
-                     int32_t n_rows, const float *h1, const float *nbar, const float *gen, const float *d_comb,
-                     const float *d_nbar_aff, const float *losses8, float *dw_part, float *dz, ggad_stream_t stream) {
-  GGAD_REQUIRE(params && x1 && x2 && ent_ptr && ent_own && labels && h1 && nbar && gen && d_comb && d_nbar_aff && losses8 &&
+                     int32_t n_rows, const float *h1, const float *nbar, const float *gen, const float *d_h1,
+                     const float *d_gen, const float *d_nbar, float *dw_part, float *dz, ggad_stream_t stream) {
+  GGAD_REQUIRE(params && x1 && x2 && ent_ptr && ent_own && labels && h1 && nbar && gen && d_h1 && d_gen && d_nbar &&
                dw_part && dz);
   GGAD_REQUIRE(dims_ok(D, F) && n_rows >= 1 && row0 >= 0);
   ParamLayout L{D, F};
   hipStream_t st = as_stream(stream);
   if (F == 17)
     k_bwd_rows<17><<<dim3(n_rows), dim3(64), (size_t)(2 * 17 * D + D) * 4, st>>>(
-        params, L, x1, x2, ent_ptr, ent_own, labels, row0, h1, nbar, gen, d_comb, d_nbar_aff, losses8, dw_part, dz);
+        params, L, x1, x2, ent_ptr, ent_own, labels, row0, h1, nbar, gen, d_h1, d_gen, d_nbar, dw_part, dz);
   else
     k_bwd_rows<0><<<dim3(n_rows), dim3(64), (size_t)(2 * F * D + D) * 4, st>>>(
-        params, L, x1, x2, ent_ptr, ent_own, labels, row0, h1, nbar, gen, d_comb, d_nbar_aff, losses8, dw_part, dz);
+        params, L, x1, x2, ent_ptr, ent_own, labels, row0, h1, nbar, gen, d_h1, d_gen, d_nbar, dw_part, dz);
   GGAD_CHECK_LAUNCH("mb_bwd_rows");
   return GGAD_OK;
 }

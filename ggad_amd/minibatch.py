@@ -86,7 +86,7 @@ class BatchChunk:
         if self.train:
             n = cap * self.D
             self.h1, self.nbar, self.gen = _f32(n, d), _f32(n, d), _f32(n, d)
-            self.d_comb, self.d_nbar_aff, self.dz = _f32(n, d), _f32(n, d), _f32(n, d)
+            self.d_h1, self.d_gen, self.d_nbar, self.dz = _f32(n, d), _f32(n, d), _f32(n, d), _f32(n, d)
         else:
             self.h1 = _f32(cap * self.D, d)
 
@@ -226,7 +226,9 @@ class MiniBatchEngine:
 
     def _ensure_loss_log(self, n: int) -> None:
         if self.loss_log.numel() < 8 * n:
-            self.loss_log = torch.zeros(8 * n, dtype=torch.float32, device=self.dev)
+            new = torch.zeros(8 * max(n, 2 * (self.loss_log.numel() // 8)), dtype=torch.float32, device=self.dev)
+            new[:self.loss_log.numel()].copy_(self.loss_log)
+            self.loss_log = new
 
     def _ensure_dw(self, rows: int) -> None:
         need = rows * self.F * self.D
@@ -249,10 +251,10 @@ class MiniBatchEngine:
         losses = self.loss_log.data_ptr() + 32 * log_slot
         self.forward_batch(ch, b, True)
         call("ggad_mb_loss", ptr(self.params), self.D, ptr(ch.h1), ptr(ch.nbar), ptr(ch.gen), ptr(ch.labels),
-             ptr(ch.src_of_pos), r0, nb, losses, ptr(ch.d_comb), ptr(ch.d_nbar_aff), ptr(self.grad_w),
+             ptr(ch.src_of_pos), r0, nb, losses, ptr(ch.d_h1), ptr(ch.d_gen), ptr(ch.d_nbar), ptr(self.grad_w),
              ptr(self.step_counter))
         call("ggad_mb_bwd_rows", ptr(self.params), self.D, self.F, ptr(ch.x1), ptr(ch.x2), ptr(ch.ent_ptr), ptr(ch.ent_own),
-             ptr(ch.labels), r0, nb, ptr(ch.h1), ptr(ch.nbar), ptr(ch.gen), ptr(ch.d_comb), ptr(ch.d_nbar_aff), losses,
+             ptr(ch.labels), r0, nb, ptr(ch.h1), ptr(ch.nbar), ptr(ch.gen), ptr(ch.d_h1), ptr(ch.d_gen), ptr(ch.d_nbar),
              ptr(self.dw_part), ptr(ch.dz))
         call("ggad_mb_grad_reduce", self.D, self.F, ptr(ch.labels), r0, nb, ptr(ch.nbar), ptr(self.dw_part), ptr(ch.dz),
              ptr(self.grad_w), ptr(self.grads))

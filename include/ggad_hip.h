@@ -130,21 +130,23 @@ int ggad_mb_fwd_rows(const float *params, int32_t D, int32_t F, const float *x1,
                      const int32_t *ent_ptr, const int32_t *ent_own, const int32_t *labels, int32_t row0,
                      int32_t n_rows, int32_t train, float *h1, float *nbar, float *gen, ggad_stream_t stream);
 
-/* Batch loss + gradients w.r.t. the per-position tensors (graphsage.py:174,192-258).
+/* Batch loss (graphsage.py:174,192-258) and its gradient w.r.t. the three row tensors
+ * (d_h1, d_gen, d_nbar; rows [row0, row0+n_rows)) and w.r.t. the scorer `weight` (grad_w[D]).
  * src_of_pos[q] = row whose embedding sits at column q of `combined_all` (label-0 rows first,
  * generated outliers last, :450); labels are paired in ORIGINAL order (quirk 1).
- * losses8 = {total, cls, margin, rec, 0.1/n1, margin_active, n0, n1}.  Also bumps *step_counter
- * (Adam step index). */
+ * losses8 = {total, cls, margin, rec, 0.1/n1, margin_active, n0, n1}.  If step_counter is not
+ * NULL it is incremented (Adam step index for ggad_mb_adam). */
 int ggad_mb_loss(const float *params, int32_t D, const float *h1, const float *nbar, const float *gen,
                  const int32_t *labels, const int32_t *src_of_pos, int32_t row0, int32_t n_rows, float *losses8,
-                 float *d_comb, float *d_nbar_aff, float *grad_w, int32_t *step_counter, ggad_stream_t stream);
+                 float *d_h1, float *d_gen, float *d_nbar, float *grad_w, int32_t *step_counter,
+                 ggad_stream_t stream);
 
-/* Per-row backward: recomputes the relu masks, produces per-row partial dW[F][D] and dZ (for dfc). */
+/* Vector-Jacobian product of ggad_mb_fwd_rows: given d_h1, d_gen (label-1 rows), d_nbar it recomputes
+ * the relu masks and writes per-row partial dW[F][D] (dw_part[(i-row0)*F*D ...]) and dZ (for d fc). */
 int ggad_mb_bwd_rows(const float *params, int32_t D, int32_t F, const float *x1, const float *x2,
                      const int32_t *ent_ptr, const int32_t *ent_own, const int32_t *labels, int32_t row0,
-                     int32_t n_rows, const float *h1, const float *nbar, const float *gen, const float *d_comb,
-                     const float *d_nbar_aff, const float *losses8, float *dw_part, float *dz,
-                     ggad_stream_t stream);
+                     int32_t n_rows, const float *h1, const float *nbar, const float *gen, const float *d_h1,
+                     const float *d_gen, const float *d_nbar, float *dw_part, float *dz, ggad_stream_t stream);
 
 /* Reduce the per-row partials into the packed gradient buffer grads[D + D*F + D*D]. */
 int ggad_mb_grad_reduce(int32_t D, int32_t F, const int32_t *labels, int32_t row0, int32_t n_rows,
