@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- training nodes/s of the DGraph-Fin mini-batch GGAD hot path on N MI355X.
+
+Workload (BASELINE.json metric, configs[4]): synthetic graph of DGraph-Fin size
+(3,700,550 nodes, 73,105,508 directed entries, 17 features), emb 64, batches of 150 + 50 nodes
+(`src/dgraph.yml`, `src/model_handler.py:317,342`), fp32.  One "step" = one optimiser step = one
+batch of 200 nodes per GPU: batch sub-graph plan + 1-hop/2-hop gather-aggregate + encoder + loss +
+backward + Adam.  Plans are built per chunk of 150 batches (one reference epoch) inside the timed
+region.  Inputs resident in HBM before the timed region: graph CSR, feature table, labels and the
+batch schedule (node ids); the schedule is produced by the reference-exact host sampler beforehand.
+
+    python bench.py --gpus 1 --steps 1500 --warmup 150
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line (rank 0).  `roofline` refers to the 2-hop gather-aggregate kernel
+(`k_gather2`, the HBM-bound kernel of the path): achieved = 72 B per gathered neighbour x
+neighbours per launch / launch time measured with HIP events on the launch stream.
+`cpu_baseline` times the dense-faithful CPU port of the reference's step (oracle/) on a bounded
+sample of the same batches (rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1500)
+    ap.add_argument("--warmup", type=int, default=150)
+    ap.add_argument("--nodes", type=int, default=3_700_550)
+    ap.add_argument("--entries", type=int, default=73_105_508)
+    ap.add_argument("--feat", type=int, default=17)
+    ap.add_argument("--emb", type=int, default=64)
+    ap.add_argument("--max-degree", type=int, default=2000)
+    ap.add_argument("--graph-kind", default="powerlaw", choices=["powerlaw", "er"])
+    ap.add_argument("--chunk", type=int, default=150, help="batches planned per launch group (reference epoch = 150)")
+    ap.add_argument("--cpu-batches", type=int, default=3, help="batches timed on the CPU port (0 = skip)")
+    ap.add_argument("--seed", type=int, default=72)
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from ggad_amd import synth
+    from ggad_amd.dgraph import normalize_features, split_dgraphfin
+    from ggad_amd.graph import DeviceGraph
+    from ggad_amd.sampler import PyCompatRandom
+    from ggad_amd.trainer import BatchSchedule, DGraphTrainer
+
+    t0 = time.time()
+    # ---------------- synthetic DGraph-size inputs (identical on every rank: same seeds)
+    rowptr, col = synth.make_graph_torch(a.nodes, a.entries, a.seed, dev, kind=a.graph_kind, max_degree=a.max_degree)
+    graph = DeviceGraph(rowptr, col, dev)
+    feat_raw = synth.make_features(a.nodes, a.feat, a.seed)
+    feat_np = normalize_features(feat_raw).astype(np.float32)            # src/model_handler.py:225
+    feat = torch.from_numpy(feat_np).to(dev)
+    labels0 = synth.make_labels(a.nodes, 15509.0 / 3700550.0, a.seed).astype(np.int32)
+    split = split_dgraphfin(labels0, a.seed, with_test=False)
+    import random as pyrandom
+    rng = PyCompatRandom.from_python_state(pyrandom.getstate())          # continue the python stream (model_handler.py:30)
+    sched = BatchSchedule(split["idx_train"], split["idx_anomaly"], split["labels"], 150, rng)
+    allreduce = None
+    if world > 1:
+        def allreduce(t):
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    trainer = DGraphTrainer(graph, feat, a.emb, sched, lr=1e-3, weight_decay=0.007, chunk_batches=a.chunk, rank=rank,
+                            world_size=world, allreduce=allreduce)
+    torch.manual_seed(a.seed)
+    w = torch.nn.init.xavier_uniform_(torch.empty(1, a.emb))
+    W = torch.nn.init.xavier_uniform_(torch.empty(a.emb, a.feat))
+    fc = torch.nn.Linear(a.emb, a.emb, bias=False).weight.detach()
+    trainer.engine.load_params(w, W, fc)
+    # batch schedule for warmup + timed steps, generated before the timed region (inputs of the hot path)
+    warm = sched.next_batches(a.warmup, rank, world)
+    timed = sched.next_batches(a.steps, rank, world)
+    setup_s = time.time() - t0
+
+    # ---------------- instrumentation of the dominant kernel (gather2) with HIP events on the launch stream
+    gather_ms, gather_nbrs = [], []
+    ev_pairs = []
+
+    def timed_build(chunk, bn, bl):
+        # BatchChunk.build records these two events around its gather2 launch (same stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        chunk.gather2_events = (e0, e1)
+        chunk.build(bn, bl)
+        chunk.gather2_events = None
+        ev_pairs.append((e0, e1, bn))
+
+    def hop2_neighbours(bn):
+        """S2 = sum over batches of sum_{u in U_b} deg(u): the neighbours one gather2 launch reads (host numpy)."""
+        rp, ci, deg = graph.rowptr_host, graph.col_host, graph.deg_host
+        tot = 0
+        for nodes in bn:
+            parts = [ci[rp[v]:rp[v + 1]] for v in nodes]
+            u = np.unique(np.concatenate(parts + [np.asarray(nodes, dtype=np.int32)]))
+            tot += int(deg[u].sum())
+        return tot
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---------------- warmup
+    if a.warmup > 0:
+        trainer.run_steps(a.warmup, prepared=warm)
+    barrier()
+    # ---------------- timed region
+    t1 = time.perf_counter()
+    nodes_local = trainer.run_steps(a.steps, prepared=timed, gather_hook=timed_build)
+    barrier()
+    elapsed = time.perf_counter() - t1
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        nn = torch.tensor([nodes_local], dtype=torch.float64, device=dev)
+        dist.all_reduce(nn, op=dist.ReduceOp.SUM)
+        nodes_total = float(nn.item())
+    else:
+        nodes_total = float(nodes_local)
+    losses = trainer.engine.losses(min(a.steps, a.chunk))
+
+    # ---------------- roofline of the dominant kernel
+    for e0, e1, bn in ev_pairs:
+        gather_ms.append(e0.elapsed_time(e1))
+        gather_nbrs.append(hop2_neighbours(bn))
+    alg_bytes = [(4 * a.feat + 4) * nb for nb in gather_nbrs]
+    ach = (sum(alg_bytes) / 1e9) / (sum(gather_ms) / 1e3) if gather_ms and sum(gather_ms) > 0 else None
+    roofline = {"kernel": "k_gather2 (2-hop gather-aggregate)", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": None,
+                "launches": len(gather_ms), "avg_launch_ms": float(np.mean(gather_ms)) if gather_ms else None,
+                "alg_bytes_per_launch": float(np.mean(alg_bytes)) if alg_bytes else None,
+                "gather_share_of_step_time": (sum(gather_ms) / 1e3) / elapsed if gather_ms else None}
+
+    # ---------------- CPU baseline: dense-faithful port of the reference's step, bounded sample
+    cpu = None
+    if rank == 0 and world == 1 and a.cpu_batches > 0:
+        from oracle import ggad_oracle as O
+        ncores = os.cpu_count() or 1
+        threads = min(24, ncores)                                       # README.md:21 "24-core CPU"
+        torch.set_num_threads(threads)
+        adj = O.LazyAdjLists(graph.rowptr_host, graph.col_host)
+        feat_t = torch.from_numpy(feat_np)
+        p = O.MiniParams(w.clone().requires_grad_(), W.clone().requires_grad_(), fc.clone().requires_grad_())
+        opt = O.make_adam(p.tensors(), 1e-3, 0.007)
+        nb = min(a.cpu_batches, len(timed[0]))
+        for b in range(nb):
+            adj.warm(timed[0][b])
+        O.dense_port_step(adj, feat_t, p, opt, timed[0][0], timed[1][0])     # warm-up step (allocator, threads)
+        tc = time.perf_counter()
+        n_cpu = 0
+        for b in range(nb):
+            O.dense_port_step(adj, feat_t, p, opt, timed[0][b], timed[1][b])
+            n_cpu += len(timed[0][b])
+        cpu_s = time.perf_counter() - tc
+        cpu = {"value": n_cpu / cpu_s, "unit": "nodes/s", "cores": threads, "kind": "port",
+               "sample": f"{nb} of the timed batches ({n_cpu} nodes), dense-mask step incl. backward+Adam, {cpu_s:.1f} s"}
+
+    if rank == 0:
+        value = nodes_total / elapsed
+        out = {
+            "metric": "training nodes/sec (DGraph-Fin mini-batch GGAD)", "value": value, "unit": "nodes/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "DGraph-Fin-size synthetic graph, mini-batch GGAD (GCN encoder)", "nodes": a.nodes,
+                       "directed_entries": int(graph.nnz), "feat": a.feat, "emb": a.emb, "batch": "150+50",
+                       "graph": f"{a.graph_kind}(alpha=2.1,max_degree={a.max_degree})", "chunk_batches": a.chunk,
+                       "parallelism": f"dp{world}", "optimizer": "adam(lr=1e-3,wd=0.007)"},
+            "roofline": roofline, "cpu_baseline": cpu,
+            "gpu_over_cpu": (value / cpu["value"]) if cpu else None,
+            "first_loss": float(losses[0][0]), "last_loss": float(losses[-1][0]), "setup_s": setup_s,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,66 @@
+"""DGraph-Fin data handling: loaders and the train/test split of the reference, host side.
+
+`split_dgraphfin` re-states `src/model_handler.py:150-178`; it deliberately uses the same CPython
+containers (``random.shuffle``, ``set`` / ``list(set)`` ordering, sklearn's ``train_test_split``) so
+that, for equal seeds, the train list, the pseudo-anomaly pool and the test list come out in the
+reference's order.  One-off work, outside every timed region.
+"""
+from __future__ import annotations
+
+import pickle
+import random
+from typing import Dict
+
+import numpy as np
+
+
+def load_dgraphfin(npz_path: str, adj_path: str):
+    """`src/utils.py:15-31`: x, y from the npz (labels = (y == 1)), pickled dict-of-sets adjacency."""
+    f = np.load(npz_path)
+    labels = (np.asarray(f["y"]).astype(np.float32) == 1).astype(np.int32)
+    feat = np.asarray(f["x"]).astype(np.float32)
+    with open(adj_path, "rb") as fh:
+        homo = pickle.load(fh)
+    return homo, feat, labels
+
+
+def normalize_features(mx: np.ndarray) -> np.ndarray:
+    """`src/utils.py:74-84`: x / (rowsum + 0.01), inf -> 0; scipy promotes to fp64, caller casts to fp32."""
+    mx = np.asarray(mx)
+    rowsum = np.array(mx.sum(1)) + 0.01
+    with np.errstate(divide="ignore"):
+        r_inv = np.power(rowsum, -1).flatten()
+    r_inv[np.isinf(r_inv)] = 0.0
+    return r_inv.astype(np.float64)[:, None] * mx.astype(np.float64)
+
+
+def split_dgraphfin(labels: np.ndarray, seed: int, test_ratio: float = 0.67, with_test: bool = True) -> Dict[str, object]:
+    """The 'dgraphfin' branch of ModelHandler.__init__ (`src/model_handler.py:29-30,150-178`).
+
+    Mutates a COPY of ``labels`` (pseudo anomalies get label 1, :165) and returns the lists the
+    training loop uses.  Consumes the global python/numpy RNGs exactly like the reference."""
+    from sklearn.model_selection import train_test_split
+    labels = np.array(labels).copy()
+    np.random.seed(seed)
+    random.seed(seed)
+    index = list(range(len(labels)))
+    idx_normal = [i for i in index if labels[i] == 0]
+    idx_real_abnormal = [i for i in index if labels[i] == 1]
+    idx_real_abnormal = idx_real_abnormal[0: int(len(idx_real_abnormal) * 0.2)]
+    random.shuffle(idx_normal)
+    idx_labeled = idx_normal[0: int(len(idx_normal) * 0.3)]
+    idx_anomaly = idx_labeled[0: int(len(idx_labeled) * 0.05)]
+    labels[idx_anomaly] = 1
+    idx_train = list(set(idx_labeled).difference(set(idx_anomaly)))
+    idx_train = idx_train + idx_real_abnormal                       # "contamination"
+    y_train = labels[idx_train]
+    idx_rest = list(set(index).difference(set(idx_labeled)))
+    idx_rest = list(set(idx_rest).difference(set(idx_real_abnormal)))
+    y_rest = labels[idx_rest]
+    if not with_test:      # bench / tests that only need the training lists
+        return dict(labels=labels, idx_train=idx_train, y_train=y_train, idx_labeled=idx_labeled,
+                    idx_anomaly=idx_anomaly, idx_rest=idx_rest)
+    idx_valid, idx_test, y_valid, y_test = train_test_split(idx_rest, y_rest, stratify=y_rest, test_size=test_ratio,
+                                                            random_state=2, shuffle=True)
+    return dict(labels=labels, idx_train=idx_train, y_train=y_train, idx_labeled=idx_labeled, idx_anomaly=idx_anomaly,
+                idx_valid=idx_valid, y_valid=y_valid, idx_test=idx_test, y_test=y_test)

@@ -56,6 +56,7 @@ class BatchChunk:
         self.cnt2 = torch.zeros(self.max_batches * graph.n, dtype=torch.int32, device=self.dev) if train else None
         self.rows_cap = 0
         self.ent_cap = 0
+        self._stage_evt = None
         self._alloc_rows(rows_cap)
         self._alloc_ents(ent_cap)
         self.n_batches = 0
@@ -63,6 +64,8 @@ class BatchChunk:
         self.ent_bound = 0
         self.batch_ptr_host = np.zeros(1, dtype=np.int32)
         self.dirty = False
+        self._stage_evt = None
+        self.gather2_events = None      # optional (start, end) torch events recorded around the gather2 launch
 
     # ---- allocation
     def _alloc_rows(self, cap: int) -> None:
@@ -121,6 +124,8 @@ class BatchChunk:
             self._alloc_ents(int(bound * 1.25) + 1024)
         bp = np.zeros(nb + 1, dtype=np.int32)
         np.cumsum(sizes, out=bp[1:])
+        if self._stage_evt is not None:
+            self._stage_evt.synchronize()       # previous upload has left the pinned staging block
         st = self.stage_host.numpy()
         o = self.max_batches + 1
         st[:nb + 1] = bp
@@ -142,6 +147,9 @@ class BatchChunk:
                 src[r0:r1] = order + r0
             st[o + 2 * cap:o + 2 * cap + rows] = src
         self.stage.copy_(self.stage_host, non_blocking=True)
+        if self.dev.type == "cuda":
+            self._stage_evt = torch.cuda.Event()
+            self._stage_evt.record()
         self.n_batches, self.n_rows, self.ent_bound = nb, rows, bound
         self.batch_ptr_host = bp
         g = self.g
@@ -157,8 +165,12 @@ class BatchChunk:
             tot = self.ent_total_ptr()
             call("ggad_mb_count2", ptr(g.rowptr), ptr(g.col), ptr(self.ent_col), ptr(self.ent_slot), tot, bound, g.n,
                  ptr(self.own1), ptr(self.cnt2))
+            if self.gather2_events is not None:
+                self.gather2_events[0].record()
             call("ggad_mb_gather2", ptr(g.rowptr), ptr(g.col), ptr(self.feat), self.F, ptr(self.ent_col),
                  ptr(self.ent_slot), ptr(self.ent_own), tot, bound, g.n, ptr(self.cnt2), ptr(self.x2))
+            if self.gather2_events is not None:
+                self.gather2_events[1].record()
 
     def ent_total_ptr(self) -> int:
         return self.ent_ptr.data_ptr() + 4 * self.n_rows

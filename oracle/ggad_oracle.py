@@ -201,6 +201,56 @@ def aggregate_batch_dense(adj_lists, feat_t: torch.Tensor, nodes, train_flag: bo
     return to_feats, tfn, mask_row, ulist
 
 
+class LazyAdjLists:
+    """dict-of-sets view of a CSR, sets built on first touch (the reference unpickles ALL of them up
+    front, `src/utils.py:26-28`; for the bounded cpu_baseline sample only the touched ones are needed;
+    call ``warm`` before timing so that set construction is not billed to the reference's loop)."""
+
+    def __init__(self, rowptr, col):
+        self.rowptr, self.col, self._c = rowptr, col, {}
+
+    def __getitem__(self, v):
+        v = int(v)
+        s = self._c.get(v)
+        if s is None:
+            s = set(self.col[self.rowptr[v]:self.rowptr[v + 1]].tolist())
+            self._c[v] = s
+        return s
+
+    def get(self, v):
+        return self[v]
+
+    def warm(self, nodes):
+        for v in nodes:
+            for u in self[v]:
+                self[u]
+
+
+def dense_port_step(adj_lists, feat_t: torch.Tensor, p: "MiniParams", opt, nodes, labels) -> float:
+    """One training step exactly as the reference executes it on its CPU path
+    (`src/model_handler.py:356-364` -> `graphsage.py:244-258,395-454,295-360`): dense masks, dense mm."""
+    nodes = [int(v) for v in nodes]
+    to_feats, tfn, mask_row, _ = aggregate_batch_dense(adj_lists, feat_t, nodes, True)
+    lab = torch.as_tensor(labels)
+    combined = F.relu(p.enc_weight.mm(to_feats.t()))
+    expand = F.relu(p.enc_weight.mm(tfn.t()))
+    nbar = mask_row.mm(expand.t())
+    a_feat = combined[:, lab == 1]
+    new = F.relu(nbar.T[:, lab == 1].t().mm(p.enc_fc_weight.t()))
+    combined_all = torch.cat((combined[:, lab == 0], new.t()), 1)
+    scores = p.weight.mm(combined_all).t()
+    cls = torch.mean(F.binary_cross_entropy_with_logits(scores.squeeze(), lab.float(), reduction="none",
+                                                        pos_weight=torch.tensor([1])))
+    aff = torch.cosine_similarity(combined_all, nbar.t(), dim=0)
+    margin = (1 - (torch.mean(aff[torch.argwhere(lab == 0)], 0) - torch.mean(aff[torch.argwhere(lab == 1)], 0))).clamp_min(min=0)
+    rec = torch.mean(torch.sqrt(torch.sum(torch.pow(a_feat - new.t(), 2), 0)))
+    total = 1 * cls + 1 * margin + 0.1 * rec
+    opt.zero_grad()
+    total.backward()
+    opt.step()
+    return total.item()
+
+
 @dataclass
 class MiniParams:
     """Trainable tensors of the DGraph model; names = the reference's state_dict keys."""
