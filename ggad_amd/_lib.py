@@ -35,7 +35,7 @@ SIGNATURES = {
     "ggad_scan_workspace_elems": (c_int64, [_L]),
     "ggad_exclusive_scan_i32": (c_int32, [_P, _P, _L, _P, _P]),
     "ggad_mb_row_degree": (c_int32, [_P, _P, _P, _P, _I, _I, _P, _P, _P]),
-    "ggad_mb_expand1": (c_int32, [_P, _P, _P, _P, _P, _I, _L, _P, _P, _P, _P, _P]),
+    "ggad_mb_expand1": (c_int32, [_P, _P, _P, _P, _P, _I, _L, _P, _P, _P, _P, _P, _P]),
     "ggad_mb_gather1": (c_int32, [_P, _I, _P, _P, _P, _I, _L, _P, _P, _P, _P, _P, _P]),
     "ggad_mb_count2": (c_int32, [_P, _P, _P, _P, _P, _L, _L, _P, _P, _P]),
     "ggad_mb_gather2": (c_int32, [_P, _P, _P, _I, _P, _P, _P, _P, _L, _L, _P, _P, _P]),
@@ -43,11 +43,15 @@ SIGNATURES = {
     "ggad_mb_param_count": (c_int64, [_I, _I]),
     "ggad_mb_param_block_elems": (c_int64, [_I, _I]),
     "ggad_mb_params_sync": (c_int32, [_P, _I, _I, _P]),
+    "ggad_mb_project": (c_int32, [_P, _I, _I, _P, _P, _I, _I, _P, _P]),
     "ggad_mb_fwd_rows": (c_int32, [_P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
-    "ggad_mb_loss": (c_int32, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
-    "ggad_mb_bwd_rows": (c_int32, [_P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "ggad_mb_grad_reduce": (c_int32, [_I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "ggad_mb_loss": (c_int32, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "ggad_mb_row_coefs": (c_int32, [_P, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "ggad_mb_bwd_parts": (c_int32, []),
+    "ggad_mb_bwd_flat": (c_int32, [_I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
+    "ggad_mb_grad_reduce": (c_int32, [_I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
     "ggad_mb_adam": (c_int32, [_P, _P, _P, _P, _I, _I, _F, _F, _F, _P, _P]),
+    "ggad_mb_train_step": (c_int32, [_P, _I, _P]),
     "ggad_mb_score": (c_int32, [_P, _I, _I, _P, _I, _P, _P]),
     "ggad_mt_new": (c_void_p, []),
     "ggad_mt_free": (None, [c_void_p]),
@@ -57,6 +61,18 @@ SIGNATURES = {
     "ggad_mt_shuffle_i64": (c_int32, [c_void_p, POINTER(c_int64), c_int64]),
     "ggad_mt_getrandbits32": (c_uint32, [c_void_p]),
 }
+
+
+
+class MbStep(ctypes.Structure):
+    """Mirror of `ggad_mb_step` (include/ggad_hip.h)."""
+    _fields_ = ([(n, c_void_p) for n in ("params", "exp_avg", "exp_avg_sq", "grads", "step_counter", "x1", "x2",
+                                         "ent_ptr", "ent_own", "ent_row", "labels", "pos_meta", "h1", "nbar", "gen",
+                                         "d_h1", "d_gen", "d_nbar", "dz", "coef_a", "coef_g", "h2", "dw_part", "grad_w",
+                                         "losses8")]
+                + [(n, c_int32) for n in ("D", "F", "row0", "n_rows", "ent0", "n_ents")]
+                + [("lr", c_float), ("weight_decay", c_float)])
+
 
 _lib = None
 

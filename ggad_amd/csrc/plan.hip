@@ -109,7 +109,8 @@ __global__ void __launch_bounds__(256) k_expand1(const int32_t *__restrict__ row
                                                  const int32_t *__restrict__ nodes, const int32_t *__restrict__ row_slot,
                                                  const int32_t *__restrict__ ent_ptr, int n_rows, int64_t n_nodes,
                                                  int32_t *__restrict__ ent_col, int32_t *__restrict__ ent_slot,
-                                                 int32_t *__restrict__ cnt1, int32_t *__restrict__ own1) {
+                                                 int32_t *__restrict__ ent_row, int32_t *__restrict__ cnt1,
+                                                 int32_t *__restrict__ own1) {
   const int row = blockIdx.x * (blockDim.x / GGAD_WAVE) + threadIdx.x / GGAD_WAVE;
   if (row >= n_rows) return;
   const int lane = lane_id();
@@ -129,6 +130,7 @@ __global__ void __launch_bounds__(256) k_expand1(const int32_t *__restrict__ row
     else j = col[s + idx - 1];
     ent_col[base + idx] = j;
     ent_slot[base + idx] = slot;
+    ent_row[base + idx] = row;
     const int old = atomicAdd(&cnt1[soff + j], 1);
     if (old == 0) own1[soff + j] = base + idx;   // first arrival owns (batch, j)
   }
@@ -309,11 +311,11 @@ int ggad_mb_row_degree(const int32_t *rowptr, const int32_t *col, const int32_t 
 
 int ggad_mb_expand1(const int32_t *rowptr, const int32_t *col, const int32_t *nodes, const int32_t *row_slot,
                     const int32_t *ent_ptr, int32_t n_rows, int64_t n_nodes, int32_t *ent_col, int32_t *ent_slot,
-                    int32_t *cnt1, int32_t *own1, ggad_stream_t stream) {
-  GGAD_REQUIRE(rowptr && col && nodes && row_slot && ent_ptr && ent_col && ent_slot && cnt1 && own1 && n_rows >= 0);
+                    int32_t *ent_row, int32_t *cnt1, int32_t *own1, ggad_stream_t stream) {
+  GGAD_REQUIRE(rowptr && col && nodes && row_slot && ent_ptr && ent_col && ent_slot && ent_row && cnt1 && own1 && n_rows >= 0);
   if (n_rows == 0) return GGAD_OK;
   k_expand1<<<dim3((n_rows + 3) / 4), dim3(256), 0, as_stream(stream)>>>(rowptr, col, nodes, row_slot, ent_ptr, n_rows,
-                                                                         n_nodes, ent_col, ent_slot, cnt1, own1);
+                                                                         n_nodes, ent_col, ent_slot, ent_row, cnt1, own1);
   GGAD_CHECK_LAUNCH("mb_expand1");
   return GGAD_OK;
 }

@@ -1,15 +1,24 @@
 // Dense per-batch step of the DGraph mini-batch path (gfx950): GCNEncoder.forward + GCN.loss
 // (src/graphsage.py:395-454, 171-258), its backward and Adam (src/model_handler.py:363-364).
 //
-// Shapes are tiny (B = 200 rows, ~4k neighbourhood entries, F = 17, D = 64, 5,248 trainable
-// scalars) and every step depends on the previous one through the weights, so these kernels are
-// latency-bound, not bandwidth-bound (SURVEY.md §7 "hard parts").  Design: one wave per batch row,
-// lane = embedding channel d (D <= 64), W^T resident in LDS (or in registers when F is a compile
-// time constant), neighbour rows fetched through the scalar cache (wave-uniform addresses), relu
-// masks recomputed in the backward instead of stored.  Four launches per step:
-//   fwd_rows -> loss (one workgroup) -> bwd_rows -> grad_reduce [-> all-reduce] -> adam
-// The projection uses the f32 VALU: at K = 17 an f32 MFMA tile (32x32x2) has the same FLOP rate
-// and would waste 32/17 of it on padding; MFMA is used for the wide full-graph projections only.
+// Shapes are tiny (B = 200 rows, a few thousand neighbourhood entries, F = 17, D = 64, 5,248
+// trainable scalars) and every step depends on the previous one through the weights, so these
+// kernels are latency-bound, not bandwidth-bound (SURVEY.md §7 "hard parts").  What matters is
+// (1) balance: batch rows have wildly different neighbourhood sizes (power-law), so the heavy
+// parts are flat over ENTRIES, not rows; (2) short dependent-load chains: indices are fetched
+// once per wave with one vector load and broadcast with v_readlane, rows are then fetched
+// through the scalar cache (wave-uniform) or as 256-byte coalesced vector loads; (3) few launches:
+//
+//   project   flat over entries   h2[u] = relu(W x2[u]) at owner entries          graphsage.py:419
+//   fwd_rows  4 waves per row     nbar = mean_{e in row} h2[own(e)], h1 = relu(W x1), gen = relu(fc nbar)
+//   loss      ONE workgroup       scores, BCE, cosine affinity margin, recon, their gradients w.r.t.
+//                                 (h1, gen, nbar, w) and the per-row backward coefficients
+//   bwd_flat  flat over entries   dW partials = sum coef (x) x, 4 waves per workgroup, combined in LDS
+//   grad_reduce [+ adam]          partials -> packed gradient block -> (all-reduce) -> Adam
+//
+// lane = embedding channel d (D <= 64).  The projection uses the f32 VALU: at K = 17 an f32 MFMA tile
+// (32x32x2) has the same FLOP rate and would waste 32/17 of it on padding; MFMA is used for the wide
+// full-graph projections only (gemm.hip).
 #include "common.h"
 
 namespace {
@@ -25,128 +34,240 @@ struct ParamLayout {
   __host__ __device__ int n_total() const { return n_train() + F * D + D * D; }
 };
 
-// h_d = sum_f Wt[f][d] * x[f] for a wave-uniform row x (scalar-cache loads), Wt in LDS.
-__device__ __forceinline__ float project_lds(const float *__restrict__ wt_lds, int D, int F, int d,
-                                             const float *__restrict__ x) {
-  float acc = 0.0f;
-  for (int f = 0; f < F; ++f) acc = fmaf(wt_lds[f * D + d], x[f], acc);
-  return acc;
+constexpr int BWD_PARTS = 128;   // workgroups (= partial dW blocks) of bwd_flat
+
+// ---- wave reductions: 4 DPP row rotations (VALU) + 2 cross-row permutes instead of 6 LDS-crossbar
+// permutes; every lane receives the total.  Fixed order -> deterministic.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float wave_sum_fast(float v) {
+  v += dpp_f<0x128>(v);   // row_ror:8
+  v += dpp_f<0x124>(v);   // row_ror:4
+  v += dpp_f<0x122>(v);   // row_ror:2
+  v += dpp_f<0x121>(v);   // row_ror:1   -> every lane holds the sum of its 16-lane row
+  v += __shfl_xor(v, 16, GGAD_WAVE);
+  v += __shfl_xor(v, 32, GGAD_WAVE);
+  return v;
 }
 
+// W^T column of this lane, either in registers (FT > 0: compile-time F) or read from LDS.
 template <int FT>
-__device__ __forceinline__ float project_reg(const float (&wreg)[FT > 0 ? FT : 1], const float *__restrict__ x) {
-  float acc = 0.0f;
+struct WCol {
+  float reg[FT > 0 ? FT : 1];
+  const float *lds;
+  int D, F, d;
+  __device__ __forceinline__ void load(const float *__restrict__ Wt, float *wt_lds, int D_, int F_, int d_, int tid, int nthreads) {
+    D = D_; F = F_; d = d_; lds = wt_lds;
+    if constexpr (FT > 0) {
 #pragma unroll
-  for (int f = 0; f < FT; ++f) acc = fmaf(wreg[f], x[f], acc);
-  return acc;
-}
-
-// ------------------------------------------------------------------ forward rows
-template <int FT>
-__global__ void __launch_bounds__(64) k_fwd_rows(const float *__restrict__ params, ParamLayout L,
-                                                 const float *__restrict__ x1, const float *__restrict__ x2,
-                                                 const int32_t *__restrict__ ent_ptr, const int32_t *__restrict__ ent_own,
-                                                 const int32_t *__restrict__ labels, int row0, int train,
-                                                 float *__restrict__ h1, float *__restrict__ nbar, float *__restrict__ gen) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int D = L.D, F = (FT > 0) ? FT : L.F;
-  const int lane = threadIdx.x, d = lane < D ? lane : D - 1;
-  const int row = row0 + blockIdx.x;
-  float *wt_lds = lds;            // F*D   (unused when FT > 0)
-  float *ns = lds + F * D;        // D
-  const float *Wt = params + L.o_Wt();
-  float wreg[FT > 0 ? FT : 1];
-  if constexpr (FT > 0) {
-#pragma unroll
-    for (int f = 0; f < FT; ++f) wreg[f] = Wt[f * D + d];
-  } else {
-    for (int i = lane; i < F * D; i += 64) wt_lds[i] = Wt[i];
-    __syncthreads();
-  }
-  auto project = [&](const float *__restrict__ x) -> float {
-    if constexpr (FT > 0) return project_reg<FT>(wreg, x);
-    else return project_lds(wt_lds, D, F, d, x);
-  };
-  const float *xr = x1 + (int64_t)row * F;
-  const float h = fmaxf(project(xr), 0.0f);                          // graphsage.py:412
-  if (lane < D) h1[(int64_t)row * D + lane] = h;
-  if (!train) return;
-  const int e0 = ent_ptr[row], e1 = ent_ptr[row + 1];
-  const int r = e1 - e0;
-  const float inv_r = 1.0f / (float)r;                                // mask_row = mask / rowsum   graphsage.py:317
-  float nb = 0.0f;
-  for (int blk = 0; blk < r; blk += 64) {
-    const int ov = (blk + lane < r) ? ent_own[e0 + blk + lane] : 0;
-    const int cnt = min(64, r - blk);
-    for (int i = 0; i < cnt; ++i) {
-      const int o = __builtin_amdgcn_readlane(ov, i);
-      const float he = fmaxf(project(x2 + (int64_t)o * F), 0.0f);     // relu(W x2[u])              graphsage.py:419
-      nb = fmaf(inv_r, he, nb);                                       // mask_row.mm(...)           graphsage.py:421
+      for (int f = 0; f < FT; ++f) reg[f] = Wt[f * D + d];
+    } else {
+      for (int i = tid; i < F * D; i += nthreads) wt_lds[i] = Wt[i];
+      __syncthreads();
     }
   }
-  if (lane < D) nbar[(int64_t)row * D + lane] = nb;
-  if (labels[row] == 1) {                                             // outlier generation         graphsage.py:428-430
-    if (lane < D) ns[lane] = nb;
-    __syncthreads();
-    const float *fcT = params + L.o_fcT();
+  // x: wave-uniform row (scalar-cache loads)
+  __device__ __forceinline__ float dot(const float *__restrict__ x) const {
     float acc = 0.0f;
-    for (int d2 = 0; d2 < D; ++d2) acc = fmaf(fcT[d2 * D + d], ns[d2], acc);
-    if (lane < D) gen[(int64_t)row * D + lane] = fmaxf(acc, 0.0f);
+    if constexpr (FT > 0) {
+#pragma unroll
+      for (int f = 0; f < FT; ++f) acc = fmaf(reg[f], x[f], acc);
+    } else {
+      for (int f = 0; f < F; ++f) acc = fmaf(lds[f * D + d], x[f], acc);
+    }
+    return acc;
   }
+};
+
+// ------------------------------------------------------------------ project: h2 at owner entries
+constexpr int PROJ_EPW = 8;   // entries per wave
+template <int FT>
+__global__ void __launch_bounds__(256) k_project(const float *__restrict__ params, ParamLayout L,
+                                                 const float *__restrict__ x2, const int32_t *__restrict__ ent_own,
+                                                 int ent0, int n_ents, float *__restrict__ h2) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int D = L.D, F = (FT > 0) ? FT : L.F;
+  const int lane = lane_id(), wid = threadIdx.x / 64, d = lane < D ? lane : D - 1;
+  WCol<FT> W;
+  W.load(params + L.o_Wt(), lds, D, F, d, threadIdx.x, blockDim.x);
+  const int base = (blockIdx.x * 4 + wid) * PROJ_EPW;
+  if (base >= n_ents) return;
+  const int ov = (lane < PROJ_EPW && base + lane < n_ents) ? ent_own[ent0 + base + lane] : -1;
+#pragma unroll
+  for (int i = 0; i < PROJ_EPW; ++i) {
+    const int o = __builtin_amdgcn_readlane(ov, i);
+    if (o != ent0 + base + i) continue;                 // not an owner (or past the end): wave-uniform branch
+    const float h = fmaxf(W.dot(x2 + (int64_t)o * F), 0.0f);                       // relu(W x2[u])   graphsage.py:419
+    if (lane < D) h2[(int64_t)(base + i) * D + lane] = h;
+  }
+}
+
+// ------------------------------------------------------------------ forward rows (4 waves per row)
+template <int FT>
+__global__ void __launch_bounds__(256) k_fwd_rows(const float *__restrict__ params, ParamLayout L,
+                                                  const float *__restrict__ x1, const float *__restrict__ h2,
+                                                  const int32_t *__restrict__ ent_ptr, const int32_t *__restrict__ ent_own,
+                                                  const int32_t *__restrict__ labels, int row0, int ent0,
+                                                  float *__restrict__ h1, float *__restrict__ nbar, float *__restrict__ gen) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int D = L.D, F = (FT > 0) ? FT : L.F;
+  const int lane = lane_id(), wid = threadIdx.x / 64, d = lane < D ? lane : D - 1;
+  const int row = row0 + blockIdx.x;
+  float *part = lds;                 // [4][64]
+  float *ns = lds + 256;             // [64]
+  float *wt_lds = lds + 320;         // F*D (FT == 0)
+  const int e0 = ent_ptr[row], e1 = ent_ptr[row + 1];
+  const int r = e1 - e0;
+  // partial sum of h2[own(e)] over e = e0 + wid, e0 + wid + 4, ...  (256-byte coalesced row loads)
+  float acc = 0.0f;
+  for (int blk = wid; blk < r; blk += 256) {
+    const int my = blk + 4 * lane;
+    const int ov = (my < r) ? ent_own[e0 + my] : 0;
+    const int cnt = min(64, (r - blk + 3) / 4);
+    int i = 0;
+    for (; i + 4 <= cnt; i += 4) {
+      const int o0 = __builtin_amdgcn_readlane(ov, i), o1 = __builtin_amdgcn_readlane(ov, i + 1);
+      const int o2 = __builtin_amdgcn_readlane(ov, i + 2), o3 = __builtin_amdgcn_readlane(ov, i + 3);
+      const float a0 = h2[(int64_t)(o0 - ent0) * D + d], a1 = h2[(int64_t)(o1 - ent0) * D + d];
+      const float a2 = h2[(int64_t)(o2 - ent0) * D + d], a3 = h2[(int64_t)(o3 - ent0) * D + d];
+      acc += a0; acc += a1; acc += a2; acc += a3;
+    }
+    for (; i < cnt; ++i) {
+      const int o = __builtin_amdgcn_readlane(ov, i);
+      acc += h2[(int64_t)(o - ent0) * D + d];
+    }
+  }
+  part[wid * 64 + lane] = acc;
+  __syncthreads();
+  const float inv_r = 1.0f / (float)r;                                      // mask_row = mask / rowsum  graphsage.py:317
+  const float nb = inv_r * ((part[lane] + part[64 + lane]) + (part[128 + lane] + part[192 + lane]));
+  const int y = labels[row];
+  if (wid == 0) {
+    if (lane < D) nbar[(int64_t)row * D + lane] = nb;                       // mask_row.mm(...)          graphsage.py:421
+    ns[lane] = (lane < D) ? nb : 0.0f;
+  }
+  {                                                                         // h1 = relu(W x1[row])      graphsage.py:412
+    WCol<FT> W;
+    if (FT == 0 || wid == 1)                                                // FT == 0: all waves fill LDS (barrier inside)
+      W.load(params + L.o_Wt(), wt_lds, D, F, d, threadIdx.x, blockDim.x);
+    if (wid == 1) {
+      const float h = fmaxf(W.dot(x1 + (int64_t)row * F), 0.0f);
+      if (lane < D) h1[(int64_t)row * D + lane] = h;
+    }
+  }
+  if (y != 1) return;                                                       // block-uniform exit
+  __syncthreads();
+  // outlier generation gen = relu(fc nbar): the 4 waves split the d2 range          graphsage.py:428-430
+  const float *fcT = params + L.o_fcT();
+  const int q = (D + 3) / 4;
+  float a = 0.0f;
+  for (int d2 = wid * q; d2 < min(D, (wid + 1) * q); ++d2) a = fmaf(fcT[d2 * D + d], ns[d2], a);
+  __syncthreads();
+  part[wid * 64 + lane] = a;
+  __syncthreads();
+  if (wid == 0 && lane < D)
+    gen[(int64_t)row * D + lane] = fmaxf((part[lane] + part[64 + lane]) + (part[128 + lane] + part[192 + lane]), 0.0f);
 }
 
 // ------------------------------------------------------------------ loss (one workgroup per batch)
 constexpr int LOSS_T = 1024;
 constexpr int LOSS_W = LOSS_T / 64;
+constexpr int LOSS_PP = 8;            // positions per wave per round (rows prefetched together)
 
-__device__ __forceinline__ float log_sigmoid(float x) {
-  return fminf(x, 0.0f) - log1pf(expf(-fabsf(x)));
-}
+__device__ __forceinline__ float log_sigmoid(float x) { return fminf(x, 0.0f) - log1pf(expf(-fabsf(x))); }
 
-struct PosVals { float s, aff, na, nbn, nac, nbc, c, nb; int y; int src; };
+struct PosVals { float s, aff, na, nbn, nac, nbc; };
 
-__device__ __forceinline__ PosVals eval_position(const float *__restrict__ w, int D, const float *__restrict__ h1,
-                                                 const float *__restrict__ nbar, const float *__restrict__ gen,
-                                                 const int32_t *__restrict__ labels, const int32_t *__restrict__ src_of_pos,
-                                                 int row0, int q, int lane) {
+__device__ __forceinline__ PosVals eval_position(float wd, float c, float nb) {
   PosVals v;
-  const int prow = row0 + q;
-  v.src = src_of_pos[prow];
-  v.y = labels[prow];
-  const bool on = lane < D;
-  const bool from_gen = labels[v.src] == 1;
-  v.c = on ? (from_gen ? gen[(int64_t)v.src * D + lane] : h1[(int64_t)v.src * D + lane]) : 0.0f;   // combined_all[:, q]
-  v.nb = on ? nbar[(int64_t)prow * D + lane] : 0.0f;                                              // to_feats_neigh[q, :]
-  const float wd = on ? w[lane] : 0.0f;
-  v.s = wave_sum(wd * v.c);                                           // scores = weight.mm(embeds)  graphsage.py:174
-  v.na = sqrtf(wave_sum(v.c * v.c));
-  v.nbn = sqrtf(wave_sum(v.nb * v.nb));
-  v.nac = fmaxf(v.na, 1e-8f);                                         // cosine_similarity eps      graphsage.py:234
+  v.s = wave_sum_fast(wd * c);                                          // scores = weight.mm(embeds)  graphsage.py:174
+  v.na = sqrtf(wave_sum_fast(c * c));
+  v.nbn = sqrtf(wave_sum_fast(nb * nb));
+  v.nac = fmaxf(v.na, 1e-8f);                                           // cosine_similarity eps      graphsage.py:234
   v.nbc = fmaxf(v.nbn, 1e-8f);
-  v.aff = wave_sum((v.c / v.nac) * (v.nb / v.nbc));
+  v.aff = wave_sum_fast((c / v.nac) * (nb / v.nbc));
   return v;
 }
 
-__global__ void __launch_bounds__(LOSS_T) k_loss(const float *__restrict__ params, int D, const float *__restrict__ h1,
-                                                 const float *__restrict__ nbar, const float *__restrict__ gen,
-                                                 const int32_t *__restrict__ labels, const int32_t *__restrict__ src_of_pos,
+// Per-row backward coefficients (shared by the fused loss kernel and the stand-alone VJP entry point):
+//   coef_a = d_h1 * [h1 > 0]                     multiplies x1[row]      in dW
+//   dz     = d_gen * [gen > 0]  (label-1 rows)   outer(dz, nbar) = d fc
+//   coef_g = (d_nbar + fc^T dz) / r              multiplies x2[own(e)] * [h2 > 0] for the row's entries
+__device__ __forceinline__ void row_coefs(const float *__restrict__ fc, int D, int lane, int row, int y, int r,
+                                          const float *__restrict__ h1, const float *__restrict__ gen,
+                                          const float *__restrict__ d_h1, const float *__restrict__ d_gen,
+                                          const float *__restrict__ d_nbar, float *__restrict__ zs_wave,
+                                          float *__restrict__ dz, float *__restrict__ coef_a, float *__restrict__ coef_g) {
+  const bool on = lane < D;
+  const int d = on ? lane : D - 1;
+  const int64_t off = (int64_t)row * D + d;
+  const float H1 = h1[off];
+  const float dH1 = d_h1[off];
+  float dNb = d_nbar[off];
+  if (y == 1) {
+    const float G = gen[off];
+    const float dG = d_gen[off];
+    const float dZ = (G > 0.0f) ? dG : 0.0f;                            // relu(fc(.))
+    if (on) dz[off] = dZ;
+    zs_wave[lane] = on ? dZ : 0.0f;                                     // per-wave LDS slice, same wave reads it back
+    float a = 0.0f;
+    for (int dd = 0; dd < D; ++dd) a = fmaf(fc[dd * D + d], zs_wave[dd], a);   // fc^T dZ
+    dNb += a;
+  }
+  if (on) {
+    coef_a[off] = (H1 > 0.0f) ? dH1 : 0.0f;
+    coef_g[off] = dNb * (1.0f / (float)r);
+  }
+}
+
+// pos_meta[q] = (src_row << 2) | (src_is_label1 << 1) | label_of_position_q     (host-built, graphsage.py:450 order)
+__global__ void __launch_bounds__(LOSS_T) k_loss(const float *__restrict__ params, ParamLayout L,
+                                                 const float *__restrict__ h1, const float *__restrict__ nbar,
+                                                 const float *__restrict__ gen, const int32_t *__restrict__ labels,
+                                                 const int32_t *__restrict__ pos_meta, const int32_t *__restrict__ ent_ptr,
                                                  int row0, int B, float *__restrict__ losses8, float *__restrict__ d_h1,
-                                                 float *__restrict__ d_gen, float *__restrict__ d_nbar,
+                                                 float *__restrict__ d_gen, float *__restrict__ d_nbar, float *__restrict__ dz,
+                                                 float *__restrict__ coef_a, float *__restrict__ coef_g,
                                                  float *__restrict__ grad_w, int32_t *__restrict__ step_counter) {
   __shared__ float red[LOSS_W][6];
   __shared__ float bc[8];
   __shared__ float gw[LOSS_W][64];
+  __shared__ float zs[LOSS_W][64];
+  const int D = L.D;
   const int lane = lane_id(), wid = threadIdx.x / 64;
-  const float *w = params;   // o_w = 0
+  const bool on = lane < D;
+  const float wd = on ? params[lane] : 0.0f;   // o_w = 0
   float s_bce = 0.f, s_a0 = 0.f, s_a1 = 0.f, s_rec = 0.f; int n0 = 0, n1 = 0;
-  for (int q = wid; q < B; q += LOSS_W) {
-    const PosVals v = eval_position(w, D, h1, nbar, gen, labels, src_of_pos, row0, q, lane);
-    s_bce += (1.0f - (float)v.y) * v.s - log_sigmoid(v.s);            // BCEWithLogits, pos_weight 1 graphsage.py:246
-    if (v.y == 0) { s_a0 += v.aff; n0++; } else { s_a1 += v.aff; n1++; }
-    if (v.y == 1) {                                                   // recon2 over label-1 rows    graphsage.py:197-198
-      const int prow = row0 + q;
-      const float dl = (lane < D) ? h1[(int64_t)prow * D + lane] - gen[(int64_t)prow * D + lane] : 0.0f;
-      s_rec += sqrtf(wave_sum(dl * dl));
+  // ---------------- pass 1: loss terms
+  for (int base = 0; base < B; base += LOSS_W * LOSS_PP) {
+    const int myq = base + wid + LOSS_W * lane;                          // lane i < PP holds the meta of position i
+    const int meta = (lane < LOSS_PP && myq < B) ? pos_meta[row0 + myq] : -1;
+    float c[LOSS_PP], nb[LOSS_PP], hs[LOSS_PP];
+    int mt[LOSS_PP];
+#pragma unroll
+    for (int i = 0; i < LOSS_PP; ++i) {
+      mt[i] = __builtin_amdgcn_readlane(meta, i);
+      const int q = base + wid + LOSS_W * i;
+      if (mt[i] >= 0 && on) {
+        const int src = mt[i] >> 2;
+        c[i] = (mt[i] & 2) ? gen[(int64_t)src * D + lane] : h1[(int64_t)src * D + lane];      // combined_all[:, q]
+        nb[i] = nbar[(int64_t)(row0 + q) * D + lane];                                        // to_feats_neigh[q, :]
+        hs[i] = (mt[i] & 2) ? h1[(int64_t)src * D + lane] : 0.0f;
+      } else { c[i] = 0.f; nb[i] = 0.f; hs[i] = 0.f; }
+    }
+#pragma unroll
+    for (int i = 0; i < LOSS_PP; ++i) {
+      if (mt[i] < 0) continue;
+      const int y = mt[i] & 1;
+      const PosVals v = eval_position(wd, c[i], nb[i]);
+      s_bce += (1.0f - (float)y) * v.s - log_sigmoid(v.s);               // BCEWithLogits, pos_weight 1 graphsage.py:246
+      if (y == 0) { s_a0 += v.aff; n0++; } else { s_a1 += v.aff; n1++; }
+      if (mt[i] & 2) {                                                   // recon2 over label-1 rows    graphsage.py:197-198
+        const float dl = hs[i] - c[i];
+        s_rec += sqrtf(wave_sum_fast(dl * dl));
+      }
     }
   }
   if (lane == 0) {
@@ -160,189 +281,179 @@ __global__ void __launch_bounds__(LOSS_T) k_loss(const float *__restrict__ param
       for (int m = 0; m < 6; ++m) t[m] += red[k][m];
     const float cls = t[0] / (float)B;
     const float an = t[1] / t[4], ab = t[2] / t[5];
-    const float m = 1.0f - (an - ab);                                 // confidence_margin = 1      graphsage.py:236-240
+    const float m = 1.0f - (an - ab);                                    // confidence_margin = 1      graphsage.py:236-240
     const float margin = fmaxf(m, 0.0f);
     const float rec = t[3] / t[5];
-    losses8[0] = cls + margin + 0.1f * rec;                           // graphsage.py:258
+    losses8[0] = cls + margin + 0.1f * rec;                              // graphsage.py:258
     losses8[1] = cls; losses8[2] = margin; losses8[3] = rec;
-    const float active = (m >= 0.0f) ? 1.0f : 0.0f;                   // clamp_min backward: pass where x >= min
-    losses8[4] = 0.1f / t[5];                                         // d total / d rec_i
+    const float active = (m >= 0.0f) ? 1.0f : 0.0f;                      // clamp_min backward: pass where x >= min
+    losses8[4] = 0.1f / t[5];
     losses8[5] = active; losses8[6] = t[4]; losses8[7] = t[5];
     bc[0] = active; bc[1] = t[4]; bc[2] = t[5]; bc[3] = 0.1f / t[5];
     if (step_counter) *step_counter += 1;
   }
   __syncthreads();
   const float active = bc[0], fn0 = bc[1], fn1 = bc[2], rec_coef = bc[3];
+  // ---------------- pass 2: gradients w.r.t. h1 / gen / nbar / w
   float gacc = 0.0f;
-  for (int q = wid; q < B; q += LOSS_W) {
-    const PosVals v = eval_position(w, D, h1, nbar, gen, labels, src_of_pos, row0, q, lane);
-    const float ds = (1.0f / (1.0f + expf(-v.s)) - (float)v.y) / (float)B;
-    const float gq = active * (v.y == 0 ? -1.0f / fn0 : 1.0f / fn1);
-    // aff = sum (c/nac)(nb/nbc); the eps clamp is applied outside autograd (torch clamps a detached copy),
-    // so d aff / d c = (nb/nbc)/nac - (aff/nac) * c/|c|
-    const float ca = v.na > 0.0f ? v.c / v.na : 0.0f;
-    const float cb = v.nbn > 0.0f ? v.nb / v.nbn : 0.0f;
-    const float dC = ds * (lane < D ? w[lane] : 0.0f) + gq * ((v.nb / v.nbc) / v.nac - (v.aff / v.nac) * ca);
-    const float dN = gq * ((v.c / v.nac) / v.nbc - (v.aff / v.nbc) * cb);
-    // column q of combined_all is h1[src] (label-0 source) or the generated outlier gen[src] (label-1 source);
-    // a label-1 source row also carries the recon term 0.1 * mean_i |h1_i - gen_i|      graphsage.py:197-198,258
-    float gH = dC, gG = 0.0f;
-    if (labels[v.src] == 1) {
-      const float hs = (lane < D) ? h1[(int64_t)v.src * D + lane] : 0.0f;
-      const float dl = hs - v.c;
-      const float nrm = sqrtf(wave_sum(dl * dl));
-      const float t = rec_coef * (dl / nrm);
-      gH = t;
-      gG = dC - t;
+  for (int base = 0; base < B; base += LOSS_W * LOSS_PP) {
+    const int myq = base + wid + LOSS_W * lane;
+    const int meta = (lane < LOSS_PP && myq < B) ? pos_meta[row0 + myq] : -1;
+    float c[LOSS_PP], nb[LOSS_PP], hs[LOSS_PP];
+    int mt[LOSS_PP];
+#pragma unroll
+    for (int i = 0; i < LOSS_PP; ++i) {
+      mt[i] = __builtin_amdgcn_readlane(meta, i);
+      const int q = base + wid + LOSS_W * i;
+      if (mt[i] >= 0 && on) {
+        const int src = mt[i] >> 2;
+        c[i] = (mt[i] & 2) ? gen[(int64_t)src * D + lane] : h1[(int64_t)src * D + lane];
+        nb[i] = nbar[(int64_t)(row0 + q) * D + lane];
+        hs[i] = (mt[i] & 2) ? h1[(int64_t)src * D + lane] : 0.0f;
+      } else { c[i] = 0.f; nb[i] = 0.f; hs[i] = 0.f; }
     }
-    if (lane < D) {
-      d_h1[(int64_t)v.src * D + lane] = gH;
-      d_gen[(int64_t)v.src * D + lane] = gG;
-      d_nbar[(int64_t)(row0 + q) * D + lane] = dN;
+#pragma unroll
+    for (int i = 0; i < LOSS_PP; ++i) {
+      if (mt[i] < 0) continue;
+      const int q = base + wid + LOSS_W * i;
+      const int y = mt[i] & 1, src = mt[i] >> 2;
+      const PosVals v = eval_position(wd, c[i], nb[i]);
+      const float ds = (1.0f / (1.0f + expf(-v.s)) - (float)y) / (float)B;
+      const float gq = active * (y == 0 ? -1.0f / fn0 : 1.0f / fn1);
+      // aff = sum (c/nac)(nb/nbc); torch clamps a detached copy of the norms, so autograd sees
+      // d aff / d c = (nb/nbc)/nac - (aff/nac) * c/|c|   (and symmetrically for nb)
+      const float ca = v.na > 0.0f ? c[i] / v.na : 0.0f;
+      const float cb = v.nbn > 0.0f ? nb[i] / v.nbn : 0.0f;
+      const float dC = ds * wd + gq * ((nb[i] / v.nbc) / v.nac - (v.aff / v.nac) * ca);
+      const float dN = gq * ((c[i] / v.nac) / v.nbc - (v.aff / v.nbc) * cb);
+      // column q of combined_all is h1[src] (label-0 source) or the generated outlier gen[src] (label-1 source);
+      // a label-1 source row also carries the recon term 0.1 * mean_i |h1_i - gen_i|      graphsage.py:197-198,258
+      float gH = dC, gG = 0.0f;
+      if (mt[i] & 2) {
+        const float dl = hs[i] - c[i];
+        const float nrm = sqrtf(wave_sum_fast(dl * dl));
+        const float t = rec_coef * (dl / nrm);
+        gH = t;
+        gG = dC - t;
+      }
+      if (on) {
+        d_h1[(int64_t)src * D + lane] = gH;
+        d_gen[(int64_t)src * D + lane] = gG;
+        d_nbar[(int64_t)(row0 + q) * D + lane] = dN;
+      }
+      gacc = fmaf(ds, c[i], gacc);
     }
-    gacc = fmaf(ds, v.c, gacc);
   }
   gw[wid][lane] = gacc;
+  __threadfence_block();
   __syncthreads();
   if (threadIdx.x < D) {
     float t = 0.0f;
     for (int k = 0; k < LOSS_W; ++k) t += gw[k][threadIdx.x];
     grad_w[threadIdx.x] = t;
   }
+  if (coef_a == nullptr) return;
+  // ---------------- pass 3: per-row backward coefficients (the other waves' stores are visible: same CU)
+  const float *fc = params + L.o_fc();
+  for (int i = wid; i < B; i += LOSS_W) {
+    const int row = row0 + i;
+    row_coefs(fc, D, lane, row, labels[row], ent_ptr[row + 1] - ent_ptr[row], h1, gen, d_h1, d_gen, d_nbar, zs[wid], dz,
+              coef_a, coef_g);
+  }
 }
 
-// ------------------------------------------------------------------ backward rows
+// stand-alone VJP front end (layered autograd API): upstream gradients given by the caller
+__global__ void __launch_bounds__(256) k_row_coefs(const float *__restrict__ params, ParamLayout L,
+                                                   const int32_t *__restrict__ labels, const int32_t *__restrict__ ent_ptr,
+                                                   int row0, int B, const float *__restrict__ h1, const float *__restrict__ gen,
+                                                   const float *__restrict__ d_h1, const float *__restrict__ d_gen,
+                                                   const float *__restrict__ d_nbar, float *__restrict__ dz,
+                                                   float *__restrict__ coef_a, float *__restrict__ coef_g) {
+  __shared__ float zs[4][64];
+  const int wid = threadIdx.x / 64;
+  const int i = blockIdx.x * 4 + wid;
+  if (i >= B) return;
+  const int row = row0 + i;
+  row_coefs(params + L.o_fc(), L.D, lane_id(), row, labels[row], ent_ptr[row + 1] - ent_ptr[row], h1, gen, d_h1, d_gen,
+            d_nbar, zs[wid], dz, coef_a, coef_g);
+}
+
+// ------------------------------------------------------------------ backward, flat over entries + rows
+// work item idx < n_ents : entry e = ent0 + idx :  coef = coef_g[row(e)] * [h2[own(e)] > 0],  x = x2[own(e)]
+//           idx >= n_ents: row  = row0 + idx - n_ents:  coef = coef_a[row],                  x = x1[row]
+// dW[d][f] = sum_items coef_d * x_f.  Every workgroup (4 waves) writes one partial [F][D].
 template <int FT>
-__global__ void __launch_bounds__(64) k_bwd_rows(const float *__restrict__ params, ParamLayout L,
-                                                 const float *__restrict__ x1, const float *__restrict__ x2,
-                                                 const int32_t *__restrict__ ent_ptr, const int32_t *__restrict__ ent_own,
-                                                 const int32_t *__restrict__ labels, int row0,
-                                                 const float *__restrict__ h1, const float *__restrict__ nbar,
-                                                 const float *__restrict__ gen, const float *__restrict__ d_h1,
-                                                 const float *__restrict__ d_gen, const float *__restrict__ d_nbar,
-                                                 float *__restrict__ dw_part, float *__restrict__ dz) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+__global__ void __launch_bounds__(256) k_bwd_flat(ParamLayout L, const float *__restrict__ x1, const float *__restrict__ x2,
+                                                  const float *__restrict__ h2, const int32_t *__restrict__ ent_own,
+                                                  const int32_t *__restrict__ ent_row, int row0, int n_rows, int ent0,
+                                                  int n_ents, const float *__restrict__ coef_a,
+                                                  const float *__restrict__ coef_g, float *__restrict__ dw_part) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // [4][F*D]
   const int D = L.D, F = (FT > 0) ? FT : L.F;
-  const int lane = threadIdx.x, d = lane < D ? lane : D - 1;
+  const int lane = lane_id(), wid = threadIdx.x / 64;
   const bool on = lane < D;
-  const int row = row0 + blockIdx.x;
-  float *wt_lds = lds;              // F*D  (FT == 0)
-  float *acc_lds = lds + F * D;     // F*D  (FT == 0)
-  float *zs = lds + 2 * F * D;      // D
-  const float *Wt = params + L.o_Wt();
-  float wreg[FT > 0 ? FT : 1];
+  const int d = on ? lane : D - 1;
   float acc[FT > 0 ? FT : 1];
+  float *acc_lds = lds + wid * F * D;
   if constexpr (FT > 0) {
 #pragma unroll
-    for (int f = 0; f < FT; ++f) { wreg[f] = Wt[f * D + d]; acc[f] = 0.0f; }
+    for (int f = 0; f < FT; ++f) acc[f] = 0.0f;
   } else {
-    for (int i = lane; i < F * D; i += 64) { wt_lds[i] = Wt[i]; acc_lds[i] = 0.0f; }
-    __syncthreads();
+    for (int i = lane; i < F * D; i += 64) acc_lds[i] = 0.0f;
   }
-  auto project = [&](const float *__restrict__ x) -> float {
-    if constexpr (FT > 0) return project_reg<FT>(wreg, x);
-    else return project_lds(wt_lds, D, F, d, x);
-  };
-  auto accumulate = [&](float coef, const float *__restrict__ x) {
-    if constexpr (FT > 0) {
-#pragma unroll
-      for (int f = 0; f < FT; ++f) acc[f] = fmaf(coef, x[f], acc[f]);
-    } else if (on) {   // lanes >= D alias channel D-1: they must not touch its accumulator
-      for (int f = 0; f < F; ++f) acc_lds[f * D + d] = fmaf(coef, x[f], acc_lds[f * D + d]);
+  const int n_items = n_ents + n_rows;
+  const int wave_g = blockIdx.x * 4 + wid, n_waves = gridDim.x * 4;
+  for (int base = wave_g; base < n_items; base += n_waves * 64) {
+    // lane l holds the indices of item base + l * n_waves
+    const int idx = base + lane * n_waves;
+    int xo = -1, co = 0, ho = 0;                     // xo: row in x2 (>= 0) or x1 (encoded as -2 - row); co: coef row; ho: h2 row
+    if (idx < n_ents) {
+      const int e = ent0 + idx;
+      const int o = ent_own[e];
+      xo = o; ho = o - ent0; co = ent_row[e];
+    } else if (idx < n_items) {
+      co = row0 + idx - n_ents; xo = -2 - co;
     }
-  };
-  const int y = labels[row];
-  const float H1 = on ? h1[(int64_t)row * D + lane] : 0.0f;
-  const float dH1 = on ? d_h1[(int64_t)row * D + lane] : 0.0f;
-  float dNb = on ? d_nbar[(int64_t)row * D + lane] : 0.0f;
-  if (y == 1) {
-    const float G = on ? gen[(int64_t)row * D + lane] : 0.0f;
-    const float dG = on ? d_gen[(int64_t)row * D + lane] : 0.0f;
-    const float dZ = (G > 0.0f) ? dG : 0.0f;                          // relu(fc(.))
-    if (on) { dz[(int64_t)row * D + lane] = dZ; zs[lane] = dZ; }
-    __syncthreads();
-    const float *fc = params + L.o_fc();
-    float a = 0.0f;
-    for (int dd = 0; dd < D; ++dd) a = fmaf(fc[dd * D + d], zs[dd], a);   // fc^T dZ
-    dNb += a;
-  }
-  const float dA = (H1 > 0.0f) ? dH1 : 0.0f;
-  accumulate(on ? dA : 0.0f, x1 + (int64_t)row * F);
-  const int e0 = ent_ptr[row], e1 = ent_ptr[row + 1];
-  const int r = e1 - e0;
-  const float g = on ? dNb * (1.0f / (float)r) : 0.0f;
-  for (int blk = 0; blk < r; blk += 64) {
-    const int ov = (blk + lane < r) ? ent_own[e0 + blk + lane] : 0;
-    const int cnt = min(64, r - blk);
+    const int cnt = min(64, (n_items - base + n_waves - 1) / n_waves);
     for (int i = 0; i < cnt; ++i) {
-      const int o = __builtin_amdgcn_readlane(ov, i);
-      const float *xr = x2 + (int64_t)o * F;
-      const float he = project(xr);
-      accumulate(he > 0.0f ? g : 0.0f, xr);
-    }
-  }
-  float *out = dw_part + (int64_t)blockIdx.x * F * D;
-  if constexpr (FT > 0) {
+      const int sx = __builtin_amdgcn_readlane(xo, i);
+      const int sc = __builtin_amdgcn_readlane(co, i);
+      const int sh = __builtin_amdgcn_readlane(ho, i);
+      float coef;
+      const float *xr;
+      if (sx >= 0) {
+        const float g = coef_g[(int64_t)sc * D + d];
+        const float hv = h2[(int64_t)sh * D + d];
+        coef = (on && hv > 0.0f) ? g : 0.0f;
+        xr = x2 + (int64_t)sx * F;
+      } else {
+        coef = on ? coef_a[(int64_t)sc * D + d] : 0.0f;
+        xr = x1 + (int64_t)(-2 - sx) * F;
+      }
+      if constexpr (FT > 0) {
 #pragma unroll
-    for (int f = 0; f < FT; ++f)
-      if (on) out[f * D + lane] = acc[f];
-  } else {
-    __syncthreads();
-    for (int i = lane; i < F * D; i += 64) out[i] = acc_lds[i];
-  }
-}
-
-// ------------------------------------------------------------------ gradient reduce, Adam, sync, score
-__global__ void __launch_bounds__(256) k_grad_reduce(ParamLayout L, const int32_t *__restrict__ labels, int row0, int B,
-                                                     const float *__restrict__ nbar, const float *__restrict__ dw_part,
-                                                     const float *__restrict__ dz, const float *__restrict__ grad_w,
-                                                     float *__restrict__ grads) {
-  const int D = L.D, F = L.F;
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < D) { grads[t] = grad_w[t]; return; }
-  int u = t - D;
-  if (u < D * F) {
-    const int f = u / D, d = u - f * D;           // consecutive threads -> consecutive d (coalesced reads)
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int b = 0;
-    for (; b + 4 <= B; b += 4) {
-      s0 += dw_part[((int64_t)(b + 0) * F + f) * D + d];
-      s1 += dw_part[((int64_t)(b + 1) * F + f) * D + d];
-      s2 += dw_part[((int64_t)(b + 2) * F + f) * D + d];
-      s3 += dw_part[((int64_t)(b + 3) * F + f) * D + d];
+        for (int f = 0; f < FT; ++f) acc[f] = fmaf(coef, xr[f], acc[f]);
+      } else if (on) {
+        for (int f = 0; f < F; ++f) acc_lds[f * D + d] = fmaf(coef, xr[f], acc_lds[f * D + d]);
+      }
     }
-    for (; b < B; ++b) s0 += dw_part[((int64_t)b * F + f) * D + d];
-    grads[L.o_W() + d * F + f] = (s0 + s1) + (s2 + s3);
-    return;
   }
-  u -= D * F;
-  if (u < D * D) {
-    const int dd = u / D, d2 = u - dd * D;        // d fc[dd][d2] = sum_i dZ_i[dd] * nbar_i[d2]
-    float s = 0.0f;
-    for (int b = 0; b < B; ++b) {
-      const int row = row0 + b;
-      if (labels[row] == 1) s = fmaf(dz[(int64_t)row * D + dd], nbar[(int64_t)row * D + d2], s);
+  if constexpr (FT > 0) {
+    if (on) {
+#pragma unroll
+      for (int f = 0; f < FT; ++f) acc_lds[f * D + d] = acc[f];
     }
-    grads[L.o_fc() + u] = s;
-  }
-}
-
-__global__ void __launch_bounds__(256) k_adam(float *__restrict__ params, float *__restrict__ m, float *__restrict__ v,
-                                              const float *__restrict__ grads, ParamLayout L, float lr, float wd,
-                                              float grad_scale, const int32_t *__restrict__ step_counter) {
-  __shared__ float sc[2];
-  if (threadIdx.x == 0) {
-    const double t = (double)(*step_counter);
-    const double bc1 = 1.0 - pow(0.9, t), bc2 = 1.0 - pow(0.999, t);
-    sc[0] = (float)((double)lr / bc1);      // step_size
-    sc[1] = (float)sqrt(bc2);               // bias_correction2_sqrt
   }
   __syncthreads();
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= L.n_train()) return;
-  const float step_size = sc[0], bc2s = sc[1];
+  float *out = dw_part + (int64_t)blockIdx.x * F * D;
+  for (int i = threadIdx.x; i < F * D; i += 256)
+    out[i] = (lds[i] + lds[F * D + i]) + (lds[2 * F * D + i] + lds[3 * F * D + i]);
+}
+
+// ------------------------------------------------------------------ gradient reduce (+ fused Adam), sync, score
+__device__ __forceinline__ void adam_update(float *__restrict__ params, float *__restrict__ m, float *__restrict__ v,
+                                            ParamLayout L, int i, float g, float wd, float step_size, float bc2s) {
   float p = params[i];
-  float g = grads[i] * grad_scale;
   g = fmaf(wd, p, g);                                       // grad.add(param, alpha=weight_decay)
   float mi = m[i], vi = v[i];
   mi = fmaf(g - mi, 0.1f, mi);                              // exp_avg.lerp_(grad, 1 - beta1)
@@ -358,6 +469,75 @@ __global__ void __launch_bounds__(256) k_adam(float *__restrict__ params, float 
     const int u = i - L.o_fc(); const int d = u / D, d2 = u - d * D;
     params[L.o_fcT() + d2 * D + d] = p;
   }
+}
+
+__device__ __forceinline__ void adam_scalars(float *sc, const int32_t *step_counter, float lr) {
+  if (threadIdx.x == 0) {
+    const double t = (double)(*step_counter);
+    const double bc1 = 1.0 - pow(0.9, t), bc2 = 1.0 - pow(0.999, t);
+    sc[0] = (float)((double)lr / bc1);      // step_size
+    sc[1] = (float)sqrt(bc2);               // bias_correction2_sqrt
+  }
+  __syncthreads();
+}
+
+template <bool FUSE_ADAM>
+__global__ void __launch_bounds__(256) k_grad_reduce(ParamLayout L, const int32_t *__restrict__ pos_meta, int row0,
+                                                     const float *__restrict__ losses8, const float *__restrict__ nbar,
+                                                     const float *__restrict__ dw_part, int n_parts,
+                                                     const float *__restrict__ dz, const float *__restrict__ grad_w,
+                                                     float *__restrict__ grads, float *__restrict__ params,
+                                                     float *__restrict__ m, float *__restrict__ v, float lr, float wd,
+                                                     const int32_t *__restrict__ step_counter) {
+  __shared__ float sc[2];
+  if (FUSE_ADAM) adam_scalars(sc, step_counter, lr);
+  const int D = L.D, F = L.F;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= L.n_train()) return;
+  float g;
+  int pidx;
+  if (t < D) {
+    g = grad_w[t]; pidx = t;
+  } else if (t < D + D * F) {
+    const int u = t - D;
+    const int f = u / D, d = u - f * D;           // consecutive threads -> consecutive d (coalesced reads)
+    const float *p = dw_part + f * D + d;
+    const int stride = F * D;
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int b = 0;
+    for (; b + 8 <= n_parts; b += 8) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s[k] += p[(int64_t)(b + k) * stride];
+    }
+    for (; b < n_parts; ++b) s[0] += p[(int64_t)b * stride];
+    g = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    pidx = L.o_W() + d * F + f;
+  } else {
+    const int u = t - D - D * F;
+    const int dd = u / D, d2 = u - dd * D;        // d fc[dd][d2] = sum_{label-1 rows i} dZ_i[dd] * nbar_i[d2]
+    const int n0 = (int)losses8[6], n1 = (int)losses8[7];
+    float s0 = 0.0f, s1 = 0.0f;
+    int j = 0;
+    for (; j + 2 <= n1; j += 2) {                 // label-1 rows = sources of the last n1 columns, in order
+      const int ra = pos_meta[row0 + n0 + j] >> 2, rb = pos_meta[row0 + n0 + j + 1] >> 2;
+      s0 = fmaf(dz[(int64_t)ra * D + dd], nbar[(int64_t)ra * D + d2], s0);
+      s1 = fmaf(dz[(int64_t)rb * D + dd], nbar[(int64_t)rb * D + d2], s1);
+    }
+    if (j < n1) { const int ra = pos_meta[row0 + n0 + j] >> 2; s0 = fmaf(dz[(int64_t)ra * D + dd], nbar[(int64_t)ra * D + d2], s0); }
+    g = s0 + s1; pidx = L.o_fc() + u;
+  }
+  grads[pidx] = g;
+  if (FUSE_ADAM) adam_update(params, m, v, L, pidx, g, wd, sc[0], sc[1]);
+}
+
+__global__ void __launch_bounds__(256) k_adam(float *__restrict__ params, float *__restrict__ m, float *__restrict__ v,
+                                              const float *__restrict__ grads, ParamLayout L, float lr, float wd,
+                                              float grad_scale, const int32_t *__restrict__ step_counter) {
+  __shared__ float sc[2];
+  adam_scalars(sc, step_counter, lr);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= L.n_train()) return;
+  adam_update(params, m, v, L, i, grads[i] * grad_scale, wd, sc[0], sc[1]);
 }
 
 __global__ void __launch_bounds__(256) k_params_sync(float *__restrict__ params, ParamLayout L) {
@@ -383,16 +563,15 @@ __global__ void __launch_bounds__(256) k_score(const float *__restrict__ params,
   const float wd = lane < D ? params[lane] : 0.0f;
   const int wpb = blockDim.x / 64;
   for (int row = blockIdx.x * wpb + threadIdx.x / 64; row < n_rows; row += gridDim.x * wpb) {
-    const float h = fmaxf(project_lds(lds, D, F, d, x1 + (int64_t)row * F), 0.0f);
-    const float s = wave_sum(wd * h);
+    const float *x = x1 + (int64_t)row * F;
+    float acc = 0.0f;
+    for (int f = 0; f < F; ++f) acc = fmaf(lds[f * D + d], x[f], acc);
+    const float s = wave_sum_fast(wd * fmaxf(acc, 0.0f));
     if (lane == 0) prob[row] = 1.0f / (1.0f + expf(-s));     // torch.sigmoid            graphsage.py:180
   }
 }
 
-template <typename KernelFn, typename... Args>
-inline void launch_rows(KernelFn k, int n_rows, size_t lds_bytes, hipStream_t st, Args... args) {
-  k<<<dim3(n_rows), dim3(64), lds_bytes, st>>>(args...);
-}
+bool dims_ok(int D, int F) { return D >= 1 && D <= GGAD_MAX_D && F >= 1 && (size_t)(4 * F * D + 512) * 4 <= 150 * 1024; }
 
 }  // namespace
 
@@ -400,11 +579,10 @@ extern "C" {
 
 int ggad_max_embed_dim(void) { return GGAD_MAX_D; }
 int ggad_max_feat_dim(void) { return GGAD_MAX_F; }
+int ggad_mb_bwd_parts(void) { return BWD_PARTS; }
 
 int64_t ggad_mb_param_count(int32_t D, int32_t F) { return (int64_t)D + (int64_t)D * F + (int64_t)D * D; }
 int64_t ggad_mb_param_block_elems(int32_t D, int32_t F) { return ggad_mb_param_count(D, F) + (int64_t)F * D + (int64_t)D * D; }
-
-static bool dims_ok(int D, int F) { return D >= 1 && D <= GGAD_MAX_D && F >= 1 && (size_t)(2 * F * D + D) * 4 <= 60 * 1024; }
 
 int ggad_mb_params_sync(float *params, int32_t D, int32_t F, ggad_stream_t stream) {
   GGAD_REQUIRE(params && dims_ok(D, F));
@@ -414,61 +592,89 @@ int ggad_mb_params_sync(float *params, int32_t D, int32_t F, ggad_stream_t strea
   return GGAD_OK;
 }
 
-int ggad_mb_fwd_rows(const float *params, int32_t D, int32_t F, const float *x1, const float *x2,
-                     const int32_t *ent_ptr, const int32_t *ent_own, const int32_t *labels, int32_t row0,
-                     int32_t n_rows, int32_t train, float *h1, float *nbar, float *gen, ggad_stream_t stream) {
-  GGAD_REQUIRE(params && x1 && h1 && dims_ok(D, F) && n_rows >= 0 && row0 >= 0);
-  GGAD_REQUIRE(!train || (x2 && ent_ptr && ent_own && labels && nbar && gen));
+int ggad_mb_project(const float *params, int32_t D, int32_t F, const float *x2, const int32_t *ent_own, int32_t ent0,
+                    int32_t n_ents, float *h2, ggad_stream_t stream) {
+  GGAD_REQUIRE(params && x2 && ent_own && h2 && dims_ok(D, F) && ent0 >= 0 && n_ents >= 0);
+  if (n_ents == 0) return GGAD_OK;
+  ParamLayout L{D, F};
+  const int blocks = (n_ents + 4 * PROJ_EPW - 1) / (4 * PROJ_EPW);
+  if (F == 17)
+    k_project<17><<<dim3(blocks), dim3(256), 0, as_stream(stream)>>>(params, L, x2, ent_own, ent0, n_ents, h2);
+  else
+    k_project<0><<<dim3(blocks), dim3(256), (size_t)F * D * 4, as_stream(stream)>>>(params, L, x2, ent_own, ent0, n_ents, h2);
+  GGAD_CHECK_LAUNCH("mb_project");
+  return GGAD_OK;
+}
+
+int ggad_mb_fwd_rows(const float *params, int32_t D, int32_t F, const float *x1, const float *h2, const int32_t *ent_ptr,
+                     const int32_t *ent_own, const int32_t *labels, int32_t row0, int32_t n_rows, int32_t ent0, float *h1,
+                     float *nbar, float *gen, ggad_stream_t stream) {
+  GGAD_REQUIRE(params && x1 && h2 && ent_ptr && ent_own && labels && h1 && nbar && gen && dims_ok(D, F));
+  GGAD_REQUIRE(n_rows >= 0 && row0 >= 0 && ent0 >= 0);
   if (n_rows == 0) return GGAD_OK;
   ParamLayout L{D, F};
-  hipStream_t st = as_stream(stream);
   if (F == 17)
-    k_fwd_rows<17><<<dim3(n_rows), dim3(64), (size_t)(17 * D + D) * 4, st>>>(params, L, x1, x2, ent_ptr, ent_own, labels, row0,
-                                                                             train, h1, nbar, gen);
+    k_fwd_rows<17><<<dim3(n_rows), dim3(256), 320 * 4, as_stream(stream)>>>(params, L, x1, h2, ent_ptr, ent_own, labels, row0,
+                                                                           ent0, h1, nbar, gen);
   else
-    k_fwd_rows<0><<<dim3(n_rows), dim3(64), (size_t)(F * D + D) * 4, st>>>(params, L, x1, x2, ent_ptr, ent_own, labels, row0,
-                                                                           train, h1, nbar, gen);
+    k_fwd_rows<0><<<dim3(n_rows), dim3(256), (size_t)(320 + F * D) * 4, as_stream(stream)>>>(
+        params, L, x1, h2, ent_ptr, ent_own, labels, row0, ent0, h1, nbar, gen);
   GGAD_CHECK_LAUNCH("mb_fwd_rows");
   return GGAD_OK;
 }
 
-int ggad_mb_loss(const float *params, int32_t D, const float *h1, const float *nbar, const float *gen,
-                 const int32_t *labels, const int32_t *src_of_pos, int32_t row0, int32_t n_rows, float *losses8,
-                 float *d_h1, float *d_gen, float *d_nbar, float *grad_w, int32_t *step_counter, ggad_stream_t stream) {
-  GGAD_REQUIRE(params && h1 && nbar && gen && labels && src_of_pos && losses8 && d_h1 && d_gen && d_nbar && grad_w);
-  GGAD_REQUIRE(D >= 1 && D <= GGAD_MAX_D && n_rows >= 1 && row0 >= 0);
-  k_loss<<<dim3(1), dim3(LOSS_T), 0, as_stream(stream)>>>(params, D, h1, nbar, gen, labels, src_of_pos, row0, n_rows, losses8,
-                                                         d_h1, d_gen, d_nbar, grad_w, step_counter);
+int ggad_mb_loss(const float *params, int32_t D, int32_t F, const float *h1, const float *nbar, const float *gen,
+                 const int32_t *labels, const int32_t *pos_meta, const int32_t *ent_ptr, int32_t row0, int32_t n_rows,
+                 float *losses8, float *d_h1, float *d_gen, float *d_nbar, float *dz, float *coef_a, float *coef_g,
+                 float *grad_w, int32_t *step_counter, ggad_stream_t stream) {
+  GGAD_REQUIRE(params && h1 && nbar && gen && labels && pos_meta && ent_ptr && losses8 && d_h1 && d_gen && d_nbar && grad_w);
+  GGAD_REQUIRE((coef_a == nullptr) == (coef_g == nullptr) && (coef_a == nullptr || dz));
+  GGAD_REQUIRE(dims_ok(D, F) && n_rows >= 1 && row0 >= 0);
+  ParamLayout L{D, F};
+  k_loss<<<dim3(1), dim3(LOSS_T), 0, as_stream(stream)>>>(params, L, h1, nbar, gen, labels, pos_meta, ent_ptr, row0, n_rows,
+                                                         losses8, d_h1, d_gen, d_nbar, dz, coef_a, coef_g, grad_w,
+                                                         step_counter);
   GGAD_CHECK_LAUNCH("mb_loss");
   return GGAD_OK;
 }
 
-int ggad_mb_bwd_rows(const float *params, int32_t D, int32_t F, const float *x1, const float *x2,
-                     const int32_t *ent_ptr, const int32_t *ent_own, const int32_t *labels, int32_t row0,
-                     int32_t n_rows, const float *h1, const float *nbar, const float *gen, const float *d_h1,
-                     const float *d_gen, const float *d_nbar, float *dw_part, float *dz, ggad_stream_t stream) {
-  GGAD_REQUIRE(params && x1 && x2 && ent_ptr && ent_own && labels && h1 && nbar && gen && d_h1 && d_gen && d_nbar &&
-               dw_part && dz);
+int ggad_mb_row_coefs(const float *params, int32_t D, int32_t F, const int32_t *labels, const int32_t *ent_ptr,
+                      int32_t row0, int32_t n_rows, const float *h1, const float *gen, const float *d_h1,
+                      const float *d_gen, const float *d_nbar, float *dz, float *coef_a, float *coef_g,
+                      ggad_stream_t stream) {
+  GGAD_REQUIRE(params && labels && ent_ptr && h1 && gen && d_h1 && d_gen && d_nbar && dz && coef_a && coef_g);
   GGAD_REQUIRE(dims_ok(D, F) && n_rows >= 1 && row0 >= 0);
   ParamLayout L{D, F};
-  hipStream_t st = as_stream(stream);
-  if (F == 17)
-    k_bwd_rows<17><<<dim3(n_rows), dim3(64), (size_t)(2 * 17 * D + D) * 4, st>>>(
-        params, L, x1, x2, ent_ptr, ent_own, labels, row0, h1, nbar, gen, d_h1, d_gen, d_nbar, dw_part, dz);
-  else
-    k_bwd_rows<0><<<dim3(n_rows), dim3(64), (size_t)(2 * F * D + D) * 4, st>>>(
-        params, L, x1, x2, ent_ptr, ent_own, labels, row0, h1, nbar, gen, d_h1, d_gen, d_nbar, dw_part, dz);
-  GGAD_CHECK_LAUNCH("mb_bwd_rows");
+  k_row_coefs<<<dim3((n_rows + 3) / 4), dim3(256), 0, as_stream(stream)>>>(params, L, labels, ent_ptr, row0, n_rows, h1, gen,
+                                                                          d_h1, d_gen, d_nbar, dz, coef_a, coef_g);
+  GGAD_CHECK_LAUNCH("mb_row_coefs");
   return GGAD_OK;
 }
 
-int ggad_mb_grad_reduce(int32_t D, int32_t F, const int32_t *labels, int32_t row0, int32_t n_rows,
-                        const float *nbar, const float *dw_part, const float *dz, const float *grad_w,
-                        float *grads, ggad_stream_t stream) {
-  GGAD_REQUIRE(labels && nbar && dw_part && dz && grad_w && grads && dims_ok(D, F) && n_rows >= 1);
+int ggad_mb_bwd_flat(int32_t D, int32_t F, const float *x1, const float *x2, const float *h2, const int32_t *ent_own,
+                     const int32_t *ent_row, int32_t row0, int32_t n_rows, int32_t ent0, int32_t n_ents,
+                     const float *coef_a, const float *coef_g, float *dw_part, ggad_stream_t stream) {
+  GGAD_REQUIRE(x1 && x2 && h2 && ent_own && ent_row && coef_a && coef_g && dw_part && dims_ok(D, F));
+  GGAD_REQUIRE(n_rows >= 1 && row0 >= 0 && ent0 >= 0 && n_ents >= 0);
   ParamLayout L{D, F};
-  k_grad_reduce<<<dim3((L.n_train() + 255) / 256), dim3(256), 0, as_stream(stream)>>>(L, labels, row0, n_rows, nbar, dw_part,
-                                                                                     dz, grad_w, grads);
+  const size_t lds = (size_t)4 * F * D * 4;
+  if (F == 17)
+    k_bwd_flat<17><<<dim3(BWD_PARTS), dim3(256), lds, as_stream(stream)>>>(L, x1, x2, h2, ent_own, ent_row, row0, n_rows, ent0,
+                                                                           n_ents, coef_a, coef_g, dw_part);
+  else
+    k_bwd_flat<0><<<dim3(BWD_PARTS), dim3(256), lds, as_stream(stream)>>>(L, x1, x2, h2, ent_own, ent_row, row0, n_rows, ent0,
+                                                                          n_ents, coef_a, coef_g, dw_part);
+  GGAD_CHECK_LAUNCH("mb_bwd_flat");
+  return GGAD_OK;
+}
+
+int ggad_mb_grad_reduce(int32_t D, int32_t F, const int32_t *pos_meta, int32_t row0, const float *losses8,
+                        const float *nbar, const float *dw_part, const float *dz, const float *grad_w, float *grads,
+                        ggad_stream_t stream) {
+  GGAD_REQUIRE(pos_meta && losses8 && nbar && dw_part && dz && grad_w && grads && dims_ok(D, F));
+  ParamLayout L{D, F};
+  k_grad_reduce<false><<<dim3((L.n_train() + 255) / 256), dim3(256), 0, as_stream(stream)>>>(
+      L, pos_meta, row0, losses8, nbar, dw_part, BWD_PARTS, dz, grad_w, grads, nullptr, nullptr, nullptr, 0.f, 0.f, nullptr);
   GGAD_CHECK_LAUNCH("mb_grad_reduce");
   return GGAD_OK;
 }
@@ -489,9 +695,33 @@ int ggad_mb_score(const float *params, int32_t D, int32_t F, const float *x1, in
   GGAD_REQUIRE(params && x1 && prob && dims_ok(D, F) && n_rows >= 0);
   if (n_rows == 0) return GGAD_OK;
   ParamLayout L{D, F};
-  const int blocks = (int)fminf((float)((n_rows + 3) / 4), 4096.0f);
+  const int blocks = (n_rows + 3) / 4 < 4096 ? (n_rows + 3) / 4 : 4096;
   k_score<<<dim3(blocks), dim3(256), (size_t)F * D * 4, as_stream(stream)>>>(params, L, x1, n_rows, prob);
   GGAD_CHECK_LAUNCH("mb_score");
+  return GGAD_OK;
+}
+
+/* One whole training step for one batch: project -> fwd_rows -> loss -> bwd_flat -> grad_reduce (+ Adam when
+ * fuse_adam != 0; otherwise the caller all-reduces s->grads and calls ggad_mb_adam). */
+int ggad_mb_train_step(const ggad_mb_step *s, int32_t fuse_adam, ggad_stream_t stream) {
+  GGAD_REQUIRE(s && s->params && s->exp_avg && s->exp_avg_sq && s->grads && s->step_counter);
+  const int D = s->D, F = s->F;
+  int rc;
+  if ((rc = ggad_mb_project(s->params, D, F, s->x2, s->ent_own, s->ent0, s->n_ents, s->h2, stream))) return rc;
+  if ((rc = ggad_mb_fwd_rows(s->params, D, F, s->x1, s->h2, s->ent_ptr, s->ent_own, s->labels, s->row0, s->n_rows, s->ent0,
+                             s->h1, s->nbar, s->gen, stream))) return rc;
+  if ((rc = ggad_mb_loss(s->params, D, F, s->h1, s->nbar, s->gen, s->labels, s->pos_meta, s->ent_ptr, s->row0, s->n_rows,
+                         s->losses8, s->d_h1, s->d_gen, s->d_nbar, s->dz, s->coef_a, s->coef_g, s->grad_w, s->step_counter,
+                         stream))) return rc;
+  if ((rc = ggad_mb_bwd_flat(D, F, s->x1, s->x2, s->h2, s->ent_own, s->ent_row, s->row0, s->n_rows, s->ent0, s->n_ents,
+                             s->coef_a, s->coef_g, s->dw_part, stream))) return rc;
+  if (!fuse_adam)
+    return ggad_mb_grad_reduce(D, F, s->pos_meta, s->row0, s->losses8, s->nbar, s->dw_part, s->dz, s->grad_w, s->grads, stream);
+  ParamLayout L{D, F};
+  k_grad_reduce<true><<<dim3((L.n_train() + 255) / 256), dim3(256), 0, as_stream(stream)>>>(
+      L, s->pos_meta, s->row0, s->losses8, s->nbar, s->dw_part, BWD_PARTS, s->dz, s->grad_w, s->grads, s->params, s->exp_avg,
+      s->exp_avg_sq, s->lr, s->weight_decay, s->step_counter);
+  GGAD_CHECK_LAUNCH("mb_train_step");
   return GGAD_OK;
 }
 

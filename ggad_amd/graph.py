@@ -33,6 +33,7 @@ class DeviceGraph:
         self.rowptr_host = rowptr.astype(np.int32, copy=False)
         self.col_host = col.astype(np.int32, copy=False)
         self.deg_host = np.diff(self.rowptr_host.astype(np.int64))
+        self._closed_deg_host = None
         self.device = torch.device(device)
         self.rowptr = torch.from_numpy(self.rowptr_host).to(self.device)
         self.col = torch.from_numpy(self.col_host).to(self.device)
@@ -70,6 +71,20 @@ class DeviceGraph:
         from .synth import csr_to_adj_lists
         return csr_to_adj_lists(self.rowptr_host, self.col_host)
 
-    def closed_degree_bound(self, nodes: np.ndarray) -> int:
-        """sum(deg + 1): host-side upper bound of the number of 1-hop entries of a chunk."""
-        return int(self.deg_host[np.asarray(nodes, dtype=np.int64)].sum() + len(nodes))
+    @property
+    def closed_deg_host(self) -> np.ndarray:
+        """|N(i) + {i}| per node = deg + 1 - [i in N(i)]  (exact; computed once, vectorised)."""
+        if self._closed_deg_host is None:
+            has_self = np.zeros(self.n, dtype=bool)
+            step = 1 << 20                                    # nodes per slab (bounds the temporary)
+            rp = self.rowptr_host
+            for a in range(0, self.n, step):
+                b = min(self.n, a + step)
+                rows = np.repeat(np.arange(a, b, dtype=np.int32), self.deg_host[a:b])
+                hit = rows == self.col_host[rp[a]:rp[b]]
+                has_self[rows[hit]] = True
+            self._closed_deg_host = (self.deg_host + 1 - has_self).astype(np.int64)
+        return self._closed_deg_host
+
+    def closed_degrees(self, nodes: np.ndarray) -> np.ndarray:
+        return self.closed_deg_host[np.asarray(nodes, dtype=np.int64)]

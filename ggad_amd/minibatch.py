@@ -15,7 +15,8 @@ PyTorch is used for device memory and streams only; all arithmetic happens in li
 """
 from __future__ import annotations
 
-from typing import List, Optional, Sequence
+import ctypes
+from typing import Optional, Sequence
 
 import numpy as np
 import torch
@@ -33,15 +34,21 @@ def _f32(n, device):
     return torch.empty(int(max(n, 1)), dtype=torch.float32, device=device)
 
 
+def _check_i32(x: int) -> None:
+    if x >= 2 ** 31:
+        raise ValueError("chunk too large for int32 entry indices; use fewer batches per chunk")
+
+
 class BatchChunk:
     """Device plan of up to ``max_batches`` batches (see module docstring).
 
     Buffers have fixed capacity and fixed addresses (so that a captured hipGraph can be replayed
-    after a rebuild); ``build`` grows them only when a chunk does not fit.
+    after a rebuild); ``build`` grows them only when a chunk does not fit (``generation`` then
+    changes, which invalidates captured graphs).
     """
 
     def __init__(self, graph: DeviceGraph, feat: torch.Tensor, embed_dim: int, max_batches: int,
-                 rows_cap: int, ent_cap: int, train: bool = True):
+                 rows_cap: int, ent_cap: int, train: bool = True, reset_mode: str = "auto"):
         self.lib = _lib.load()
         self.g = graph
         self.feat = feat
@@ -50,21 +57,24 @@ class BatchChunk:
         self.dev = feat.device
         self.train = train
         self.max_batches = int(max_batches)
+        self.reset_mode = reset_mode
+        _check_i32(self.max_batches * graph.n)
         # per-batch counter slots: int32[max_batches][n]; zero on entry, zeroed again by reset()
         self.cnt1 = torch.zeros(self.max_batches * graph.n, dtype=torch.int32, device=self.dev)
         self.own1 = torch.zeros(self.max_batches * graph.n, dtype=torch.int32, device=self.dev)
         self.cnt2 = torch.zeros(self.max_batches * graph.n, dtype=torch.int32, device=self.dev) if train else None
         self.rows_cap = 0
         self.ent_cap = 0
+        self.generation = 0
         self._stage_evt = None
         self._alloc_rows(rows_cap)
         self._alloc_ents(ent_cap)
         self.n_batches = 0
         self.n_rows = 0
-        self.ent_bound = 0
+        self.n_ents = 0
         self.batch_ptr_host = np.zeros(1, dtype=np.int32)
+        self.ent_ptr_host = np.zeros(1, dtype=np.int64)
         self.dirty = False
-        self._stage_evt = None
         self.gather2_events = None      # optional (start, end) torch events recorded around the gather2 launch
 
     # ---- allocation
@@ -72,15 +82,18 @@ class BatchChunk:
         cap = int(cap)
         d = self.dev
         self.rows_cap = cap
-        # one int32 staging block uploaded per build: batch_ptr | nodes | labels | src_of_pos
-        self.stage_host = torch.empty(self.max_batches + 1 + 3 * cap, dtype=torch.int32).pin_memory() \
-            if torch.cuda.is_available() else torch.empty(self.max_batches + 1 + 3 * cap, dtype=torch.int32)
-        self.stage = _i32(self.max_batches + 1 + 3 * cap, d)
+        self.generation += 1
+        # one int32 staging block uploaded per build: batch_ptr | nodes | labels | pos_meta
+        n_stage = self.max_batches + 1 + 3 * cap
+        self.stage_host = torch.empty(n_stage, dtype=torch.int32)
+        if d.type == "cuda":
+            self.stage_host = self.stage_host.pin_memory()
+        self.stage = _i32(n_stage, d)
         o = self.max_batches + 1
         self.batch_ptr = self.stage[:o]
         self.nodes = self.stage[o:o + cap]
         self.labels = self.stage[o + cap:o + 2 * cap]
-        self.src_of_pos = self.stage[o + 2 * cap:o + 3 * cap]
+        self.pos_meta = self.stage[o + 2 * cap:o + 3 * cap]
         self.row_r = _i32(cap, d)
         self.row_slot = _i32(cap, d)
         self.ent_ptr = _i32(cap + 1, d)
@@ -90,14 +103,14 @@ class BatchChunk:
             n = cap * self.D
             self.h1, self.nbar, self.gen = _f32(n, d), _f32(n, d), _f32(n, d)
             self.d_h1, self.d_gen, self.d_nbar, self.dz = _f32(n, d), _f32(n, d), _f32(n, d), _f32(n, d)
-        else:
-            self.h1 = _f32(cap * self.D, d)
+            self.coef_a, self.coef_g = _f32(n, d), _f32(n, d)
 
     def _alloc_ents(self, cap: int) -> None:
         cap = int(cap)
         d = self.dev
         self.ent_cap = cap
-        self.ent_col, self.ent_slot = _i32(cap, d), _i32(cap, d)
+        self.generation += 1
+        self.ent_col, self.ent_slot, self.ent_row = _i32(cap, d), _i32(cap, d), _i32(cap, d)
         self.ent_own, self.ent_c1 = _i32(cap, d), _i32(cap, d)
         self.x2 = _f32(cap * self.F, d) if self.train else None
 
@@ -116,12 +129,15 @@ class BatchChunk:
         nodes = np.concatenate([np.asarray(b, dtype=np.int64) for b in batches])
         if nodes.min() < 0 or nodes.max() >= self.g.n:
             raise ValueError("batch node id out of range")
-        bound = self.g.closed_degree_bound(nodes)
-        _lib_check_i32(bound)
+        r_host = self.g.closed_degrees(nodes)                  # exact |N(i) + {i}| per row
+        ent_ptr_host = np.zeros(rows + 1, dtype=np.int64)
+        np.cumsum(r_host, out=ent_ptr_host[1:])
+        n_ents = int(ent_ptr_host[-1])
+        _check_i32(n_ents)
         if rows > self.rows_cap:
             self._alloc_rows(int(rows * 1.25) + 64)
-        if bound > self.ent_cap:
-            self._alloc_ents(int(bound * 1.25) + 1024)
+        if n_ents > self.ent_cap:
+            self._alloc_ents(int(n_ents * 1.25) + 1024)
         bp = np.zeros(nb + 1, dtype=np.int32)
         np.cumsum(sizes, out=bp[1:])
         if self._stage_evt is not None:
@@ -138,60 +154,85 @@ class BatchChunk:
             lab = np.concatenate([np.asarray(l, dtype=np.int64) for l in labels])
             if len(lab) != rows:
                 raise ValueError("labels / batches length mismatch")
+            if ((lab != 0) & (lab != 1)).any():
+                raise ValueError("labels must be 0/1")
             st[o + cap:o + cap + rows] = lab
-            # column q of `combined_all` holds: label-0 rows in order, then label-1 rows (graphsage.py:450)
-            src = np.empty(rows, dtype=np.int32)
+            # column q of `combined_all` holds the label-0 rows in order, then the label-1 rows (graphsage.py:450);
+            # pos_meta[q] = (src_row << 2) | (label[src] << 1) | label[q]
+            meta = np.empty(rows, dtype=np.int64)
             for b in range(nb):
                 r0, r1 = bp[b], bp[b + 1]
-                order = np.argsort(lab[r0:r1] != 0, kind="stable")
-                src[r0:r1] = order + r0
-            st[o + 2 * cap:o + 2 * cap + rows] = src
+                lb = lab[r0:r1]
+                order = np.argsort(lb != 0, kind="stable")
+                meta[r0:r1] = ((order + r0) << 2) | (lb[order] << 1) | lb
+            st[o + 2 * cap:o + 2 * cap + rows] = meta
         self.stage.copy_(self.stage_host, non_blocking=True)
         if self.dev.type == "cuda":
             self._stage_evt = torch.cuda.Event()
             self._stage_evt.record()
-        self.n_batches, self.n_rows, self.ent_bound = nb, rows, bound
+        self.n_batches, self.n_rows, self.n_ents = nb, rows, n_ents
         self.batch_ptr_host = bp
+        self.ent_ptr_host = ent_ptr_host
         g = self.g
         call("ggad_mb_row_degree", ptr(g.rowptr), ptr(g.col), ptr(self.nodes), ptr(self.batch_ptr), nb, rows,
              ptr(self.row_r), ptr(self.row_slot))
         call("ggad_exclusive_scan_i32", ptr(self.row_r), ptr(self.ent_ptr), rows, ptr(self.scan_ws))
         call("ggad_mb_expand1", ptr(g.rowptr), ptr(g.col), ptr(self.nodes), ptr(self.row_slot), ptr(self.ent_ptr), rows,
-             g.n, ptr(self.ent_col), ptr(self.ent_slot), ptr(self.cnt1), ptr(self.own1))
+             g.n, ptr(self.ent_col), ptr(self.ent_slot), ptr(self.ent_row), ptr(self.cnt1), ptr(self.own1))
         self.dirty = True
         call("ggad_mb_gather1", ptr(self.feat), self.F, ptr(self.row_slot), ptr(self.ent_ptr), ptr(self.ent_col), rows,
              g.n, ptr(self.cnt1), ptr(self.own1), ptr(self.ent_own), ptr(self.ent_c1), ptr(self.x1))
         if self.train:
             tot = self.ent_total_ptr()
-            call("ggad_mb_count2", ptr(g.rowptr), ptr(g.col), ptr(self.ent_col), ptr(self.ent_slot), tot, bound, g.n,
+            call("ggad_mb_count2", ptr(g.rowptr), ptr(g.col), ptr(self.ent_col), ptr(self.ent_slot), tot, n_ents, g.n,
                  ptr(self.own1), ptr(self.cnt2))
             if self.gather2_events is not None:
                 self.gather2_events[0].record()
             call("ggad_mb_gather2", ptr(g.rowptr), ptr(g.col), ptr(self.feat), self.F, ptr(self.ent_col),
-                 ptr(self.ent_slot), ptr(self.ent_own), tot, bound, g.n, ptr(self.cnt2), ptr(self.x2))
+                 ptr(self.ent_slot), ptr(self.ent_own), tot, n_ents, g.n, ptr(self.cnt2), ptr(self.x2))
             if self.gather2_events is not None:
                 self.gather2_events[1].record()
 
     def ent_total_ptr(self) -> int:
         return self.ent_ptr.data_ptr() + 4 * self.n_rows
 
+    def _memset_is_cheaper(self) -> bool:
+        """Zeroing whole slots streams 4*n bytes per batch; walking touches one 64-byte sector per counted
+        2-hop neighbour.  Estimated from the graph's mean neighbour degree (sum deg^2 / sum deg)."""
+        if self.reset_mode in ("memset", "walk"):
+            return self.reset_mode == "memset"
+        g = self.g
+        if not hasattr(g, "_mean_nbr_deg"):
+            d = g.deg_host.astype(np.float64)
+            g._mean_nbr_deg = float((d * d).sum() / max(1.0, d.sum()))
+        walk_bytes = self.n_ents * g._mean_nbr_deg * 64.0
+        return walk_bytes > self.n_batches * g.n * 4.0 * 2.0
+
     def reset(self) -> None:
-        """Zero the counter slots again (walks the entries of the last build)."""
+        """Zero the counter slots again (memset of the used slots, or a walk over the entries of the last build)."""
         if not self.dirty:
             return
         g = self.g
-        call("ggad_mb_plan_reset", ptr(g.rowptr), ptr(g.col), ptr(self.ent_col), ptr(self.ent_slot), ptr(self.ent_own),
-             self.ent_total_ptr(), self.ent_bound, g.n, ptr(self.cnt1), ptr(self.cnt2) if self.train else 0,
-             1 if self.train else 0)
+        if self.train and self._memset_is_cheaper():
+            used = self.n_batches * g.n
+            self.cnt1[:used].zero_()
+            self.cnt2[:used].zero_()
+        else:
+            call("ggad_mb_plan_reset", ptr(g.rowptr), ptr(g.col), ptr(self.ent_col), ptr(self.ent_slot), ptr(self.ent_own),
+                 self.ent_total_ptr(), self.n_ents, g.n, ptr(self.cnt1), ptr(self.cnt2) if self.train else 0,
+                 1 if self.train else 0)
         self.dirty = False
 
     def batch_rows(self, b: int):
         return int(self.batch_ptr_host[b]), int(self.batch_ptr_host[b + 1])
 
+    def batch_ents(self, b: int):
+        r0, r1 = self.batch_rows(b)
+        return int(self.ent_ptr_host[r0]), int(self.ent_ptr_host[r1])
 
-def _lib_check_i32(x: int) -> None:
-    if x >= 2 ** 31:
-        raise ValueError("chunk too large for int32 entry indices; use fewer batches per chunk")
+    def max_batch_ents(self) -> int:
+        e = self.ent_ptr_host[self.batch_ptr_host]
+        return int(np.diff(e).max()) if len(e) > 1 else 0
 
 
 class MiniBatchEngine:
@@ -212,8 +253,10 @@ class MiniBatchEngine:
         self.grads = torch.zeros(self.n_train, dtype=torch.float32, device=self.dev)
         self.grad_w = torch.zeros(self.D, dtype=torch.float32, device=self.dev)
         self.step_counter = torch.zeros(1, dtype=torch.int32, device=self.dev)
-        self.dw_part = None
-        self.loss_log = torch.zeros(8, dtype=torch.float32, device=self.dev)
+        self.n_parts = int(self.lib.ggad_mb_bwd_parts())
+        self.dw_part = torch.zeros(self.n_parts * self.F * self.D, dtype=torch.float32, device=self.dev)
+        self.h2 = _f32(1024 * self.D, self.dev)
+        self.loss_log = torch.zeros(8 * 256, dtype=torch.float32, device=self.dev)
         D, F = self.D, self.F
         # views with the reference's state_dict names/shapes
         self.weight = self.params[0:D].view(1, D)
@@ -236,40 +279,40 @@ class MiniBatchEngine:
         self.exp_avg_sq.zero_()
         self.step_counter.zero_()
 
-    def _ensure_loss_log(self, n: int) -> None:
-        if self.loss_log.numel() < 8 * n:
-            new = torch.zeros(8 * max(n, 2 * (self.loss_log.numel() // 8)), dtype=torch.float32, device=self.dev)
+    def ensure_capacity(self, ch: BatchChunk, log_slots: int) -> None:
+        """Grow scratch that depends on the chunk (never called inside a captured region)."""
+        need = max(1, ch.max_batch_ents()) * self.D
+        if self.h2.numel() < need:
+            self.h2 = _f32(int(need * 1.25), self.dev)
+        if self.loss_log.numel() < 8 * log_slots:
+            new = torch.zeros(8 * max(log_slots, 2 * (self.loss_log.numel() // 8)), dtype=torch.float32, device=self.dev)
             new[:self.loss_log.numel()].copy_(self.loss_log)
             self.loss_log = new
 
-    def _ensure_dw(self, rows: int) -> None:
-        need = rows * self.F * self.D
-        if self.dw_part is None or self.dw_part.numel() < need:
-            self.dw_part = _f32(need, self.dev)
-
     # ---- kernel chain
-    def forward_batch(self, ch: BatchChunk, b: int, train: bool = True) -> None:
+    def step_desc(self, ch: BatchChunk, b: int, log_slot: int) -> "_lib.MbStep":
         r0, r1 = ch.batch_rows(b)
-        call("ggad_mb_fwd_rows", ptr(self.params), self.D, self.F, ptr(ch.x1), ptr(ch.x2) if train else 0,
-             ptr(ch.ent_ptr), ptr(ch.ent_own), ptr(ch.labels), r0, r1 - r0, 1 if train else 0,
-             ptr(ch.h1), ptr(ch.nbar) if train else 0, ptr(ch.gen) if train else 0)
+        e0, e1 = ch.batch_ents(b)
+        s = _lib.MbStep()
+        s.params, s.exp_avg, s.exp_avg_sq, s.grads = ptr(self.params), ptr(self.exp_avg), ptr(self.exp_avg_sq), ptr(self.grads)
+        s.step_counter = ptr(self.step_counter)
+        s.x1, s.x2 = ptr(ch.x1), ptr(ch.x2)
+        s.ent_ptr, s.ent_own, s.ent_row = ptr(ch.ent_ptr), ptr(ch.ent_own), ptr(ch.ent_row)
+        s.labels, s.pos_meta = ptr(ch.labels), ptr(ch.pos_meta)
+        s.h1, s.nbar, s.gen = ptr(ch.h1), ptr(ch.nbar), ptr(ch.gen)
+        s.d_h1, s.d_gen, s.d_nbar, s.dz = ptr(ch.d_h1), ptr(ch.d_gen), ptr(ch.d_nbar), ptr(ch.dz)
+        s.coef_a, s.coef_g = ptr(ch.coef_a), ptr(ch.coef_g)
+        s.h2, s.dw_part, s.grad_w = ptr(self.h2), ptr(self.dw_part), ptr(self.grad_w)
+        s.losses8 = self.loss_log.data_ptr() + 32 * log_slot
+        s.D, s.F, s.row0, s.n_rows, s.ent0, s.n_ents = self.D, self.F, r0, r1 - r0, e0, e1 - e0
+        s.lr, s.weight_decay = self.lr, self.wd
+        return s
 
     def loss_and_grads(self, ch: BatchChunk, b: int, log_slot: int = 0) -> None:
         """forward + loss + backward for batch b; gradients land in self.grads (packed w | W | fc)."""
-        r0, r1 = ch.batch_rows(b)
-        nb = r1 - r0
-        self._ensure_dw(nb)
-        self._ensure_loss_log(log_slot + 1)
-        losses = self.loss_log.data_ptr() + 32 * log_slot
-        self.forward_batch(ch, b, True)
-        call("ggad_mb_loss", ptr(self.params), self.D, ptr(ch.h1), ptr(ch.nbar), ptr(ch.gen), ptr(ch.labels),
-             ptr(ch.src_of_pos), r0, nb, losses, ptr(ch.d_h1), ptr(ch.d_gen), ptr(ch.d_nbar), ptr(self.grad_w),
-             ptr(self.step_counter))
-        call("ggad_mb_bwd_rows", ptr(self.params), self.D, self.F, ptr(ch.x1), ptr(ch.x2), ptr(ch.ent_ptr), ptr(ch.ent_own),
-             ptr(ch.labels), r0, nb, ptr(ch.h1), ptr(ch.nbar), ptr(ch.gen), ptr(ch.d_h1), ptr(ch.d_gen), ptr(ch.d_nbar),
-             ptr(self.dw_part), ptr(ch.dz))
-        call("ggad_mb_grad_reduce", self.D, self.F, ptr(ch.labels), r0, nb, ptr(ch.nbar), ptr(self.dw_part), ptr(ch.dz),
-             ptr(self.grad_w), ptr(self.grads))
+        self.ensure_capacity(ch, log_slot + 1)
+        s = self.step_desc(ch, b, log_slot)
+        _lib.check(self.lib.ggad_mb_train_step(ctypes.byref(s), 0, _lib.current_stream()), "ggad_mb_train_step")
 
     def adam_step(self, grad_scale: float = 1.0) -> None:
         call("ggad_mb_adam", ptr(self.params), ptr(self.exp_avg), ptr(self.exp_avg_sq), ptr(self.grads), self.D, self.F,
@@ -277,16 +320,30 @@ class MiniBatchEngine:
 
     def train_chunk(self, ch: BatchChunk, allreduce=None, world_size: int = 1, log_base: int = 0) -> None:
         """One optimiser step per batch of the chunk (src/model_handler.py:330-364)."""
+        self.ensure_capacity(ch, log_base + ch.n_batches)
+        stream = _lib.current_stream()
+        fuse = 1 if (allreduce is None and world_size == 1) else 0
         for b in range(ch.n_batches):
-            self.loss_and_grads(ch, b, log_base + b)
-            if allreduce is not None:
-                allreduce(self.grads)
-            self.adam_step(1.0 / world_size)
+            s = self.step_desc(ch, b, log_base + b)
+            _lib.check(self.lib.ggad_mb_train_step(ctypes.byref(s), fuse, stream), "ggad_mb_train_step")
+            if not fuse:
+                if allreduce is not None:
+                    allreduce(self.grads)
+                self.adam_step(1.0 / world_size)
+
+    def forward_batch(self, ch: BatchChunk, b: int) -> None:
+        """project + fwd_rows only (layered API / tests): fills ch.h1, ch.nbar, ch.gen for batch b."""
+        self.ensure_capacity(ch, 1)
+        r0, r1 = ch.batch_rows(b)
+        e0, e1 = ch.batch_ents(b)
+        call("ggad_mb_project", ptr(self.params), self.D, self.F, ptr(ch.x2), ptr(ch.ent_own), e0, e1 - e0, ptr(self.h2))
+        call("ggad_mb_fwd_rows", ptr(self.params), self.D, self.F, ptr(ch.x1), ptr(self.h2), ptr(ch.ent_ptr), ptr(ch.ent_own),
+             ptr(ch.labels), r0, r1 - r0, e0, ptr(ch.h1), ptr(ch.nbar), ptr(ch.gen))
 
     def score_chunk(self, ch: BatchChunk, out: torch.Tensor) -> None:
         """to_prob for every row of an inference chunk (src/graphsage.py:178-181)."""
         call("ggad_mb_score", ptr(self.params), self.D, self.F, ptr(ch.x1), ch.n_rows, ptr(out))
 
     def losses(self, n: int) -> np.ndarray:
-        """(n, 4) array of {total, cls, margin, rec} for the last n logged steps (synchronises)."""
+        """(n, 4) array of {total, cls, margin, rec} for the first n logged steps (synchronises)."""
         return self.loss_log[:8 * n].view(n, 8)[:, :4].cpu().numpy()

@@ -74,10 +74,10 @@ int ggad_mb_row_degree(const int32_t *rowptr, const int32_t *col, const int32_t 
 
 /* Materialise entries (ent_ptr = exclusive scan of row_r), count c_j = number of rows of the
  * batch whose closed neighbourhood holds j (column sums of the dense mask, graphsage.py:315)
- * into cnt1[slot][j], elect owners into own1[slot][j]; ent_slot[e] = slot.   graphsage.py:305-311 */
+ * into cnt1[slot][j], elect owners into own1[slot][j]; ent_slot[e] = slot, ent_row[e] = row.   graphsage.py:305-311 */
 int ggad_mb_expand1(const int32_t *rowptr, const int32_t *col, const int32_t *nodes, const int32_t *row_slot,
                     const int32_t *ent_ptr, int32_t n_rows, int64_t n_nodes, int32_t *ent_col, int32_t *ent_slot,
-                    int32_t *cnt1, int32_t *own1, ggad_stream_t stream);
+                    int32_t *ent_row, int32_t *cnt1, int32_t *own1, ggad_stream_t stream);
 
 /* ent_own[e], ent_c1[e] from the slot arrays, and the 1-hop aggregate
  * x1[i] = sum_j feat[j] / (sqrt(r_i) sqrt(c_j)).                        graphsage.py:314-326 */
@@ -123,35 +123,45 @@ int64_t ggad_mb_param_block_elems(int32_t D, int32_t F); /* + transposed copies 
 /* Refresh the transposed copies after the host wrote w/W/fc (load_state_dict). */
 int ggad_mb_params_sync(float *params, int32_t D, int32_t F, ggad_stream_t stream);
 
-/* Per-row forward for rows [row0, row0+n_rows):  h1 = relu(W x1) (graphsage.py:412),
- * nbar = mean over the closed neighbourhood of relu(W x2[owner]) (:419-421) and, on label-1
- * rows, the generated outlier g = relu(fc nbar) (:428-430).  train = 0: h1 only. */
-int ggad_mb_fwd_rows(const float *params, int32_t D, int32_t F, const float *x1, const float *x2,
-                     const int32_t *ent_ptr, const int32_t *ent_own, const int32_t *labels, int32_t row0,
-                     int32_t n_rows, int32_t train, float *h1, float *nbar, float *gen, ggad_stream_t stream);
+/* One batch = rows [row0, row0+n_rows) and entries [ent0, ent0+n_ents) of the chunk.
+ *
+ * ggad_mb_project : h2[e-ent0] = relu(W x2[e]) at owner entries (flat over entries).       graphsage.py:419
+ * ggad_mb_fwd_rows: nbar = mean over the closed neighbourhood of h2[owner] (:421), h1 = relu(W x1) (:412)
+ *                   and, on label-1 rows, the generated outlier gen = relu(fc nbar) (:428-430). */
+int ggad_mb_project(const float *params, int32_t D, int32_t F, const float *x2, const int32_t *ent_own, int32_t ent0,
+                    int32_t n_ents, float *h2, ggad_stream_t stream);
+int ggad_mb_fwd_rows(const float *params, int32_t D, int32_t F, const float *x1, const float *h2, const int32_t *ent_ptr,
+                     const int32_t *ent_own, const int32_t *labels, int32_t row0, int32_t n_rows, int32_t ent0, float *h1,
+                     float *nbar, float *gen, ggad_stream_t stream);
 
 /* Batch loss (graphsage.py:174,192-258) and its gradient w.r.t. the three row tensors
  * (d_h1, d_gen, d_nbar; rows [row0, row0+n_rows)) and w.r.t. the scorer `weight` (grad_w[D]).
- * src_of_pos[q] = row whose embedding sits at column q of `combined_all` (label-0 rows first,
- * generated outliers last, :450); labels are paired in ORIGINAL order (quirk 1).
- * losses8 = {total, cls, margin, rec, 0.1/n1, margin_active, n0, n1}.  If step_counter is not
- * NULL it is incremented (Adam step index for ggad_mb_adam). */
-int ggad_mb_loss(const float *params, int32_t D, const float *h1, const float *nbar, const float *gen,
-                 const int32_t *labels, const int32_t *src_of_pos, int32_t row0, int32_t n_rows, float *losses8,
-                 float *d_h1, float *d_gen, float *d_nbar, float *grad_w, int32_t *step_counter,
-                 ggad_stream_t stream);
+ * pos_meta[q] = (src << 2) | (src_is_label1 << 1) | label[q], src = row whose embedding sits at column q
+ * of `combined_all` (label-0 rows first, generated outliers last, :450); labels are paired in ORIGINAL
+ * order (quirk 1).  losses8 = {total, cls, margin, rec, 0.1/n1, margin_active, n0, n1}.
+ * If coef_a/coef_g/dz are not NULL the per-row backward coefficients (see ggad_mb_row_coefs) are produced
+ * in the same launch.  If step_counter is not NULL it is incremented (Adam step index). */
+int ggad_mb_loss(const float *params, int32_t D, int32_t F, const float *h1, const float *nbar, const float *gen,
+                 const int32_t *labels, const int32_t *pos_meta, const int32_t *ent_ptr, int32_t row0, int32_t n_rows,
+                 float *losses8, float *d_h1, float *d_gen, float *d_nbar, float *dz, float *coef_a, float *coef_g,
+                 float *grad_w, int32_t *step_counter, ggad_stream_t stream);
 
-/* Vector-Jacobian product of ggad_mb_fwd_rows: given d_h1, d_gen (label-1 rows), d_nbar it recomputes
- * the relu masks and writes per-row partial dW[F][D] (dw_part[(i-row0)*F*D ...]) and dZ (for d fc). */
-int ggad_mb_bwd_rows(const float *params, int32_t D, int32_t F, const float *x1, const float *x2,
-                     const int32_t *ent_ptr, const int32_t *ent_own, const int32_t *labels, int32_t row0,
-                     int32_t n_rows, const float *h1, const float *nbar, const float *gen, const float *d_h1,
-                     const float *d_gen, const float *d_nbar, float *dw_part, float *dz, ggad_stream_t stream);
+/* Vector-Jacobian product of project + fwd_rows for arbitrary upstream gradients (layered autograd API):
+ *   row_coefs: coef_a = d_h1 [h1>0];  dz = d_gen [gen>0];  coef_g = (d_nbar + fc^T dz) / r
+ *   bwd_flat : dW partials, flat over the batch's entries and rows, ggad_mb_bwd_parts() blocks of [F][D]. */
+int ggad_mb_row_coefs(const float *params, int32_t D, int32_t F, const int32_t *labels, const int32_t *ent_ptr,
+                      int32_t row0, int32_t n_rows, const float *h1, const float *gen, const float *d_h1,
+                      const float *d_gen, const float *d_nbar, float *dz, float *coef_a, float *coef_g,
+                      ggad_stream_t stream);
+int ggad_mb_bwd_parts(void);
+int ggad_mb_bwd_flat(int32_t D, int32_t F, const float *x1, const float *x2, const float *h2, const int32_t *ent_own,
+                     const int32_t *ent_row, int32_t row0, int32_t n_rows, int32_t ent0, int32_t n_ents,
+                     const float *coef_a, const float *coef_g, float *dw_part, ggad_stream_t stream);
 
-/* Reduce the per-row partials into the packed gradient buffer grads[D + D*F + D*D]. */
-int ggad_mb_grad_reduce(int32_t D, int32_t F, const int32_t *labels, int32_t row0, int32_t n_rows,
-                        const float *nbar, const float *dw_part, const float *dz, const float *grad_w,
-                        float *grads, ggad_stream_t stream);
+/* Reduce the partials into the packed gradient buffer grads[D + D*F + D*D] (w | W | fc). */
+int ggad_mb_grad_reduce(int32_t D, int32_t F, const int32_t *pos_meta, int32_t row0, const float *losses8,
+                        const float *nbar, const float *dw_part, const float *dz, const float *grad_w, float *grads,
+                        ggad_stream_t stream);
 
 /* torch.optim.Adam.step (betas .9/.999, eps 1e-8, L2 weight decay added to the gradient) on the
  * packed block; grad_scale multiplies the gradient first (1/world_size after an all-reduce sum).
@@ -159,6 +169,21 @@ int ggad_mb_grad_reduce(int32_t D, int32_t F, const int32_t *labels, int32_t row
 int ggad_mb_adam(float *params, float *exp_avg, float *exp_avg_sq, const float *grads, int32_t D, int32_t F,
                  float lr, float weight_decay, float grad_scale, const int32_t *step_counter,
                  ggad_stream_t stream);
+
+/* Whole training step of one batch in one host call: project -> fwd_rows -> loss -> bwd_flat -> grad_reduce,
+ * with Adam fused into the last launch when fuse_adam != 0 (single GPU); with fuse_adam == 0 the caller
+ * all-reduces `grads` and then calls ggad_mb_adam.  All members are device pointers. */
+typedef struct ggad_mb_step {
+  float *params, *exp_avg, *exp_avg_sq, *grads;
+  int32_t *step_counter;
+  const float *x1, *x2;
+  const int32_t *ent_ptr, *ent_own, *ent_row, *labels, *pos_meta;
+  float *h1, *nbar, *gen, *d_h1, *d_gen, *d_nbar, *dz, *coef_a, *coef_g;
+  float *h2, *dw_part, *grad_w, *losses8;
+  int32_t D, F, row0, n_rows, ent0, n_ents;
+  float lr, weight_decay;
+} ggad_mb_step;
+int ggad_mb_train_step(const ggad_mb_step *step, int32_t fuse_adam, ggad_stream_t stream);
 
 /* Inference: prob[i] = sigmoid(w . relu(W x1[i]))                   graphsage.py:178-181 */
 int ggad_mb_score(const float *params, int32_t D, int32_t F, const float *x1, int32_t n_rows, float *prob,

@@ -47,9 +47,12 @@ def _check_plan_against_oracle(g, ch, batches, feat_np, atol=2e-6):
     rp, ci = g["rowptr"], g["col"]
     ent_ptr = ch.ent_ptr[:ch.n_rows + 1].cpu().numpy()
     etot = int(ent_ptr[-1])
+    assert np.array_equal(ent_ptr, ch.ent_ptr_host)          # host-side exact entry offsets == device scan
     ent_col = ch.ent_col[:etot].cpu().numpy()
     ent_own = ch.ent_own[:etot].cpu().numpy()
     ent_c1 = ch.ent_c1[:etot].cpu().numpy()
+    ent_row = ch.ent_row[:etot].cpu().numpy()
+    assert np.array_equal(ent_row, np.repeat(np.arange(ch.n_rows), np.diff(ent_ptr)))
     F = feat_np.shape[1]
     x1 = ch.x1[:ch.n_rows * F].view(-1, F).cpu().numpy()
     x2 = ch.x2[:etot * F].view(-1, F).cpu().numpy() if ch.train else None
@@ -230,3 +233,26 @@ def test_rebuild_reuses_clean_slots():
         ch.build(batches, labels)           # build() resets the previous plan first
         torch.cuda.synchronize()
         _check_plan_against_oracle(g, ch, batches, g["feat"], atol=3e-6)
+
+
+def test_fused_adam_chunk_equals_stepwise():
+    g, batches, labels = _random_case(n=8000, n_entries=60000, f=17, d=64, seed=9, nb=4, bsz=120, n_ano=30)
+    torch.manual_seed(1)
+    w = torch.nn.init.xavier_uniform_(torch.empty(1, 64))
+    W = torch.nn.init.xavier_uniform_(torch.empty(64, 17))
+    fc = torch.nn.init.xavier_uniform_(torch.empty(64, 64))
+    outs = []
+    for fused in (True, False):
+        graph, feat, ch = _setup(g, max_batches=4)
+        eng = MiniBatchEngine(17, 64, DEV)
+        eng.load_params(w, W, fc)
+        ch.build(batches, labels)
+        if fused:
+            eng.train_chunk(ch)                        # Adam fused into the last launch of every step
+        else:
+            for b in range(4):
+                eng.loss_and_grads(ch, b, b)
+                eng.adam_step()
+        outs.append((eng.params.cpu().numpy().copy(), eng.losses(4).copy()))
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
