@@ -45,11 +45,12 @@ SIGNATURES = {
     "ggad_mb_params_sync": (c_int32, [_P, _I, _I, _P]),
     "ggad_mb_project": (c_int32, [_P, _I, _I, _P, _P, _I, _I, _P, _P]),
     "ggad_mb_fwd_rows": (c_int32, [_P, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P]),
-    "ggad_mb_loss": (c_int32, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "ggad_mb_loss_workspace_elems": (c_int64, [_I]),
+    "ggad_mb_loss": (c_int32, [_P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ggad_mb_row_coefs": (c_int32, [_P, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ggad_mb_bwd_parts": (c_int32, []),
     "ggad_mb_bwd_flat": (c_int32, [_I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P]),
-    "ggad_mb_grad_reduce": (c_int32, [_I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "ggad_mb_grad_reduce": (c_int32, [_I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "ggad_mb_adam": (c_int32, [_P, _P, _P, _P, _I, _I, _F, _F, _F, _P, _P]),
     "ggad_mb_train_step": (c_int32, [_P, _I, _P]),
     "ggad_mb_score": (c_int32, [_P, _I, _I, _P, _I, _P, _P]),
@@ -67,9 +68,8 @@ SIGNATURES = {
 class MbStep(ctypes.Structure):
     """Mirror of `ggad_mb_step` (include/ggad_hip.h)."""
     _fields_ = ([(n, c_void_p) for n in ("params", "exp_avg", "exp_avg_sq", "grads", "step_counter", "x1", "x2",
-                                         "ent_ptr", "ent_own", "ent_row", "labels", "pos_meta", "h1", "nbar", "gen",
-                                         "d_h1", "d_gen", "d_nbar", "dz", "coef_a", "coef_g", "h2", "dw_part", "grad_w",
-                                         "losses8")]
+                                         "ent_ptr", "ent_own", "ent_row", "labels", "pos_meta", "row_pos", "h1", "nbar",
+                                         "gen", "dz", "coef_a", "coef_g", "h2", "dw_part", "loss_ws", "losses8")]
                 + [(n, c_int32) for n in ("D", "F", "row0", "n_rows", "ent0", "n_ents")]
                 + [("lr", c_float), ("weight_decay", c_float)])
 

@@ -10,9 +10,10 @@
 // through the scalar cache (wave-uniform) or as 256-byte coalesced vector loads; (3) few launches:
 //
 //   project   flat over entries   h2[u] = relu(W x2[u]) at owner entries          graphsage.py:419
-//   fwd_rows  4 waves per row     nbar = mean_{e in row} h2[own(e)], h1 = relu(W x1), gen = relu(fc nbar)
-//   loss      ONE workgroup       scores, BCE, cosine affinity margin, recon, their gradients w.r.t.
-//                                 (h1, gen, nbar, w) and the per-row backward coefficients
+//   fwd_rows  16 waves per row    nbar = mean_{e in row} h2[own(e)], h1 = relu(W x1), gen = relu(fc nbar)
+//   loss_pos  1 wave / position   scores, BCE, cosine affinity, norms, recon norms + per-workgroup partial sums
+//   loss_rows 1 wave / row        loss scalars, gradients w.r.t. (h1, gen, nbar, w) folded into the per-row
+//                                 backward coefficients
 //   bwd_flat  flat over entries   dW partials = sum coef (x) x, 4 waves per workgroup, combined in LDS
 //   grad_reduce [+ adam]          partials -> packed gradient block -> (all-reduce) -> Adam
 //
@@ -104,9 +105,10 @@ __global__ void __launch_bounds__(256) k_project(const float *__restrict__ param
   }
 }
 
-// ------------------------------------------------------------------ forward rows (4 waves per row)
+// ------------------------------------------------------------------ forward rows (FWD_NW waves per row)
+constexpr int FWD_NW = 16;     // a hub row (thousands of entries) is the critical path of the launch
 template <int FT>
-__global__ void __launch_bounds__(256) k_fwd_rows(const float *__restrict__ params, ParamLayout L,
+__global__ void __launch_bounds__(FWD_NW * 64) k_fwd_rows(const float *__restrict__ params, ParamLayout L,
                                                   const float *__restrict__ x1, const float *__restrict__ h2,
                                                   const int32_t *__restrict__ ent_ptr, const int32_t *__restrict__ ent_own,
                                                   const int32_t *__restrict__ labels, int row0, int ent0,
@@ -115,17 +117,17 @@ __global__ void __launch_bounds__(256) k_fwd_rows(const float *__restrict__ para
   const int D = L.D, F = (FT > 0) ? FT : L.F;
   const int lane = lane_id(), wid = threadIdx.x / 64, d = lane < D ? lane : D - 1;
   const int row = row0 + blockIdx.x;
-  float *part = lds;                 // [4][64]
-  float *ns = lds + 256;             // [64]
-  float *wt_lds = lds + 320;         // F*D (FT == 0)
+  float *part = lds;                 // [FWD_NW][64]
+  float *ns = lds + FWD_NW * 64;     // [64]
+  float *wt_lds = ns + 64;           // F*D (FT == 0)
   const int e0 = ent_ptr[row], e1 = ent_ptr[row + 1];
   const int r = e1 - e0;
-  // partial sum of h2[own(e)] over e = e0 + wid, e0 + wid + 4, ...  (256-byte coalesced row loads)
+  // partial sum of h2[own(e)] over e = e0 + wid, e0 + wid + NW, ...  (256-byte coalesced row loads)
   float acc = 0.0f;
-  for (int blk = wid; blk < r; blk += 256) {
-    const int my = blk + 4 * lane;
+  for (int blk = wid; blk < r; blk += FWD_NW * 64) {
+    const int my = blk + FWD_NW * lane;
     const int ov = (my < r) ? ent_own[e0 + my] : 0;
-    const int cnt = min(64, (r - blk + 3) / 4);
+    const int cnt = min(64, (r - blk + FWD_NW - 1) / FWD_NW);
     int i = 0;
     for (; i + 4 <= cnt; i += 4) {
       const int o0 = __builtin_amdgcn_readlane(ov, i), o1 = __builtin_amdgcn_readlane(ov, i + 1);
@@ -142,7 +144,10 @@ __global__ void __launch_bounds__(256) k_fwd_rows(const float *__restrict__ para
   part[wid * 64 + lane] = acc;
   __syncthreads();
   const float inv_r = 1.0f / (float)r;                                      // mask_row = mask / rowsum  graphsage.py:317
-  const float nb = inv_r * ((part[lane] + part[64 + lane]) + (part[128 + lane] + part[192 + lane]));
+  float tot = 0.0f;
+#pragma unroll
+  for (int k = 0; k < FWD_NW; ++k) tot += part[k * 64 + lane];              // fixed order
+  const float nb = inv_r * tot;
   const int y = labels[row];
   if (wid == 0) {
     if (lane < D) nbar[(int64_t)row * D + lane] = nb;                       // mask_row.mm(...)          graphsage.py:421
@@ -159,23 +164,29 @@ __global__ void __launch_bounds__(256) k_fwd_rows(const float *__restrict__ para
   }
   if (y != 1) return;                                                       // block-uniform exit
   __syncthreads();
-  // outlier generation gen = relu(fc nbar): the 4 waves split the d2 range          graphsage.py:428-430
+  // outlier generation gen = relu(fc nbar): the waves split the d2 range              graphsage.py:428-430
   const float *fcT = params + L.o_fcT();
-  const int q = (D + 3) / 4;
+  const int q = (D + FWD_NW - 1) / FWD_NW;
   float a = 0.0f;
   for (int d2 = wid * q; d2 < min(D, (wid + 1) * q); ++d2) a = fmaf(fcT[d2 * D + d], ns[d2], a);
   __syncthreads();
   part[wid * 64 + lane] = a;
   __syncthreads();
-  if (wid == 0 && lane < D)
-    gen[(int64_t)row * D + lane] = fmaxf((part[lane] + part[64 + lane]) + (part[128 + lane] + part[192 + lane]), 0.0f);
+  if (wid == 0 && lane < D) {
+    float g = 0.0f;
+#pragma unroll
+    for (int k = 0; k < FWD_NW; ++k) g += part[k * 64 + lane];
+    gen[(int64_t)row * D + lane] = fmaxf(g, 0.0f);
+  }
 }
 
-// ------------------------------------------------------------------ loss (one workgroup per batch)
-constexpr int LOSS_T = 1024;
-constexpr int LOSS_W = LOSS_T / 64;
-constexpr int LOSS_PP = 8;            // positions per wave per round (rows prefetched together)
-
+// ------------------------------------------------------------------ loss: two launches, both spread over the chip
+// (a single-workgroup version was VALU-issue-bound on ONE CU: ~400 wave-instructions per position x 200
+//  positions on 4 SIMDs = 45 us; spread over 50 workgroups each launch is a few us)
+//   k_loss_pos : one wave per POSITION q of combined_all: score, BCE term, cosine affinity, norms, recon norm
+//                -> pos_scal[q][8] and per-workgroup partial sums
+//   k_loss_rows: one wave per ROW: reduces the partials (every wave, same fixed order), then the gradients
+//                w.r.t. this row's h1 / gen / nbar, folded straight into the backward coefficients.
 __device__ __forceinline__ float log_sigmoid(float x) { return fminf(x, 0.0f) - log1pf(expf(-fabsf(x))); }
 
 struct PosVals { float s, aff, na, nbn, nac, nbc; };
@@ -191,7 +202,153 @@ __device__ __forceinline__ PosVals eval_position(float wd, float c, float nb) {
   return v;
 }
 
-// Per-row backward coefficients (shared by the fused loss kernel and the stand-alone VJP entry point):
+__host__ __device__ inline int loss_nwg(int B) { return (B + 3) / 4; }
+
+// pos_meta[q] = (src_row << 2) | (src_is_label1 << 1) | label_of_position_q     (host-built, graphsage.py:450 order)
+__global__ void __launch_bounds__(256) k_loss_pos(const float *__restrict__ params, int D, const float *__restrict__ h1,
+                                                  const float *__restrict__ nbar, const float *__restrict__ gen,
+                                                  const int32_t *__restrict__ pos_meta, int row0, int B,
+                                                  float *__restrict__ pos_scal, float *__restrict__ part) {
+  __shared__ float red[4][8];
+  const int lane = lane_id(), wid = threadIdx.x / 64;
+  const bool on = lane < D;
+  const int q = blockIdx.x * 4 + wid;
+  float o[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (q < B) {
+    const int meta = pos_meta[row0 + q];
+    const int src = meta >> 2, y = meta & 1;
+    const bool from_gen = (meta & 2) != 0;
+    const float wd = on ? params[lane] : 0.0f;
+    const float c = on ? (from_gen ? gen[(int64_t)src * D + lane] : h1[(int64_t)src * D + lane]) : 0.0f;   // combined_all[:, q]
+    const float nb = on ? nbar[(int64_t)(row0 + q) * D + lane] : 0.0f;                                    // to_feats_neigh[q, :]
+    const float hs = (on && from_gen) ? h1[(int64_t)src * D + lane] : 0.0f;
+    const PosVals v = eval_position(wd, c, nb);
+    float recn = 0.0f;
+    if (from_gen) { const float dl = hs - c; recn = sqrtf(wave_sum_fast(dl * dl)); }   // recon2   graphsage.py:197-198
+    o[0] = (1.0f - (float)y) * v.s - log_sigmoid(v.s);                   // BCEWithLogits, pos_weight 1 graphsage.py:246
+    o[1] = y == 0 ? v.aff : 0.0f; o[2] = y == 1 ? v.aff : 0.0f; o[3] = recn;
+    o[4] = y == 0 ? 1.0f : 0.0f;  o[5] = y == 1 ? 1.0f : 0.0f;
+    if (lane == 0) {
+      float *ps = pos_scal + (int64_t)q * 8;
+      ps[0] = v.s; ps[1] = v.aff; ps[2] = v.na; ps[3] = v.nbn; ps[4] = recn;
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) red[wid][k] = o[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int k = threadIdx.x;
+    part[(int64_t)blockIdx.x * 8 + k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_loss_rows(const float *__restrict__ params, ParamLayout L,
+                                                   const float *__restrict__ h1, const float *__restrict__ nbar,
+                                                   const float *__restrict__ gen, const int32_t *__restrict__ labels,
+                                                   const int32_t *__restrict__ pos_meta, const int32_t *__restrict__ row_pos,
+                                                   const int32_t *__restrict__ ent_ptr, int row0, int B,
+                                                   const float *__restrict__ pos_scal, const float *__restrict__ part,
+                                                   float *__restrict__ gw_part, float *__restrict__ losses8,
+                                                   float *__restrict__ d_h1, float *__restrict__ d_gen,
+                                                   float *__restrict__ d_nbar, float *__restrict__ dz,
+                                                   float *__restrict__ coef_a, float *__restrict__ coef_g,
+                                                   int32_t *__restrict__ step_counter) {
+  __shared__ float gw[4][64];
+  __shared__ float zs[4][64];
+  __shared__ float fc_lds[GGAD_MAX_D * GGAD_MAX_D];
+  const int D = L.D;
+  const int lane = lane_id(), wid = threadIdx.x / 64;
+  const bool on = lane < D;
+  const int d = on ? lane : D - 1;
+  for (int i = threadIdx.x; i < D * D; i += 256) fc_lds[i] = params[L.o_fc() + i];
+  // every wave reduces the per-workgroup partials the same way -> identical scalars everywhere
+  const int nwg = loss_nwg(B);
+  float t[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    float v = 0.0f;
+    for (int g = lane; g < nwg; g += 64) v += part[(int64_t)g * 8 + k];
+    t[k] = wave_sum_fast(v);
+  }
+  const float fB = (float)B;
+  const float cls = t[0] / fB;
+  const float an = t[1] / t[4], ab = t[2] / t[5];
+  const float mg = 1.0f - (an - ab);                                     // confidence_margin = 1      graphsage.py:236-240
+  const float active = (mg >= 0.0f) ? 1.0f : 0.0f;                       // clamp_min backward: pass where x >= min
+  const float rec_coef = 0.1f / t[5];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const float margin = fmaxf(mg, 0.0f), rec = t[3] / t[5];
+    losses8[0] = cls + margin + 0.1f * rec;                              // graphsage.py:258
+    losses8[1] = cls; losses8[2] = margin; losses8[3] = rec;
+    losses8[4] = rec_coef; losses8[5] = active; losses8[6] = t[4]; losses8[7] = t[5];
+    if (step_counter) *step_counter += 1;
+  }
+  __syncthreads();   // fc_lds ready
+  const int i = blockIdx.x * 4 + wid;
+  float gwd = 0.0f;
+  if (i < B) {
+    const int row = row0 + i;
+    const int y = labels[row];
+    const int r = ent_ptr[row + 1] - ent_ptr[row];
+    const float wd = on ? params[lane] : 0.0f;
+    const int64_t off = (int64_t)row * D + d;
+    const float H1 = h1[off];
+    const float NB = nbar[off];
+    const float G = (y == 1) ? gen[off] : 0.0f;
+    const float C = (y == 1) ? G : H1;                                   // this row's column of combined_all
+    // ---- C-side: this row is the source of column q1
+    const int q1 = row_pos[row];
+    const float *p1 = pos_scal + (int64_t)q1 * 8;
+    const float s1 = p1[0], aff1 = p1[1], na1 = p1[2], nbn1 = p1[3], recn = p1[4];
+    const int y1 = pos_meta[row0 + q1] & 1;
+    const float nbq = nbar[(int64_t)(row0 + q1) * D + d];
+    const float nac1 = fmaxf(na1, 1e-8f), nbc1 = fmaxf(nbn1, 1e-8f);
+    const float ds = (1.0f / (1.0f + expf(-s1)) - (float)y1) / fB;
+    const float gq1 = active * (y1 == 0 ? -1.0f / t[4] : 1.0f / t[5]);
+    // aff = sum (c/nac)(nb/nbc); torch clamps a detached copy of the norms, so autograd sees
+    // d aff / d c = (nb/nbc)/nac - (aff/nac) * c/|c|   (and symmetrically for nb)
+    const float ca = na1 > 0.0f ? C / na1 : 0.0f;
+    const float dC = ds * wd + gq1 * ((nbq / nbc1) / nac1 - (aff1 / nac1) * ca);
+    float gH = dC, gG = 0.0f;
+    if (y == 1) {                                                        // recon term 0.1 * mean_i |h1_i - gen_i|  graphsage.py:258
+      const float tt = rec_coef * ((H1 - G) / recn);
+      gH = tt; gG = dC - tt;
+    }
+    gwd = ds * C;
+    // ---- nb-side: position i pairs nbar[row] with column i of combined_all
+    const float *p2 = pos_scal + (int64_t)i * 8;
+    const float aff2 = p2[1], na2 = p2[2], nbn2 = p2[3];
+    const int m2 = pos_meta[row0 + i];
+    const int src2 = m2 >> 2;
+    const float c2 = (m2 & 2) ? gen[(int64_t)src2 * D + d] : h1[(int64_t)src2 * D + d];
+    const float nac2 = fmaxf(na2, 1e-8f), nbc2 = fmaxf(nbn2, 1e-8f);
+    const float gq2 = active * (y == 0 ? -1.0f / t[4] : 1.0f / t[5]);
+    const float cb = nbn2 > 0.0f ? NB / nbn2 : 0.0f;
+    float dNb = gq2 * ((c2 / nac2) / nbc2 - (aff2 / nbc2) * cb);
+    if (d_h1 != nullptr && on) { d_h1[off] = gH; d_gen[off] = gG; d_nbar[off] = dNb; }
+    // ---- backward coefficients of this row
+    if (y == 1) {
+      const float dZ = (G > 0.0f) ? gG : 0.0f;                           // relu(fc(.))
+      if (on) dz[off] = dZ;
+      zs[wid][lane] = on ? dZ : 0.0f;
+      float a = 0.0f;
+      for (int dd = 0; dd < D; ++dd) a = fmaf(fc_lds[dd * D + d], zs[wid][dd], a);   // fc^T dZ
+      dNb += a;
+    }
+    if (on) {
+      coef_a[off] = (H1 > 0.0f) ? gH : 0.0f;
+      coef_g[off] = dNb * (1.0f / (float)r);
+    }
+  }
+  gw[wid][lane] = on ? gwd : 0.0f;
+  __syncthreads();
+  if (threadIdx.x < 64)
+    gw_part[(int64_t)blockIdx.x * 64 + threadIdx.x] = (gw[0][threadIdx.x] + gw[1][threadIdx.x]) + (gw[2][threadIdx.x] + gw[3][threadIdx.x]);
+}
+
+// Per-row backward coefficients for ARBITRARY upstream gradients (layered autograd API):
 //   coef_a = d_h1 * [h1 > 0]                     multiplies x1[row]      in dW
 //   dz     = d_gen * [gen > 0]  (label-1 rows)   outer(dz, nbar) = d fc
 //   coef_g = (d_nbar + fc^T dz) / r              multiplies x2[own(e)] * [h2 > 0] for the row's entries
@@ -219,146 +376,6 @@ __device__ __forceinline__ void row_coefs(const float *__restrict__ fc, int D, i
   if (on) {
     coef_a[off] = (H1 > 0.0f) ? dH1 : 0.0f;
     coef_g[off] = dNb * (1.0f / (float)r);
-  }
-}
-
-// pos_meta[q] = (src_row << 2) | (src_is_label1 << 1) | label_of_position_q     (host-built, graphsage.py:450 order)
-__global__ void __launch_bounds__(LOSS_T) k_loss(const float *__restrict__ params, ParamLayout L,
-                                                 const float *__restrict__ h1, const float *__restrict__ nbar,
-                                                 const float *__restrict__ gen, const int32_t *__restrict__ labels,
-                                                 const int32_t *__restrict__ pos_meta, const int32_t *__restrict__ ent_ptr,
-                                                 int row0, int B, float *__restrict__ losses8, float *__restrict__ d_h1,
-                                                 float *__restrict__ d_gen, float *__restrict__ d_nbar, float *__restrict__ dz,
-                                                 float *__restrict__ coef_a, float *__restrict__ coef_g,
-                                                 float *__restrict__ grad_w, int32_t *__restrict__ step_counter) {
-  __shared__ float red[LOSS_W][6];
-  __shared__ float bc[8];
-  __shared__ float gw[LOSS_W][64];
-  __shared__ float zs[LOSS_W][64];
-  const int D = L.D;
-  const int lane = lane_id(), wid = threadIdx.x / 64;
-  const bool on = lane < D;
-  const float wd = on ? params[lane] : 0.0f;   // o_w = 0
-  float s_bce = 0.f, s_a0 = 0.f, s_a1 = 0.f, s_rec = 0.f; int n0 = 0, n1 = 0;
-  // ---------------- pass 1: loss terms
-  for (int base = 0; base < B; base += LOSS_W * LOSS_PP) {
-    const int myq = base + wid + LOSS_W * lane;                          // lane i < PP holds the meta of position i
-    const int meta = (lane < LOSS_PP && myq < B) ? pos_meta[row0 + myq] : -1;
-    float c[LOSS_PP], nb[LOSS_PP], hs[LOSS_PP];
-    int mt[LOSS_PP];
-#pragma unroll
-    for (int i = 0; i < LOSS_PP; ++i) {
-      mt[i] = __builtin_amdgcn_readlane(meta, i);
-      const int q = base + wid + LOSS_W * i;
-      if (mt[i] >= 0 && on) {
-        const int src = mt[i] >> 2;
-        c[i] = (mt[i] & 2) ? gen[(int64_t)src * D + lane] : h1[(int64_t)src * D + lane];      // combined_all[:, q]
-        nb[i] = nbar[(int64_t)(row0 + q) * D + lane];                                        // to_feats_neigh[q, :]
-        hs[i] = (mt[i] & 2) ? h1[(int64_t)src * D + lane] : 0.0f;
-      } else { c[i] = 0.f; nb[i] = 0.f; hs[i] = 0.f; }
-    }
-#pragma unroll
-    for (int i = 0; i < LOSS_PP; ++i) {
-      if (mt[i] < 0) continue;
-      const int y = mt[i] & 1;
-      const PosVals v = eval_position(wd, c[i], nb[i]);
-      s_bce += (1.0f - (float)y) * v.s - log_sigmoid(v.s);               // BCEWithLogits, pos_weight 1 graphsage.py:246
-      if (y == 0) { s_a0 += v.aff; n0++; } else { s_a1 += v.aff; n1++; }
-      if (mt[i] & 2) {                                                   // recon2 over label-1 rows    graphsage.py:197-198
-        const float dl = hs[i] - c[i];
-        s_rec += sqrtf(wave_sum_fast(dl * dl));
-      }
-    }
-  }
-  if (lane == 0) {
-    red[wid][0] = s_bce; red[wid][1] = s_a0; red[wid][2] = s_a1; red[wid][3] = s_rec;
-    red[wid][4] = (float)n0; red[wid][5] = (float)n1;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float t[6] = {0, 0, 0, 0, 0, 0};
-    for (int k = 0; k < LOSS_W; ++k)
-      for (int m = 0; m < 6; ++m) t[m] += red[k][m];
-    const float cls = t[0] / (float)B;
-    const float an = t[1] / t[4], ab = t[2] / t[5];
-    const float m = 1.0f - (an - ab);                                    // confidence_margin = 1      graphsage.py:236-240
-    const float margin = fmaxf(m, 0.0f);
-    const float rec = t[3] / t[5];
-    losses8[0] = cls + margin + 0.1f * rec;                              // graphsage.py:258
-    losses8[1] = cls; losses8[2] = margin; losses8[3] = rec;
-    const float active = (m >= 0.0f) ? 1.0f : 0.0f;                      // clamp_min backward: pass where x >= min
-    losses8[4] = 0.1f / t[5];
-    losses8[5] = active; losses8[6] = t[4]; losses8[7] = t[5];
-    bc[0] = active; bc[1] = t[4]; bc[2] = t[5]; bc[3] = 0.1f / t[5];
-    if (step_counter) *step_counter += 1;
-  }
-  __syncthreads();
-  const float active = bc[0], fn0 = bc[1], fn1 = bc[2], rec_coef = bc[3];
-  // ---------------- pass 2: gradients w.r.t. h1 / gen / nbar / w
-  float gacc = 0.0f;
-  for (int base = 0; base < B; base += LOSS_W * LOSS_PP) {
-    const int myq = base + wid + LOSS_W * lane;
-    const int meta = (lane < LOSS_PP && myq < B) ? pos_meta[row0 + myq] : -1;
-    float c[LOSS_PP], nb[LOSS_PP], hs[LOSS_PP];
-    int mt[LOSS_PP];
-#pragma unroll
-    for (int i = 0; i < LOSS_PP; ++i) {
-      mt[i] = __builtin_amdgcn_readlane(meta, i);
-      const int q = base + wid + LOSS_W * i;
-      if (mt[i] >= 0 && on) {
-        const int src = mt[i] >> 2;
-        c[i] = (mt[i] & 2) ? gen[(int64_t)src * D + lane] : h1[(int64_t)src * D + lane];
-        nb[i] = nbar[(int64_t)(row0 + q) * D + lane];
-        hs[i] = (mt[i] & 2) ? h1[(int64_t)src * D + lane] : 0.0f;
-      } else { c[i] = 0.f; nb[i] = 0.f; hs[i] = 0.f; }
-    }
-#pragma unroll
-    for (int i = 0; i < LOSS_PP; ++i) {
-      if (mt[i] < 0) continue;
-      const int q = base + wid + LOSS_W * i;
-      const int y = mt[i] & 1, src = mt[i] >> 2;
-      const PosVals v = eval_position(wd, c[i], nb[i]);
-      const float ds = (1.0f / (1.0f + expf(-v.s)) - (float)y) / (float)B;
-      const float gq = active * (y == 0 ? -1.0f / fn0 : 1.0f / fn1);
-      // aff = sum (c/nac)(nb/nbc); torch clamps a detached copy of the norms, so autograd sees
-      // d aff / d c = (nb/nbc)/nac - (aff/nac) * c/|c|   (and symmetrically for nb)
-      const float ca = v.na > 0.0f ? c[i] / v.na : 0.0f;
-      const float cb = v.nbn > 0.0f ? nb[i] / v.nbn : 0.0f;
-      const float dC = ds * wd + gq * ((nb[i] / v.nbc) / v.nac - (v.aff / v.nac) * ca);
-      const float dN = gq * ((c[i] / v.nac) / v.nbc - (v.aff / v.nbc) * cb);
-      // column q of combined_all is h1[src] (label-0 source) or the generated outlier gen[src] (label-1 source);
-      // a label-1 source row also carries the recon term 0.1 * mean_i |h1_i - gen_i|      graphsage.py:197-198,258
-      float gH = dC, gG = 0.0f;
-      if (mt[i] & 2) {
-        const float dl = hs[i] - c[i];
-        const float nrm = sqrtf(wave_sum_fast(dl * dl));
-        const float t = rec_coef * (dl / nrm);
-        gH = t;
-        gG = dC - t;
-      }
-      if (on) {
-        d_h1[(int64_t)src * D + lane] = gH;
-        d_gen[(int64_t)src * D + lane] = gG;
-        d_nbar[(int64_t)(row0 + q) * D + lane] = dN;
-      }
-      gacc = fmaf(ds, c[i], gacc);
-    }
-  }
-  gw[wid][lane] = gacc;
-  __threadfence_block();
-  __syncthreads();
-  if (threadIdx.x < D) {
-    float t = 0.0f;
-    for (int k = 0; k < LOSS_W; ++k) t += gw[k][threadIdx.x];
-    grad_w[threadIdx.x] = t;
-  }
-  if (coef_a == nullptr) return;
-  // ---------------- pass 3: per-row backward coefficients (the other waves' stores are visible: same CU)
-  const float *fc = params + L.o_fc();
-  for (int i = wid; i < B; i += LOSS_W) {
-    const int row = row0 + i;
-    row_coefs(fc, D, lane, row, labels[row], ent_ptr[row + 1] - ent_ptr[row], h1, gen, d_h1, d_gen, d_nbar, zs[wid], dz,
-              coef_a, coef_g);
   }
 }
 
@@ -481,51 +498,65 @@ __device__ __forceinline__ void adam_scalars(float *sc, const int32_t *step_coun
   __syncthreads();
 }
 
+// block = 64 parameters x 4 sub-reducers (threadIdx.x = parameter, threadIdx.y = quarter of the terms)
 template <bool FUSE_ADAM>
 __global__ void __launch_bounds__(256) k_grad_reduce(ParamLayout L, const int32_t *__restrict__ pos_meta, int row0,
                                                      const float *__restrict__ losses8, const float *__restrict__ nbar,
                                                      const float *__restrict__ dw_part, int n_parts,
-                                                     const float *__restrict__ dz, const float *__restrict__ grad_w,
-                                                     float *__restrict__ grads, float *__restrict__ params,
+                                                     const float *__restrict__ dz, const float *__restrict__ gw_part,
+                                                     int n_gw, float *__restrict__ grads, float *__restrict__ params,
                                                      float *__restrict__ m, float *__restrict__ v, float lr, float wd,
                                                      const int32_t *__restrict__ step_counter) {
   __shared__ float sc[2];
-  if (FUSE_ADAM) adam_scalars(sc, step_counter, lr);
+  __shared__ float red[4][64];
+  const int tid = threadIdx.y * 64 + threadIdx.x;
+  if (FUSE_ADAM) {
+    if (tid == 0) {
+      const double t = (double)(*step_counter);
+      const double bc1 = 1.0 - pow(0.9, t), bc2 = 1.0 - pow(0.999, t);
+      sc[0] = (float)((double)lr / bc1);      // step_size
+      sc[1] = (float)sqrt(bc2);               // bias_correction2_sqrt
+    }
+  }
   const int D = L.D, F = L.F;
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= L.n_train()) return;
-  float g;
-  int pidx;
+  const int t = blockIdx.x * 64 + threadIdx.x;
+  const int sub = threadIdx.y;
+  float g = 0.0f;
+  int pidx = -1;
   if (t < D) {
-    g = grad_w[t]; pidx = t;
+    for (int k = sub; k < n_gw; k += 4) g += gw_part[(int64_t)k * 64 + t];      // d w = sum_q ds_q * combined_all[:, q]
+    pidx = t;
   } else if (t < D + D * F) {
     const int u = t - D;
     const int f = u / D, d = u - f * D;           // consecutive threads -> consecutive d (coalesced reads)
     const float *p = dw_part + f * D + d;
     const int stride = F * D;
+    const int per = (n_parts + 3) / 4;
+    const int b0 = sub * per, b1 = min(n_parts, b0 + per);
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int b = 0;
-    for (; b + 8 <= n_parts; b += 8) {
+    int b = b0;
+    for (; b + 8 <= b1; b += 8) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) s[k] += p[(int64_t)(b + k) * stride];
     }
-    for (; b < n_parts; ++b) s[0] += p[(int64_t)b * stride];
+    for (; b < b1; ++b) s[0] += p[(int64_t)b * stride];
     g = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
     pidx = L.o_W() + d * F + f;
-  } else {
+  } else if (t < L.n_train()) {
     const int u = t - D - D * F;
     const int dd = u / D, d2 = u - dd * D;        // d fc[dd][d2] = sum_{label-1 rows i} dZ_i[dd] * nbar_i[d2]
     const int n0 = (int)losses8[6], n1 = (int)losses8[7];
-    float s0 = 0.0f, s1 = 0.0f;
-    int j = 0;
-    for (; j + 2 <= n1; j += 2) {                 // label-1 rows = sources of the last n1 columns, in order
-      const int ra = pos_meta[row0 + n0 + j] >> 2, rb = pos_meta[row0 + n0 + j + 1] >> 2;
+    float s0 = 0.0f;
+    for (int j = sub; j < n1; j += 4) {           // label-1 rows = sources of the last n1 columns, in order
+      const int ra = pos_meta[row0 + n0 + j] >> 2;
       s0 = fmaf(dz[(int64_t)ra * D + dd], nbar[(int64_t)ra * D + d2], s0);
-      s1 = fmaf(dz[(int64_t)rb * D + dd], nbar[(int64_t)rb * D + d2], s1);
     }
-    if (j < n1) { const int ra = pos_meta[row0 + n0 + j] >> 2; s0 = fmaf(dz[(int64_t)ra * D + dd], nbar[(int64_t)ra * D + d2], s0); }
-    g = s0 + s1; pidx = L.o_fc() + u;
+    g = s0; pidx = L.o_fc() + u;
   }
+  red[sub][threadIdx.x] = g;
+  __syncthreads();
+  if (sub != 0 || pidx < 0) return;
+  g = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
   grads[pidx] = g;
   if (FUSE_ADAM) adam_update(params, m, v, L, pidx, g, wd, sc[0], sc[1]);
 }
@@ -614,26 +645,33 @@ int ggad_mb_fwd_rows(const float *params, int32_t D, int32_t F, const float *x1,
   if (n_rows == 0) return GGAD_OK;
   ParamLayout L{D, F};
   if (F == 17)
-    k_fwd_rows<17><<<dim3(n_rows), dim3(256), 320 * 4, as_stream(stream)>>>(params, L, x1, h2, ent_ptr, ent_own, labels, row0,
-                                                                           ent0, h1, nbar, gen);
+    k_fwd_rows<17><<<dim3(n_rows), dim3(FWD_NW * 64), (FWD_NW + 1) * 64 * 4, as_stream(stream)>>>(
+        params, L, x1, h2, ent_ptr, ent_own, labels, row0, ent0, h1, nbar, gen);
   else
-    k_fwd_rows<0><<<dim3(n_rows), dim3(256), (size_t)(320 + F * D) * 4, as_stream(stream)>>>(
+    k_fwd_rows<0><<<dim3(n_rows), dim3(FWD_NW * 64), (size_t)((FWD_NW + 1) * 64 + F * D) * 4, as_stream(stream)>>>(
         params, L, x1, h2, ent_ptr, ent_own, labels, row0, ent0, h1, nbar, gen);
   GGAD_CHECK_LAUNCH("mb_fwd_rows");
   return GGAD_OK;
 }
 
+int64_t ggad_mb_loss_workspace_elems(int32_t n_rows) { return (int64_t)n_rows * 8 + (int64_t)loss_nwg(n_rows) * 72; }
+
 int ggad_mb_loss(const float *params, int32_t D, int32_t F, const float *h1, const float *nbar, const float *gen,
-                 const int32_t *labels, const int32_t *pos_meta, const int32_t *ent_ptr, int32_t row0, int32_t n_rows,
-                 float *losses8, float *d_h1, float *d_gen, float *d_nbar, float *dz, float *coef_a, float *coef_g,
-                 float *grad_w, int32_t *step_counter, ggad_stream_t stream) {
-  GGAD_REQUIRE(params && h1 && nbar && gen && labels && pos_meta && ent_ptr && losses8 && d_h1 && d_gen && d_nbar && grad_w);
-  GGAD_REQUIRE((coef_a == nullptr) == (coef_g == nullptr) && (coef_a == nullptr || dz));
+                 const int32_t *labels, const int32_t *pos_meta, const int32_t *row_pos, const int32_t *ent_ptr,
+                 int32_t row0, int32_t n_rows, float *loss_ws, float *losses8, float *d_h1, float *d_gen, float *d_nbar,
+                 float *dz, float *coef_a, float *coef_g, int32_t *step_counter, ggad_stream_t stream) {
+  GGAD_REQUIRE(params && h1 && nbar && gen && labels && pos_meta && row_pos && ent_ptr && loss_ws && losses8);
+  GGAD_REQUIRE(dz && coef_a && coef_g);
+  GGAD_REQUIRE((d_h1 == nullptr) == (d_gen == nullptr) && (d_h1 == nullptr) == (d_nbar == nullptr));
   GGAD_REQUIRE(dims_ok(D, F) && n_rows >= 1 && row0 >= 0);
   ParamLayout L{D, F};
-  k_loss<<<dim3(1), dim3(LOSS_T), 0, as_stream(stream)>>>(params, L, h1, nbar, gen, labels, pos_meta, ent_ptr, row0, n_rows,
-                                                         losses8, d_h1, d_gen, d_nbar, dz, coef_a, coef_g, grad_w,
-                                                         step_counter);
+  const int nwg = loss_nwg(n_rows);
+  float *pos_scal = loss_ws, *part = loss_ws + (int64_t)n_rows * 8, *gw_part = part + (int64_t)nwg * 8;
+  hipStream_t st = as_stream(stream);
+  k_loss_pos<<<dim3(nwg), dim3(256), 0, st>>>(params, D, h1, nbar, gen, pos_meta, row0, n_rows, pos_scal, part);
+  k_loss_rows<<<dim3(nwg), dim3(256), 0, st>>>(params, L, h1, nbar, gen, labels, pos_meta, row_pos, ent_ptr, row0, n_rows,
+                                              pos_scal, part, gw_part, losses8, d_h1, d_gen, d_nbar, dz, coef_a, coef_g,
+                                              step_counter);
   GGAD_CHECK_LAUNCH("mb_loss");
   return GGAD_OK;
 }
@@ -668,13 +706,16 @@ int ggad_mb_bwd_flat(int32_t D, int32_t F, const float *x1, const float *x2, con
   return GGAD_OK;
 }
 
-int ggad_mb_grad_reduce(int32_t D, int32_t F, const int32_t *pos_meta, int32_t row0, const float *losses8,
-                        const float *nbar, const float *dw_part, const float *dz, const float *grad_w, float *grads,
-                        ggad_stream_t stream) {
-  GGAD_REQUIRE(pos_meta && losses8 && nbar && dw_part && dz && grad_w && grads && dims_ok(D, F));
+int ggad_mb_grad_reduce(int32_t D, int32_t F, const int32_t *pos_meta, int32_t row0, int32_t n_rows,
+                        const float *losses8, const float *nbar, const float *dw_part, const float *dz,
+                        const float *loss_ws, float *grads, ggad_stream_t stream) {
+  GGAD_REQUIRE(pos_meta && losses8 && nbar && dw_part && dz && loss_ws && grads && dims_ok(D, F) && n_rows >= 1);
   ParamLayout L{D, F};
-  k_grad_reduce<false><<<dim3((L.n_train() + 255) / 256), dim3(256), 0, as_stream(stream)>>>(
-      L, pos_meta, row0, losses8, nbar, dw_part, BWD_PARTS, dz, grad_w, grads, nullptr, nullptr, nullptr, 0.f, 0.f, nullptr);
+  const int nwg = loss_nwg(n_rows);
+  const float *gw_part = loss_ws + (int64_t)n_rows * 8 + (int64_t)nwg * 8;
+  k_grad_reduce<false><<<dim3((L.n_train() + 63) / 64), dim3(64, 4), 0, as_stream(stream)>>>(
+      L, pos_meta, row0, losses8, nbar, dw_part, BWD_PARTS, dz, gw_part, nwg, grads, nullptr, nullptr, nullptr, 0.f, 0.f,
+      nullptr);
   GGAD_CHECK_LAUNCH("mb_grad_reduce");
   return GGAD_OK;
 }
@@ -710,17 +751,20 @@ int ggad_mb_train_step(const ggad_mb_step *s, int32_t fuse_adam, ggad_stream_t s
   if ((rc = ggad_mb_project(s->params, D, F, s->x2, s->ent_own, s->ent0, s->n_ents, s->h2, stream))) return rc;
   if ((rc = ggad_mb_fwd_rows(s->params, D, F, s->x1, s->h2, s->ent_ptr, s->ent_own, s->labels, s->row0, s->n_rows, s->ent0,
                              s->h1, s->nbar, s->gen, stream))) return rc;
-  if ((rc = ggad_mb_loss(s->params, D, F, s->h1, s->nbar, s->gen, s->labels, s->pos_meta, s->ent_ptr, s->row0, s->n_rows,
-                         s->losses8, s->d_h1, s->d_gen, s->d_nbar, s->dz, s->coef_a, s->coef_g, s->grad_w, s->step_counter,
-                         stream))) return rc;
+  if ((rc = ggad_mb_loss(s->params, D, F, s->h1, s->nbar, s->gen, s->labels, s->pos_meta, s->row_pos, s->ent_ptr, s->row0,
+                         s->n_rows, s->loss_ws, s->losses8, nullptr, nullptr, nullptr, s->dz, s->coef_a, s->coef_g,
+                         s->step_counter, stream))) return rc;
   if ((rc = ggad_mb_bwd_flat(D, F, s->x1, s->x2, s->h2, s->ent_own, s->ent_row, s->row0, s->n_rows, s->ent0, s->n_ents,
                              s->coef_a, s->coef_g, s->dw_part, stream))) return rc;
   if (!fuse_adam)
-    return ggad_mb_grad_reduce(D, F, s->pos_meta, s->row0, s->losses8, s->nbar, s->dw_part, s->dz, s->grad_w, s->grads, stream);
+    return ggad_mb_grad_reduce(D, F, s->pos_meta, s->row0, s->n_rows, s->losses8, s->nbar, s->dw_part, s->dz, s->loss_ws,
+                               s->grads, stream);
   ParamLayout L{D, F};
-  k_grad_reduce<true><<<dim3((L.n_train() + 255) / 256), dim3(256), 0, as_stream(stream)>>>(
-      L, s->pos_meta, s->row0, s->losses8, s->nbar, s->dw_part, BWD_PARTS, s->dz, s->grad_w, s->grads, s->params, s->exp_avg,
-      s->exp_avg_sq, s->lr, s->weight_decay, s->step_counter);
+  const int nwg = loss_nwg(s->n_rows);
+  const float *gw_part = s->loss_ws + (int64_t)s->n_rows * 8 + (int64_t)nwg * 8;
+  k_grad_reduce<true><<<dim3((L.n_train() + 63) / 64), dim3(64, 4), 0, as_stream(stream)>>>(
+      L, s->pos_meta, s->row0, s->losses8, s->nbar, s->dw_part, BWD_PARTS, s->dz, gw_part, nwg, s->grads, s->params,
+      s->exp_avg, s->exp_avg_sq, s->lr, s->weight_decay, s->step_counter);
   GGAD_CHECK_LAUNCH("mb_train_step");
   return GGAD_OK;
 }

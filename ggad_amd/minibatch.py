@@ -83,8 +83,8 @@ class BatchChunk:
         d = self.dev
         self.rows_cap = cap
         self.generation += 1
-        # one int32 staging block uploaded per build: batch_ptr | nodes | labels | pos_meta
-        n_stage = self.max_batches + 1 + 3 * cap
+        # one int32 staging block uploaded per build: batch_ptr | nodes | labels | pos_meta | row_pos
+        n_stage = self.max_batches + 1 + 4 * cap
         self.stage_host = torch.empty(n_stage, dtype=torch.int32)
         if d.type == "cuda":
             self.stage_host = self.stage_host.pin_memory()
@@ -94,6 +94,7 @@ class BatchChunk:
         self.nodes = self.stage[o:o + cap]
         self.labels = self.stage[o + cap:o + 2 * cap]
         self.pos_meta = self.stage[o + 2 * cap:o + 3 * cap]
+        self.row_pos = self.stage[o + 3 * cap:o + 4 * cap]
         self.row_r = _i32(cap, d)
         self.row_slot = _i32(cap, d)
         self.ent_ptr = _i32(cap + 1, d)
@@ -102,8 +103,8 @@ class BatchChunk:
         if self.train:
             n = cap * self.D
             self.h1, self.nbar, self.gen = _f32(n, d), _f32(n, d), _f32(n, d)
-            self.d_h1, self.d_gen, self.d_nbar, self.dz = _f32(n, d), _f32(n, d), _f32(n, d), _f32(n, d)
-            self.coef_a, self.coef_g = _f32(n, d), _f32(n, d)
+            self.dz, self.coef_a, self.coef_g = _f32(n, d), _f32(n, d), _f32(n, d)
+            self.d_h1 = self.d_gen = self.d_nbar = None        # raw loss gradients: allocated on demand (debug / tests)
 
     def _alloc_ents(self, cap: int) -> None:
         cap = int(cap)
@@ -159,13 +160,17 @@ class BatchChunk:
             st[o + cap:o + cap + rows] = lab
             # column q of `combined_all` holds the label-0 rows in order, then the label-1 rows (graphsage.py:450);
             # pos_meta[q] = (src_row << 2) | (label[src] << 1) | label[q]
+            # row_pos[row] = column of that row (inverse permutation, batch-relative)
             meta = np.empty(rows, dtype=np.int64)
+            rpos = np.empty(rows, dtype=np.int64)
             for b in range(nb):
                 r0, r1 = bp[b], bp[b + 1]
                 lb = lab[r0:r1]
                 order = np.argsort(lb != 0, kind="stable")
                 meta[r0:r1] = ((order + r0) << 2) | (lb[order] << 1) | lb
+                rpos[r0 + order] = np.arange(r1 - r0)
             st[o + 2 * cap:o + 2 * cap + rows] = meta
+            st[o + 3 * cap:o + 3 * cap + rows] = rpos
         self.stage.copy_(self.stage_host, non_blocking=True)
         if self.dev.type == "cuda":
             self._stage_evt = torch.cuda.Event()
@@ -251,7 +256,7 @@ class MiniBatchEngine:
         self.exp_avg = torch.zeros(self.n_train, dtype=torch.float32, device=self.dev)
         self.exp_avg_sq = torch.zeros(self.n_train, dtype=torch.float32, device=self.dev)
         self.grads = torch.zeros(self.n_train, dtype=torch.float32, device=self.dev)
-        self.grad_w = torch.zeros(self.D, dtype=torch.float32, device=self.dev)
+        self.loss_ws = _f32(self.lib.ggad_mb_loss_workspace_elems(256), self.dev)
         self.step_counter = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self.n_parts = int(self.lib.ggad_mb_bwd_parts())
         self.dw_part = torch.zeros(self.n_parts * self.F * self.D, dtype=torch.float32, device=self.dev)
@@ -284,6 +289,10 @@ class MiniBatchEngine:
         need = max(1, ch.max_batch_ents()) * self.D
         if self.h2.numel() < need:
             self.h2 = _f32(int(need * 1.25), self.dev)
+        max_rows = int(np.diff(ch.batch_ptr_host).max()) if ch.n_batches else 1
+        need = int(self.lib.ggad_mb_loss_workspace_elems(max_rows))
+        if self.loss_ws.numel() < need:
+            self.loss_ws = _f32(need, self.dev)
         if self.loss_log.numel() < 8 * log_slots:
             new = torch.zeros(8 * max(log_slots, 2 * (self.loss_log.numel() // 8)), dtype=torch.float32, device=self.dev)
             new[:self.loss_log.numel()].copy_(self.loss_log)
@@ -298,11 +307,10 @@ class MiniBatchEngine:
         s.step_counter = ptr(self.step_counter)
         s.x1, s.x2 = ptr(ch.x1), ptr(ch.x2)
         s.ent_ptr, s.ent_own, s.ent_row = ptr(ch.ent_ptr), ptr(ch.ent_own), ptr(ch.ent_row)
-        s.labels, s.pos_meta = ptr(ch.labels), ptr(ch.pos_meta)
+        s.labels, s.pos_meta, s.row_pos = ptr(ch.labels), ptr(ch.pos_meta), ptr(ch.row_pos)
         s.h1, s.nbar, s.gen = ptr(ch.h1), ptr(ch.nbar), ptr(ch.gen)
-        s.d_h1, s.d_gen, s.d_nbar, s.dz = ptr(ch.d_h1), ptr(ch.d_gen), ptr(ch.d_nbar), ptr(ch.dz)
-        s.coef_a, s.coef_g = ptr(ch.coef_a), ptr(ch.coef_g)
-        s.h2, s.dw_part, s.grad_w = ptr(self.h2), ptr(self.dw_part), ptr(self.grad_w)
+        s.dz, s.coef_a, s.coef_g = ptr(ch.dz), ptr(ch.coef_a), ptr(ch.coef_g)
+        s.h2, s.dw_part, s.loss_ws = ptr(self.h2), ptr(self.dw_part), ptr(self.loss_ws)
         s.losses8 = self.loss_log.data_ptr() + 32 * log_slot
         s.D, s.F, s.row0, s.n_rows, s.ent0, s.n_ents = self.D, self.F, r0, r1 - r0, e0, e1 - e0
         s.lr, s.weight_decay = self.lr, self.wd

@@ -134,17 +134,19 @@ int ggad_mb_fwd_rows(const float *params, int32_t D, int32_t F, const float *x1,
                      const int32_t *ent_own, const int32_t *labels, int32_t row0, int32_t n_rows, int32_t ent0, float *h1,
                      float *nbar, float *gen, ggad_stream_t stream);
 
-/* Batch loss (graphsage.py:174,192-258) and its gradient w.r.t. the three row tensors
- * (d_h1, d_gen, d_nbar; rows [row0, row0+n_rows)) and w.r.t. the scorer `weight` (grad_w[D]).
+/* Batch loss (graphsage.py:174,192-258), two launches (one wave per position, then one wave per row).
  * pos_meta[q] = (src << 2) | (src_is_label1 << 1) | label[q], src = row whose embedding sits at column q
- * of `combined_all` (label-0 rows first, generated outliers last, :450); labels are paired in ORIGINAL
- * order (quirk 1).  losses8 = {total, cls, margin, rec, 0.1/n1, margin_active, n0, n1}.
- * If coef_a/coef_g/dz are not NULL the per-row backward coefficients (see ggad_mb_row_coefs) are produced
- * in the same launch.  If step_counter is not NULL it is incremented (Adam step index). */
+ * of `combined_all` (label-0 rows first, generated outliers last, :450); row_pos[row] = column of that row;
+ * labels are paired in ORIGINAL order (quirk 1).
+ * Outputs: losses8 = {total, cls, margin, rec, 0.1/n1, margin_active, n0, n1}; the per-row backward
+ * coefficients dz / coef_a / coef_g (see ggad_mb_row_coefs) of the TOTAL loss; the partial sums of d w in
+ * loss_ws (float[ggad_mb_loss_workspace_elems(n_rows)], consumed by ggad_mb_grad_reduce); optionally the raw
+ * gradients d_h1 / d_gen / d_nbar (all three or none).  If step_counter is not NULL it is incremented. */
+int64_t ggad_mb_loss_workspace_elems(int32_t n_rows);
 int ggad_mb_loss(const float *params, int32_t D, int32_t F, const float *h1, const float *nbar, const float *gen,
-                 const int32_t *labels, const int32_t *pos_meta, const int32_t *ent_ptr, int32_t row0, int32_t n_rows,
-                 float *losses8, float *d_h1, float *d_gen, float *d_nbar, float *dz, float *coef_a, float *coef_g,
-                 float *grad_w, int32_t *step_counter, ggad_stream_t stream);
+                 const int32_t *labels, const int32_t *pos_meta, const int32_t *row_pos, const int32_t *ent_ptr,
+                 int32_t row0, int32_t n_rows, float *loss_ws, float *losses8, float *d_h1, float *d_gen, float *d_nbar,
+                 float *dz, float *coef_a, float *coef_g, int32_t *step_counter, ggad_stream_t stream);
 
 /* Vector-Jacobian product of project + fwd_rows for arbitrary upstream gradients (layered autograd API):
  *   row_coefs: coef_a = d_h1 [h1>0];  dz = d_gen [gen>0];  coef_g = (d_nbar + fc^T dz) / r
@@ -159,9 +161,9 @@ int ggad_mb_bwd_flat(int32_t D, int32_t F, const float *x1, const float *x2, con
                      const float *coef_a, const float *coef_g, float *dw_part, ggad_stream_t stream);
 
 /* Reduce the partials into the packed gradient buffer grads[D + D*F + D*D] (w | W | fc). */
-int ggad_mb_grad_reduce(int32_t D, int32_t F, const int32_t *pos_meta, int32_t row0, const float *losses8,
-                        const float *nbar, const float *dw_part, const float *dz, const float *grad_w, float *grads,
-                        ggad_stream_t stream);
+int ggad_mb_grad_reduce(int32_t D, int32_t F, const int32_t *pos_meta, int32_t row0, int32_t n_rows,
+                        const float *losses8, const float *nbar, const float *dw_part, const float *dz,
+                        const float *loss_ws, float *grads, ggad_stream_t stream);
 
 /* torch.optim.Adam.step (betas .9/.999, eps 1e-8, L2 weight decay added to the gradient) on the
  * packed block; grad_scale multiplies the gradient first (1/world_size after an all-reduce sum).
@@ -177,9 +179,9 @@ typedef struct ggad_mb_step {
   float *params, *exp_avg, *exp_avg_sq, *grads;
   int32_t *step_counter;
   const float *x1, *x2;
-  const int32_t *ent_ptr, *ent_own, *ent_row, *labels, *pos_meta;
-  float *h1, *nbar, *gen, *d_h1, *d_gen, *d_nbar, *dz, *coef_a, *coef_g;
-  float *h2, *dw_part, *grad_w, *losses8;
+  const int32_t *ent_ptr, *ent_own, *ent_row, *labels, *pos_meta, *row_pos;
+  float *h1, *nbar, *gen, *dz, *coef_a, *coef_g;
+  float *h2, *dw_part, *loss_ws, *losses8;
   int32_t D, F, row0, n_rows, ent0, n_ents;
   float lr, weight_decay;
 } ggad_mb_step;
