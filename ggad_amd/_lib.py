@@ -53,6 +53,8 @@ SIGNATURES = {
     "ggad_mb_grad_reduce": (c_int32, [_I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "ggad_mb_adam": (c_int32, [_P, _P, _P, _P, _I, _I, _F, _F, _F, _P, _P]),
     "ggad_mb_train_step": (c_int32, [_P, _I, _P]),
+    "ggad_mb_encode": (c_int32, [_P, _I, _I, _P, _I, _P, _P]),
+    "ggad_seg_mean": (c_int32, [_P, _I, _P, _P, _I, _P, _P]),
     "ggad_mb_score": (c_int32, [_P, _I, _I, _P, _I, _P, _P]),
     "ggad_mt_new": (c_void_p, []),
     "ggad_mt_free": (None, [c_void_p]),

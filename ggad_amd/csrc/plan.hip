@@ -210,6 +210,34 @@ __global__ void __launch_bounds__(256) k_gather1(const float *__restrict__ feat,
   }
 }
 
+// out[row] = mean of feat rows over an explicit ragged neighbour list (MeanAggregator, graphsage.py:66-99)
+__global__ void __launch_bounds__(256) k_seg_mean(const float *__restrict__ feat, int F, const int32_t *__restrict__ seg_ptr,
+                                                  const int32_t *__restrict__ seg_col, int n_rows, float *__restrict__ out) {
+  const int row = blockIdx.x * (blockDim.x / GGAD_WAVE) + threadIdx.x / GGAD_WAVE;
+  if (row >= n_rows) return;
+  const int lane = lane_id();
+  const int e0 = seg_ptr[row], e1 = seg_ptr[row + 1];
+  const int r = e1 - e0;
+  const float inv = 1.0f / (float)r;                       // mask.div(num_neigh)            graphsage.py:92-93
+  const int rpi = F <= 64 ? 64 / F : 1;
+  const int fchunks = F <= 64 ? 1 : (F + 63) / 64;
+  for (int fc = 0; fc < fchunks; ++fc) {
+    const int fbase = fc * 64;
+    const int fw = F <= 64 ? F : min(64, F - fbase);
+    const int g = lane / fw, f = lane - g * fw;
+    const bool lane_active = g < rpi;
+    float acc = 0.0f;
+    for (int blk = 0; blk < r; blk += GGAD_WAVE) {
+      const int idx = blk + lane;
+      int j = 0; float w = 0.0f;
+      if (idx < r) { j = seg_col[e0 + idx]; w = inv; }
+      gather_block(feat, F, fbase, rpi, g, f, lane_active, j, w, min(GGAD_WAVE, r - blk), acc);
+    }
+    const float tot = (F <= 64) ? reduce_groups(acc, fw, rpi) : acc;
+    if (lane < fw) out[(int64_t)row * F + fbase + lane] = tot;
+  }
+}
+
 __global__ void __launch_bounds__(256) k_count2(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                 const int32_t *__restrict__ ent_col, const int32_t *__restrict__ ent_slot,
                                                 const int32_t *__restrict__ ent_total, int64_t n_nodes,
@@ -329,6 +357,15 @@ int ggad_mb_gather1(const float *feat, int32_t feat_dim, const int32_t *row_slot
   k_gather1<<<dim3((n_rows + 3) / 4), dim3(256), 0, as_stream(stream)>>>(feat, feat_dim, row_slot, ent_ptr, ent_col, n_rows,
                                                                          n_nodes, cnt1, own1, ent_own, ent_c1, x1);
   GGAD_CHECK_LAUNCH("mb_gather1");
+  return GGAD_OK;
+}
+
+int ggad_seg_mean(const float *feat, int32_t feat_dim, const int32_t *seg_ptr, const int32_t *seg_col, int32_t n_rows,
+                  float *out, ggad_stream_t stream) {
+  GGAD_REQUIRE(feat && seg_ptr && seg_col && out && feat_dim >= 1 && feat_dim <= GGAD_MAX_F && n_rows >= 0);
+  if (n_rows == 0) return GGAD_OK;
+  k_seg_mean<<<dim3((n_rows + 3) / 4), dim3(256), 0, as_stream(stream)>>>(feat, feat_dim, seg_ptr, seg_col, n_rows, out);
+  GGAD_CHECK_LAUNCH("seg_mean");
   return GGAD_OK;
 }
 

@@ -602,6 +602,24 @@ __global__ void __launch_bounds__(256) k_score(const float *__restrict__ params,
   }
 }
 
+// h[row][d] = relu(W x1[row]) for every row (inference embeddings, GCNEncoder.forward with train_flag False)
+__global__ void __launch_bounds__(256) k_encode(const float *__restrict__ params, ParamLayout L, const float *__restrict__ x1,
+                                                int n_rows, float *__restrict__ h) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int D = L.D, F = L.F;
+  const float *Wt = params + L.o_Wt();
+  for (int i = threadIdx.x; i < F * D; i += blockDim.x) lds[i] = Wt[i];
+  __syncthreads();
+  const int lane = lane_id(), d = lane < D ? lane : D - 1;
+  const int wpb = blockDim.x / 64;
+  for (int row = blockIdx.x * wpb + threadIdx.x / 64; row < n_rows; row += gridDim.x * wpb) {
+    const float *x = x1 + (int64_t)row * F;
+    float acc = 0.0f;
+    for (int f = 0; f < F; ++f) acc = fmaf(lds[f * D + d], x[f], acc);
+    if (lane < D) h[(int64_t)row * D + lane] = fmaxf(acc, 0.0f);                  // graphsage.py:412
+  }
+}
+
 bool dims_ok(int D, int F) { return D >= 1 && D <= GGAD_MAX_D && F >= 1 && (size_t)(4 * F * D + 512) * 4 <= 150 * 1024; }
 
 }  // namespace
@@ -739,6 +757,17 @@ int ggad_mb_score(const float *params, int32_t D, int32_t F, const float *x1, in
   const int blocks = (n_rows + 3) / 4 < 4096 ? (n_rows + 3) / 4 : 4096;
   k_score<<<dim3(blocks), dim3(256), (size_t)F * D * 4, as_stream(stream)>>>(params, L, x1, n_rows, prob);
   GGAD_CHECK_LAUNCH("mb_score");
+  return GGAD_OK;
+}
+
+int ggad_mb_encode(const float *params, int32_t D, int32_t F, const float *x1, int32_t n_rows, float *h,
+                   ggad_stream_t stream) {
+  GGAD_REQUIRE(params && x1 && h && dims_ok(D, F) && n_rows >= 0);
+  if (n_rows == 0) return GGAD_OK;
+  ParamLayout L{D, F};
+  const int blocks = (n_rows + 3) / 4 < 4096 ? (n_rows + 3) / 4 : 4096;
+  k_encode<<<dim3(blocks), dim3(256), (size_t)F * D * 4, as_stream(stream)>>>(params, L, x1, n_rows, h);
+  GGAD_CHECK_LAUNCH("mb_encode");
   return GGAD_OK;
 }
 

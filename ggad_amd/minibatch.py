@@ -75,6 +75,7 @@ class BatchChunk:
         self.batch_ptr_host = np.zeros(1, dtype=np.int32)
         self.ent_ptr_host = np.zeros(1, dtype=np.int64)
         self.dirty = False
+        self.build_count = 0
         self.gather2_events = None      # optional (start, end) torch events recorded around the gather2 launch
 
     # ---- allocation
@@ -176,6 +177,7 @@ class BatchChunk:
             self._stage_evt = torch.cuda.Event()
             self._stage_evt.record()
         self.n_batches, self.n_rows, self.n_ents = nb, rows, n_ents
+        self.build_count += 1
         self.batch_ptr_host = bp
         self.ent_ptr_host = ent_ptr_host
         g = self.g

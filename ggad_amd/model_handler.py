@@ -1,0 +1,145 @@
+"""`ModelHandler` -- drop-in for the reference's DGraph driver (`src/model_handler.py`).
+
+    ModelHandler(config).train() -> (f1_macro, f1_binary_1, f1_binary_0, auc, gmean)
+
+Same config keys (`src/dgraph.yml`), same split, same batch schedule for equal seeds, same prints,
+same checkpoint format (state_dict keys of `GCN`).  What differs is where the work runs: the batch
+sub-graphs, the aggregation, the model step and Adam are HIP kernels on the MI355X; the python
+`random` stream is continued by the native sampler; validation scores thousands of reference batches
+per launch.  Only ``model: 'GCN'`` is runnable -- as in the reference.
+
+Extra, optional config keys:  ``device`` (cuda index), ``num_batches`` (default 150, the reference's
+hard override `:317`), ``data`` = (adj_lists | DeviceGraph | (rowptr, col), feat_data, labels) to bypass
+the file loader, ``log_every``.  Under `torch.distributed` (backend nccl = RCCL) batches are dealt
+round-robin over the ranks and gradients are all-reduced once per step.
+"""
+from __future__ import annotations
+
+import argparse
+import datetime
+import os
+import random
+import time
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .dgraph import load_dgraphfin, normalize_features, split_dgraphfin
+from .graph import DeviceGraph
+from .graphsage import GCN, FeatureTable, GCNAggregator, GCNEncoder
+from .sage_utils import test_sage
+from .sampler import PyCompatRandom
+from .trainer import BatchSchedule, DGraphTrainer
+
+
+class ModelHandler(object):
+
+    def __init__(self, config):
+        args = argparse.Namespace(**config)
+        data = getattr(args, "data", None)
+        if data is not None:
+            homo, feat_data, labels = data
+            labels = np.array(labels)
+        elif args.data_name == "dgraphfin":
+            homo, feat_data, labels = load_dgraphfin("../data/dgraphfin.npz", args.data_dir + "dgraphfin_adj_list")
+        else:
+            raise ValueError("only data_name 'dgraphfin' (or an explicit `data` entry) is supported by the GGAD path")
+        sp = split_dgraphfin(labels, args.seed, getattr(args, "test_ratio", 0.67))     # model_handler.py:29-30,150-178
+        labels = sp["labels"]
+        print(f"Run on {args.data_name}, postive/total num: {np.sum(labels)}/{len(labels)}, train num {len(sp['y_train'])}," +
+              f"valid num {len(sp['y_valid'])}, valid positive num {np.sum(sp['y_valid'])} , test num {len(sp['y_test'])}, "
+              f"test positive num {np.sum(sp['y_test'])}")
+        print(f"Classification threshold: {args.thres}")
+        print(f"Feature dimension: {feat_data.shape[1]}")
+        feat_data = normalize_features(feat_data)                                      # model_handler.py:225
+        print(f"Model: {args.model}, multi-relation aggregator: {args.multi_relation}, emb_size: {args.emb_size}.")
+        self.args = args
+        self.dataset = {"feat_data": feat_data, "labels": labels, "adj_lists": homo, "homo": homo,
+                        "idx_train": sp["idx_train"], "idx_valid": sp["idx_valid"], "idx_test": sp["idx_test"],
+                        "y_train": sp["y_train"], "y_valid": sp["y_valid"], "y_test": sp["y_test"],
+                        "idx_labeled": sp["idx_labeled"], "idx_anomaly": sp["idx_anomaly"]}
+
+    def train(self):
+        args = self.args
+        if args.model != "GCN":
+            raise NotImplementedError("only model 'GCN' is trainable, as in the reference (SURVEY.md §3.2 quirk 7)")
+        if not torch.cuda.is_available():
+            raise RuntimeError("ModelHandler.train needs an MI355X: the GGAD hot path has no CPU fallback")
+        dist = torch.distributed if (torch.distributed.is_available() and torch.distributed.is_initialized()) else None
+        world = dist.get_world_size() if dist else 1
+        rank = dist.get_rank() if dist else 0
+        dev = torch.device("cuda", int(getattr(args, "device", torch.cuda.current_device())))
+        torch.cuda.set_device(dev)
+        feat_data, adj_lists = self.dataset["feat_data"], self.dataset["adj_lists"]
+        idx_train = self.dataset["idx_train"]
+        idx_valid, y_valid, idx_test, y_test = (self.dataset["idx_test"], self.dataset["y_test"],
+                                                self.dataset["idx_test"], self.dataset["y_test"])   # :260-261
+        n, f = feat_data.shape
+        # same RNG consumption as the reference: nn.Embedding's default init draws N x F normals (:263)
+        nn.Embedding(n, f)
+        if isinstance(adj_lists, DeviceGraph):
+            graph = adj_lists
+        elif isinstance(adj_lists, tuple):
+            graph = DeviceGraph(adj_lists[0], adj_lists[1], dev)
+        else:
+            graph = DeviceGraph.from_adj_lists(adj_lists, n, dev)
+        features = FeatureTable(torch.FloatTensor(np.asarray(feat_data, dtype=np.float32)))
+        agg_gcn = GCNAggregator(features, cuda=True)
+        enc_gcn = GCNEncoder(features, f, args.emb_size, graph, agg_gcn, gcn=True, cuda=True)
+        gnn_model = GCN(2, enc_gcn)
+        engine = enc_gcn.engine
+        engine.lr, engine.wd = float(args.lr), float(args.weight_decay)
+        engine.sync_params()
+
+        timestamp = datetime.datetime.fromtimestamp(int(time.time())).strftime("%Y-%m-%d %H-%M-%S")
+        dir_saver = args.save_dir + timestamp
+        path_saver = os.path.join(dir_saver, "{}_{}.pkl".format(args.data_name, args.model))
+        f1_mac_best, auc_best, ep_best = 0, 0, -1
+
+        num_batches = int(getattr(args, "num_batches", 150))                            # :317
+        rng = PyCompatRandom.from_python_state(random.getstate())
+        sched = BatchSchedule(idx_train, self.dataset["idx_anomaly"], self.dataset["labels"], args.batch_size, rng,
+                              n_pseudo=50, batches_per_epoch=num_batches)
+        allreduce = None
+        if world > 1:
+            def allreduce(t):
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        steps_per_epoch = max(1, num_batches // world)
+        trainer = DGraphTrainer(graph, features.weight.data, args.emb_size, sched, chunk_batches=steps_per_epoch, rank=rank,
+                                world_size=world, allreduce=allreduce, engine=engine)
+        self.trainer, self.model = trainer, gnn_model
+        total_time = 0.0
+        for epoch in range(args.num_epochs):
+            t0 = time.time()
+            trainer.run_steps(steps_per_epoch)
+            torch.cuda.synchronize()
+            epoch_time = time.time() - t0
+            l = engine.losses(steps_per_epoch).astype(np.float64)
+            self.last_epoch_losses = l
+            if rank == 0:
+                print(f"Epoch: {epoch}, loss: {l[:, 0].mean()}, marigin_loss: {l[:, 2].mean()}, time: {epoch_time}s")
+                print("loss_cls", l[:, 1].mean())
+                print("total_time is", total_time)
+                print("loss_constraint", l[:, 2].mean())
+            if epoch % args.valid_epochs == 0 and rank == 0:
+                print("Valid at epoch {}".format(epoch))
+                f1_mac_val, f1_1_val, f1_0_val, auc_val, gmean_val = test_sage(idx_valid, y_valid, gnn_model,
+                                                                               args.batch_size, args.thres)
+                if auc_val > auc_best:
+                    f1_mac_best, auc_best, ep_best = f1_mac_val, auc_val, epoch
+                    if not os.path.exists(dir_saver):
+                        os.makedirs(dir_saver)
+                    print("  Saving model ...")
+                    torch.save(gnn_model.state_dict(), path_saver)
+            if dist:
+                dist.barrier()
+            total_time += time.time() - t0
+        random.setstate(rng.to_python_state())       # hand the stream back to python `random`
+        if rank == 0 and ep_best >= 0:
+            print("Restore model from epoch {}".format(ep_best))
+            print("Model path: {}".format(path_saver))
+            gnn_model.load_state_dict(torch.load(path_saver))
+            engine.sync_params()
+        res = test_sage(idx_test, y_test, gnn_model, args.batch_size, args.thres) if rank == 0 else (0, 0, 0, 0, 0)
+        return res

@@ -1,0 +1,78 @@
+"""Evaluation helpers of the DGraph path (reference `src/utils.py:207-260,324-326`), host side.
+
+Scores come from the HIP inference path (`GCN.to_prob` semantics: per-batch normalisation with the
+reference's batch boundaries); the metrics themselves are sklearn's, as in the reference."""
+from __future__ import annotations
+
+from typing import Sequence
+
+import numpy as np
+import torch
+from sklearn.metrics import average_precision_score, confusion_matrix, f1_score, roc_auc_score
+
+from .minibatch import BatchChunk
+
+
+def prob2pred(y_prob: np.ndarray, thres: float = 0.5) -> np.ndarray:
+    """`src/utils.py:250-260`."""
+    return (np.asarray(y_prob) >= thres).astype(np.int32)
+
+
+def conf_gmean(conf: np.ndarray) -> float:
+    """`src/utils.py:324-326`."""
+    tn, fp, fn, tp = conf.ravel()
+    return float((tp * tn / ((tp + fn) * (tn + fp))) ** 0.5)
+
+
+def score_nodes(model, test_cases: Sequence[int], batch_size: int, batches_per_launch: int = 2048) -> np.ndarray:
+    """Probabilities for `test_cases`, batched EXACTLY like `test_sage` (`src/utils.py:216-230`):
+    consecutive slices of `batch_size`; the column counts of the aggregation are per slice (quirk 2).
+    Thousands of reference batches are planned and scored per launch group."""
+    enc = model.enc
+    eng = enc.engine
+    cases = np.asarray(test_cases, dtype=np.int64)
+    n = len(cases)
+    out = torch.empty(n, dtype=torch.float32, device=eng.dev)
+    if n == 0:
+        return out.cpu().numpy()
+    from .graphsage import _as_graph
+    graph = _as_graph(enc.adj_lists, enc.features.weight.shape[0], eng.dev)
+    # slots are N ints per batch: bound the number of batches in flight by memory (<= ~2 GiB of counters)
+    per_launch = int(max(1, min(batches_per_launch, (1 << 29) // max(1, graph.n))))
+    key = ("eval", id(graph), per_launch)
+    cache = getattr(model, "_eval_chunks", None)
+    if cache is None:
+        cache = model._eval_chunks = {}
+    ch = cache.get(key)
+    if ch is None:
+        ch = cache[key] = BatchChunk(graph, enc.features.weight.data, enc.embed_dim, per_launch,
+                                     per_launch * batch_size, per_launch * batch_size * 8, train=False)
+    eng.sync_params()
+    step = per_launch * batch_size
+    for s in range(0, n, step):
+        part = cases[s:s + step]
+        batches = [part[i:i + batch_size] for i in range(0, len(part), batch_size)]
+        ch.build(batches)
+        eng.score_chunk(ch, out[s:s + len(part)])
+    ch.reset()
+    return out.cpu().numpy()
+
+
+def test_sage(test_cases, labels, model, batch_size, thres=0.5):
+    """Reference `test_sage` (`src/utils.py:207-247`): same prints, same return tuple."""
+    probs = score_nodes(model, test_cases, batch_size)
+    preds = prob2pred(probs, thres)
+    labels = np.asarray(labels)
+    auc_gnn = roc_auc_score(labels, probs)
+    ap = average_precision_score(labels, probs, average="macro", pos_label=1, sample_weight=None)
+    f1_binary_1 = f1_score(labels, preds, pos_label=1, average="binary")
+    f1_binary_0 = f1_score(labels, preds, pos_label=0, average="binary")
+    f1_macro = f1_score(labels, preds, average="macro")
+    conf = confusion_matrix(labels, preds)
+    tn, fp, fn, tp = conf.ravel()
+    gmean = conf_gmean(conf)
+    print(f"   GNN F1-binary-1: {f1_binary_1:.4f}\tF1-binary-0: {f1_binary_0:.4f}" +
+          f"\tF1-macro: {f1_macro:.4f}\tG-Mean: {gmean:.4f}\tAUC: {auc_gnn:.4f}")
+    print("Testing AP:", ap)
+    print(f"   GNN TP: {tp}\tTN: {tn}\tFN: {fn}\tFP: {fp}")
+    return f1_macro, f1_binary_1, f1_binary_0, auc_gnn, gmean

@@ -85,6 +85,11 @@ int ggad_mb_gather1(const float *feat, int32_t feat_dim, const int32_t *row_slot
                     const int32_t *ent_col, int32_t n_rows, int64_t n_nodes, const int32_t *cnt1,
                     const int32_t *own1, int32_t *ent_own, int32_t *ent_c1, float *x1, ggad_stream_t stream);
 
+/* out[i] = mean of feat rows over the explicit ragged list seg_col[seg_ptr[i] .. seg_ptr[i+1])
+ * (MeanAggregator.forward with host-side sampling, graphsage.py:66-99). */
+int ggad_seg_mean(const float *feat, int32_t feat_dim, const int32_t *seg_ptr, const int32_t *seg_col, int32_t n_rows,
+                  float *out, ggad_stream_t stream);
+
 /* The per-entry kernels below launch one wave per entry for n_entries_cap entries (a host-side
  * upper bound, e.g. sum(deg+1)) and read the true count from *ent_total (= ent_ptr[n_rows]).
  *
@@ -186,6 +191,10 @@ typedef struct ggad_mb_step {
   float lr, weight_decay;
 } ggad_mb_step;
 int ggad_mb_train_step(const ggad_mb_step *step, int32_t fuse_adam, ggad_stream_t stream);
+
+/* Inference embeddings: h[i] = relu(W x1[i])  (GCNEncoder.forward, train_flag False).   graphsage.py:412 */
+int ggad_mb_encode(const float *params, int32_t D, int32_t F, const float *x1, int32_t n_rows, float *h,
+                   ggad_stream_t stream);
 
 /* Inference: prob[i] = sigmoid(w . relu(W x1[i]))                   graphsage.py:178-181 */
 int ggad_mb_score(const float *params, int32_t D, int32_t F, const float *x1, int32_t n_rows, float *prob,

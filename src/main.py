@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Entry point of the DGraph mini-batch GGAD run:  cd src && python main.py [--config dgraph.yml] [--multi_run]
+
+Mirrors the reference's `src/main.py` CLI (`--config`, `--multi_run`, YAML keys of dgraph.yml) on top of the
+MI355X-native `ggad_amd.model_handler.ModelHandler`.  For N GPUs launch it with
+`python -m torch.distributed.run --nproc-per-node N main.py ...`: batches are then sharded over the ranks."""
+import argparse
+import itertools
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import yaml
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from ggad_amd.model_handler import ModelHandler  # noqa: E402
+
+
+def set_random_seed(seed):
+    torch.manual_seed(seed)
+    torch.cuda.manual_seed_all(seed)
+    np.random.seed(seed)
+
+
+def print_config(config):
+    bar = "**************** MODEL CONFIGURATION ****************"
+    print(bar)
+    for key in sorted(config):
+        print("{}{} -->   {}".format(key, " " * (24 - len(key)), config[key]))
+    print(bar)
+
+
+def expand_grid(config):
+    """Every list-valued key is a swept hyper-parameter; yields one flat config per combination."""
+    swept = [k for k, v in config.items() if isinstance(v, list)]
+    fixed = {k: v for k, v in config.items() if k not in swept}
+    for combo in itertools.product(*(config[k] for k in swept)):
+        cfg = dict(fixed)
+        cfg.update(dict(zip(swept, combo)))
+        yield swept, cfg
+
+
+def run_once(config):
+    set_random_seed(config["seed"])
+    return ModelHandler(config).train()
+
+
+def main(config):
+    print_config(config)
+    f1_mac, f1_1, f1_0, auc, gmean = run_once(config)
+    print("F1-Macro: {}".format(f1_mac))
+    print("AUC: {}".format(auc))
+    print("G-Mean: {}".format(gmean))
+
+
+def multi_run_main(config):
+    print_config(config)
+    results = []
+    for i, (swept, cfg) in enumerate(expand_grid(config)):
+        print("Running {}:\n".format(i))
+        for k in swept:
+            cfg["save_dir"] += "{}_{}_".format(k, cfg[k])
+        print(cfg["save_dir"])
+        st = time.time()
+        results.append(run_once(cfg))
+        print("Running {} done, elapsed time {}s".format(i, time.time() - st))
+    arr = np.array(results, dtype=np.float64)
+    names = ["F1-Macro", "F1-binary-1", "F1-binary-0", "AUC", "G-Mean"]
+    for j in (0, 3, 4):
+        print("{}: {}".format(names[j], arr[:, j].tolist()))
+    for j, name in enumerate(names):
+        std = arr[:, j].std(ddof=1) if len(arr) > 1 else float("nan")
+        print("{}: {}+{}".format(name, arr[:, j].mean(), std))
+
+
+def init_distributed():
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        torch.distributed.init_process_group("nccl")
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=str, default="dgraph.yml", help="")
+    ap.add_argument("--multi_run", action="store_true", help="flag: multi run")
+    a = ap.parse_args()
+    with open(a.config, "r") as fh:
+        cfg = yaml.load(fh, Loader=yaml.FullLoader)
+    init_distributed()
+    (multi_run_main if a.multi_run else main)(cfg)
