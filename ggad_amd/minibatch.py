@@ -16,7 +16,7 @@ PyTorch is used for device memory and streams only; all arithmetic happens in li
 from __future__ import annotations
 
 import ctypes
-from typing import Optional, Sequence
+from typing import Callable, Optional, Sequence
 
 import numpy as np
 import torch
@@ -242,6 +242,16 @@ class BatchChunk:
         return int(np.diff(e).max()) if len(e) > 1 else 0
 
 
+def reduce_gradients(grads: torch.Tensor, world_size: int, allreduce: Optional[Callable]) -> float:
+    """The data-parallel exchange step: ONE all-reduce(SUM) of the packed gradient block; returns the scale
+    (1/W) the optimiser applies.  Kept separate so that the CPU (gloo) tests drive the very same contract."""
+    if world_size > 1:
+        if allreduce is None:
+            raise ValueError("world_size > 1 needs an all-reduce callable")
+        allreduce(grads)
+    return 1.0 / world_size
+
+
 class MiniBatchEngine:
     """Parameters, optimiser state and the per-batch kernel chain."""
 
@@ -337,9 +347,7 @@ class MiniBatchEngine:
             s = self.step_desc(ch, b, log_base + b)
             _lib.check(self.lib.ggad_mb_train_step(ctypes.byref(s), fuse, stream), "ggad_mb_train_step")
             if not fuse:
-                if allreduce is not None:
-                    allreduce(self.grads)
-                self.adam_step(1.0 / world_size)
+                self.adam_step(reduce_gradients(self.grads, world_size, allreduce))
 
     def forward_batch(self, ch: BatchChunk, b: int) -> None:
         """project + fwd_rows only (layered API / tests): fills ch.h1, ch.nbar, ch.gen for batch b."""

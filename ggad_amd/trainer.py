@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 from .graph import DeviceGraph
-from .minibatch import BatchChunk, MiniBatchEngine
+from .minibatch import BatchChunk, MiniBatchEngine, reduce_gradients  # noqa: F401 (re-exported)
 from .sampler import PyCompatRandom
 
 
@@ -101,3 +101,4 @@ class DGraphTrainer:
             done += k
         self.steps_done += n_steps
         return nodes_seen
+

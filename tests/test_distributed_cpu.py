@@ -1,0 +1,131 @@
+"""Data-parallel layer on CPU: 2 gloo ranks.
+
+The HIP kernels cannot run here, so the per-batch gradient engine is the CPU oracle; what is under test
+is the host logic the GPU path uses unchanged: the rank-independent batch stream and its round-robin
+dealing (`BatchSchedule.next_batches`), the single all-reduce(SUM) + 1/W contract (`reduce_gradients`)
+and that every rank ends with the same weights as a one-process run that averages the W gradients."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from ggad_amd import synth
+from ggad_amd.sampler import PyCompatRandom
+from ggad_amd.trainer import BatchSchedule, reduce_gradients
+from oracle import ggad_oracle as O
+
+
+def _inputs():
+    n, f, d = 3000, 17, 16
+    rowptr, col = synth.make_graph(n, 20000, 4, kind="powerlaw", max_degree=60)
+    feat = O.normalize_rows(synth.make_features(n, f, 4)).astype(np.float32)
+    labels = np.zeros(n, dtype=np.int64)
+    pool = np.arange(100, 400)
+    labels[pool] = 1
+    train = np.arange(400, 2400)
+    torch.manual_seed(3)
+    w = torch.nn.init.xavier_uniform_(torch.empty(1, d))
+    W = torch.nn.init.xavier_uniform_(torch.empty(d, f))
+    fc = torch.nn.init.xavier_uniform_(torch.empty(d, d))
+    return rowptr, col, feat, labels, train, pool, (w, W, fc)
+
+
+def _schedule(labels, train, pool):
+    return BatchSchedule(train.copy(), pool.copy(), labels, batch_size=30, rng=PyCompatRandom(72), n_pseudo=10,
+                         batches_per_epoch=5)
+
+
+def _flat_grads(p, rowptr, col, feat, nodes, lab):
+    for t in p.tensors():
+        t.grad = None
+    agg = O.aggregate_batch(rowptr, col, feat, nodes, True)
+    O.batch_loss(p, agg, lab)[0].backward()
+    return torch.cat([t.grad.reshape(-1) for t in p.tensors()])
+
+
+def _apply(p, opt, flat, scale):
+    off = 0
+    for t in p.tensors():
+        k = t.numel()
+        t.grad = (flat[off:off + k] * scale).view_as(t).clone()
+        off += k
+    opt.step()
+
+
+def _worker(rank, world, port, steps, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    rowptr, col, feat, labels, train, pool, init = _inputs()
+    sched = _schedule(labels, train, pool)
+    p = O.MiniParams(*[t.clone().requires_grad_() for t in init])
+    opt = O.make_adam(p.tensors(), 1e-3, 0.007)
+    seen = []
+    for s in range(steps):
+        bn, bl = sched.next_batches(1, rank, world)
+        seen.append(bn[0].copy())
+        g = _flat_grads(p, rowptr, col, feat, bn[0], bl[0])
+        scale = reduce_gradients(g, world, lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM))
+        _apply(p, opt, g, scale)
+    out[rank] = (torch.cat([t.detach().reshape(-1) for t in p.tensors()]).numpy(), np.stack(seen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_two_rank_data_parallel_matches_gradient_averaging():
+    world, steps = 2, 4
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), steps, out), nprocs=world, join=True)
+    w0, seen0 = out[0]
+    w1, seen1 = out[1]
+    np.testing.assert_array_equal(w0, w1)                       # identical update on every rank
+    # single-process restatement: same stream, W batches per step, averaged gradients
+    rowptr, col, feat, labels, train, pool, init = _inputs()
+    sched = _schedule(labels, train, pool)
+    p = O.MiniParams(*[t.clone().requires_grad_() for t in init])
+    opt = O.make_adam(p.tensors(), 1e-3, 0.007)
+    for s in range(steps):
+        gs = []
+        for r in range(world):
+            nodes, lab = sched.next_batch()
+            assert np.array_equal(nodes, (seen0, seen1)[r][s])   # rank r took batch s*W + r of the common stream
+            gs.append(_flat_grads(p, rowptr, col, feat, nodes, lab))
+        _apply(p, opt, gs[0] + gs[1], 1.0 / world)
+    ref = torch.cat([t.detach().reshape(-1) for t in p.tensors()]).numpy()
+    np.testing.assert_allclose(w0, ref, atol=1e-6, rtol=0)
+
+
+def test_world_one_is_the_reference_schedule():
+    """W = 1: batch b of epoch e = train[b*bs:(b+1)*bs] + first n_pseudo of the freshly shuffled pool,
+    driven by the python `random` stream (model_handler.py:314,333-347)."""
+    import random
+    _, _, _, labels, train, pool, _ = _inputs()
+    sched = _schedule(labels, train, pool)
+    random.seed(72)
+    tr, pl = train.tolist(), pool.tolist()
+    for epoch in range(2):
+        random.shuffle(tr)
+        for b in range(5):
+            batch = tr[b * 30:(b + 1) * 30]
+            random.shuffle(pl)
+            batch = batch + pl[:10]
+            nodes, lab = sched.next_batch()
+            assert nodes.tolist() == batch
+            assert lab.tolist() == labels[np.array(batch)].tolist()
+    assert reduce_gradients(torch.zeros(3), 1, None) == 1.0
+    with pytest.raises(ValueError):
+        reduce_gradients(torch.zeros(3), 2, None)
