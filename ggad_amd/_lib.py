@@ -56,6 +56,18 @@ SIGNATURES = {
     "ggad_mb_encode": (c_int32, [_P, _I, _I, _P, _I, _P, _P]),
     "ggad_seg_mean": (c_int32, [_P, _I, _P, _P, _I, _P, _P]),
     "ggad_mb_score": (c_int32, [_P, _I, _I, _P, _I, _P, _P]),
+    "ggad_gemm_workspace_elems": (c_int64, [_I, _I, _I]),
+    "ggad_gemm_f32": (c_int32, [_P, _P, _P, _I, _I, _I, _L, _L, _L, _L, _L, _P, _I, _P, _P]),
+    "ggad_spmm_csr_f32": (c_int32, [_P, _P, _P, _P, _L, _I, _P, _I, _P, _P, _P, _L, _P, _P]),
+    "ggad_prelu_bwd_splits": (c_int32, [_I]),
+    "ggad_prelu_bwd_f32": (c_int32, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
+    "ggad_relu_bwd_f32": (c_int32, [_P, _P, _L, _P, _P]),
+    "ggad_rownorm_f32": (c_int32, [_P, _I, _I, _P, _P, _P]),
+    "ggad_rownorm_bwd_f32": (c_int32, [_P, _P, _P, _I, _I, _P, _P]),
+    "ggad_rowdot_f32": (c_int32, [_P, _P, _P, _I, _I, _P, _P, _P]),
+    "ggad_rows_scale_f32": (c_int32, [_P, _P, _P, _I, _I, _I, _P, _P]),
+    "ggad_full_loss_f32": (c_int32, [_P, _P, _I, _I, _P, _P, _I, _F, _P, _P, _P, _P, _P]),
+    "ggad_adam_f32": (c_int32, [_P, _P, _P, _P, _L, _F, _F, _P, _I, _P]),
     "ggad_mt_new": (c_void_p, []),
     "ggad_mt_free": (None, [c_void_p]),
     "ggad_mt_seed_u64": (c_int32, [c_void_p, c_uint64]),

@@ -1,0 +1,276 @@
+"""Full-graph GGAD on one MI355X: sparse structures + autograd wrappers over the HIP kernels.
+
+The reference keeps `adj` and `raw_adj` as dense (1,N,N) tensors and multiplies them densely
+(`run.py:98-110`, `model.py:31,151-155`, `run.py:182-188`).  Here they are CSR in HBM
+(`FullGraphAdj`), every product is an edge-parallel HIP kernel and autograd only chains those kernels:
+
+    GcnLayerFn   X W^T (MFMA GEMM) -> A_hat . (CSR SpMM, fused bias + PReLU) ; backward = PReLU' , A_hat^T SpMM, GEMMs
+    LinearFn     nn.Linear without bias (+ fused ReLU)                       ; backward = two GEMMs
+    SpmmRowsFn   A_hat[abn, :] @ emb  (outlier generation, model.py:151-155) ; backward = static transposed sub-CSR
+    GgadLossFn   BCE + local-affinity margin + reconstruction (run.py:165-210), affinity as
+                 aff_j = r_inv_j <e_hat_j, (R^T e_hat)_j>  evaluated only where the loss reads it
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import call, ptr
+
+
+def _dev_i32(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
+
+
+def _dev_f32(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+
+
+class Csr:
+    """Device CSR (int32 indices, fp32 values) with sorted columns."""
+
+    def __init__(self, mat, dev):
+        m = mat.tocsr().copy()
+        m.sum_duplicates()
+        m.sort_indices()
+        if m.nnz >= 2 ** 31:
+            raise ValueError("matrix too large for int32 CSR")
+        self.shape = m.shape
+        self.nnz = int(m.nnz)
+        self.rowptr = _dev_i32(m.indptr, dev)
+        self.col = _dev_i32(m.indices, dev)
+        self.val = _dev_f32(m.data.astype(np.float32), dev)     # run.py:103-109 casts the fp64 values to fp32
+        self.host = m
+
+
+class FullGraphAdj:
+    """Everything the full-graph step needs from the two adjacency matrices, built once on the host.
+
+    ``adj_norm``  = normalize_adj(A) + I  (`utils.py:47-54`, `run.py:101`)   -> A_hat and A_hat^T
+    ``raw``       = A + I                 (`run.py:100`)                      -> R^T (column view) and 1/colsum
+    """
+
+    def __init__(self, adj_norm, raw, device):
+        import scipy.sparse as sp
+        self.dev = torch.device(device)
+        an = sp.csr_matrix(adj_norm)
+        self.n = an.shape[0]
+        self.A = Csr(an, self.dev)
+        at = an.T.tocsr()
+        self.symmetric = (abs(an - at).nnz == 0)
+        self.At = self.A if self.symmetric else Csr(at, self.dev)
+        rw = sp.csr_matrix(raw)
+        self.raw_host = rw
+        self.Rt = Csr(rw.T.tocsr(), self.dev)                   # row j of R^T = column j of raw_adj
+        colsum = np.asarray(rw.astype(np.float32).sum(0)).reshape(-1).astype(np.float32)   # torch.sum(raw_adj, 0), fp32
+        with np.errstate(divide="ignore"):
+            r_inv = np.float32(1.0) / colsum
+        r_inv[np.isinf(r_inv)] = 0.0                            # run.py:185-186
+        self.r_inv_host = r_inv
+        self._abn: Dict[tuple, tuple] = {}
+        self._loss: Dict[tuple, tuple] = {}
+
+    @classmethod
+    def from_dense(cls, adj, raw_adj, device):
+        import scipy.sparse as sp
+        a = adj.detach().cpu().numpy() if isinstance(adj, torch.Tensor) else np.asarray(adj)
+        r = raw_adj.detach().cpu().numpy() if isinstance(raw_adj, torch.Tensor) else np.asarray(raw_adj)
+        return cls(sp.csr_matrix(a.reshape(a.shape[-2], a.shape[-1])), sp.csr_matrix(r.reshape(r.shape[-2], r.shape[-1])),
+                   device)
+
+    def abn_structs(self, abn_idx) -> Tuple[torch.Tensor, Csr]:
+        """rows_sel for A_hat[abn, :] and the transposed sub-matrix (N x A) for its backward."""
+        key = tuple(int(i) for i in abn_idx)
+        s = self._abn.get(key)
+        if s is None:
+            idx = np.asarray(key, dtype=np.int64)
+            sub = self.A.host[idx, :]
+            s = (_dev_i32(idx, self.dev), Csr(sub.T.tocsr(), self.dev))
+            self._abn[key] = s
+        return s
+
+    def loss_structs(self, normal_idx, abn_idx):
+        """J = normal_idx ++ abn_idx (the rows whose affinity the loss reads) and R[:, J] as an N x |J| CSR."""
+        key = (tuple(int(i) for i in normal_idx), tuple(int(i) for i in abn_idx))
+        s = self._loss.get(key)
+        if s is None:
+            J = np.asarray(key[0] + key[1], dtype=np.int64)
+            sub = self.Rt.host[J, :]                            # |J| x N : rows of R^T
+            s = dict(J=_dev_i32(J, self.dev), n_normal=len(key[0]), n_out=len(key[1]),
+                     r_inv_J=_dev_f32(self.r_inv_host[J], self.dev), RJ=Csr(sub.T.tocsr(), self.dev))
+            self._loss[key] = s
+        return s
+
+
+# ------------------------------------------------------------------------------------------------ kernels
+def gemm(A: torch.Tensor, B: torch.Tensor, trans_a: bool, trans_b: bool, bias=None, relu: bool = False) -> torch.Tensor:
+    """C = op(A) op(B) on the matrix cores; A, B row-major 2-D fp32."""
+    A, B = A.contiguous(), B.contiguous()
+    M, K = (A.shape[1], A.shape[0]) if trans_a else (A.shape[0], A.shape[1])
+    K2, N = (B.shape[1], B.shape[0]) if trans_b else (B.shape[0], B.shape[1])
+    if K != K2:
+        raise ValueError("gemm shape mismatch")
+    sam, sak = (1, A.shape[1]) if trans_a else (A.shape[1], 1)
+    sbk, sbn = (1, B.shape[1]) if trans_b else (B.shape[1], 1)
+    C = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    lib = _lib.load()
+    ws_n = int(lib.ggad_gemm_workspace_elems(M, N, K))
+    ws = torch.empty(ws_n, dtype=torch.float32, device=A.device) if ws_n else None
+    call("ggad_gemm_f32", ptr(A), ptr(B), ptr(C), M, N, K, sam, sak, sbk, sbn, N, ptr(bias) if bias is not None else 0,
+         1 if relu else 0, ptr(ws) if ws is not None else 0)
+    return C
+
+
+def spmm(csr: Csr, X: torch.Tensor, rows_sel: Optional[torch.Tensor] = None, bias=None, prelu_a=None, want_pre=False):
+    X = X.contiguous()
+    W = X.shape[1]
+    n_out = int(rows_sel.numel()) if rows_sel is not None else csr.shape[0]
+    out = torch.empty(n_out, W, dtype=torch.float32, device=X.device)
+    pre = torch.empty_like(out) if want_pre else None
+    call("ggad_spmm_csr_f32", ptr(csr.rowptr), ptr(csr.col), ptr(csr.val), ptr(X), W, W,
+         ptr(rows_sel) if rows_sel is not None else 0, n_out, ptr(bias) if bias is not None else 0,
+         ptr(prelu_a) if prelu_a is not None else 0, ptr(out), W, ptr(pre) if pre is not None else 0)
+    return (out, pre) if want_pre else out
+
+
+# ------------------------------------------------------------------------------------------------ autograd
+class GcnLayerFn(torch.autograd.Function):
+    """out = PReLU(A_hat (X W^T) + b)   (reference GCN.forward, `model.py:26-35`)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, prelu_a, adj: FullGraphAdj):
+        t = gemm(x, weight, False, True)                                     # seq_fts = fc(seq)        model.py:27
+        out, z = spmm(adj.A, t, bias=bias, prelu_a=prelu_a, want_pre=True)   # bmm(adj, .) + bias, act  model.py:31-35
+        ctx.save_for_backward(x, weight, z, prelu_a)
+        ctx.adj = adj
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, z, prelu_a = ctx.saved_tensors
+        adj = ctx.adj
+        g = g.contiguous()
+        M, W = z.shape
+        lib = _lib.load()
+        S = int(lib.ggad_prelu_bwd_splits(M))
+        ws = torch.empty(2 * S * W, dtype=torch.float32, device=z.device)
+        dz = torch.empty_like(z)
+        db = torch.empty(W, dtype=torch.float32, device=z.device)
+        da = torch.empty(1, dtype=torch.float32, device=z.device)
+        call("ggad_prelu_bwd_f32", ptr(g), ptr(z), ptr(prelu_a), M, W, ptr(dz), ptr(db), ptr(da), ptr(ws))
+        dt = spmm(adj.At, dz)                                                # A_hat^T dZ
+        dw = gemm(dt, x, True, False)                                        # (H x N)(N x F)
+        dx = gemm(dt, weight, False, False) if ctx.needs_input_grad[0] else None
+        return dx, dw, (db if ctx.has_bias else None), da.view_as(prelu_a), None
+
+
+class LinearFn(torch.autograd.Function):
+    """y = [relu](x W^T): nn.Linear(bias=False) of the scorer MLP / fc4 (`model.py:156,176-180`)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, relu: bool):
+        y = gemm(x, weight, False, True, relu=relu)
+        ctx.save_for_backward(x, weight, y)
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, y = ctx.saved_tensors
+        g = g.contiguous()
+        if ctx.relu:
+            dz = torch.empty_like(g)
+            call("ggad_relu_bwd_f32", ptr(g), ptr(y), g.numel(), ptr(dz))
+        else:
+            dz = g
+        dx = gemm(dz, weight, False, False) if ctx.needs_input_grad[0] else None
+        dw = gemm(dz, x, True, False)
+        return dx, dw, None
+
+
+class SpmmRowsFn(torch.autograd.Function):
+    """A_hat[rows, :] @ emb  (`model.py:151-155`)."""
+
+    @staticmethod
+    def forward(ctx, emb, adj: FullGraphAdj, rows_sel, sub_t: Csr):
+        ctx.sub_t = sub_t
+        return spmm(adj.A, emb, rows_sel=rows_sel)
+
+    @staticmethod
+    def backward(ctx, g):
+        return spmm(ctx.sub_t, g.contiguous()), None, None, None
+
+
+class GgadLossFn(torch.autograd.Function):
+    """(total, margin, bce, rec) of `run.py:165-210`; only `total` is differentiable."""
+
+    @staticmethod
+    def forward(ctx, emb, logits, emb_con, emb_abn, adj: FullGraphAdj, ls, margin: float):
+        emb = emb.contiguous()
+        n, h = emb.shape
+        dev = emb.device
+        inv = torch.empty(n, dtype=torch.float32, device=dev)
+        en = torch.empty_like(emb)
+        call("ggad_rownorm_f32", ptr(emb), n, h, ptr(inv), ptr(en))                       # run.py:177-180
+        J, L = ls["J"], int(ls["J"].numel())
+        s_j = spmm(adj.Rt, en, rows_sel=J)                                                # (R^T e_hat)[J]
+        aff = torch.empty(L, dtype=torch.float32, device=dev)
+        call("ggad_rowdot_f32", ptr(en), ptr(J), ptr(s_j), L, h, ptr(ls["r_inv_J"]), ptr(aff))   # run.py:182-188
+        losses = torch.empty(4, dtype=torch.float32, device=dev)
+        d_logits = torch.empty(L, dtype=torch.float32, device=dev)
+        g_aff = torch.empty(L, dtype=torch.float32, device=dev)
+        emb_con, emb_abn, logits = emb_con.contiguous(), emb_abn.contiguous(), logits.contiguous()
+        dD = torch.empty_like(emb_con)
+        call("ggad_full_loss_f32", ptr(logits), ptr(aff), ls["n_normal"], ls["n_out"], ptr(emb_con), ptr(emb_abn), h,
+             float(margin), ptr(losses), ptr(d_logits), ptr(g_aff), ptr(dD))
+        ctx.save_for_backward(en, inv, s_j, g_aff, d_logits, dD)
+        ctx.adj, ctx.ls = adj, ls
+        ctx.affinity = aff
+        return losses[0], losses[1], losses[2], losses[3]
+
+    @staticmethod
+    def backward(ctx, g_total, g_margin, g_bce, g_rec):
+        en, inv, s_j, g_aff, d_logits, dD = ctx.saved_tensors
+        adj, ls = ctx.adj, ctx.ls
+        n, h = en.shape
+        J, L, nn_ = ls["J"], int(ls["J"].numel()), ls["n_normal"]
+        c = g_aff * ls["r_inv_J"] * g_total                                               # d total / d (e_hat_j . S_j)
+        xc = torch.empty(L, h, dtype=torch.float32, device=en.device)
+        call("ggad_rows_scale_f32", ptr(en), ptr(J), ptr(c), L, h, 0, ptr(xc))            # c_j e_hat_j
+        den = spmm(ls["RJ"], xc)                                                          # sum_j R_ij c_j e_hat_j
+        # + c_j S_j on rows J; normal and abnormal segments are each duplicate-free
+        call("ggad_rows_scale_f32", ptr(s_j), ptr(J), ptr(c), nn_, h, 1, ptr(den))
+        call("ggad_rows_scale_f32", s_j.data_ptr() + 4 * nn_ * h, J.data_ptr() + 4 * nn_, c.data_ptr() + 4 * nn_, L - nn_, h, 1,
+             ptr(den))
+        d_emb = torch.empty_like(en)
+        call("ggad_rownorm_bwd_f32", ptr(en), ptr(inv), ptr(den), n, h, ptr(d_emb))
+        return d_emb, d_logits * g_total, dD * g_total, -dD * g_total, None, None, None
+
+
+class FlatAdam:
+    """torch.optim.Adam semantics (lr, weight_decay, betas .9/.999, eps 1e-8) executed by the HIP Adam kernel on
+    the parameters that received a gradient (params with ``grad is None`` are skipped, as torch does)."""
+
+    def __init__(self, params: Sequence[torch.nn.Parameter], lr: float, weight_decay: float = 0.0):
+        self.params = [p for p in params]
+        self.lr, self.wd = float(lr), float(weight_decay)
+        self.state = {}
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+    def step(self):
+        for p in self.params:
+            if p.grad is None:
+                continue
+            st = self.state.get(p)
+            if st is None:
+                st = self.state[p] = (torch.zeros_like(p.data), torch.zeros_like(p.data),
+                                      torch.zeros(1, dtype=torch.int32, device=p.device))
+            g = p.grad.contiguous()
+            call("ggad_adam_f32", ptr(p.data), ptr(st[0]), ptr(st[1]), ptr(g), p.numel(), self.lr, self.wd, ptr(st[2]), 1)

@@ -1,0 +1,148 @@
+"""Drop-in replacements for the reference's `model.py` classes (full-graph GGAD), backed by libggad_hip.so.
+
+    GCN(in_ft, out_ft, act, bias=True).forward(seq, adj, sparse=False)                       reference :7,26
+    Model(n_in, n_h, activation, negsamp_round, readout)
+        .forward(seq1, adj, sample_abnormal_idx, normal_idx, train_flag, args, sparse=False)
+        -> (emb, emb_combine, f_3, emb_con, emb_abnormal)                                    reference :109,133,191
+
+Same constructor order (so the same seed gives the same initial weights: every nn.Linear default-inits and is
+then xavier'd, unused gcn3 / fc5 / fc6 / disc consume RNG too), same parameter names (state_dict interchange),
+same output shapes.  `adj` may be the reference's dense (1,N,N) tensor -- converted once and cached -- or,
+preferably, a `ggad_amd.fullgraph.FullGraphAdj`.  The N(mean,var) noise of `model.py:143` is drawn from the CPU
+generator exactly like the reference (also in eval mode) and then moved to the GPU.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .fullgraph import FullGraphAdj, GcnLayerFn, LinearFn, SpmmRowsFn
+
+_ADJ_CACHE = {}
+
+
+def as_full_adj(adj, device) -> FullGraphAdj:
+    if isinstance(adj, FullGraphAdj):
+        return adj
+    key = id(adj)
+    hit = _ADJ_CACHE.get(key)
+    if hit is None or hit[0] is not adj:
+        # a dense adjacency alone carries no raw_adj: the affinity structures are filled with the pattern of adj
+        hit = (adj, FullGraphAdj.from_dense(adj, (adj != 0).float() if isinstance(adj, torch.Tensor) else (adj != 0), device))
+        _ADJ_CACHE[key] = hit
+    return hit[1]
+
+
+class GCN(nn.Module):
+    def __init__(self, in_ft, out_ft, act, bias=True):
+        super().__init__()
+        self.fc = nn.Linear(in_ft, out_ft, bias=False)
+        self.act = nn.PReLU() if act == "prelu" else act
+        if bias:
+            self.bias = nn.Parameter(torch.FloatTensor(out_ft))
+            self.bias.data.fill_(0.0)
+        else:
+            self.register_parameter("bias", None)
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                torch.nn.init.xavier_uniform_(m.weight.data)
+                if m.bias is not None:
+                    m.bias.data.fill_(0.0)
+
+    def forward(self, seq, adj, sparse=False):
+        fa = as_full_adj(adj, self.fc.weight.device)
+        x = seq.reshape(-1, seq.shape[-1]).to(self.fc.weight.device)
+        if isinstance(self.act, nn.PReLU) and self.act.weight.numel() == 1:
+            out = GcnLayerFn.apply(x, self.fc.weight, self.bias, self.act.weight, fa)
+        else:
+            one = torch.ones(1, device=x.device)
+            out = self.act(GcnLayerFn.apply(x, self.fc.weight, self.bias, one, fa))   # slope 1 = identity, then `act`
+        return out.unsqueeze(0) if seq.dim() == 3 else out
+
+
+class AvgReadout(nn.Module):
+    def forward(self, seq):
+        return torch.mean(seq, 1)
+
+
+class MaxReadout(nn.Module):
+    def forward(self, seq):
+        return torch.max(seq, 1).values
+
+
+class MinReadout(nn.Module):
+    def forward(self, seq):
+        return torch.min(seq, 1).values
+
+
+class WSReadout(nn.Module):
+    def forward(self, seq, query):
+        sim = torch.softmax(torch.matmul(seq, query.permute(0, 2, 1)), dim=1).repeat(1, 1, 64)
+        return torch.sum(torch.mul(seq, sim), 1)
+
+
+class Discriminator(nn.Module):
+    """Unused by GGAD's forward; kept for state_dict / RNG-order compatibility (`model.py:72-105`)."""
+
+    def __init__(self, n_h, negsamp_round):
+        super().__init__()
+        self.f_k = nn.Bilinear(n_h, n_h, 1)
+        torch.nn.init.xavier_uniform_(self.f_k.weight.data)
+        if self.f_k.bias is not None:
+            self.f_k.bias.data.fill_(0.0)
+        self.negsamp_round = negsamp_round
+
+    def forward(self, c, h_pl):
+        scs = [self.f_k(h_pl, c)]
+        c_mi = c
+        for _ in range(self.negsamp_round):
+            c_mi = torch.cat((c_mi[-2:-1, :], c_mi[:-1, :]), 0)
+            scs.append(self.f_k(h_pl, c_mi))
+        return torch.cat(tuple(scs))
+
+
+class Model(nn.Module):
+    def __init__(self, n_in, n_h, activation, negsamp_round, readout):
+        super().__init__()
+        self.read_mode = readout
+        self.gcn1 = GCN(n_in, n_h, activation)
+        self.gcn2 = GCN(n_h, n_h, activation)
+        self.gcn3 = GCN(n_h, n_h, activation)
+        self.fc1 = nn.Linear(n_h, int(n_h / 2), bias=False)
+        self.fc2 = nn.Linear(int(n_h / 2), int(n_h / 4), bias=False)
+        self.fc3 = nn.Linear(int(n_h / 4), 1, bias=False)
+        self.fc4 = nn.Linear(n_h, n_h, bias=False)
+        self.fc6 = nn.Linear(n_h, n_h, bias=False)
+        self.fc5 = nn.Linear(n_h, n_in, bias=False)
+        self.act = nn.ReLU()
+        self.read = {"max": MaxReadout, "min": MinReadout, "avg": AvgReadout, "weighted_sum": WSReadout}[readout]()
+        self.disc = Discriminator(n_h, negsamp_round)
+
+    def _score(self, x):
+        f = LinearFn.apply(x, self.fc1.weight, True)                       # fc1 + relu     model.py:176-177
+        f = LinearFn.apply(f, self.fc2.weight, True)                       # fc2 + relu     :178-179
+        return LinearFn.apply(f, self.fc3.weight, False)                   # fc3            :180
+
+    def forward(self, seq1, adj, sample_abnormal_idx, normal_idx, train_flag, args, sparse=False):
+        dev = self.fc1.weight.device
+        fa = as_full_adj(adj, dev)
+        x = seq1.reshape(-1, seq1.shape[-1]).to(dev)
+        h_1 = GcnLayerFn.apply(x, self.gcn1.fc.weight, self.gcn1.bias, self.gcn1.act.weight, fa)
+        emb = GcnLayerFn.apply(h_1, self.gcn2.fc.weight, self.gcn2.bias, self.gcn2.act.weight, fa)      # (N, H)
+        abn = torch.as_tensor(list(sample_abnormal_idx), dtype=torch.long, device=dev)
+        emb_abnormal = emb[abn].unsqueeze(0)
+        noise = torch.randn(emb_abnormal.size()) * args.var + args.mean                                 # CPU generator, :143
+        emb_abnormal = emb_abnormal + noise.to(dev)
+        emb_con = None
+        emb_combine = None
+        if train_flag:
+            rows_sel, sub_t = fa.abn_structs(sample_abnormal_idx)
+            emb_con = SpmmRowsFn.apply(emb, fa, rows_sel, sub_t)                                        # :151-155
+            emb_con = LinearFn.apply(emb_con, self.fc4.weight, True)                                    # relu(fc4(.))  :156
+            nrm = torch.as_tensor(list(normal_idx), dtype=torch.long, device=dev)
+            emb_combine = torch.cat((emb[nrm], emb_con), 0)                                             # :159
+            f_3 = self._score(emb_combine)
+            emb = emb.index_copy(0, abn, emb_con)                                                       # :182 (in-place there)
+            return emb.unsqueeze(0), emb_combine.unsqueeze(0), f_3.unsqueeze(0), emb_con, emb_abnormal
+        f_3 = self._score(emb)
+        return emb.unsqueeze(0), emb_combine, f_3.unsqueeze(0), emb_con, emb_abnormal

@@ -201,6 +201,57 @@ int ggad_mb_score(const float *params, int32_t D, int32_t F, const float *x1, in
                   ggad_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
+ * Full-graph path (run.py + model.py): sparse products over the edges instead of dense N x N matrices
+ * ---------------------------------------------------------------------------------- */
+
+/* C[M x N] = epilogue(A * B), fp32 on the matrix cores (v_mfma_f32_32x32x2_f32, exact f32).
+ * A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn]: NN / NT / TN by strides.  Replaces nn.Linear /
+ * torch.mm and their autograd (model.py:27,156,176-180).  bias[N] and relu are optional epilogues.
+ * workspace: float[ggad_gemm_workspace_elems(M,N,K)] (0 = no split-K needed; may be NULL). */
+int64_t ggad_gemm_workspace_elems(int32_t M, int32_t N, int32_t K);
+int ggad_gemm_f32(const float *A, const float *B, float *C, int32_t M, int32_t N, int32_t K, int64_t sam, int64_t sak,
+                  int64_t sbk, int64_t sbn, int64_t ldc, const float *bias, int32_t relu, float *workspace,
+                  ggad_stream_t stream);
+
+/* out[r] = act( sum_e val[e] * X[col[e]] + bias ), r-th output row = CSR row rows_sel[r] (or r if NULL);
+ * act = PReLU with slope *prelu_a if given; out_pre (optional) receives the pre-activation.  W % 4 == 0.
+ * Replaces torch.bmm(adj, .) + bias + PReLU (model.py:31-35), adj[0, abn, :] @ emb (model.py:151-155),
+ * the column sums of sim * raw_adj (run.py:182-188, as R^T e_hat) and every transposed product in backward. */
+int ggad_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, const float *val, const float *X, int64_t ldx, int32_t W,
+                      const int32_t *rows_sel, int32_t n_out, const float *bias, const float *prelu_a, float *out,
+                      int64_t ldo, float *out_pre, ggad_stream_t stream);
+
+/* PReLU backward: dz = g * (z > 0 ? 1 : a); db[W] = column sums of dz; *da = sum g * z * [z <= 0].
+ * workspace: float[2 * ggad_prelu_bwd_splits(M) * W].  db / da may be NULL. */
+int32_t ggad_prelu_bwd_splits(int32_t M);
+int ggad_prelu_bwd_f32(const float *g, const float *z, const float *prelu_a, int32_t M, int32_t W, float *dz, float *db,
+                       float *da, float *workspace, ggad_stream_t stream);
+/* dz = g * [y > 0] */
+int ggad_relu_bwd_f32(const float *g, const float *y, int64_t n, float *dz, ggad_stream_t stream);
+
+/* Row L2 normalisation e_hat = e / |e| with 1/0 -> 0 (run.py:177-180) and its vector-Jacobian product. */
+int ggad_rownorm_f32(const float *X, int32_t M, int32_t W, float *inv, float *Xn, ggad_stream_t stream);
+int ggad_rownorm_bwd_f32(const float *Xn, const float *inv, const float *dXn, int32_t M, int32_t W, float *dX,
+                         ggad_stream_t stream);
+/* out[p] = scale[p] * <A[sel[p]], B[p]>   (affinity_j = r_inv_j <e_hat_j, (R^T e_hat)_j>, run.py:188) */
+int ggad_rowdot_f32(const float *A, const int32_t *sel, const float *B, int32_t n, int32_t W, const float *scale, float *out,
+                    ggad_stream_t stream);
+/* scatter_add = 0: out[p] = coef[p] * X[sel[p]];  1: out[sel[p]] += coef[p] * X[p]  (sel must be duplicate-free) */
+int ggad_rows_scale_f32(const float *X, const int32_t *sel, const float *coef, int32_t n, int32_t W, int32_t scatter_add,
+                        float *out, ggad_stream_t stream);
+
+/* The scalar part of the loss block of run.py:165-210 and its gradients: logits[L], aff[L] (L = n_normal + n_out,
+ * normal_idx entries first), emb_con / emb_abn (n_out x H).  losses4 = {total, margin, bce, rec};
+ * d_logits[L]; g_aff[L] = d total / d aff; dD = d total / d (emb_con - emb_abn). */
+int ggad_full_loss_f32(const float *logits, const float *aff, int32_t n_normal, int32_t n_out, const float *emb_con,
+                       const float *emb_abn, int32_t H, float margin, float *losses4, float *d_logits, float *g_aff,
+                       float *dD, ggad_stream_t stream);
+
+/* torch.optim.Adam.step on a flat fp32 block; uses step index *step_counter + 1 and (bump_after != 0) advances it. */
+int ggad_adam_f32(float *params, float *exp_avg, float *exp_avg_sq, const float *grads, int64_t n, float lr,
+                  float weight_decay, int32_t *step_counter, int32_t bump_after, ggad_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
  * Host-side sampler: bit-exact CPython random.shuffle (MT19937 + getrandbits rejection),
  * replaces the python shuffles inside the reference's timed loop
  * (src/model_handler.py:314,341; 28 ms / batch there).  HOST pointers.

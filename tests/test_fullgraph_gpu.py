@@ -1,0 +1,131 @@
+"""GPU parity tests of the full-graph GGAD path (CSR SpMM / MFMA GEMM / affinity kernels through the C-ABI and the
+drop-in `Model` / `GCN` classes) against golden vectors captured from the imported reference (dense N x N path)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from ggad_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from ggad_amd import fullgraph as FG
+    from ggad_amd import utils as U
+    from ggad_amd.model import GCN, Model
+
+DEV = "cuda:0"
+
+
+def _adj(g):
+    import scipy.sparse as sp
+    n = int(g["n"])
+    a = synth.csr_to_scipy(g["rowptr"], g["col"], n)
+    adj_norm = U.normalize_adj(a) + sp.eye(n)            # run.py:98,101
+    raw = a + sp.eye(n)                                  # run.py:100
+    return FG.FullGraphAdj(adj_norm, raw, DEV)
+
+
+@pytest.mark.parametrize("shape", [(70, 50, 33), (300, 300, 7535), (1, 75, 1000), (130, 1, 40), (64, 64, 16), (257, 129, 3000)])
+def test_gemm_f32_all_layouts(shape):
+    m, n, k = shape
+    rng = np.random.default_rng(m + n + k)
+    for ta in (False, True):
+        for tb in (False, True):
+            a = rng.standard_normal((k, m) if ta else (m, k)).astype(np.float32)
+            b = rng.standard_normal((n, k) if tb else (k, n)).astype(np.float32)   # asymmetric, non-square: catches transposes
+            bias = rng.standard_normal(n).astype(np.float32)
+            ref = (a.T if ta else a).astype(np.float64) @ (b.T if tb else b).astype(np.float64)
+            got = FG.gemm(torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV), ta, tb).cpu().numpy()
+            scale = np.abs(ref).max() + 1.0
+            assert np.abs(got - ref).max() / scale < 2e-6, (shape, ta, tb)
+            got2 = FG.gemm(torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV), ta, tb, bias=torch.from_numpy(bias).to(DEV),
+                           relu=True).cpu().numpy()
+            assert np.abs(got2 - np.maximum(ref + bias, 0)).max() / scale < 2e-6
+
+
+@pytest.mark.parametrize("name", ["fullgraph_reddit_like.npz", "fullgraph_amazon_like.npz"])
+def test_preprocessing_matches_reference(name):
+    g = load_golden(name)
+    np.testing.assert_allclose(U.preprocess_features(g["feat_raw"]).astype(np.float32), g["features"], atol=1e-7, rtol=0)
+    fa = _adj(g)
+    import scipy.sparse as sp
+    n = int(g["n"])
+    ref = sp.coo_matrix((g["adjn_val"], (g["adjn_row"], g["adjn_col"])), shape=(n, n)).tocsr()
+    ref.sum_duplicates(); ref.sort_indices()
+    assert np.array_equal(fa.A.rowptr.cpu().numpy(), ref.indptr) and np.array_equal(fa.A.col.cpu().numpy(), ref.indices)
+    np.testing.assert_array_equal(fa.A.val.cpu().numpy(), ref.data.astype(np.float32))
+
+
+@pytest.mark.parametrize("name", ["fullgraph_reddit_like.npz", "fullgraph_amazon_like.npz"])
+def test_model_forward_loss_backward_trajectory(name):
+    g = load_golden(name)
+    fa = _adj(g)
+    f, h = int(g["f"]), int(g["n_h"])
+    torch.manual_seed(123)
+    model = Model(f, h, "prelu", 1, "avg")
+    sd = {k[len("init."):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("init.")}
+    assert sorted(sd.keys()) == sorted(model.state_dict().keys())        # same parameter names as the reference
+    model.load_state_dict(sd)
+    model.to(DEV)
+    opt = FG.FlatAdam(model.parameters(), lr=1e-3, weight_decay=0.0)
+    feats = torch.from_numpy(g["features"])[None].to(DEV)
+    abn, nrm = g["abn_idx"].tolist(), g["normal_idx"].tolist()
+    args = types.SimpleNamespace(mean=float(g["mean"]), var=float(g["var"]))
+    ls = fa.loss_structs(nrm, abn)
+    for step in range(len(g["losses"])):
+        model.train()
+        opt.zero_grad()
+        torch.manual_seed(1000 + step)
+        emb, emb_combine, logits, emb_con, emb_abnormal = model(feats, fa, abn, nrm, True, args)
+        assert emb.shape == (1, int(g["n"]), h) and logits.shape == (1, len(nrm) + len(abn), 1)
+        total, l_margin, l_bce, l_rec = FG.GgadLossFn.apply(emb[0], logits[0, :, 0], emb_con, emb_abnormal[0], fa, ls, 0.7)
+        total.backward()
+        np.testing.assert_allclose([total.item(), l_margin.item(), l_bce.item(), l_rec.item()], g["losses"][step], atol=1e-5)
+        if step == 0:
+            np.testing.assert_allclose(emb[0].detach().cpu().numpy(), g["emb"], atol=3e-6)
+            np.testing.assert_allclose(emb_combine[0].detach().cpu().numpy(), g["emb_combine"], atol=3e-6)
+            np.testing.assert_allclose(logits[0, :, 0].detach().cpu().numpy(), g["logits"], atol=3e-6)
+            np.testing.assert_allclose(emb_con.detach().cpu().numpy(), g["emb_con"], atol=3e-6)
+            np.testing.assert_allclose(emb_abnormal[0].detach().cpu().numpy(), g["emb_abnormal"], atol=3e-6)
+            for k, p in model.named_parameters():
+                if ("grad." + k) in g:
+                    np.testing.assert_allclose(p.grad.cpu().numpy(), g["grad." + k], atol=4e-6, rtol=2e-4, err_msg=k)
+                else:
+                    assert p.grad is None, k          # gcn3 / fc5 / fc6 / disc never receive a gradient
+        opt.step()
+        if step == 0:
+            for k, v in model.state_dict().items():
+                np.testing.assert_allclose(v.cpu().numpy(), g["step1." + k], atol=3e-6, err_msg=k)
+    for k, v in model.state_dict().items():
+        np.testing.assert_allclose(v.cpu().numpy(), g["final." + k], atol=3e-5, err_msg=k)
+    model.eval()
+    torch.manual_seed(5000)
+    with torch.no_grad():
+        _, comb, le, con, _ = model(feats, fa, abn, nrm, False, args)
+    assert comb is None and con is None
+    le = le[0, :, 0].cpu().numpy()
+    np.testing.assert_allclose(le, g["eval_logits"], atol=5e-5)
+    from sklearn.metrics import average_precision_score, roc_auc_score
+    yt = g["ano"][g["idx_test"]]
+    assert abs(roc_auc_score(yt, le[g["idx_test"]]) - float(g["eval_auc"])) < 1e-4
+    assert abs(average_precision_score(yt, le[g["idx_test"]]) - float(g["eval_ap"])) < 1e-4
+
+
+def test_gcn_layer_accepts_dense_adjacency_like_the_reference(g_full_reddit):
+    g = g_full_reddit
+    import scipy.sparse as sp
+    n, f, h = int(g["n"]), int(g["f"]), int(g["n_h"])
+    a = synth.csr_to_scipy(g["rowptr"], g["col"], n)
+    dense = torch.FloatTensor(np.asarray((U.normalize_adj(a) + sp.eye(n)).todense()))[None]     # run.py:101-108
+    layer = GCN(f, h, "prelu").to(DEV)
+    with torch.no_grad():
+        layer.fc.weight.copy_(torch.from_numpy(g["init.gcn1.fc.weight"]))
+        layer.bias.copy_(torch.from_numpy(g["init.gcn1.bias"]))
+    x = torch.from_numpy(g["features"])[None]
+    out = layer(x.to(DEV), dense)
+    ref = torch.nn.functional.prelu(torch.bmm(dense, x @ layer.fc.weight.detach().cpu().t()) + layer.bias.detach().cpu(),
+                                    layer.act.weight.detach().cpu())
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.numpy(), atol=3e-6)
