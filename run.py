@@ -1,0 +1,130 @@
+#!/usr/bin/env python3
+"""Full-graph GGAD on one MI355X:  python run.py --dataset reddit [--synthetic]
+
+Same command line and per-dataset overrides as the reference's `run.py` (`:18-66`: lr 1e-3; epochs photo 100 /
+elliptic 150 / reddit 300 / t_finance 500 / Amazon 800; noise N(0.02, 0.01) for reddit and photo, else 0), same
+seeding, same prints, same evaluation cadence (AUROC / AP on idx_test every 10 epochs with sklearn).  The
+arithmetic of the epoch -- two GCN layers, outlier generation, scorer MLP, BCE + local-affinity margin +
+reconstruction loss, backward, Adam -- runs in the HIP kernels of libggad_hip.so (sparse CSR / edge-parallel
+instead of the reference's dense N x N tensors).  Extra flags: `--synthetic` (no dataset ships with this repo:
+builds a graph of the dataset's published size from the seed), `--device`.
+"""
+import argparse
+import os
+import random
+import sys
+import time
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+from sklearn.metrics import average_precision_score, roc_auc_score
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from ggad_amd import synth  # noqa: E402
+from ggad_amd.fullgraph import FlatAdam, FullGraphAdj, GgadLossFn  # noqa: E402
+from ggad_amd.model import Model  # noqa: E402
+from ggad_amd.utils import load_mat, normalize_adj, preprocess_features, split_nodes  # noqa: E402
+
+# published sizes (reference README.md:53-58): nodes, directed entries, features, anomaly rate
+SIZES = {"reddit": (10984, 168016, 64, 0.033), "Amazon": (11944, 4398392, 25, 0.069), "photo": (7535, 119043, 745, 0.092),
+         "t_finance": (39357, 21222543, 10, 0.046), "elliptic": (46564, 73248, 93, 0.098)}
+EPOCHS = {"photo": 100, "elliptic": 150, "reddit": 300, "t_finance": 500, "Amazon": 800}
+
+
+def parse():
+    p = argparse.ArgumentParser(description="")
+    p.add_argument("--dataset", type=str, default="reddit")
+    p.add_argument("--lr", type=float)
+    p.add_argument("--weight_decay", type=float, default=0.0)
+    p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--embedding_dim", type=int, default=300)
+    p.add_argument("--num_epoch", type=int)
+    p.add_argument("--drop_prob", type=float, default=0.0)
+    p.add_argument("--readout", type=str, default="avg")
+    p.add_argument("--auc_test_rounds", type=int, default=256)
+    p.add_argument("--negsamp_ratio", type=int, default=1)
+    p.add_argument("--mean", type=float, default=0.0)
+    p.add_argument("--var", type=float, default=0.0)
+    p.add_argument("--synthetic", action="store_true", help="generate a graph of the dataset's size instead of loading ./dataset/*.mat")
+    p.add_argument("--device", type=int, default=0)
+    p.add_argument("--quiet", action="store_true")
+    a = p.parse_args()
+    if a.lr is None:
+        a.lr = 1e-3
+    if a.num_epoch is None:
+        a.num_epoch = EPOCHS.get(a.dataset, 100)
+    a.mean, a.var = (0.02, 0.01) if a.dataset in ["reddit", "photo"] else (0.0, 0.0)      # run.py:61-66 (CLI values overwritten)
+    return a
+
+
+def load(args):
+    if args.synthetic or not os.path.exists("./dataset/{}.mat".format(args.dataset)):
+        if not args.synthetic:
+            print("./dataset/{}.mat not found: using a synthetic graph of the same size".format(args.dataset))
+        n, ne, f, rate = SIZES[args.dataset]
+        rowptr, col = synth.make_graph(n, ne, args.seed, kind="powerlaw", max_degree=max(64, n // 8))
+        adj = synth.csr_to_scipy(rowptr, col, n)
+        feat = sp.lil_matrix(synth.make_features(n, f, args.seed))
+        ano = synth.make_labels(n, rate, args.seed)
+        all_idx, idx_train, idx_val, idx_test, normal_idx, abn_idx = split_nodes(ano, args.dataset, verbose=not args.quiet)
+        return adj, feat, ano, idx_test, normal_idx, abn_idx
+    adj, feat, labels, all_idx, idx_train, idx_val, idx_test, ano, _, _, normal_idx, abn_idx = load_mat(args.dataset)
+    return adj, feat, ano, idx_test, normal_idx, abn_idx
+
+
+def main():
+    args = parse()
+    print("Dataset: ", args.dataset)
+    np.random.seed(args.seed)
+    torch.manual_seed(args.seed)
+    torch.cuda.manual_seed_all(args.seed)
+    random.seed(args.seed)
+    if not torch.cuda.is_available():
+        sys.exit("run.py needs an MI355X: the GGAD hot path has no CPU fallback")
+    dev = torch.device("cuda", args.device)
+    adj, features, ano_label, idx_test, normal_label_idx, abnormal_label_idx = load(args)
+    if args.dataset in ["Amazon", "tf_finace", "reddit", "elliptic"]:                 # run.py:87 (typo kept: never T-Finance)
+        features = preprocess_features(features)
+    else:
+        features = np.asarray(features.todense())
+    nb_nodes, ft_size = features.shape
+    print(adj.sum())
+    full = FullGraphAdj(normalize_adj(adj) + sp.eye(nb_nodes), adj + sp.eye(nb_nodes), dev)     # run.py:98-101, CSR in HBM
+    feats = torch.FloatTensor(np.asarray(features, dtype=np.float32)[np.newaxis]).to(dev)
+    model = Model(ft_size, args.embedding_dim, "prelu", args.negsamp_ratio, args.readout).to(dev)
+    optimiser = FlatAdam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
+    ls = full.loss_structs(normal_label_idx, abnormal_label_idx)
+    total_time = 0.0
+    for epoch in range(args.num_epoch):
+        start_time = time.time()
+        model.train()
+        optimiser.zero_grad()
+        emb, emb_combine, logits, emb_con, emb_abnormal = model(feats, full, abnormal_label_idx, normal_label_idx, True, args)
+        loss, loss_margin, loss_bce, loss_rec = GgadLossFn.apply(emb[0], logits[0, :, 0], emb_con, emb_abnormal[0], full, ls, 0.7)
+        loss.backward()
+        optimiser.step()
+        torch.cuda.synchronize()
+        total_time += time.time() - start_time
+        if not args.quiet:
+            print("Total time is", total_time)
+        if epoch % 2 == 0 and not args.quiet:
+            print("Epoch:", "%04d" % epoch, "train_loss_margin=", "{:.5f}".format(loss_margin.item()))
+            print("Epoch:", "%04d" % epoch, "train_loss_bce=", "{:.5f}".format(loss_bce.item()))
+            print("Epoch:", "%04d" % epoch, "rec_loss=", "{:.5f}".format(loss_rec.item()))
+            print("Epoch:", "%04d" % epoch, "train_loss=", "{:.5f}".format(loss.item()))
+            print("=====================================================================")
+        if epoch % 10 == 0:
+            model.eval()
+            with torch.no_grad():
+                _, _, logits_eval, _, _ = model(feats, full, abnormal_label_idx, normal_label_idx, False, args)
+            scores = np.squeeze(logits_eval[:, idx_test, :].cpu().numpy())
+            auc = roc_auc_score(ano_label[idx_test], scores)
+            print("Testing {} AUC:{:.4f}".format(args.dataset, auc))
+            ap = average_precision_score(ano_label[idx_test], scores, average="macro", pos_label=1, sample_weight=None)
+            print("Testing AP:", ap)
+    print("nodes/s (training window, run.py:146->214): {:.1f}".format(nb_nodes * args.num_epoch / total_time))
+
+
+if __name__ == "__main__":
+    main()
