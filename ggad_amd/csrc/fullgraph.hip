@@ -17,57 +17,118 @@
 namespace {
 
 constexpr int SPMM_MAXCH = 4;   // float4 chunks of 64 lanes: W <= 1024
+constexpr int SPMM_SEG = 64;    // neighbours per segment (= one wave-wide index load)
 
-__global__ void __launch_bounds__(256) k_spmm(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                              const float *__restrict__ val, const float *__restrict__ X, int64_t ldx, int W,
-                                              const int32_t *__restrict__ rows_sel, int n_out, const float *__restrict__ bias,
-                                              const float *__restrict__ prelu_a, float *__restrict__ out, int64_t ldo,
-                                              float *__restrict__ out_pre) {
-  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= n_out) return;
+__device__ __forceinline__ void spmm_epilogue_store(float4 z, int vi, const float *__restrict__ bias, const float *prelu_a,
+                                                    float a, float *__restrict__ out_row, float *__restrict__ pre_row) {
+  if (bias) {
+    const float4 b = reinterpret_cast<const float4 *>(bias)[vi];
+    z.x += b.x; z.y += b.y; z.z += b.z; z.w += b.w;                          // out += bias              model.py:32-33
+  }
+  if (pre_row) reinterpret_cast<float4 *>(pre_row)[vi] = z;
+  if (prelu_a) {                                                               // PReLU                    model.py:35
+    z.x = z.x > 0.f ? z.x : a * z.x; z.y = z.y > 0.f ? z.y : a * z.y;
+    z.z = z.z > 0.f ? z.z : a * z.z; z.w = z.w > 0.f ? z.w : a * z.w;
+  }
+  reinterpret_cast<float4 *>(out_row)[vi] = z;
+}
+
+// One wave per SEGMENT (<= 64 consecutive neighbours of one row): rows are split so that a hub row does not
+// serialise the launch (power-law graphs: max degree ~ N/8).  seg_out[s] >= 0: the row has this single segment,
+// finish it here (bias / PReLU epilogue, write out[seg_out]); seg_out[s] < 0: write the partial sum to
+// part[s]; k_spmm_combine adds the partials of such rows in segment order.
+__global__ void __launch_bounds__(256) k_spmm_seg(const int32_t *__restrict__ col, const float *__restrict__ val,
+                                                  const int32_t *__restrict__ seg_beg, const int32_t *__restrict__ seg_end,
+                                                  const int32_t *__restrict__ seg_out, int n_seg,
+                                                  const float *__restrict__ X, int64_t ldx, int W,
+                                                  const float *__restrict__ bias, const float *__restrict__ prelu_a,
+                                                  float *__restrict__ out, int64_t ldo, float *__restrict__ out_pre,
+                                                  float *__restrict__ part) {
+  const int sidx = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (sidx >= n_seg) return;
   const int lane = lane_id();
-  const int src = rows_sel ? rows_sel[r] : r;
-  const int s = rowptr[src], t = rowptr[src + 1];
+  const int s = seg_beg[sidx], t = seg_end[sidx];
   const int nvec = W >> 2;
   float4 acc[SPMM_MAXCH];
 #pragma unroll
   for (int c = 0; c < SPMM_MAXCH; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int blk = s; blk < t; blk += 64) {
-    const int e = blk + lane;
-    const int cv = (e < t) ? col[e] : 0;
-    const float vv = (e < t) ? (val ? val[e] : 1.0f) : 0.0f;
-    const int cnt = min(64, t - blk);
-    for (int i = 0; i < cnt; ++i) {
-      const int c = __builtin_amdgcn_readlane(cv, i);
-      const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vv), i));
-      const float4 *xr = reinterpret_cast<const float4 *>(X + (int64_t)c * ldx);
+  const int e = s + lane;
+  const int cv = (e < t) ? col[e] : 0;
+  const float vv = (e < t) ? (val ? val[e] : 1.0f) : 0.0f;
+  const int cnt = t - s;
+  int i = 0;
+  for (; i + 4 <= cnt; i += 4) {                       // 4 neighbours x up to 4 float4 loads in flight per lane
+    int c[4]; float v[4];
 #pragma unroll
-      for (int ch = 0; ch < SPMM_MAXCH; ++ch) {
-        const int vi = ch * 64 + lane;
-        if (vi < nvec) {
-          const float4 x = xr[vi];
-          acc[ch].x = fmaf(v, x.x, acc[ch].x); acc[ch].y = fmaf(v, x.y, acc[ch].y);
-          acc[ch].z = fmaf(v, x.z, acc[ch].z); acc[ch].w = fmaf(v, x.w, acc[ch].w);
+    for (int u = 0; u < 4; ++u) {
+      c[u] = __builtin_amdgcn_readlane(cv, i + u);
+      v[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vv), i + u));
+    }
+#pragma unroll
+    for (int ch = 0; ch < SPMM_MAXCH; ++ch) {
+      const int vi = ch * 64 + lane;
+      if (vi < nvec) {
+        float4 x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x[u] = reinterpret_cast<const float4 *>(X + (int64_t)c[u] * ldx)[vi];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          acc[ch].x = fmaf(v[u], x[u].x, acc[ch].x); acc[ch].y = fmaf(v[u], x[u].y, acc[ch].y);
+          acc[ch].z = fmaf(v[u], x[u].z, acc[ch].z); acc[ch].w = fmaf(v[u], x[u].w, acc[ch].w);
         }
       }
     }
   }
+  for (; i < cnt; ++i) {
+    const int c = __builtin_amdgcn_readlane(cv, i);
+    const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vv), i));
+    const float4 *xr = reinterpret_cast<const float4 *>(X + (int64_t)c * ldx);
+#pragma unroll
+    for (int ch = 0; ch < SPMM_MAXCH; ++ch) {
+      const int vi = ch * 64 + lane;
+      if (vi < nvec) {
+        const float4 x = xr[vi];
+        acc[ch].x = fmaf(v, x.x, acc[ch].x); acc[ch].y = fmaf(v, x.y, acc[ch].y);
+        acc[ch].z = fmaf(v, x.z, acc[ch].z); acc[ch].w = fmaf(v, x.w, acc[ch].w);
+      }
+    }
+  }
+  const int orow = seg_out[sidx];
   const float a = prelu_a ? *prelu_a : 1.0f;
 #pragma unroll
   for (int ch = 0; ch < SPMM_MAXCH; ++ch) {
     const int vi = ch * 64 + lane;
     if (vi < nvec) {
-      float4 z = acc[ch];
-      if (bias) {
-        const float4 b = reinterpret_cast<const float4 *>(bias)[vi];
-        z.x += b.x; z.y += b.y; z.z += b.z; z.w += b.w;                      // out += bias              model.py:32-33
+      if (orow >= 0)
+        spmm_epilogue_store(acc[ch], vi, bias, prelu_a, a, out + (int64_t)orow * ldo, out_pre ? out_pre + (int64_t)orow * ldo : nullptr);
+      else
+        reinterpret_cast<float4 *>(part + (int64_t)sidx * W)[vi] = acc[ch];
+    }
+  }
+}
+
+// rows split into several segments: out[row] = epilogue(sum of part[first .. first + count))   (fixed order)
+__global__ void __launch_bounds__(256) k_spmm_combine(const int32_t *__restrict__ multi_row, const int32_t *__restrict__ multi_first,
+                                                      const int32_t *__restrict__ multi_count, int n_multi,
+                                                      const float *__restrict__ part, int W, const float *__restrict__ bias,
+                                                      const float *__restrict__ prelu_a, float *__restrict__ out, int64_t ldo,
+                                                      float *__restrict__ out_pre) {
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= n_multi) return;
+  const int lane = lane_id();
+  const int orow = multi_row[m], first = multi_first[m], count = multi_count[m];
+  const int nvec = W >> 2;
+  const float a = prelu_a ? *prelu_a : 1.0f;
+#pragma unroll
+  for (int ch = 0; ch < SPMM_MAXCH; ++ch) {
+    const int vi = ch * 64 + lane;
+    if (vi < nvec) {
+      float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int k = 0; k < count; ++k) {
+        const float4 p = reinterpret_cast<const float4 *>(part + (int64_t)(first + k) * W)[vi];
+        z.x += p.x; z.y += p.y; z.z += p.z; z.w += p.w;
       }
-      if (out_pre) reinterpret_cast<float4 *>(out_pre + (int64_t)r * ldo)[vi] = z;
-      if (prelu_a) {                                                           // PReLU                    model.py:35
-        z.x = z.x > 0.f ? z.x : a * z.x; z.y = z.y > 0.f ? z.y : a * z.y;
-        z.z = z.z > 0.f ? z.z : a * z.z; z.w = z.w > 0.f ? z.w : a * z.w;
-      }
-      reinterpret_cast<float4 *>(out + (int64_t)r * ldo)[vi] = z;
+      spmm_epilogue_store(z, vi, bias, prelu_a, a, out + (int64_t)orow * ldo, out_pre ? out_pre + (int64_t)orow * ldo : nullptr);
     }
   }
 }
@@ -276,14 +337,22 @@ __global__ void k_bump(int32_t *c) { *c += 1; }
 
 extern "C" {
 
-int ggad_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, const float *val, const float *X, int64_t ldx, int32_t W,
-                      const int32_t *rows_sel, int32_t n_out, const float *bias, const float *prelu_a, float *out,
-                      int64_t ldo, float *out_pre, ggad_stream_t stream) {
-  GGAD_REQUIRE(rowptr && col && X && out && W >= 4 && (W & 3) == 0 && W <= 256 * SPMM_MAXCH && n_out >= 0);
-  GGAD_REQUIRE((ldx & 3) == 0 && (ldo & 3) == 0 && ldx >= W && ldo >= W);
-  if (n_out == 0) return GGAD_OK;
-  k_spmm<<<dim3((n_out + 3) / 4), dim3(256), 0, as_stream(stream)>>>(rowptr, col, val, X, ldx, W, rows_sel, n_out, bias, prelu_a,
-                                                                     out, ldo, out_pre);
+int ggad_spmm_seg_len(void) { return SPMM_SEG; }
+
+int ggad_spmm_csr_f32(const int32_t *col, const float *val, const int32_t *seg_beg, const int32_t *seg_end,
+                      const int32_t *seg_out, int32_t n_seg, const int32_t *multi_row, const int32_t *multi_first,
+                      const int32_t *multi_count, int32_t n_multi, const float *X, int64_t ldx, int32_t W, const float *bias,
+                      const float *prelu_a, float *out, int64_t ldo, float *out_pre, float *part, ggad_stream_t stream) {
+  GGAD_REQUIRE(col && seg_beg && seg_end && seg_out && X && out && W >= 4 && (W & 3) == 0 && W <= 256 * SPMM_MAXCH);
+  GGAD_REQUIRE((ldx & 3) == 0 && (ldo & 3) == 0 && ldx >= W && ldo >= W && n_seg >= 0 && n_multi >= 0);
+  GGAD_REQUIRE(n_multi == 0 || (multi_row && multi_first && multi_count && part));
+  if (n_seg == 0) return GGAD_OK;
+  hipStream_t st = as_stream(stream);
+  k_spmm_seg<<<dim3((n_seg + 3) / 4), dim3(256), 0, st>>>(col, val, seg_beg, seg_end, seg_out, n_seg, X, ldx, W, bias, prelu_a, out,
+                                                         ldo, out_pre, part);
+  if (n_multi > 0)
+    k_spmm_combine<<<dim3((n_multi + 3) / 4), dim3(256), 0, st>>>(multi_row, multi_first, multi_count, n_multi, part, W, bias,
+                                                                 prelu_a, out, ldo, out_pre);
   GGAD_CHECK_LAUNCH("spmm_csr_f32");
   return GGAD_OK;
 }

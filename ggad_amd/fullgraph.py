@@ -44,6 +44,37 @@ class Csr:
         self.col = _dev_i32(m.indices, dev)
         self.val = _dev_f32(m.data.astype(np.float32), dev)     # run.py:103-109 casts the fp64 values to fp32
         self.host = m
+        self.dev = dev
+        self._plans = {}
+
+    def plan(self, rows_sel: Optional[np.ndarray] = None, key=None):
+        """Segment tables for ggad_spmm_csr_f32 (whole matrix, or the row subset `rows_sel`); cached."""
+        key = "all" if rows_sel is None else key
+        p = self._plans.get(key) if key is not None else None
+        if p is not None:
+            return p
+        seg = int(_lib.load().ggad_spmm_seg_len())
+        rp = self.host.indptr.astype(np.int64)
+        rows = np.arange(self.shape[0], dtype=np.int64) if rows_sel is None else np.asarray(rows_sel, dtype=np.int64)
+        beg, end = rp[rows], rp[rows + 1]
+        nseg = np.maximum(1, (end - beg + seg - 1) // seg)
+        first = np.zeros(len(rows) + 1, dtype=np.int64)
+        np.cumsum(nseg, out=first[1:])
+        total = int(first[-1])
+        owner = np.repeat(np.arange(len(rows), dtype=np.int64), nseg)           # output row of every segment
+        k = np.arange(total, dtype=np.int64) - first[owner]                     # index of the segment inside its row
+        sbeg = beg[owner] + k * seg
+        send = np.minimum(end[owner], sbeg + seg)
+        single = nseg[owner] == 1
+        seg_out = np.where(single, owner, -1)
+        multi = np.nonzero(nseg > 1)[0]
+        dev = self.dev
+        p = dict(seg_beg=_dev_i32(sbeg, dev), seg_end=_dev_i32(send, dev), seg_out=_dev_i32(seg_out, dev), n_seg=total,
+                 multi_row=_dev_i32(multi, dev), multi_first=_dev_i32(first[multi], dev), multi_count=_dev_i32(nseg[multi], dev),
+                 n_multi=int(len(multi)), n_out=int(len(rows)), part=None)
+        if key is not None:
+            self._plans[key] = p
+        return p
 
 
 class FullGraphAdj:
@@ -82,13 +113,13 @@ class FullGraphAdj:
                    device)
 
     def abn_structs(self, abn_idx) -> Tuple[torch.Tensor, Csr]:
-        """rows_sel for A_hat[abn, :] and the transposed sub-matrix (N x A) for its backward."""
+        """SpMM plan for the rows A_hat[abn, :] and the transposed sub-matrix (N x A) for its backward."""
         key = tuple(int(i) for i in abn_idx)
         s = self._abn.get(key)
         if s is None:
             idx = np.asarray(key, dtype=np.int64)
             sub = self.A.host[idx, :]
-            s = (_dev_i32(idx, self.dev), Csr(sub.T.tocsr(), self.dev))
+            s = (self.A.plan(idx, key=("rows", key)), Csr(sub.T.tocsr(), self.dev))
             self._abn[key] = s
         return s
 
@@ -100,7 +131,8 @@ class FullGraphAdj:
             J = np.asarray(key[0] + key[1], dtype=np.int64)
             sub = self.Rt.host[J, :]                            # |J| x N : rows of R^T
             s = dict(J=_dev_i32(J, self.dev), n_normal=len(key[0]), n_out=len(key[1]),
-                     r_inv_J=_dev_f32(self.r_inv_host[J], self.dev), RJ=Csr(sub.T.tocsr(), self.dev))
+                     r_inv_J=_dev_f32(self.r_inv_host[J], self.dev), RJ=Csr(sub.T.tocsr(), self.dev),
+                     Rt_plan=self.Rt.plan(J, key=("rows", key)))
             self._loss[key] = s
         return s
 
@@ -124,15 +156,22 @@ def gemm(A: torch.Tensor, B: torch.Tensor, trans_a: bool, trans_b: bool, bias=No
     return C
 
 
-def spmm(csr: Csr, X: torch.Tensor, rows_sel: Optional[torch.Tensor] = None, bias=None, prelu_a=None, want_pre=False):
+def spmm(csr: Csr, X: torch.Tensor, plan=None, bias=None, prelu_a=None, want_pre=False):
+    """out = act(csr[rows] @ X + bias); `plan` = csr.plan(...) selects the rows (default: all)."""
     X = X.contiguous()
     W = X.shape[1]
-    n_out = int(rows_sel.numel()) if rows_sel is not None else csr.shape[0]
-    out = torch.empty(n_out, W, dtype=torch.float32, device=X.device)
+    p = plan if plan is not None else csr.plan()
+    out = torch.empty(p["n_out"], W, dtype=torch.float32, device=X.device)
     pre = torch.empty_like(out) if want_pre else None
-    call("ggad_spmm_csr_f32", ptr(csr.rowptr), ptr(csr.col), ptr(csr.val), ptr(X), W, W,
-         ptr(rows_sel) if rows_sel is not None else 0, n_out, ptr(bias) if bias is not None else 0,
-         ptr(prelu_a) if prelu_a is not None else 0, ptr(out), W, ptr(pre) if pre is not None else 0)
+    part = None
+    if p["n_multi"] > 0:
+        part = p.get("part")
+        if part is None or part.numel() < p["n_seg"] * W:
+            part = p["part"] = torch.empty(p["n_seg"] * W, dtype=torch.float32, device=X.device)
+    call("ggad_spmm_csr_f32", ptr(csr.col), ptr(csr.val), ptr(p["seg_beg"]), ptr(p["seg_end"]), ptr(p["seg_out"]), p["n_seg"],
+         ptr(p["multi_row"]), ptr(p["multi_first"]), ptr(p["multi_count"]), p["n_multi"], ptr(X), W, W,
+         ptr(bias) if bias is not None else 0, ptr(prelu_a) if prelu_a is not None else 0, ptr(out), W,
+         ptr(pre) if pre is not None else 0, ptr(part) if part is not None else 0)
     return (out, pre) if want_pre else out
 
 
@@ -196,9 +235,9 @@ class SpmmRowsFn(torch.autograd.Function):
     """A_hat[rows, :] @ emb  (`model.py:151-155`)."""
 
     @staticmethod
-    def forward(ctx, emb, adj: FullGraphAdj, rows_sel, sub_t: Csr):
+    def forward(ctx, emb, adj: FullGraphAdj, rows_plan, sub_t: Csr):
         ctx.sub_t = sub_t
-        return spmm(adj.A, emb, rows_sel=rows_sel)
+        return spmm(adj.A, emb, plan=rows_plan)
 
     @staticmethod
     def backward(ctx, g):
@@ -217,7 +256,7 @@ class GgadLossFn(torch.autograd.Function):
         en = torch.empty_like(emb)
         call("ggad_rownorm_f32", ptr(emb), n, h, ptr(inv), ptr(en))                       # run.py:177-180
         J, L = ls["J"], int(ls["J"].numel())
-        s_j = spmm(adj.Rt, en, rows_sel=J)                                                # (R^T e_hat)[J]
+        s_j = spmm(adj.Rt, en, plan=ls["Rt_plan"])                                        # (R^T e_hat)[J]
         aff = torch.empty(L, dtype=torch.float32, device=dev)
         call("ggad_rowdot_f32", ptr(en), ptr(J), ptr(s_j), L, h, ptr(ls["r_inv_J"]), ptr(aff))   # run.py:182-188
         losses = torch.empty(4, dtype=torch.float32, device=dev)

@@ -213,13 +213,20 @@ int ggad_gemm_f32(const float *A, const float *B, float *C, int32_t M, int32_t N
                   int64_t sbk, int64_t sbn, int64_t ldc, const float *bias, int32_t relu, float *workspace,
                   ggad_stream_t stream);
 
-/* out[r] = act( sum_e val[e] * X[col[e]] + bias ), r-th output row = CSR row rows_sel[r] (or r if NULL);
+/* out[r] = act( sum_e val[e] * X[col[e]] + bias ) over CSR rows cut into SEGMENTS of <= ggad_spmm_seg_len()
+ * consecutive entries [seg_beg, seg_end): one wave per segment, so a hub row never serialises the launch.
+ * seg_out[s] >= 0: the row consists of this one segment and is finished in place (output row seg_out[s]);
+ * seg_out[s] < 0: the partial sum goes to part[s][W] and the row is listed in multi_row / multi_first /
+ * multi_count (output row, first segment, number of segments), summed in segment order by a second launch.
+ * The segment tables are built once per matrix (and per row subset) on the host.
  * act = PReLU with slope *prelu_a if given; out_pre (optional) receives the pre-activation.  W % 4 == 0.
  * Replaces torch.bmm(adj, .) + bias + PReLU (model.py:31-35), adj[0, abn, :] @ emb (model.py:151-155),
  * the column sums of sim * raw_adj (run.py:182-188, as R^T e_hat) and every transposed product in backward. */
-int ggad_spmm_csr_f32(const int32_t *rowptr, const int32_t *col, const float *val, const float *X, int64_t ldx, int32_t W,
-                      const int32_t *rows_sel, int32_t n_out, const float *bias, const float *prelu_a, float *out,
-                      int64_t ldo, float *out_pre, ggad_stream_t stream);
+int ggad_spmm_seg_len(void);
+int ggad_spmm_csr_f32(const int32_t *col, const float *val, const int32_t *seg_beg, const int32_t *seg_end,
+                      const int32_t *seg_out, int32_t n_seg, const int32_t *multi_row, const int32_t *multi_first,
+                      const int32_t *multi_count, int32_t n_multi, const float *X, int64_t ldx, int32_t W, const float *bias,
+                      const float *prelu_a, float *out, int64_t ldo, float *out_pre, float *part, ggad_stream_t stream);
 
 /* PReLU backward: dz = g * (z > 0 ? 1 : a); db[W] = column sums of dz; *da = sum g * z * [z <= 0].
  * workspace: float[2 * ggad_prelu_bwd_splits(M) * W].  db / da may be NULL. */

@@ -96,6 +96,7 @@ def main():
     optimiser = FlatAdam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
     ls = full.loss_structs(normal_label_idx, abnormal_label_idx)
     total_time = 0.0
+    epoch_times = []
     for epoch in range(args.num_epoch):
         start_time = time.time()
         model.train()
@@ -105,7 +106,8 @@ def main():
         loss.backward()
         optimiser.step()
         torch.cuda.synchronize()
-        total_time += time.time() - start_time
+        epoch_times.append(time.time() - start_time)
+        total_time += epoch_times[-1]
         if not args.quiet:
             print("Total time is", total_time)
         if epoch % 2 == 0 and not args.quiet:
@@ -124,6 +126,9 @@ def main():
             ap = average_precision_score(ano_label[idx_test], scores, average="macro", pos_label=1, sample_weight=None)
             print("Testing AP:", ap)
     print("nodes/s (training window, run.py:146->214): {:.1f}".format(nb_nodes * args.num_epoch / total_time))
+    med = float(np.median(epoch_times))
+    print("median epoch {:.3f} ms -> {:.1f} nodes/s (first epoch {:.1f} ms incl. one-off plan building / module load)".format(
+        med * 1e3, nb_nodes / med, epoch_times[0] * 1e3))
 
 
 if __name__ == "__main__":
