@@ -7,8 +7,9 @@
 //
 //   C[m][n] = epilogue( sum_k A(m,k) * B(k,n) )        A(m,k) = A[m*sam + k*sak], B(k,n) = B[k*sbk + n*sbn]
 //
-// so NN / NT / TN are the same kernel with different strides.  Workgroup = 4 waves = a 64 x 64 tile of C
-// (each wave one 32 x 32 MFMA accumulator), K stepped by 16 through LDS; both LDS tiles are k-major
+// so NN / NT / TN are the same kernel with different strides.  Workgroup = 4 waves = a 128 x 64 tile of C
+// (each wave two 32 x 32 MFMA accumulators), K stepped by 32 through LDS with register prefetch of the next
+// K-tile; both LDS tiles are k-major
 // (As[k][m], Bs[k][n]) because the MFMA fragment of lane l is A[m = l & 31][k = l >> 5] /
 // B[k = l >> 5][n = l & 31]: 32 consecutive lanes read 32 consecutive words -> conflict-free ds_read_b32.
 // Long-K / few-tile shapes (weight gradients: K = number of nodes) are split along K over gridDim.z into
@@ -17,46 +18,81 @@
 
 namespace {
 
-constexpr int BM = 64, BN = 64, BK = 16, LDS_LD = 65;   // +1 pad: the transposing store is conflict-free
+constexpr int BM = 128, BN = 64, BK = 32;
+constexpr int LDA_S = BM + 1, LDB_S = BN + 1;       // +1 pad: the transposing LDS store is conflict-free
+constexpr int A_PER_T = BM * BK / 256;              // 16 elements of the A tile per thread
+constexpr int B_PER_T = BN * BK / 256;              // 8 elements of the B tile per thread
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
+// Workgroup = 4 waves = a 128 x 64 tile of C; wave (wr, wc) owns rows [64 wr, 64 wr + 64) x cols [32 wc, 32 wc + 32):
+// two 32x32 MFMA accumulators.  K is stepped by 32; the next K-tile is fetched from global memory into registers
+// while the current one is consumed from LDS (global latency hidden behind 32 MFMAs = 2048 cycles per wave).
 __global__ void __launch_bounds__(256) k_gemm_f32(const float *__restrict__ A, const float *__restrict__ B,
                                                   float *__restrict__ C, int M, int N, int K, int64_t sam, int64_t sak,
                                                   int64_t sbk, int64_t sbn, int64_t ldc, const float *__restrict__ bias,
                                                   int relu, int k_per_split, int64_t c_split_stride) {
-  __shared__ float As[BK][LDS_LD];
-  __shared__ float Bs[BK][LDS_LD];
+  __shared__ float As[BK][LDA_S];
+  __shared__ float Bs[BK][LDB_S];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid >> 1, wc = wid & 1;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int k_begin = blockIdx.z * k_per_split;
   const int k_end = min(K, k_begin + k_per_split);
-  floatx16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  // thread -> (row, k) mapping for the global loads: unit stride along the fastest index of each operand
+  floatx16 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  floatx16 acc1 = acc0;
+  // thread -> (row, k) mapping of the global loads: unit stride along the fastest index of each operand
   const bool a_kfast = (sak == 1);
   const bool b_nfast = (sbn == 1);
-  for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+  float ra[A_PER_T], rb[B_PER_T];
+  auto a_pos = [&](int p, int &m, int &k) {
+    if (a_kfast) { k = tid & 31; m = (tid >> 5) + 8 * p; } else { m = tid & 127; k = (tid >> 7) + 2 * p; }
+  };
+  auto b_pos = [&](int p, int &n, int &k) {
+    if (b_nfast) { n = tid & 63; k = (tid >> 6) + 4 * p; } else { k = tid & 31; n = (tid >> 5) + 8 * p; }
+  };
+  auto fetch = [&](int k0) {
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      int m, k;
-      if (a_kfast) { k = tid & 15; m = (tid >> 4) + 16 * p; } else { m = tid & 63; k = (tid >> 6) + 4 * p; }
+    for (int p = 0; p < A_PER_T; ++p) {
+      int m, k; a_pos(p, m, k);
       const int gm = m0 + m, gk = k0 + k;
-      As[k][m] = (gm < M && gk < k_end) ? A[(int64_t)gm * sam + (int64_t)gk * sak] : 0.0f;
-      int n, kb;
-      if (b_nfast) { n = tid & 63; kb = (tid >> 6) + 4 * p; } else { kb = tid & 15; n = (tid >> 4) + 16 * p; }
-      const int gn = n0 + n, gkb = k0 + kb;
-      Bs[kb][n] = (gn < N && gkb < k_end) ? B[(int64_t)gkb * sbk + (int64_t)gn * sbn] : 0.0f;
+      ra[p] = (gm < M && gk < k_end) ? A[(int64_t)gm * sam + (int64_t)gk * sak] : 0.0f;
     }
+#pragma unroll
+    for (int p = 0; p < B_PER_T; ++p) {
+      int n, k; b_pos(p, n, k);
+      const int gn = n0 + n, gk = k0 + k;
+      rb[p] = (gn < N && gk < k_end) ? B[(int64_t)gk * sbk + (int64_t)gn * sbn] : 0.0f;
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int p = 0; p < A_PER_T; ++p) { int m, k; a_pos(p, m, k); As[k][m] = ra[p]; }
+#pragma unroll
+    for (int p = 0; p < B_PER_T; ++p) { int n, k; b_pos(p, n, k); Bs[k][n] = rb[p]; }
+  };
+  if (k_begin < k_end) {
+    fetch(k_begin);
+    stash();
     __syncthreads();
-    const int i = lane & 31, kk = lane >> 5;
+  }
+  const int i = lane & 31, kk = lane >> 5;
+  for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+    const bool more = (k0 + BK) < k_end;
+    if (more) fetch(k0 + BK);
 #pragma unroll
     for (int ks = 0; ks < BK; ks += 2) {
-      const float a = As[ks + kk][wr * 32 + i];
       const float b = Bs[ks + kk][wc * 32 + i];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+      const float a0 = As[ks + kk][wr * 64 + i];
+      const float a1 = As[ks + kk][wr * 64 + 32 + i];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
     }
     __syncthreads();
+    if (more) {
+      stash();
+      __syncthreads();
+    }
   }
   // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   float *Cout = C + (int64_t)blockIdx.z * c_split_stride;
@@ -65,11 +101,16 @@ __global__ void __launch_bounds__(256) k_gemm_f32(const float *__restrict__ A, c
     const float bv = (bias != nullptr) ? bias[col] : 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int row = m0 + wr * 64 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
       if (row < M) {
-        float v = acc[r] + bv;
+        float v = acc0[r] + bv;
         if (relu) v = fmaxf(v, 0.0f);
         Cout[(int64_t)row * ldc + col] = v;
+      }
+      if (row + 32 < M) {
+        float v = acc1[r] + bv;
+        if (relu) v = fmaxf(v, 0.0f);
+        Cout[(int64_t)(row + 32) * ldc + col] = v;
       }
     }
   }
