@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--graph-kind", default="powerlaw", choices=["powerlaw", "er"])
     ap.add_argument("--chunk", type=int, default=150, help="batches planned per launch group (reference epoch = 150)")
     ap.add_argument("--cpu-batches", type=int, default=3, help="batches timed on the CPU port (0 = skip)")
+    ap.add_argument("--layout", default="packed", choices=["packed", "plain"],
+                    help="packed: 2-hop counters inside 128-byte feature rows (chunk <= 15 batches); plain: separate slot arrays")
     ap.add_argument("--seed", type=int, default=72)
     return ap.parse_args()
 
@@ -93,7 +95,7 @@ def main():
         def allreduce(t):
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
     trainer = DGraphTrainer(graph, feat, a.emb, sched, lr=1e-3, weight_decay=0.007, chunk_batches=a.chunk, rank=rank,
-                            world_size=world, allreduce=allreduce)
+                            world_size=world, allreduce=allreduce, packed=(a.layout == "packed"))
     torch.manual_seed(a.seed)
     w = torch.nn.init.xavier_uniform_(torch.empty(1, a.emb))
     W = torch.nn.init.xavier_uniform_(torch.empty(a.emb, a.feat))
@@ -149,7 +151,7 @@ def main():
         nodes_total = float(nn.item())
     else:
         nodes_total = float(nodes_local)
-    losses = trainer.engine.losses(min(a.steps, a.chunk))
+    losses = trainer.engine.losses(a.steps)
 
     # ---------------- roofline of the dominant kernel
     for e0, e1, bn in ev_pairs:
@@ -195,7 +197,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "DGraph-Fin-size synthetic graph, mini-batch GGAD (GCN encoder)", "nodes": a.nodes,
                        "directed_entries": int(graph.nnz), "feat": a.feat, "emb": a.emb, "batch": "150+50",
-                       "graph": f"{a.graph_kind}(alpha=2.1,max_degree={a.max_degree})", "chunk_batches": a.chunk,
+                       "graph": f"{a.graph_kind}(alpha=2.1,max_degree={a.max_degree})", "chunk_batches": trainer.chunk_batches, "layout": a.layout,
                        "parallelism": f"dp{world}", "optimizer": "adam(lr=1e-3,wd=0.007)"},
             "roofline": roofline, "cpu_baseline": cpu,
             "gpu_over_cpu": (value / cpu["value"]) if cpu else None,

@@ -36,10 +36,12 @@ SIGNATURES = {
     "ggad_exclusive_scan_i32": (c_int32, [_P, _P, _L, _P, _P]),
     "ggad_mb_row_degree": (c_int32, [_P, _P, _P, _P, _I, _I, _P, _P, _P]),
     "ggad_mb_expand1": (c_int32, [_P, _P, _P, _P, _P, _I, _L, _P, _P, _P, _P, _P, _P]),
-    "ggad_mb_gather1": (c_int32, [_P, _I, _P, _P, _P, _I, _L, _P, _P, _P, _P, _P, _P]),
-    "ggad_mb_count2": (c_int32, [_P, _P, _P, _P, _P, _L, _L, _P, _P, _P]),
-    "ggad_mb_gather2": (c_int32, [_P, _P, _P, _I, _P, _P, _P, _P, _L, _L, _P, _P, _P]),
-    "ggad_mb_plan_reset": (c_int32, [_P, _P, _P, _P, _P, _P, _L, _L, _P, _P, _I, _P]),
+    "ggad_mb_gather1": (c_int32, [_P, _I, _I, _P, _P, _P, _I, _L, _P, _P, _P, _P, _P, _P]),
+    "ggad_mb_packed_stride": (c_int32, [_I]),
+    "ggad_mb_count2": (c_int32, [_P, _P, _P, _P, _P, _L, _L, _P, _P, _P, _I, _I, _P]),
+    "ggad_mb_gather2": (c_int32, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _L, _L, _P, _P, _P]),
+    "ggad_mb_reset_packed": (c_int32, [_P, _L, _I, _I, _I, _P]),
+    "ggad_mb_plan_reset": (c_int32, [_P, _P, _P, _P, _P, _P, _L, _L, _P, _P, _I, _P, _I, _I, _P]),
     "ggad_mb_param_count": (c_int64, [_I, _I]),
     "ggad_mb_param_block_elems": (c_int64, [_I, _I]),
     "ggad_mb_params_sync": (c_int32, [_P, _I, _I, _P]),

@@ -141,6 +141,7 @@ __global__ void __launch_bounds__(256) k_expand1(const int32_t *__restrict__ row
 // f = lane % F the feature.  Accumulates into acc (per lane partial for (g, f)).
 __device__ __forceinline__ void gather_block(const float *__restrict__ feat, int F, int fbase, int rpi, int g, int f,
                                              bool lane_active, int j, float w, int count, float &acc) {
+  // F here is the ROW STRIDE in floats (== feature width for an unpadded table)
   const int iters = (count + rpi - 1) / rpi;
   int t = 0;
   for (; t + 4 <= iters; t += 4) {
@@ -174,7 +175,7 @@ __device__ __forceinline__ float reduce_groups(float acc, int F, int rpi) {
   return tot;
 }
 
-__global__ void __launch_bounds__(256) k_gather1(const float *__restrict__ feat, int F, const int32_t *__restrict__ row_slot,
+__global__ void __launch_bounds__(256) k_gather1(const float *__restrict__ feat, int F, int stride, const int32_t *__restrict__ row_slot,
                                                  const int32_t *__restrict__ ent_ptr, const int32_t *__restrict__ ent_col,
                                                  int n_rows, int64_t n_nodes, const int32_t *__restrict__ cnt1,
                                                  const int32_t *__restrict__ own1, int32_t *__restrict__ ent_own,
@@ -203,7 +204,7 @@ __global__ void __launch_bounds__(256) k_gather1(const float *__restrict__ feat,
         if (fc == 0) { ent_own[e0 + idx] = own1[soff + j]; ent_c1[e0 + idx] = c; }
         w = inv_sr / sqrtf((float)c);                      // .div(col_normalized)
       }
-      gather_block(feat, F, fbase, rpi, g, f, lane_active, j, w, min(GGAD_WAVE, r - blk), acc);
+      gather_block(feat, stride, fbase, rpi, g, f, lane_active, j, w, min(GGAD_WAVE, r - blk), acc);
     }
     const float tot = (F <= 64) ? reduce_groups(acc, fw, rpi) : acc;
     if (lane < fw) x1[(int64_t)row * F + fbase + lane] = tot;
@@ -241,18 +242,93 @@ __global__ void __launch_bounds__(256) k_seg_mean(const float *__restrict__ feat
 __global__ void __launch_bounds__(256) k_count2(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                 const int32_t *__restrict__ ent_col, const int32_t *__restrict__ ent_slot,
                                                 const int32_t *__restrict__ ent_total, int64_t n_nodes,
-                                                const int32_t *__restrict__ own1, int32_t *__restrict__ cnt2) {
+                                                const int32_t *__restrict__ own1, int32_t *__restrict__ cnt2,
+                                                float *__restrict__ featp, int stride, int F) {
   const int e = blockIdx.x * (blockDim.x / GGAD_WAVE) + threadIdx.x / GGAD_WAVE;
   if (e >= *ent_total) return;
   const int u = ent_col[e];
-  const int64_t soff = (int64_t)ent_slot[e] * n_nodes;
+  const int slot = ent_slot[e];
+  const int64_t soff = (int64_t)slot * n_nodes;
   if (own1[soff + u] != e) return;                         // each distinct u of the batch once (set semantics)
   const int s = rowptr[u], t = rowptr[u + 1];
-  for (int i = s + lane_id(); i < t; i += GGAD_WAVE) atomicAdd(&cnt2[soff + col[i]], 1);
+  if (cnt2 != nullptr) {
+    for (int i = s + lane_id(); i < t; i += GGAD_WAVE) atomicAdd(&cnt2[soff + col[i]], 1);
+  } else {   // packed layout: the counter of (slot, k) lives in k's feature row, word F + slot
+    int32_t *base = reinterpret_cast<int32_t *>(featp) + F + slot;
+    for (int i = s + lane_id(); i < t; i += GGAD_WAVE) atomicAdd(base + (int64_t)col[i] * stride, 1);
+  }
+}
+
+// Packed layout (row = F features + per-slot int32 counters, 128-byte aligned): ONE random line per gathered
+// neighbour delivers both x_k and c'_k.  Lanes per row = F + 1 (the extra lane fetches the counter word).
+__global__ void __launch_bounds__(256) k_gather2_packed(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                        const float *__restrict__ featp, int F, int stride,
+                                                        const int32_t *__restrict__ ent_col, const int32_t *__restrict__ ent_slot,
+                                                        const int32_t *__restrict__ ent_own, const int32_t *__restrict__ ent_total,
+                                                        float *__restrict__ x2) {
+  const int e = blockIdx.x * (blockDim.x / GGAD_WAVE) + threadIdx.x / GGAD_WAVE;
+  if (e >= *ent_total) return;
+  if (ent_own[e] != e) return;
+  const int lane = lane_id();
+  const int u = ent_col[e];
+  const int slot = ent_slot[e];
+  const int s = rowptr[u], t = rowptr[u + 1];
+  const int deg = t - s;
+  const float inv_sr = 1.0f / sqrtf((float)deg);
+  const int lpr = F + 1, rpi = 64 / lpr;
+  const int g = lane / lpr, f = lane - g * lpr;
+  const bool lane_active = g < rpi;
+  const int foff = (f < F) ? f : F + slot;                 // word inside the row this lane fetches
+  float acc = 0.0f;
+  for (int blk = 0; blk < deg; blk += GGAD_WAVE) {
+    const int idx = blk + lane;
+    const int k = (idx < deg) ? col[s + idx] : 0;
+    const int count = min(GGAD_WAVE, deg - blk);
+    const int iters = (count + rpi - 1) / rpi;
+    int tt = 0;
+    for (; tt + 4 <= iters; tt += 4) {
+      float x[4]; bool ok[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int src = (tt + q) * rpi + g;
+        const int kk = __shfl(k, src & 63, GGAD_WAVE);
+        ok[q] = lane_active && src < count;
+        x[q] = ok[q] ? featp[(int64_t)kk * stride + foff] : 0.0f;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float cw = __shfl(x[q], (g * lpr + F) & 63, GGAD_WAVE);        // counter word of this lane's group
+        const float w = inv_sr / sqrtf((float)__float_as_int(cw));
+        acc = ok[q] ? fmaf(w, x[q], acc) : acc;
+      }
+    }
+    for (; tt < iters; ++tt) {
+      const int src = tt * rpi + g;
+      const int kk = __shfl(k, src & 63, GGAD_WAVE);
+      const bool ok = lane_active && src < count;
+      const float x = ok ? featp[(int64_t)kk * stride + foff] : 0.0f;
+      const float cw = __shfl(x, (g * lpr + F) & 63, GGAD_WAVE);
+      const float w = inv_sr / sqrtf((float)__float_as_int(cw));
+      acc = ok ? fmaf(w, x, acc) : acc;
+    }
+  }
+  // sum the rpi group partials of feature f into lanes [0, F)
+  float tot = acc;
+  for (int gg = 1; gg < rpi; ++gg) tot += __shfl(acc, (lane + gg * lpr) & 63, GGAD_WAVE);
+  if (deg == 0) tot = inv_sr * 0.0f;
+  if (lane < F) x2[(int64_t)e * F + lane] = tot;
+}
+
+__global__ void __launch_bounds__(256) k_reset_packed(float *__restrict__ featp, int64_t n_nodes, int stride, int F, int n_slots) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_nodes * n_slots) return;
+  const int64_t node = i / n_slots;
+  const int sl = (int)(i - node * n_slots);
+  reinterpret_cast<int32_t *>(featp)[node * stride + F + sl] = 0;
 }
 
 __global__ void __launch_bounds__(256) k_gather2(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                                 const float *__restrict__ feat, int F, const int32_t *__restrict__ ent_col,
+                                                 const float *__restrict__ feat, int F, int stride, const int32_t *__restrict__ ent_col,
                                                  const int32_t *__restrict__ ent_slot, const int32_t *__restrict__ ent_own,
                                                  const int32_t *__restrict__ ent_total, int64_t n_nodes,
                                                  const int32_t *__restrict__ cnt2, float *__restrict__ x2) {
@@ -280,7 +356,7 @@ __global__ void __launch_bounds__(256) k_gather2(const int32_t *__restrict__ row
         k = col[s + idx];
         w = inv_sr / sqrtf((float)cnt2[soff + k]);
       }
-      gather_block(feat, F, fbase, rpi, g, f, lane_active, k, w, min(GGAD_WAVE, deg - blk), acc);
+      gather_block(feat, stride, fbase, rpi, g, f, lane_active, k, w, min(GGAD_WAVE, deg - blk), acc);
     }
     float tot = (F <= 64) ? reduce_groups(acc, fw, rpi) : acc;
     if (deg == 0) tot = inv_sr * 0.0f;
@@ -292,15 +368,21 @@ __global__ void __launch_bounds__(256) k_plan_reset(const int32_t *__restrict__ 
                                                     const int32_t *__restrict__ ent_col, const int32_t *__restrict__ ent_slot,
                                                     const int32_t *__restrict__ ent_own, const int32_t *__restrict__ ent_total,
                                                     int64_t n_nodes, int32_t *__restrict__ cnt1, int32_t *__restrict__ cnt2,
-                                                    int with_hop2) {
+                                                    int with_hop2, float *__restrict__ featp, int stride, int F) {
   const int e = blockIdx.x * (blockDim.x / GGAD_WAVE) + threadIdx.x / GGAD_WAVE;
   if (e >= *ent_total) return;
   const int u = ent_col[e];
-  const int64_t soff = (int64_t)ent_slot[e] * n_nodes;
+  const int slot = ent_slot[e];
+  const int64_t soff = (int64_t)slot * n_nodes;
   if (lane_id() == 0) cnt1[soff + u] = 0;
   if (!with_hop2 || ent_own[e] != e) return;
   const int s = rowptr[u], t = rowptr[u + 1];
-  for (int i = s + lane_id(); i < t; i += GGAD_WAVE) cnt2[soff + col[i]] = 0;
+  if (cnt2 != nullptr) {
+    for (int i = s + lane_id(); i < t; i += GGAD_WAVE) cnt2[soff + col[i]] = 0;
+  } else {
+    int32_t *base = reinterpret_cast<int32_t *>(featp) + F + slot;
+    for (int i = s + lane_id(); i < t; i += GGAD_WAVE) base[(int64_t)col[i] * stride] = 0;
+  }
 }
 
 }  // namespace
@@ -348,13 +430,13 @@ int ggad_mb_expand1(const int32_t *rowptr, const int32_t *col, const int32_t *no
   return GGAD_OK;
 }
 
-int ggad_mb_gather1(const float *feat, int32_t feat_dim, const int32_t *row_slot, const int32_t *ent_ptr,
+int ggad_mb_gather1(const float *feat, int32_t feat_dim, int32_t feat_stride, const int32_t *row_slot, const int32_t *ent_ptr,
                     const int32_t *ent_col, int32_t n_rows, int64_t n_nodes, const int32_t *cnt1,
                     const int32_t *own1, int32_t *ent_own, int32_t *ent_c1, float *x1, ggad_stream_t stream) {
   GGAD_REQUIRE(feat && row_slot && ent_ptr && ent_col && cnt1 && own1 && ent_own && ent_c1 && x1);
-  GGAD_REQUIRE(feat_dim >= 1 && feat_dim <= GGAD_MAX_F && n_rows >= 0);
+  GGAD_REQUIRE(feat_dim >= 1 && feat_dim <= GGAD_MAX_F && feat_stride >= feat_dim && n_rows >= 0);
   if (n_rows == 0) return GGAD_OK;
-  k_gather1<<<dim3((n_rows + 3) / 4), dim3(256), 0, as_stream(stream)>>>(feat, feat_dim, row_slot, ent_ptr, ent_col, n_rows,
+  k_gather1<<<dim3((n_rows + 3) / 4), dim3(256), 0, as_stream(stream)>>>(feat, feat_dim, feat_stride, row_slot, ent_ptr, ent_col, n_rows,
                                                                          n_nodes, cnt1, own1, ent_own, ent_c1, x1);
   GGAD_CHECK_LAUNCH("mb_gather1");
   return GGAD_OK;
@@ -369,36 +451,57 @@ int ggad_seg_mean(const float *feat, int32_t feat_dim, const int32_t *seg_ptr, c
   return GGAD_OK;
 }
 
+int ggad_mb_packed_stride(int32_t feat_dim) { return ((feat_dim + 1 + 31) / 32) * 32; }
+
 int ggad_mb_count2(const int32_t *rowptr, const int32_t *col, const int32_t *ent_col, const int32_t *ent_slot,
                    const int32_t *ent_total, int64_t n_entries_cap, int64_t n_nodes, const int32_t *own1,
-                   int32_t *cnt2, ggad_stream_t stream) {
-  GGAD_REQUIRE(rowptr && col && ent_col && ent_slot && ent_total && own1 && cnt2 && n_entries_cap >= 0);
+                   int32_t *cnt2, float *feat_packed, int32_t feat_dim, int32_t feat_stride, ggad_stream_t stream) {
+  GGAD_REQUIRE(rowptr && col && ent_col && ent_slot && ent_total && own1 && n_entries_cap >= 0);
+  GGAD_REQUIRE(cnt2 || (feat_packed && feat_stride > feat_dim && feat_dim >= 1));
   if (n_entries_cap == 0) return GGAD_OK;
-  k_count2<<<dim3((unsigned)((n_entries_cap + 3) / 4)), dim3(256), 0, as_stream(stream)>>>(rowptr, col, ent_col, ent_slot,
-                                                                                           ent_total, n_nodes, own1, cnt2);
+  k_count2<<<dim3((unsigned)((n_entries_cap + 3) / 4)), dim3(256), 0, as_stream(stream)>>>(
+      rowptr, col, ent_col, ent_slot, ent_total, n_nodes, own1, cnt2, feat_packed, feat_stride, feat_dim);
   GGAD_CHECK_LAUNCH("mb_count2");
   return GGAD_OK;
 }
 
-int ggad_mb_gather2(const int32_t *rowptr, const int32_t *col, const float *feat, int32_t feat_dim,
+int ggad_mb_gather2(const int32_t *rowptr, const int32_t *col, const float *feat, int32_t feat_dim, int32_t feat_stride,
                     const int32_t *ent_col, const int32_t *ent_slot, const int32_t *ent_own, const int32_t *ent_total,
                     int64_t n_entries_cap, int64_t n_nodes, const int32_t *cnt2, float *x2, ggad_stream_t stream) {
-  GGAD_REQUIRE(rowptr && col && feat && ent_col && ent_slot && ent_own && ent_total && cnt2 && x2);
-  GGAD_REQUIRE(feat_dim >= 1 && feat_dim <= GGAD_MAX_F && n_entries_cap >= 0);
+  GGAD_REQUIRE(rowptr && col && feat && ent_col && ent_slot && ent_own && ent_total && x2);
+  GGAD_REQUIRE(feat_dim >= 1 && feat_dim <= GGAD_MAX_F && feat_stride >= feat_dim && n_entries_cap >= 0);
+  GGAD_REQUIRE(cnt2 || (feat_stride > feat_dim && feat_dim + 1 <= 64));
   if (n_entries_cap == 0) return GGAD_OK;
-  k_gather2<<<dim3((unsigned)((n_entries_cap + 3) / 4)), dim3(256), 0, as_stream(stream)>>>(
-      rowptr, col, feat, feat_dim, ent_col, ent_slot, ent_own, ent_total, n_nodes, cnt2, x2);
+  if (cnt2 == nullptr)
+    k_gather2_packed<<<dim3((unsigned)((n_entries_cap + 3) / 4)), dim3(256), 0, as_stream(stream)>>>(
+        rowptr, col, feat, feat_dim, feat_stride, ent_col, ent_slot, ent_own, ent_total, x2);
+  else
+    k_gather2<<<dim3((unsigned)((n_entries_cap + 3) / 4)), dim3(256), 0, as_stream(stream)>>>(
+        rowptr, col, feat, feat_dim, feat_stride, ent_col, ent_slot, ent_own, ent_total, n_nodes, cnt2, x2);
   GGAD_CHECK_LAUNCH("mb_gather2");
+  return GGAD_OK;
+}
+
+int ggad_mb_reset_packed(float *feat_packed, int64_t n_nodes, int32_t feat_dim, int32_t feat_stride, int32_t n_slots,
+                         ggad_stream_t stream) {
+  GGAD_REQUIRE(feat_packed && n_nodes >= 0 && feat_dim >= 1 && n_slots >= 0 && feat_dim + n_slots <= feat_stride);
+  const int64_t tot = n_nodes * n_slots;
+  if (tot == 0) return GGAD_OK;
+  k_reset_packed<<<dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, as_stream(stream)>>>(feat_packed, n_nodes, feat_stride,
+                                                                                           feat_dim, n_slots);
+  GGAD_CHECK_LAUNCH("mb_reset_packed");
   return GGAD_OK;
 }
 
 int ggad_mb_plan_reset(const int32_t *rowptr, const int32_t *col, const int32_t *ent_col, const int32_t *ent_slot,
                        const int32_t *ent_own, const int32_t *ent_total, int64_t n_entries_cap, int64_t n_nodes,
-                       int32_t *cnt1, int32_t *cnt2, int32_t with_hop2, ggad_stream_t stream) {
-  GGAD_REQUIRE(rowptr && col && ent_col && ent_slot && ent_own && ent_total && cnt1 && (cnt2 || !with_hop2));
+                       int32_t *cnt1, int32_t *cnt2, int32_t with_hop2, float *feat_packed, int32_t feat_dim,
+                       int32_t feat_stride, ggad_stream_t stream) {
+  GGAD_REQUIRE(rowptr && col && ent_col && ent_slot && ent_own && ent_total && cnt1);
+  GGAD_REQUIRE(!with_hop2 || cnt2 || (feat_packed && feat_stride > feat_dim));
   if (n_entries_cap == 0) return GGAD_OK;
   k_plan_reset<<<dim3((unsigned)((n_entries_cap + 3) / 4)), dim3(256), 0, as_stream(stream)>>>(
-      rowptr, col, ent_col, ent_slot, ent_own, ent_total, n_nodes, cnt1, cnt2, with_hop2);
+      rowptr, col, ent_col, ent_slot, ent_own, ent_total, n_nodes, cnt1, cnt2, with_hop2, feat_packed, feat_stride, feat_dim);
   GGAD_CHECK_LAUNCH("mb_plan_reset");
   return GGAD_OK;
 }

@@ -39,6 +39,16 @@ def _check_i32(x: int) -> None:
         raise ValueError("chunk too large for int32 entry indices; use fewer batches per chunk")
 
 
+def pack_features(feat: torch.Tensor) -> torch.Tensor:
+    """(N, F) feature table -> packed (N, stride) table: F features then zeroed per-slot int32 counters, rows
+    128-byte aligned (`ggad_mb_packed_stride`).  One random line per gathered neighbour then holds x_k AND c'_k."""
+    n, f = feat.shape
+    stride = int(_lib.load().ggad_mb_packed_stride(f))
+    out = torch.zeros(n, stride, dtype=torch.float32, device=feat.device)
+    out[:, :f] = feat
+    return out
+
+
 class BatchChunk:
     """Device plan of up to ``max_batches`` batches (see module docstring).
 
@@ -48,11 +58,15 @@ class BatchChunk:
     """
 
     def __init__(self, graph: DeviceGraph, feat: torch.Tensor, embed_dim: int, max_batches: int,
-                 rows_cap: int, ent_cap: int, train: bool = True, reset_mode: str = "auto"):
+                 rows_cap: int, ent_cap: int, train: bool = True, reset_mode: str = "auto", feat_dim: Optional[int] = None):
         self.lib = _lib.load()
         self.g = graph
         self.feat = feat
-        self.F = int(feat.shape[1])
+        self.stride = int(feat.shape[1])
+        self.F = int(feat_dim) if feat_dim is not None else self.stride
+        self.packed = self.stride > self.F        # counters of the 2-hop histogram live inside the feature rows
+        if self.packed and train and max_batches > self.stride - self.F:
+            raise ValueError(f"packed feature rows hold {self.stride - self.F} counter slots, chunk wants {max_batches}")
         self.D = int(embed_dim)
         self.dev = feat.device
         self.train = train
@@ -62,7 +76,8 @@ class BatchChunk:
         # per-batch counter slots: int32[max_batches][n]; zero on entry, zeroed again by reset()
         self.cnt1 = torch.zeros(self.max_batches * graph.n, dtype=torch.int32, device=self.dev)
         self.own1 = torch.zeros(self.max_batches * graph.n, dtype=torch.int32, device=self.dev)
-        self.cnt2 = torch.zeros(self.max_batches * graph.n, dtype=torch.int32, device=self.dev) if train else None
+        self.cnt2 = torch.zeros(self.max_batches * graph.n, dtype=torch.int32, device=self.dev) \
+            if (train and not self.packed) else None
         self.rows_cap = 0
         self.ent_cap = 0
         self.generation = 0
@@ -187,16 +202,17 @@ class BatchChunk:
         call("ggad_mb_expand1", ptr(g.rowptr), ptr(g.col), ptr(self.nodes), ptr(self.row_slot), ptr(self.ent_ptr), rows,
              g.n, ptr(self.ent_col), ptr(self.ent_slot), ptr(self.ent_row), ptr(self.cnt1), ptr(self.own1))
         self.dirty = True
-        call("ggad_mb_gather1", ptr(self.feat), self.F, ptr(self.row_slot), ptr(self.ent_ptr), ptr(self.ent_col), rows,
+        call("ggad_mb_gather1", ptr(self.feat), self.F, self.stride, ptr(self.row_slot), ptr(self.ent_ptr), ptr(self.ent_col), rows,
              g.n, ptr(self.cnt1), ptr(self.own1), ptr(self.ent_own), ptr(self.ent_c1), ptr(self.x1))
         if self.train:
             tot = self.ent_total_ptr()
             call("ggad_mb_count2", ptr(g.rowptr), ptr(g.col), ptr(self.ent_col), ptr(self.ent_slot), tot, n_ents, g.n,
-                 ptr(self.own1), ptr(self.cnt2))
+                 ptr(self.own1), ptr(self.cnt2) if self.cnt2 is not None else 0, ptr(self.feat), self.F, self.stride)
             if self.gather2_events is not None:
                 self.gather2_events[0].record()
-            call("ggad_mb_gather2", ptr(g.rowptr), ptr(g.col), ptr(self.feat), self.F, ptr(self.ent_col),
-                 ptr(self.ent_slot), ptr(self.ent_own), tot, n_ents, g.n, ptr(self.cnt2), ptr(self.x2))
+            call("ggad_mb_gather2", ptr(g.rowptr), ptr(g.col), ptr(self.feat), self.F, self.stride, ptr(self.ent_col),
+                 ptr(self.ent_slot), ptr(self.ent_own), tot, n_ents, g.n, ptr(self.cnt2) if self.cnt2 is not None else 0,
+                 ptr(self.x2))
             if self.gather2_events is not None:
                 self.gather2_events[1].record()
 
@@ -220,14 +236,19 @@ class BatchChunk:
         if not self.dirty:
             return
         g = self.g
-        if self.train and self._memset_is_cheaper():
+        stream_reset = self.train and self._memset_is_cheaper()
+        if stream_reset and not self.packed:
             used = self.n_batches * g.n
             self.cnt1[:used].zero_()
             self.cnt2[:used].zero_()
         else:
+            # walk the entries: always for the (small) 1-hop counters, and for the 2-hop ones on sparse graphs
+            hop2 = 1 if (self.train and not stream_reset) else 0
             call("ggad_mb_plan_reset", ptr(g.rowptr), ptr(g.col), ptr(self.ent_col), ptr(self.ent_slot), ptr(self.ent_own),
-                 self.ent_total_ptr(), self.n_ents, g.n, ptr(self.cnt1), ptr(self.cnt2) if self.train else 0,
-                 1 if self.train else 0)
+                 self.ent_total_ptr(), self.n_ents, g.n, ptr(self.cnt1), ptr(self.cnt2) if self.cnt2 is not None else 0, hop2,
+                 ptr(self.feat) if self.packed else 0, self.F, self.stride)
+            if stream_reset:   # packed: one streaming pass over the counter words of the used slots
+                call("ggad_mb_reset_packed", ptr(self.feat), g.n, self.F, self.stride, self.n_batches)
         self.dirty = False
 
     def batch_rows(self, b: int):

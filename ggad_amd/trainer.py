@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 from .graph import DeviceGraph
-from .minibatch import BatchChunk, MiniBatchEngine, reduce_gradients  # noqa: F401 (re-exported)
+from .minibatch import BatchChunk, MiniBatchEngine, pack_features, reduce_gradients  # noqa: F401 (re-exported)
 from .sampler import PyCompatRandom
 
 
@@ -69,17 +69,25 @@ class DGraphTrainer:
     def __init__(self, graph: DeviceGraph, feat: torch.Tensor, embed_dim: int, schedule: BatchSchedule,
                  lr: float = 1e-3, weight_decay: float = 0.007, chunk_batches: int = 150, rank: int = 0,
                  world_size: int = 1, allreduce: Optional[Callable[[torch.Tensor], None]] = None,
-                 engine: Optional[MiniBatchEngine] = None):
+                 engine: Optional[MiniBatchEngine] = None, packed: bool = True):
+        """`feat` is the plain (N, F) table; with `packed` (default) the plans run on a private padded copy whose
+        rows also hold the per-batch 2-hop counters (15 slots for F = 17), so a chunk is at most that many batches."""
         self.graph, self.feat = graph, feat
         self.schedule = schedule
         self.rank, self.world = int(rank), int(world_size)
         self.allreduce = allreduce if self.world > 1 else None
         self.engine = engine or MiniBatchEngine(feat.shape[1], embed_dim, feat.device, lr, weight_decay)
         self.chunk_batches = int(chunk_batches)
+        f = int(feat.shape[1])
+        self.packed = bool(packed) and f + 1 <= 64
+        table = feat
+        if self.packed:
+            table = pack_features(feat)
+            self.chunk_batches = max(1, min(self.chunk_batches, table.shape[1] - f))
         rows = self.chunk_batches * (schedule.bs + schedule.n_pseudo)
         mean_deg = max(1.0, graph.nnz / max(1, graph.n))
-        self.chunk = BatchChunk(graph, feat, embed_dim, self.chunk_batches, rows, int(rows * (mean_deg + 1) * 1.5) + 1024,
-                                train=True)
+        self.chunk = BatchChunk(graph, table, embed_dim, self.chunk_batches, rows, int(rows * (mean_deg + 1) * 1.5) + 1024,
+                                train=True, feat_dim=f)
         self.steps_done = 0
 
     def run_steps(self, n_steps: int, prepared: Optional[Tuple[List[np.ndarray], List[np.ndarray]]] = None,
@@ -96,7 +104,7 @@ class DGraphTrainer:
             else:
                 bn, bl = self.schedule.next_batches(k, self.rank, self.world)
             self.chunk.build(bn, bl) if gather_hook is None else gather_hook(self.chunk, bn, bl)
-            self.engine.train_chunk(self.chunk, self.allreduce, self.world, log_base=0)
+            self.engine.train_chunk(self.chunk, self.allreduce, self.world, log_base=done)   # loss log slot = step index
             nodes_seen += sum(len(b) for b in bn)
             done += k
         self.steps_done += n_steps

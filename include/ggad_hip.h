@@ -80,8 +80,9 @@ int ggad_mb_expand1(const int32_t *rowptr, const int32_t *col, const int32_t *no
                     int32_t *ent_row, int32_t *cnt1, int32_t *own1, ggad_stream_t stream);
 
 /* ent_own[e], ent_c1[e] from the slot arrays, and the 1-hop aggregate
- * x1[i] = sum_j feat[j] / (sqrt(r_i) sqrt(c_j)).                        graphsage.py:314-326 */
-int ggad_mb_gather1(const float *feat, int32_t feat_dim, const int32_t *row_slot, const int32_t *ent_ptr,
+ * x1[i] = sum_j feat[j] / (sqrt(r_i) sqrt(c_j)).                        graphsage.py:314-326
+ * feat rows are feat_stride floats apart (feat_stride == feat_dim for a plain table). */
+int ggad_mb_gather1(const float *feat, int32_t feat_dim, int32_t feat_stride, const int32_t *row_slot, const int32_t *ent_ptr,
                     const int32_t *ent_col, int32_t n_rows, int64_t n_nodes, const int32_t *cnt1,
                     const int32_t *own1, int32_t *ent_own, int32_t *ent_c1, float *x1, ggad_stream_t stream);
 
@@ -94,22 +95,32 @@ int ggad_seg_mean(const float *feat, int32_t feat_dim, const int32_t *seg_ptr, c
  * upper bound, e.g. sum(deg+1)) and read the true count from *ent_total (= ent_ptr[n_rows]).
  *
  * cnt2[slot][k] += 1 for every k in N(u), u an owner entry: column sums of the U x U2 mask
- * (graphsage.py:335-348; rows are adj_list.get(u) WITHOUT self union).                     */
+ * (graphsage.py:335-348; rows are adj_list.get(u) WITHOUT self union).
+ *
+ * PACKED layout (cnt2 == NULL): the feature table has rows of ggad_mb_packed_stride(F) floats (128-byte
+ * aligned): F features followed by one int32 counter per slot; the counter of (slot, k) is word F + slot of
+ * row k.  One random 128-byte line per gathered neighbour then delivers both x_k and c'_k (measured +48 %
+ * rows/s over a separate counter array, scripts/gather_bench.hip).  At most stride - F slots per chunk. */
+int ggad_mb_packed_stride(int32_t feat_dim);
 int ggad_mb_count2(const int32_t *rowptr, const int32_t *col, const int32_t *ent_col, const int32_t *ent_slot,
                    const int32_t *ent_total, int64_t n_entries_cap, int64_t n_nodes, const int32_t *own1,
-                   int32_t *cnt2, ggad_stream_t stream);
+                   int32_t *cnt2, float *feat_packed, int32_t feat_dim, int32_t feat_stride, ggad_stream_t stream);
 
 /* 2-hop aggregate at owner entries:
  * x2[e] = sum_{k in N(u)} feat[k] / (sqrt(|N(u)|) sqrt(c'_k)).          graphsage.py:346-355
  * Dominant kernel of the path: HBM gather of feat rows, 4*F+8 algorithmic bytes per neighbour. */
-int ggad_mb_gather2(const int32_t *rowptr, const int32_t *col, const float *feat, int32_t feat_dim,
+int ggad_mb_gather2(const int32_t *rowptr, const int32_t *col, const float *feat, int32_t feat_dim, int32_t feat_stride,
                     const int32_t *ent_col, const int32_t *ent_slot, const int32_t *ent_own, const int32_t *ent_total,
                     int64_t n_entries_cap, int64_t n_nodes, const int32_t *cnt2, float *x2, ggad_stream_t stream);
 
+/* Packed layout: zero the first n_slots counters of every feature row (streaming pass). */
+int ggad_mb_reset_packed(float *feat_packed, int64_t n_nodes, int32_t feat_dim, int32_t feat_stride, int32_t n_slots,
+                         ggad_stream_t stream);
 /* Restore the counter slots to zero by re-walking the chunk (with_hop2 = 0 for inference plans). */
 int ggad_mb_plan_reset(const int32_t *rowptr, const int32_t *col, const int32_t *ent_col, const int32_t *ent_slot,
                        const int32_t *ent_own, const int32_t *ent_total, int64_t n_entries_cap, int64_t n_nodes,
-                       int32_t *cnt1, int32_t *cnt2, int32_t with_hop2, ggad_stream_t stream);
+                       int32_t *cnt1, int32_t *cnt2, int32_t with_hop2, float *feat_packed, int32_t feat_dim,
+                       int32_t feat_stride, ggad_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Mini-batch path: dense step = GCNEncoder.forward + GCN.loss + backward + Adam

@@ -256,3 +256,29 @@ def test_fused_adam_chunk_equals_stepwise():
         outs.append((eng.params.cpu().numpy().copy(), eng.losses(4).copy()))
     np.testing.assert_array_equal(outs[0][0], outs[1][0])
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("f,reset_mode", [(17, "memset"), (17, "walk"), (9, "auto"), (40, "auto")])
+def test_packed_feature_rows_layout(f, reset_mode):
+    """2-hop counters inside 128-byte feature rows (ggad_mb_packed_stride): same results as the oracle, rows restored."""
+    from ggad_amd.minibatch import pack_features
+    g, batches, labels = _random_case(n=20000, n_entries=160000, f=f, d=32, seed=60 + f, nb=3, bsz=200, n_ano=50)
+    graph = DeviceGraph(g["rowptr"], g["col"], DEV)
+    plain = torch.from_numpy(np.ascontiguousarray(g["feat"])).to(DEV)
+    table = pack_features(plain)
+    stride = table.shape[1]
+    assert stride % 32 == 0 and stride > f
+    ch = BatchChunk(graph, table, 32, max_batches=min(4, stride - f), rows_cap=64, ent_cap=64, train=True,
+                    reset_mode=reset_mode, feat_dim=f)
+    assert ch.packed and ch.cnt2 is None
+    for rep in range(2):
+        ch.build(batches, labels)
+        torch.cuda.synchronize()
+        _check_plan_against_oracle(g, ch, batches, g["feat"], atol=3e-6)
+    ch.reset()
+    torch.cuda.synchronize()
+    assert torch.equal(table[:, :f], plain)                                   # features untouched
+    assert int(table[:, f:].view(torch.int32).abs().sum()) == 0               # every counter word back to zero
+    assert int(ch.cnt1.abs().sum()) == 0
+    with pytest.raises(ValueError):
+        BatchChunk(graph, table, 32, max_batches=stride - f + 1, rows_cap=64, ent_cap=64, train=True, feat_dim=f)
