@@ -48,8 +48,10 @@ def parse():
     ap.add_argument("--graph-kind", default="powerlaw", choices=["powerlaw", "er"])
     ap.add_argument("--chunk", type=int, default=150, help="batches planned per launch group (reference epoch = 150)")
     ap.add_argument("--cpu-batches", type=int, default=3, help="batches timed on the CPU port (0 = skip)")
-    ap.add_argument("--layout", default="packed", choices=["packed", "plain"],
-                    help="packed: 2-hop counters inside 128-byte feature rows (chunk <= 15 batches); plain: separate slot arrays")
+    ap.add_argument("--no-overlap", action="store_true", help="plan and dense steps on one stream")
+    ap.add_argument("--hop2", default="global", choices=["tiled", "ktile", "global", "packed"],
+                    help="tiled: LDS-tiled 2-hop kernel; global: atomics on per-batch counter slots in HBM; "
+                         "packed: global counters inside 128-byte feature rows (chunk <= 15 batches)")
     ap.add_argument("--seed", type=int, default=72)
     return ap.parse_args()
 
@@ -95,7 +97,8 @@ def main():
         def allreduce(t):
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
     trainer = DGraphTrainer(graph, feat, a.emb, sched, lr=1e-3, weight_decay=0.007, chunk_batches=a.chunk, rank=rank,
-                            world_size=world, allreduce=allreduce, packed=(a.layout == "packed"))
+                            world_size=world, allreduce=allreduce, packed=(a.hop2 == "packed"),
+                            hop2=(a.hop2 if a.hop2 in ("tiled", "ktile") else "global"), overlap=not a.no_overlap)
     torch.manual_seed(a.seed)
     w = torch.nn.init.xavier_uniform_(torch.empty(1, a.emb))
     W = torch.nn.init.xavier_uniform_(torch.empty(a.emb, a.feat))
@@ -159,7 +162,10 @@ def main():
         gather_nbrs.append(hop2_neighbours(bn))
     alg_bytes = [(4 * a.feat + 4) * nb for nb in gather_nbrs]
     ach = (sum(alg_bytes) / 1e9) / (sum(gather_ms) / 1e3) if gather_ms and sum(gather_ms) > 0 else None
-    roofline = {"kernel": "k_gather2 (2-hop gather-aggregate)", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
+    kname = {"tiled": "k_hop2_tiled (LDS-tiled 2-hop count + gather-aggregate)",
+             "ktile": "k_count2_tile + k_gather2_tile (k-tile-major 2-hop count + gather-aggregate, all launches)"}.get(
+        trainer.chunk.last_hop2, "k_gather2 (2-hop gather-aggregate)")
+    roofline = {"kernel": kname, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": None,
                 "launches": len(gather_ms), "avg_launch_ms": float(np.mean(gather_ms)) if gather_ms else None,
                 "alg_bytes_per_launch": float(np.mean(alg_bytes)) if alg_bytes else None,
@@ -197,7 +203,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "DGraph-Fin-size synthetic graph, mini-batch GGAD (GCN encoder)", "nodes": a.nodes,
                        "directed_entries": int(graph.nnz), "feat": a.feat, "emb": a.emb, "batch": "150+50",
-                       "graph": f"{a.graph_kind}(alpha=2.1,max_degree={a.max_degree})", "chunk_batches": trainer.chunk_batches, "layout": a.layout,
+                       "graph": f"{a.graph_kind}(alpha=2.1,max_degree={a.max_degree})", "chunk_batches": trainer.chunk_batches, "hop2": a.hop2, "overlap": trainer.overlap,
                        "parallelism": f"dp{world}", "optimizer": "adam(lr=1e-3,wd=0.007)"},
             "roofline": roofline, "cpu_baseline": cpu,
             "gpu_over_cpu": (value / cpu["value"]) if cpu else None,

@@ -1,0 +1,372 @@
+// LDS-tiled 2-hop aggregation of the DGraph mini-batch path (gfx950).
+//
+// Computes, for every owner entry u of a batch (the reference's `unique_nodes_list`, graphsage.py:306),
+//     x2[u] = sum_{k in N(u)} feat[k] / (sqrt(|N(u)|) sqrt(c'_k)),     c'_k = #{owners u' of the batch : k in N(u')}
+// i.e. mask_neigh.mm(embed_matrix_expand) with the batch-dependent column normalisation of graphsage.py:335-355.
+//
+// The straightforward formulation (plan.hip: k_count2 + k_gather2) makes three random DRAM accesses per
+// (u, k) pair -- an atomic on a 14.8 MB per-batch counter array, a read of that counter, a read of the feature
+// row -- and is bound by random 64-byte sector traffic (~3.7 TB/s of sectors = 1.8 TB/s algorithmic).
+// Here the node id space is cut into TILES of 65,536 consecutive ids.  One workgroup owns one batch and
+// walks the tiles in order; inside a tile
+//   * c'_k lives in LDS (65,536 16-bit counters = 128 KB of the CU's 160 KB), incremented with ds_add;
+//   * the neighbours of owner u that fall into the tile are a CONTIGUOUS piece of u's sorted CSR row,
+//     found through a static per-node table of tile offsets (built once per graph);
+//   * the feature rows touched are confined to one 4.4 MB slab of the table, which every batch-workgroup
+//     reads at about the same time -> served by L2 / Infinity Cache instead of DRAM.
+// No global atomics, no per-batch counter arrays in HBM, fixed summation order (tiles ascending, CSR order
+// inside a tile) -> deterministic.  Requires < 65,536 owners per batch (16-bit counters); the host falls back
+// to the global-counter path otherwise.
+#include "common.h"
+
+namespace {
+
+constexpr int TILE_SHIFT = 16;
+constexpr int TILE = 1 << TILE_SHIFT;
+constexpr int H2_T = 1024;             // threads per workgroup (16 waves)
+constexpr int H2_W = H2_T / 64;
+constexpr int SHORT_MAX = 4;           // segments up to this length are processed one owner per lane
+
+__global__ void __launch_bounds__(256) k_tile_offsets(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                      int64_t n_nodes, int n_tiles, int32_t *__restrict__ off) {
+  const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= n_nodes) return;
+  const int s = rowptr[u], e = rowptr[u + 1];
+  int32_t *o = off + u * (n_tiles + 1);
+  int t = 0;
+  for (int i = s; i < e; ++i) {
+    const int tile = col[i] >> TILE_SHIFT;
+    while (t <= tile) { o[t] = i - s; ++t; }
+  }
+  while (t <= n_tiles) { o[t] = e - s; ++t; }
+}
+
+__global__ void __launch_bounds__(256) k_owner_flags(const int32_t *__restrict__ ent_own, const int32_t *__restrict__ ent_total,
+                                                     int64_t n_cap, int32_t *__restrict__ flags) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_cap) return;
+  flags[e] = (e < *ent_total && ent_own[e] == (int32_t)e) ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(256) k_owner_compact(const int32_t *__restrict__ flags, const int32_t *__restrict__ pos,
+                                                       int64_t n_cap, int32_t *__restrict__ own_list) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_cap) return;
+  if (flags[e]) own_list[pos[e]] = (int32_t)e;
+}
+
+__device__ __forceinline__ void lds_count(uint32_t *cnt, int k) {
+  const int loc = k & (TILE - 1);
+  atomicAdd(&cnt[loc >> 1], 1u << ((loc & 1) << 4));
+}
+__device__ __forceinline__ float lds_weight(const uint32_t *cnt, int k, float inv_sr) {
+  const int loc = k & (TILE - 1);
+  const uint32_t c = (cnt[loc >> 1] >> ((loc & 1) << 4)) & 0xFFFFu;
+  return inv_sr / sqrtf((float)c);                       // mask.div(row_normalized).div(col_normalized)  graphsage.py:348
+}
+
+template <int FT>
+__global__ void __launch_bounds__(H2_T) k_hop2_tiled(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                     const float *__restrict__ feat, int F_rt, int stride,
+                                                     const int32_t *__restrict__ tile_off, int n_tiles,
+                                                     const int32_t *__restrict__ own_list, const int32_t *__restrict__ own_pos,
+                                                     const int32_t *__restrict__ batch_ent_ptr,
+                                                     const int32_t *__restrict__ ent_col, float *__restrict__ x2) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t cnt[];     // TILE / 2 words
+  const int F = (FT > 0) ? FT : F_rt;
+  const int lane = lane_id(), wid = threadIdx.x >> 6;
+  const int b = blockIdx.x;
+  const int o0 = own_pos[batch_ent_ptr[b]], o1 = own_pos[batch_ent_ptr[b + 1]];
+  const int n_own = o1 - o0;
+  const int NT1 = n_tiles + 1;
+  const int rpi = F <= 64 ? 64 / F : 1;
+  const int g = lane / (F <= 64 ? F : 64), f = lane - g * (F <= 64 ? F : 64);
+  const bool lane_active = g < rpi;
+  for (int t = 0; t < n_tiles; ++t) {
+    for (int i = threadIdx.x; i < TILE / 2; i += H2_T) cnt[i] = 0u;
+    __syncthreads();
+    // ---------------- count c'_k for the keys of this tile
+    for (int base = wid * 64; base < n_own; base += H2_W * 64) {
+      const int i = base + lane;
+      const bool valid = i < n_own;
+      int rp = 0, lo = 0, n = 0;
+      if (valid) {
+        const int u = ent_col[own_list[o0 + i]];
+        rp = rowptr[u];
+        lo = tile_off[(int64_t)u * NT1 + t];
+        n = tile_off[(int64_t)u * NT1 + t + 1] - lo;
+      }
+      if (n > 0 && n <= SHORT_MAX) {
+#pragma unroll
+        for (int j = 0; j < SHORT_MAX; ++j)
+          if (j < n) lds_count(cnt, col[rp + lo + j]);
+      }
+      unsigned long long mask = __ballot(n > SHORT_MAX);
+      while (mask) {
+        const int l = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        const int beg = __builtin_amdgcn_readlane(rp, l) + __builtin_amdgcn_readlane(lo, l);
+        const int nl = __builtin_amdgcn_readlane(n, l);
+        for (int idx = lane; idx < nl; idx += 64) lds_count(cnt, col[beg + idx]);
+      }
+    }
+    __syncthreads();
+    // ---------------- gather: x2[u] += sum over u's neighbours in this tile
+    for (int base = wid * 64; base < n_own; base += H2_W * 64) {
+      const int i = base + lane;
+      const bool valid = i < n_own;
+      int rp = 0, lo = 0, n = 0, e = 0;
+      float inv_sr = 0.0f;
+      if (valid) {
+        e = own_list[o0 + i];
+        const int u = ent_col[e];
+        rp = rowptr[u];
+        const int deg = rowptr[u + 1] - rp;
+        inv_sr = 1.0f / sqrtf((float)deg);
+        lo = tile_off[(int64_t)u * NT1 + t];
+        n = tile_off[(int64_t)u * NT1 + t + 1] - lo;
+      }
+      if (n > 0 && n <= SHORT_MAX) {                      // one owner per lane: short segment, own accumulators
+        float *dst = x2 + (int64_t)e * F;
+        if constexpr (FT > 0) {
+          float a[FT];
+#pragma unroll
+          for (int q = 0; q < FT; ++q) a[q] = 0.0f;
+#pragma unroll
+          for (int j = 0; j < SHORT_MAX; ++j) {
+            if (j < n) {
+              const int k = col[rp + lo + j];
+              const float w = lds_weight(cnt, k, inv_sr);
+              const float *x = feat + (int64_t)k * stride;
+#pragma unroll
+              for (int q = 0; q < FT; ++q) a[q] = fmaf(w, x[q], a[q]);
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < FT; ++q) dst[q] += a[q];
+        } else {
+          for (int j = 0; j < n; ++j) {
+            const int k = col[rp + lo + j];
+            const float w = lds_weight(cnt, k, inv_sr);
+            const float *x = feat + (int64_t)k * stride;
+            for (int q = 0; q < F; ++q) dst[q] = fmaf(w, x[q], dst[q]);
+          }
+        }
+      }
+      unsigned long long mask = __ballot(n > SHORT_MAX);
+      while (mask) {                                       // long segment: the whole wave works on one owner
+        const int l = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        const int beg = __builtin_amdgcn_readlane(rp, l) + __builtin_amdgcn_readlane(lo, l);
+        const int nl = __builtin_amdgcn_readlane(n, l);
+        const int el = __builtin_amdgcn_readlane(e, l);
+        const float isr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inv_sr), l));
+        const int fchunks = F <= 64 ? 1 : (F + 63) / 64;
+        for (int fc = 0; fc < fchunks; ++fc) {
+          const int fbase = fc * 64;
+          const int fw = F <= 64 ? F : min(64, F - fbase);
+          const int gg = F <= 64 ? g : lane / fw, ff = F <= 64 ? f : lane - (lane / fw) * fw;
+          const bool act = F <= 64 ? lane_active : (lane / fw) < 1;
+          float acc = 0.0f;
+          for (int blk = 0; blk < nl; blk += 64) {
+            const int idx = blk + lane;
+            int k = 0; float w = 0.0f;
+            if (idx < nl) { k = col[beg + idx]; w = lds_weight(cnt, k, isr); }
+            const int count = min(64, nl - blk);
+            const int iters = (count + rpi - 1) / rpi;
+            for (int tt = 0; tt < iters; ++tt) {
+              const int src = tt * rpi + gg;
+              const int kk = __shfl(k, src & 63, GGAD_WAVE);
+              const float ws = __shfl(w, src & 63, GGAD_WAVE);
+              const float x = (act && src < count) ? feat[(int64_t)kk * stride + fbase + ff] : 0.0f;
+              acc = fmaf((src < count) ? ws : 0.0f, x, acc);
+            }
+          }
+          float tot = acc;
+          if (F <= 64)
+            for (int q = 1; q < rpi; ++q) tot += __shfl(acc, (lane + q * fw) & 63, GGAD_WAVE);
+          if (lane < fw) x2[(int64_t)el * F + fbase + lane] += tot;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // isolated owners: the dense 0/0 row of the reference -> NaN (quirk 3)
+  for (int i = threadIdx.x; i < n_own; i += H2_T) {
+    const int e = own_list[o0 + i];
+    const int u = ent_col[e];
+    if (rowptr[u + 1] == rowptr[u]) {
+      const float nanv = (1.0f / sqrtf(0.0f)) * 0.0f;
+      for (int q = 0; q < F; ++q) x2[(int64_t)e * F + q] = nanv;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K-TILE-MAJOR variant with the counters in HBM slots (as plan.hip) but the WORK ordered by tile: launch t touches
+// only counters [t*65536, (t+1)*65536) of every slot (256 KB per batch -> the whole working set of a launch, a few
+// tens of MB, stays in L2 / Infinity Cache) and one 4.4 MB slab of the feature table.  One wave per owner entry;
+// x2[e] accumulates over the launches in stream order (tiles ascending) -> deterministic.
+__global__ void __launch_bounds__(256) k_count2_tile(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                     const int32_t *__restrict__ tile_off, int n_tiles, int tile,
+                                                     const int32_t *__restrict__ own_list, const int32_t *__restrict__ n_own,
+                                                     const int32_t *__restrict__ ent_col, const int32_t *__restrict__ ent_slot,
+                                                     int64_t n_nodes, int32_t *__restrict__ cnt2) {
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= *n_own) return;
+  const int e = own_list[p];
+  const int u = ent_col[e];
+  const int64_t ob = (int64_t)u * (n_tiles + 1) + tile;
+  const int lo = tile_off[ob], hi = tile_off[ob + 1];
+  if (hi <= lo) return;
+  const int64_t soff = (int64_t)ent_slot[e] * n_nodes;
+  const int beg = rowptr[u];
+  for (int i = lo + lane_id(); i < hi; i += GGAD_WAVE) atomicAdd(&cnt2[soff + col[beg + i]], 1);
+}
+
+__global__ void __launch_bounds__(256) k_gather2_tile(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                      const float *__restrict__ feat, int F, int stride,
+                                                      const int32_t *__restrict__ tile_off, int n_tiles, int tile,
+                                                      const int32_t *__restrict__ own_list, const int32_t *__restrict__ n_own,
+                                                      const int32_t *__restrict__ ent_col, const int32_t *__restrict__ ent_slot,
+                                                      int64_t n_nodes, const int32_t *__restrict__ cnt2, float *__restrict__ x2) {
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= *n_own) return;
+  const int lane = lane_id();
+  const int e = own_list[p];
+  const int u = ent_col[e];
+  const int64_t ob = (int64_t)u * (n_tiles + 1) + tile;
+  const int lo = tile_off[ob], hi = tile_off[ob + 1];
+  const int beg = rowptr[u];
+  const int deg = rowptr[u + 1] - beg;
+  if (deg == 0 && tile == 0) {                          // isolated owner: NaN row (quirk 3)
+    const float nanv = (1.0f / sqrtf(0.0f)) * 0.0f;
+    for (int q = lane; q < F; q += 64) x2[(int64_t)e * F + q] = nanv;
+    return;
+  }
+  if (hi <= lo) return;
+  const int64_t soff = (int64_t)ent_slot[e] * n_nodes;
+  const float inv_sr = 1.0f / sqrtf((float)deg);
+  const int nl = hi - lo;
+  const int rpi = F <= 64 ? 64 / F : 1;
+  const int fchunks = F <= 64 ? 1 : (F + 63) / 64;
+  for (int fc = 0; fc < fchunks; ++fc) {
+    const int fbase = fc * 64;
+    const int fw = F <= 64 ? F : min(64, F - fbase);
+    const int g = lane / fw, f = lane - g * fw;
+    const bool act = g < rpi;
+    float acc = 0.0f;
+    for (int blk = 0; blk < nl; blk += 64) {
+      const int idx = blk + lane;
+      int k = 0; float w = 0.0f;
+      if (idx < nl) { k = col[beg + lo + idx]; w = inv_sr / sqrtf((float)cnt2[soff + k]); }
+      const int count = min(64, nl - blk);
+      const int iters = (count + rpi - 1) / rpi;
+      int tt = 0;
+      for (; tt + 4 <= iters; tt += 4) {
+        float x[4], ww[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int src = (tt + q) * rpi + g;
+          const int kk = __shfl(k, src & 63, GGAD_WAVE);
+          const float ws = __shfl(w, src & 63, GGAD_WAVE);
+          ww[q] = (src < count) ? ws : 0.0f;
+          x[q] = (act && src < count) ? feat[(int64_t)kk * stride + fbase + f] : 0.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = fmaf(ww[q], x[q], acc);
+      }
+      for (; tt < iters; ++tt) {
+        const int src = tt * rpi + g;
+        const int kk = __shfl(k, src & 63, GGAD_WAVE);
+        const float ws = __shfl(w, src & 63, GGAD_WAVE);
+        const float x = (act && src < count) ? feat[(int64_t)kk * stride + fbase + f] : 0.0f;
+        acc = fmaf((src < count) ? ws : 0.0f, x, acc);
+      }
+    }
+    float tot = acc;
+    if (F <= 64)
+      for (int q = 1; q < rpi; ++q) tot += __shfl(acc, (lane + q * fw) & 63, GGAD_WAVE);
+    if (lane < fw) x2[(int64_t)e * F + fbase + lane] += tot;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ggad_mb_tile_size(void) { return TILE; }
+int64_t ggad_mb_tile_offsets_elems(int64_t n_nodes) { return n_nodes * (((n_nodes + TILE - 1) >> TILE_SHIFT) + 1); }
+
+int ggad_mb_tile_offsets(const int32_t *rowptr, const int32_t *col, int64_t n_nodes, int32_t *tile_off, ggad_stream_t stream) {
+  GGAD_REQUIRE(rowptr && col && tile_off && n_nodes >= 0);
+  if (n_nodes == 0) return GGAD_OK;
+  const int n_tiles = (int)((n_nodes + TILE - 1) >> TILE_SHIFT);
+  k_tile_offsets<<<dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0, as_stream(stream)>>>(rowptr, col, n_nodes, n_tiles, tile_off);
+  GGAD_CHECK_LAUNCH("mb_tile_offsets");
+  return GGAD_OK;
+}
+
+/* flags[e] = entry e is an owner; caller scans flags -> own_pos (exclusive, n_cap + 1 values) */
+int ggad_mb_owner_flags(const int32_t *ent_own, const int32_t *ent_total, int64_t n_entries_cap, int32_t *flags,
+                        ggad_stream_t stream) {
+  GGAD_REQUIRE(ent_own && ent_total && flags && n_entries_cap >= 0);
+  if (n_entries_cap == 0) return GGAD_OK;
+  k_owner_flags<<<dim3((unsigned)((n_entries_cap + 255) / 256)), dim3(256), 0, as_stream(stream)>>>(ent_own, ent_total,
+                                                                                                   n_entries_cap, flags);
+  GGAD_CHECK_LAUNCH("mb_owner_flags");
+  return GGAD_OK;
+}
+
+int ggad_mb_hop2_tiled(const int32_t *rowptr, const int32_t *col, const float *feat, int32_t feat_dim, int32_t feat_stride,
+                       int64_t n_nodes, const int32_t *tile_off, const int32_t *flags, const int32_t *own_pos,
+                       int32_t *own_list, const int32_t *batch_ent_ptr, int32_t n_batches, const int32_t *ent_col,
+                       int64_t n_entries_cap, float *x2, ggad_stream_t stream) {
+  GGAD_REQUIRE(rowptr && col && feat && tile_off && flags && own_pos && own_list && batch_ent_ptr && ent_col && x2);
+  GGAD_REQUIRE(feat_dim >= 1 && feat_dim <= GGAD_MAX_F && feat_stride >= feat_dim && n_batches >= 0 && n_entries_cap >= 0);
+  if (n_batches == 0 || n_entries_cap == 0) return GGAD_OK;
+  hipStream_t st = as_stream(stream);
+  const int n_tiles = (int)((n_nodes + TILE - 1) >> TILE_SHIFT);
+  k_owner_compact<<<dim3((unsigned)((n_entries_cap + 255) / 256)), dim3(256), 0, st>>>(flags, own_pos, n_entries_cap, own_list);
+  const size_t lds = (size_t)TILE / 2 * sizeof(uint32_t);
+  if (feat_dim == 17) {
+    static bool attr17 = false;
+    if (!attr17) { hipFuncSetAttribute((const void *)k_hop2_tiled<17>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr17 = true; }
+    k_hop2_tiled<17><<<dim3(n_batches), dim3(H2_T), lds, st>>>(rowptr, col, feat, feat_dim, feat_stride, tile_off, n_tiles, own_list,
+                                                              own_pos, batch_ent_ptr, ent_col, x2);
+  } else {
+    static bool attr0 = false;
+    if (!attr0) { hipFuncSetAttribute((const void *)k_hop2_tiled<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr0 = true; }
+    k_hop2_tiled<0><<<dim3(n_batches), dim3(H2_T), lds, st>>>(rowptr, col, feat, feat_dim, feat_stride, tile_off, n_tiles, own_list,
+                                                             own_pos, batch_ent_ptr, ent_col, x2);
+  }
+  GGAD_CHECK_LAUNCH("mb_hop2_tiled");
+  return GGAD_OK;
+}
+
+/* K-tile-major 2-hop with HBM counter slots: for every tile one count launch over all owners, then (after all
+ * counts) one gather launch per tile; own_list / own_pos as in ggad_mb_hop2_tiled (compaction done here).
+ * cnt2[n_slots][n_nodes] must be zero on entry; x2 must be zero on entry. */
+int ggad_mb_hop2_ktile(const int32_t *rowptr, const int32_t *col, const float *feat, int32_t feat_dim, int32_t feat_stride,
+                       int64_t n_nodes, const int32_t *tile_off, const int32_t *flags, const int32_t *own_pos,
+                       int32_t *own_list, const int32_t *ent_col, const int32_t *ent_slot, int64_t n_entries_cap,
+                       int32_t *cnt2, float *x2, ggad_stream_t stream) {
+  GGAD_REQUIRE(rowptr && col && feat && tile_off && flags && own_pos && own_list && ent_col && ent_slot && cnt2 && x2);
+  GGAD_REQUIRE(feat_dim >= 1 && feat_dim <= GGAD_MAX_F && feat_stride >= feat_dim && n_entries_cap >= 0);
+  if (n_entries_cap == 0) return GGAD_OK;
+  hipStream_t st = as_stream(stream);
+  const int n_tiles = (int)((n_nodes + TILE - 1) >> TILE_SHIFT);
+  k_owner_compact<<<dim3((unsigned)((n_entries_cap + 255) / 256)), dim3(256), 0, st>>>(flags, own_pos, n_entries_cap, own_list);
+  const int32_t *n_own = own_pos + n_entries_cap;      // total of the exclusive scan
+  const unsigned blocks = (unsigned)((n_entries_cap + 3) / 4);
+  for (int t = 0; t < n_tiles; ++t)
+    k_count2_tile<<<dim3(blocks), dim3(256), 0, st>>>(rowptr, col, tile_off, n_tiles, t, own_list, n_own, ent_col, ent_slot,
+                                                     n_nodes, cnt2);
+  for (int t = 0; t < n_tiles; ++t)
+    k_gather2_tile<<<dim3(blocks), dim3(256), 0, st>>>(rowptr, col, feat, feat_dim, feat_stride, tile_off, n_tiles, t, own_list,
+                                                      n_own, ent_col, ent_slot, n_nodes, cnt2, x2);
+  GGAD_CHECK_LAUNCH("mb_hop2_ktile");
+  return GGAD_OK;
+}
+
+}  // extern "C"

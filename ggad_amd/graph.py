@@ -86,5 +86,17 @@ class DeviceGraph:
             self._closed_deg_host = (self.deg_host + 1 - has_self).astype(np.int64)
         return self._closed_deg_host
 
+    def tile_offsets(self) -> torch.Tensor:
+        """Static per-node table of CSR-row offsets at the 65,536-id tile boundaries (LDS-tiled 2-hop kernel)."""
+        t = getattr(self, "_tile_off", None)
+        if t is None:
+            from . import _lib
+            lib = _lib.load()
+            t = torch.empty(int(lib.ggad_mb_tile_offsets_elems(self.n)), dtype=torch.int32, device=self.device)
+            with torch.cuda.device(self.device):
+                _lib.call("ggad_mb_tile_offsets", self.rowptr.data_ptr(), self.col.data_ptr(), self.n, t.data_ptr())
+            self._tile_off = t
+        return t
+
     def closed_degrees(self, nodes: np.ndarray) -> np.ndarray:
         return self.closed_deg_host[np.asarray(nodes, dtype=np.int64)]

@@ -58,13 +58,18 @@ class BatchChunk:
     """
 
     def __init__(self, graph: DeviceGraph, feat: torch.Tensor, embed_dim: int, max_batches: int,
-                 rows_cap: int, ent_cap: int, train: bool = True, reset_mode: str = "auto", feat_dim: Optional[int] = None):
+                 rows_cap: int, ent_cap: int, train: bool = True, reset_mode: str = "auto", feat_dim: Optional[int] = None,
+                 hop2: str = "global"):
         self.lib = _lib.load()
         self.g = graph
         self.feat = feat
         self.stride = int(feat.shape[1])
         self.F = int(feat_dim) if feat_dim is not None else self.stride
         self.packed = self.stride > self.F        # counters of the 2-hop histogram live inside the feature rows
+        # 2-hop mode: "tiled" = LDS-tiled kernel (no counter arrays in HBM); "global" = atomics on per-batch slots
+        self.hop2 = "global" if self.packed else hop2
+        if self.hop2 not in ("tiled", "ktile", "global"):
+            raise ValueError("hop2 must be 'tiled', 'ktile' or 'global'")
         if self.packed and train and max_batches > self.stride - self.F:
             raise ValueError(f"packed feature rows hold {self.stride - self.F} counter slots, chunk wants {max_batches}")
         self.D = int(embed_dim)
@@ -76,8 +81,10 @@ class BatchChunk:
         # per-batch counter slots: int32[max_batches][n]; zero on entry, zeroed again by reset()
         self.cnt1 = torch.zeros(self.max_batches * graph.n, dtype=torch.int32, device=self.dev)
         self.own1 = torch.zeros(self.max_batches * graph.n, dtype=torch.int32, device=self.dev)
-        self.cnt2 = torch.zeros(self.max_batches * graph.n, dtype=torch.int32, device=self.dev) \
-            if (train and not self.packed) else None
+        self.cnt2 = None
+        self._cnt2_elems = self.max_batches * graph.n
+        if train and not self.packed and self.hop2 in ("global", "ktile"):
+            self.cnt2 = torch.zeros(self._cnt2_elems, dtype=torch.int32, device=self.dev)
         self.rows_cap = 0
         self.ent_cap = 0
         self.generation = 0
@@ -100,13 +107,14 @@ class BatchChunk:
         self.rows_cap = cap
         self.generation += 1
         # one int32 staging block uploaded per build: batch_ptr | nodes | labels | pos_meta | row_pos
-        n_stage = self.max_batches + 1 + 4 * cap
+        n_stage = 2 * (self.max_batches + 1) + 4 * cap
         self.stage_host = torch.empty(n_stage, dtype=torch.int32)
         if d.type == "cuda":
             self.stage_host = self.stage_host.pin_memory()
         self.stage = _i32(n_stage, d)
         o = self.max_batches + 1
         self.batch_ptr = self.stage[:o]
+        self.batch_ent_ptr = self.stage[n_stage - o:]            # first entry of every batch (tail of the block)
         self.nodes = self.stage[o:o + cap]
         self.labels = self.stage[o + cap:o + 2 * cap]
         self.pos_meta = self.stage[o + 2 * cap:o + 3 * cap]
@@ -130,6 +138,9 @@ class BatchChunk:
         self.ent_col, self.ent_slot, self.ent_row = _i32(cap, d), _i32(cap, d), _i32(cap, d)
         self.ent_own, self.ent_c1 = _i32(cap, d), _i32(cap, d)
         self.x2 = _f32(cap * self.F, d) if self.train else None
+        if self.train and self.hop2 in ("tiled", "ktile"):
+            self.own_flags, self.own_pos, self.own_list = _i32(cap, d), _i32(cap + 1, d), _i32(cap, d)
+            self.own_scan_ws = _i32(self.lib.ggad_scan_workspace_elems(cap), d)
 
     # ---- build
     def build(self, batches: Sequence[np.ndarray], labels: Optional[Sequence[np.ndarray]] = None) -> None:
@@ -187,6 +198,9 @@ class BatchChunk:
                 rpos[r0 + order] = np.arange(r1 - r0)
             st[o + 2 * cap:o + 2 * cap + rows] = meta
             st[o + 3 * cap:o + 3 * cap + rows] = rpos
+        bep = ent_ptr_host[bp]                                   # entry offsets of the batch starts
+        st[len(st) - o:len(st) - o + nb + 1] = bep
+        st[len(st) - o + nb + 1:] = bep[-1]
         self.stage.copy_(self.stage_host, non_blocking=True)
         if self.dev.type == "cuda":
             self._stage_evt = torch.cuda.Event()
@@ -204,7 +218,36 @@ class BatchChunk:
         self.dirty = True
         call("ggad_mb_gather1", ptr(self.feat), self.F, self.stride, ptr(self.row_slot), ptr(self.ent_ptr), ptr(self.ent_col), rows,
              g.n, ptr(self.cnt1), ptr(self.own1), ptr(self.ent_own), ptr(self.ent_c1), ptr(self.x1))
-        if self.train:
+        if self.train and self._use_tiled():
+            tot = self.ent_total_ptr()
+            e = n_ents
+            self.x2[:e * self.F].zero_()
+            call("ggad_mb_owner_flags", ptr(self.ent_own), tot, e, ptr(self.own_flags))
+            call("ggad_exclusive_scan_i32", ptr(self.own_flags), ptr(self.own_pos), e, ptr(self.own_scan_ws))
+            if self.gather2_events is not None:
+                self.gather2_events[0].record()
+            call("ggad_mb_hop2_tiled", ptr(g.rowptr), ptr(g.col), ptr(self.feat), self.F, self.stride, g.n,
+                 ptr(g.tile_offsets()), ptr(self.own_flags), ptr(self.own_pos), ptr(self.own_list), ptr(self.batch_ent_ptr),
+                 nb, ptr(self.ent_col), e, ptr(self.x2))
+            if self.gather2_events is not None:
+                self.gather2_events[1].record()
+        elif self.train and self.hop2 == "ktile" and self.n_ents <= (1 << 22):
+            self.last_hop2 = "ktile"
+            tot = self.ent_total_ptr()
+            e = n_ents
+            self.x2[:e * self.F].zero_()
+            call("ggad_mb_owner_flags", ptr(self.ent_own), tot, e, ptr(self.own_flags))
+            call("ggad_exclusive_scan_i32", ptr(self.own_flags), ptr(self.own_pos), e, ptr(self.own_scan_ws))
+            if self.gather2_events is not None:
+                self.gather2_events[0].record()
+            call("ggad_mb_hop2_ktile", ptr(g.rowptr), ptr(g.col), ptr(self.feat), self.F, self.stride, g.n,
+                 ptr(g.tile_offsets()), ptr(self.own_flags), ptr(self.own_pos), ptr(self.own_list), ptr(self.ent_col),
+                 ptr(self.ent_slot), e, ptr(self.cnt2), ptr(self.x2))
+            if self.gather2_events is not None:
+                self.gather2_events[1].record()
+        elif self.train:
+            if self.cnt2 is None and not self.packed:        # tiled mode fell back (a batch with >= 65,536 entries)
+                self.cnt2 = torch.zeros(self._cnt2_elems, dtype=torch.int32, device=self.dev)
             tot = self.ent_total_ptr()
             call("ggad_mb_count2", ptr(g.rowptr), ptr(g.col), ptr(self.ent_col), ptr(self.ent_slot), tot, n_ents, g.n,
                  ptr(self.own1), ptr(self.cnt2) if self.cnt2 is not None else 0, ptr(self.feat), self.F, self.stride)
@@ -215,6 +258,17 @@ class BatchChunk:
                  ptr(self.x2))
             if self.gather2_events is not None:
                 self.gather2_events[1].record()
+
+    def _use_tiled(self) -> bool:
+        """LDS-tiled 2-hop needs < 65,536 owners per batch (16-bit counters) and <= 4 Mi entries per chunk (scan)."""
+        self.last_hop2 = "global"
+        if self.hop2 != "tiled":
+            return False
+        per_batch = np.diff(self.ent_ptr_host[self.batch_ptr_host])
+        if per_batch.max() >= 65536 or self.n_ents > (1 << 22):
+            return False
+        self.last_hop2 = "tiled"
+        return True
 
     def ent_total_ptr(self) -> int:
         return self.ent_ptr.data_ptr() + 4 * self.n_rows
@@ -236,6 +290,12 @@ class BatchChunk:
         if not self.dirty:
             return
         g = self.g
+        if self.train and getattr(self, "last_hop2", "global") == "tiled":
+            # only the small 1-hop slots were touched
+            call("ggad_mb_plan_reset", ptr(g.rowptr), ptr(g.col), ptr(self.ent_col), ptr(self.ent_slot), ptr(self.ent_own),
+                 self.ent_total_ptr(), self.n_ents, g.n, ptr(self.cnt1), 0, 0, 0, self.F, self.stride)
+            self.dirty = False
+            return
         stream_reset = self.train and self._memset_is_cheaper()
         if stream_reset and not self.packed:
             used = self.n_batches * g.n

@@ -110,18 +110,28 @@ class ModelHandler(object):
                                 world_size=world, allreduce=allreduce, engine=engine)
         self.trainer, self.model = trainer, gnn_model
         total_time = 0.0
-        for epoch in range(args.num_epochs):
+        epoch = 0
+        while epoch < args.num_epochs:
+            # run up to (and including) the next validation epoch in one call: the sampler thread then prefetches
+            # the following epochs' batch schedules while the GPU trains (reference validates when epoch % valid_epochs == 0)
+            last = epoch
+            while last % args.valid_epochs != 0 and last + 1 < args.num_epochs:
+                last += 1
+            n_ep = last - epoch + 1
             t0 = time.time()
-            trainer.run_steps(steps_per_epoch)
+            trainer.run_steps(steps_per_epoch * n_ep)
             torch.cuda.synchronize()
-            epoch_time = time.time() - t0
-            l = engine.losses(steps_per_epoch).astype(np.float64)
-            self.last_epoch_losses = l
-            if rank == 0:
-                print(f"Epoch: {epoch}, loss: {l[:, 0].mean()}, marigin_loss: {l[:, 2].mean()}, time: {epoch_time}s")
-                print("loss_cls", l[:, 1].mean())
-                print("total_time is", total_time)
-                print("loss_constraint", l[:, 2].mean())
+            block_time = time.time() - t0
+            lall = engine.losses(steps_per_epoch * n_ep).astype(np.float64)
+            for j in range(n_ep):
+                l = lall[j * steps_per_epoch:(j + 1) * steps_per_epoch]
+                self.last_epoch_losses = l
+                if rank == 0:
+                    print(f"Epoch: {epoch + j}, loss: {l[:, 0].mean()}, marigin_loss: {l[:, 2].mean()}, time: {block_time / n_ep}s")
+                    print("loss_cls", l[:, 1].mean())
+                    print("total_time is", total_time)
+                    print("loss_constraint", l[:, 2].mean())
+            epoch = last
             if epoch % args.valid_epochs == 0 and rank == 0:
                 print("Valid at epoch {}".format(epoch))
                 f1_mac_val, f1_1_val, f1_0_val, auc_val, gmean_val = test_sage(idx_valid, y_valid, gnn_model,
@@ -135,6 +145,7 @@ class ModelHandler(object):
             if dist:
                 dist.barrier()
             total_time += time.time() - t0
+            epoch += 1
         random.setstate(rng.to_python_state())       # hand the stream back to python `random`
         if rank == 0 and ep_best >= 0:
             print("Restore model from epoch {}".format(ep_best))

@@ -69,9 +69,16 @@ class DGraphTrainer:
     def __init__(self, graph: DeviceGraph, feat: torch.Tensor, embed_dim: int, schedule: BatchSchedule,
                  lr: float = 1e-3, weight_decay: float = 0.007, chunk_batches: int = 150, rank: int = 0,
                  world_size: int = 1, allreduce: Optional[Callable[[torch.Tensor], None]] = None,
-                 engine: Optional[MiniBatchEngine] = None, packed: bool = True):
-        """`feat` is the plain (N, F) table; with `packed` (default) the plans run on a private padded copy whose
-        rows also hold the per-batch 2-hop counters (15 slots for F = 17), so a chunk is at most that many batches."""
+                 engine: Optional[MiniBatchEngine] = None, packed: bool = False, hop2: str = "global",
+                 overlap: bool = False, prefetch: bool = True):
+        """`feat` is the plain (N, F) table.  hop2 = "global" (default, fastest measured): per-batch counter slots in
+        HBM; "tiled" / "ktile": LDS-tiled / tile-ordered variants; with `packed` the global counters
+        live inside a private padded copy of the feature rows (15 slots for F = 17 -> chunks of <= 15 batches).
+        `overlap`: two chunk buffers; the plan + gather of chunk c+1 runs on a side stream while the dense steps of
+        chunk c run on a high-priority stream (measured: no gain on MI355X -- the 900 tiny dependent launches of a
+        chunk queue behind the 600k-wave gather launches -- hence off by default).
+        `prefetch`: the host sampler (bit-exact CPython shuffle, ~0.6 ms per batch for the 55k pool) runs in a
+        background thread one chunk ahead; the C call releases the GIL, so sampling overlaps the GPU work."""
         self.graph, self.feat = graph, feat
         self.schedule = schedule
         self.rank, self.world = int(rank), int(world_size)
@@ -86,27 +93,99 @@ class DGraphTrainer:
             self.chunk_batches = max(1, min(self.chunk_batches, table.shape[1] - f))
         rows = self.chunk_batches * (schedule.bs + schedule.n_pseudo)
         mean_deg = max(1.0, graph.nnz / max(1, graph.n))
-        self.chunk = BatchChunk(graph, table, embed_dim, self.chunk_batches, rows, int(rows * (mean_deg + 1) * 1.5) + 1024,
-                                train=True, feat_dim=f)
+        ent_cap = int(rows * (mean_deg + 1) * 1.5) + 1024
+        self.chunk = BatchChunk(graph, table, embed_dim, self.chunk_batches, rows, ent_cap, train=True, feat_dim=f, hop2=hop2)
+        self.overlap = bool(overlap) and feat.device.type == "cuda" and not self.packed
+        self.chunks = [self.chunk]
+        if self.overlap:
+            self.chunks.append(BatchChunk(graph, table, embed_dim, self.chunk_batches, rows, ent_cap, train=True, feat_dim=f,
+                                          hop2=hop2))
+            # the dense chain is ~900 tiny dependent launches per chunk: give it the high-priority queue so that its
+            # workgroups are not stuck behind the 600k-wave gather launches of the side stream
+            self.side = torch.cuda.Stream(device=feat.device, priority=0)
+            self.hi = torch.cuda.Stream(device=feat.device, priority=-1)
         self.steps_done = 0
+        self.prefetch = bool(prefetch)
 
     def run_steps(self, n_steps: int, prepared: Optional[Tuple[List[np.ndarray], List[np.ndarray]]] = None,
                   gather_hook=None) -> int:
         """Run n optimiser steps; returns nodes processed by THIS rank."""
-        done = 0
-        nodes_seen = 0
-        pos = 0
-        while done < n_steps:
-            k = min(self.chunk_batches, n_steps - done)
+        sizes = []
+        left = n_steps
+        while left > 0:
+            sizes.append(min(self.chunk_batches, left))
+            left -= sizes[-1]
+        pos = [0]
+
+        producer = None
+        if prepared is None and self.prefetch and len(sizes) > 1:
+            import queue
+            import threading
+            q = queue.Queue(maxsize=2)
+
+            def produce():
+                try:
+                    for k in sizes:
+                        q.put(self.schedule.next_batches(k, self.rank, self.world))
+                except BaseException as exc:      # surface sampler errors in the consumer
+                    q.put(exc)
+            producer = threading.Thread(target=produce, daemon=True)
+            producer.start()
+
+        def take(k):
             if prepared is not None:
-                bn, bl = prepared[0][pos:pos + k], prepared[1][pos:pos + k]
-                pos += k
-            else:
-                bn, bl = self.schedule.next_batches(k, self.rank, self.world)
-            self.chunk.build(bn, bl) if gather_hook is None else gather_hook(self.chunk, bn, bl)
-            self.engine.train_chunk(self.chunk, self.allreduce, self.world, log_base=done)   # loss log slot = step index
-            nodes_seen += sum(len(b) for b in bn)
-            done += k
+                bn, bl = prepared[0][pos[0]:pos[0] + k], prepared[1][pos[0]:pos[0] + k]
+                pos[0] += k
+                return bn, bl
+            if producer is not None:
+                item = q.get()
+                if isinstance(item, BaseException):
+                    raise item
+                return item
+            return self.schedule.next_batches(k, self.rank, self.world)
+
+        def build(ch, bn, bl):
+            ch.build(bn, bl) if gather_hook is None else gather_hook(ch, bn, bl)
+
+        nodes_seen, done = 0, 0
+        if not self.overlap or len(sizes) == 1:
+            for k in sizes:
+                bn, bl = take(k)
+                build(self.chunk, bn, bl)
+                self.engine.train_chunk(self.chunk, self.allreduce, self.world, log_base=done)   # loss log slot = step index
+                nodes_seen += sum(len(b) for b in bn)
+                done += k
+        else:
+            outer = torch.cuda.current_stream()
+            main = self.hi
+            main.wait_stream(outer)
+            side = self.side
+            built = [torch.cuda.Event(), torch.cuda.Event()]
+            freed = [torch.cuda.Event(), torch.cuda.Event()]
+            side.wait_stream(main)
+            bn, bl = take(sizes[0])
+            with torch.cuda.stream(side):
+                build(self.chunks[0], bn, bl)
+                built[0].record(side)
+            for c, k in enumerate(sizes):
+                cur, nxt = c % 2, (c + 1) % 2
+                nodes_seen += sum(len(b) for b in bn)
+                if c + 1 < len(sizes):
+                    bn, bl = take(sizes[c + 1])
+                    with torch.cuda.stream(side):
+                        if c >= 1:
+                            side.wait_event(freed[nxt])        # the dense steps that read this buffer have finished
+                        build(self.chunks[nxt], bn, bl)
+                        built[nxt].record(side)
+                main.wait_event(built[cur])
+                self.chunk = self.chunks[cur]
+                with torch.cuda.stream(main):
+                    self.engine.train_chunk(self.chunks[cur], self.allreduce, self.world, log_base=done)
+                freed[cur].record(main)
+                done += k
+            outer.wait_stream(main)
+            outer.wait_stream(side)
+        if producer is not None:
+            producer.join()
         self.steps_done += n_steps
         return nodes_seen
-

@@ -113,6 +113,33 @@ int ggad_mb_gather2(const int32_t *rowptr, const int32_t *col, const float *feat
                     const int32_t *ent_col, const int32_t *ent_slot, const int32_t *ent_own, const int32_t *ent_total,
                     int64_t n_entries_cap, int64_t n_nodes, const int32_t *cnt2, float *x2, ggad_stream_t stream);
 
+/* LDS-TILED 2-hop aggregation (hop2_tiled.hip): same result as ggad_mb_count2 + ggad_mb_gather2 without any
+ * per-batch counter array in HBM.  Node ids are cut into tiles of ggad_mb_tile_size() = 65,536 ids; one
+ * workgroup per batch walks the tiles, keeps c'_k of the current tile in LDS (16-bit counters, so every batch
+ * must have < 65,536 owners) and reads each owner's neighbours of the tile as one contiguous piece of its CSR
+ * row through tile_off[n_nodes][n_tiles + 1] (ggad_mb_tile_offsets, built once per graph; int32 x
+ * ggad_mb_tile_offsets_elems(n_nodes)).  x2 must be zero on entry.
+ *   flags[e]     = 1 if entry e is an owner (ggad_mb_owner_flags)
+ *   own_pos[]    = exclusive scan of flags (n_entries_cap + 1 values, ggad_exclusive_scan_i32)
+ *   own_list[]   = workspace, n_entries_cap ints;  batch_ent_ptr[g] = first entry of batch g (n_batches + 1). */
+int ggad_mb_tile_size(void);
+int64_t ggad_mb_tile_offsets_elems(int64_t n_nodes);
+int ggad_mb_tile_offsets(const int32_t *rowptr, const int32_t *col, int64_t n_nodes, int32_t *tile_off, ggad_stream_t stream);
+int ggad_mb_owner_flags(const int32_t *ent_own, const int32_t *ent_total, int64_t n_entries_cap, int32_t *flags,
+                        ggad_stream_t stream);
+int ggad_mb_hop2_tiled(const int32_t *rowptr, const int32_t *col, const float *feat, int32_t feat_dim, int32_t feat_stride,
+                       int64_t n_nodes, const int32_t *tile_off, const int32_t *flags, const int32_t *own_pos,
+                       int32_t *own_list, const int32_t *batch_ent_ptr, int32_t n_batches, const int32_t *ent_col,
+                       int64_t n_entries_cap, float *x2, ggad_stream_t stream);
+
+/* K-TILE-MAJOR 2-hop: same tables as ggad_mb_hop2_tiled but with the per-batch counters in HBM slots
+ * (cnt2[n_slots][n_nodes], zero on entry) and the WORK ordered by tile: launch t touches only the counters and
+ * feature rows of ids [t*65536, (t+1)*65536), so the working set of a launch stays in L2 / Infinity Cache. */
+int ggad_mb_hop2_ktile(const int32_t *rowptr, const int32_t *col, const float *feat, int32_t feat_dim, int32_t feat_stride,
+                       int64_t n_nodes, const int32_t *tile_off, const int32_t *flags, const int32_t *own_pos,
+                       int32_t *own_list, const int32_t *ent_col, const int32_t *ent_slot, int64_t n_entries_cap,
+                       int32_t *cnt2, float *x2, ggad_stream_t stream);
+
 /* Packed layout: zero the first n_slots counters of every feature row (streaming pass). */
 int ggad_mb_reset_packed(float *feat_packed, int64_t n_nodes, int32_t feat_dim, int32_t feat_stride, int32_t n_slots,
                          ggad_stream_t stream);

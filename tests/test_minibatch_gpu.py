@@ -22,11 +22,11 @@ from oracle import ggad_oracle as O
 DEV = "cuda:0"
 
 
-def _setup(g, train=True, max_batches=8):
+def _setup(g, train=True, max_batches=8, hop2="tiled"):
     graph = DeviceGraph(g["rowptr"], g["col"], DEV)
     feat = torch.from_numpy(np.ascontiguousarray(g["feat"])).to(DEV)
     d = int(g["d"])
-    ch = BatchChunk(graph, feat, d, max_batches=max_batches, rows_cap=64, ent_cap=64, train=train)
+    ch = BatchChunk(graph, feat, d, max_batches=max_batches, rows_cap=64, ent_cap=64, train=train, hop2=hop2)
     return graph, feat, ch
 
 
@@ -79,10 +79,11 @@ def _check_plan_against_oracle(g, ch, batches, feat_np, atol=2e-6):
                                        err_msg=f"x2 batch {b}")
 
 
+@pytest.mark.parametrize("hop2", ["tiled", "ktile", "global"])
 @pytest.mark.parametrize("name", ["minibatch_small.npz", "minibatch_dense.npz"])
-def test_plan_matches_golden_and_oracle(name):
+def test_plan_matches_golden_and_oracle(name, hop2):
     g = load_golden(name)
-    graph, feat, ch = _setup(g)
+    graph, feat, ch = _setup(g, hop2=hop2)
     batches = [b for b in g["batches"]]
     ch.build(batches, [l for l in g["labels"]])
     torch.cuda.synchronize()
@@ -104,7 +105,8 @@ def test_plan_matches_golden_and_oracle(name):
     # slots are clean again after reset
     ch.reset()
     torch.cuda.synchronize()
-    assert int(ch.cnt1.abs().sum()) == 0 and int(ch.cnt2.abs().sum()) == 0
+    assert ch.last_hop2 == hop2
+    assert int(ch.cnt1.abs().sum()) == 0 and (ch.cnt2 is None or int(ch.cnt2.abs().sum()) == 0)
 
 
 @pytest.mark.parametrize("name", ["minibatch_small.npz", "minibatch_dense.npz"])
@@ -191,10 +193,11 @@ def _random_case(n, n_entries, f, d, seed, nb, bsz, n_ano):
     return dict(rowptr=rowptr, col=col, feat=feat, f=f, d=d), batches, labels
 
 
+@pytest.mark.parametrize("hop2", ["tiled", "ktile", "global"])
 @pytest.mark.parametrize("f,d", [(17, 64), (9, 32), (40, 64), (70, 48)])
-def test_random_graph_vs_oracle(f, d):
+def test_random_graph_vs_oracle(f, d, hop2):
     g, batches, labels = _random_case(n=20000, n_entries=160000, f=f, d=d, seed=21 + f, nb=3, bsz=200, n_ano=50)
-    graph, feat, ch = _setup(g, max_batches=4)
+    graph, feat, ch = _setup(g, max_batches=4, hop2=hop2)
     ch.build(batches, labels)
     torch.cuda.synchronize()
     _check_plan_against_oracle(g, ch, batches, g["feat"], atol=3e-6)
@@ -254,8 +257,9 @@ def test_fused_adam_chunk_equals_stepwise():
                 eng.loss_and_grads(ch, b, b)
                 eng.adam_step()
         outs.append((eng.params.cpu().numpy().copy(), eng.losses(4).copy()))
-    np.testing.assert_array_equal(outs[0][0], outs[1][0])
-    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    for o in outs[1:]:        # side-stream planning and the background sampler thread change nothing
+        np.testing.assert_array_equal(outs[0][0], o[0])
+        np.testing.assert_array_equal(outs[0][1], o[1])
 
 
 @pytest.mark.parametrize("f,reset_mode", [(17, "memset"), (17, "walk"), (9, "auto"), (40, "auto")])
@@ -282,3 +286,57 @@ def test_packed_feature_rows_layout(f, reset_mode):
     assert int(ch.cnt1.abs().sum()) == 0
     with pytest.raises(ValueError):
         BatchChunk(graph, table, 32, max_batches=stride - f + 1, rows_cap=64, ent_cap=64, train=True, feat_dim=f)
+
+
+def test_tiled_hop2_many_tiles_and_isolated_owner():
+    """> 1 tile of 65,536 ids (n = 150k -> 3 tiles), hub rows spanning all tiles, and a node whose only neighbour is a
+    self loop removed: deg-0 owners must come out NaN like the dense 0/0 row of the reference (quirk 3)."""
+    n = 150000
+    rowptr, col = synth.make_graph(n, 1500000, 5, kind="powerlaw", max_degree=1500)
+    feat = O.normalize_rows(synth.make_features(n, 17, 5)).astype(np.float32)
+    g = dict(rowptr=rowptr, col=col, feat=feat, f=17, d=64)
+    rng = np.random.default_rng(1)
+    hub = int(np.argmax(np.diff(rowptr)))
+    batches, labels = [], []
+    for b in range(3):
+        nodes = rng.choice(n, size=200, replace=False)
+        nodes[0] = hub
+        lab = np.zeros(200, dtype=np.int64); lab[150:] = 1
+        batches.append(nodes); labels.append(lab)
+    for hop2 in ("tiled", "ktile", "global"):
+        graph, ft, ch = _setup(g, max_batches=3, hop2=hop2)
+        ch.build(batches, labels)
+        torch.cuda.synchronize()
+        assert ch.last_hop2 == hop2
+        _check_plan_against_oracle(g, ch, batches, feat, atol=3e-6)
+
+
+def test_overlapped_chunks_equal_serial_execution():
+    """Plan of chunk c+1 on a side stream while chunk c trains: same weights and losses as the one-stream order."""
+    from ggad_amd.sampler import PyCompatRandom
+    from ggad_amd.trainer import BatchSchedule, DGraphTrainer
+    n = 30000
+    rowptr, col = synth.make_graph(n, 300000, 2, kind="powerlaw", max_degree=400)
+    feat_np = O.normalize_rows(synth.make_features(n, 17, 2)).astype(np.float32)
+    labels = np.zeros(n, dtype=np.int64)
+    pool = np.arange(1000, 1600)
+    labels[pool] = 1
+    train = np.arange(2000, 20000)
+    torch.manual_seed(4)
+    w = torch.nn.init.xavier_uniform_(torch.empty(1, 64))
+    W = torch.nn.init.xavier_uniform_(torch.empty(64, 17))
+    fc = torch.nn.init.xavier_uniform_(torch.empty(64, 64))
+    outs = []
+    for overlap, prefetch in ((False, False), (True, False), (False, True)):
+        graph = DeviceGraph(rowptr, col, DEV)
+        feat = torch.from_numpy(feat_np).to(DEV)
+        sched = BatchSchedule(train.copy(), pool.copy(), labels, 60, PyCompatRandom(72), n_pseudo=20, batches_per_epoch=5)
+        tr = DGraphTrainer(graph, feat, 64, sched, chunk_batches=3, overlap=overlap, prefetch=prefetch)
+        assert tr.overlap == overlap
+        tr.engine.load_params(w, W, fc)
+        tr.run_steps(11)                                   # chunks of 3,3,3,2 -> both buffers reused
+        torch.cuda.synchronize()
+        outs.append((tr.engine.params.cpu().numpy().copy(), tr.engine.losses(11).copy()))
+    for o in outs[1:]:        # side-stream planning and the background sampler thread change nothing
+        np.testing.assert_array_equal(outs[0][0], o[0])
+        np.testing.assert_array_equal(outs[0][1], o[1])
