@@ -165,8 +165,15 @@ def main():
     kname = {"tiled": "k_hop2_tiled (LDS-tiled 2-hop count + gather-aggregate)",
              "ktile": "k_count2_tile + k_gather2_tile (k-tile-major 2-hop count + gather-aggregate, all launches)"}.get(
         trainer.chunk.last_hop2, "k_gather2 (2-hop gather-aggregate)")
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_gather2.json")
+    if trainer.chunk.last_hop2 == "global" and os.path.exists(pmc_path) and gather_nbrs:
+        # HBM-side bytes per launch from the rocprofv3 PMC pass of this same command (FETCH_SIZE x 1024, see the json's note),
+        # scaled by the neighbours this run's launches gathered
+        with open(pmc_path) as fh:
+            traffic = json.load(fh)["bytes_per_neighbour"] * float(np.mean(gather_nbrs))
     roofline = {"kernel": kname, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": None,
+                "unit": "GB/s", "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": traffic,
                 "launches": len(gather_ms), "avg_launch_ms": float(np.mean(gather_ms)) if gather_ms else None,
                 "alg_bytes_per_launch": float(np.mean(alg_bytes)) if alg_bytes else None,
                 "gather_share_of_step_time": (sum(gather_ms) / 1e3) / elapsed if gather_ms else None}
