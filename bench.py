@@ -49,8 +49,9 @@ def parse():
     ap.add_argument("--chunk", type=int, default=150, help="batches planned per launch group (reference epoch = 150)")
     ap.add_argument("--cpu-batches", type=int, default=3, help="batches timed on the CPU port (0 = skip)")
     ap.add_argument("--no-overlap", action="store_true", help="plan and dense steps on one stream")
-    ap.add_argument("--hop2", default="global", choices=["tiled", "ktile", "global", "packed"],
-                    help="tiled: LDS-tiled 2-hop kernel; global: atomics on per-batch counter slots in HBM; "
+    ap.add_argument("--hop2", default="ldsw", choices=["ldsw", "tiled", "ktile", "global", "packed"],
+                    help="ldsw: LDS counting per (tile, batch) + streamed per-pair counts (default); tiled / ktile: earlier LDS variants; "
+                         "global: atomics on per-batch counter slots in HBM; "
                          "packed: global counters inside 128-byte feature rows (chunk <= 15 batches)")
     ap.add_argument("--seed", type=int, default=72)
     return ap.parse_args()
@@ -98,7 +99,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
     trainer = DGraphTrainer(graph, feat, a.emb, sched, lr=1e-3, weight_decay=0.007, chunk_batches=a.chunk, rank=rank,
                             world_size=world, allreduce=allreduce, packed=(a.hop2 == "packed"),
-                            hop2=(a.hop2 if a.hop2 in ("tiled", "ktile") else "global"), overlap=not a.no_overlap)
+                            hop2=(a.hop2 if a.hop2 in ("tiled", "ktile", "ldsw") else "global"), overlap=not a.no_overlap)
     torch.manual_seed(a.seed)
     w = torch.nn.init.xavier_uniform_(torch.empty(1, a.emb))
     W = torch.nn.init.xavier_uniform_(torch.empty(a.emb, a.feat))
@@ -160,14 +161,19 @@ def main():
     for e0, e1, bn in ev_pairs:
         gather_ms.append(e0.elapsed_time(e1))
         gather_nbrs.append(hop2_neighbours(bn))
-    alg_bytes = [(4 * a.feat + 4) * nb for nb in gather_nbrs]
+    mode = trainer.chunk.last_hop2
+    # algorithmic bytes per gathered neighbour: the feature row (4 F) + the column id (4) [+ the streamed 2-byte
+    # pair count in "ldsw"; the counter word of the other variants is charged to the id's 4 bytes as before]
+    per_nbr = 4 * a.feat + 4 + (2 if mode == "ldsw" else 0)
+    alg_bytes = [per_nbr * nb for nb in gather_nbrs]
     ach = (sum(alg_bytes) / 1e9) / (sum(gather_ms) / 1e3) if gather_ms and sum(gather_ms) > 0 else None
-    kname = {"tiled": "k_hop2_tiled (LDS-tiled 2-hop count + gather-aggregate)",
+    kname = {"ldsw": "k_gather2_w (2-hop gather-aggregate, streamed pair counts)",
+             "tiled": "k_hop2_tiled (LDS-tiled 2-hop count + gather-aggregate)",
              "ktile": "k_count2_tile + k_gather2_tile (k-tile-major 2-hop count + gather-aggregate, all launches)"}.get(
         trainer.chunk.last_hop2, "k_gather2 (2-hop gather-aggregate)")
     traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_gather2.json")
-    if trainer.chunk.last_hop2 == "global" and os.path.exists(pmc_path) and gather_nbrs:
+    pmc_path = os.path.join(ROOT, "profiles", {"global": "r01_pmc_gather2.json", "ldsw": "r01_pmc_gather2w.json"}.get(mode, "none"))
+    if os.path.exists(pmc_path) and gather_nbrs:
         # HBM-side bytes per launch from the rocprofv3 PMC pass of this same command (FETCH_SIZE x 1024, see the json's note),
         # scaled by the neighbours this run's launches gathered
         with open(pmc_path) as fh:
@@ -175,7 +181,7 @@ def main():
     roofline = {"kernel": kname, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": traffic,
                 "launches": len(gather_ms), "avg_launch_ms": float(np.mean(gather_ms)) if gather_ms else None,
-                "alg_bytes_per_launch": float(np.mean(alg_bytes)) if alg_bytes else None,
+                "alg_bytes_per_launch": float(np.mean(alg_bytes)) if alg_bytes else None, "alg_bytes_per_neighbour": per_nbr,
                 "gather_share_of_step_time": (sum(gather_ms) / 1e3) / elapsed if gather_ms else None}
 
     # ---------------- CPU baseline: dense-faithful port of the reference's step, bounded sample

@@ -41,8 +41,12 @@ SIGNATURES = {
     "ggad_mb_count2": (c_int32, [_P, _P, _P, _P, _P, _L, _L, _P, _P, _P, _I, _I, _P]),
     "ggad_mb_gather2": (c_int32, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _L, _L, _P, _P, _P]),
     "ggad_mb_tile_size": (c_int32, []),
-    "ggad_mb_tile_offsets_elems": (c_int64, [_L]),
-    "ggad_mb_tile_offsets": (c_int32, [_P, _P, _L, _P, _P]),
+    "ggad_mb_tile_offsets_elems": (c_int64, [_L, _I]),
+    "ggad_mb_tile_offsets": (c_int32, [_P, _P, _L, _I, _P, _P]),
+    "ggad_mb_ldsw_tile_shift": (c_int32, []),
+    "ggad_mb_ldsw_max_owners": (c_int32, []),
+    "ggad_mb_hop2_ldsw_count": (c_int32, [_P, _P, _L, _P, _P, _P, _P, _P, _I, _P, _L, _P, _P, _P, _P, _P]),
+    "ggad_mb_hop2_ldsw_gather": (c_int32, [_P, _P, _P, _I, _I, _P, _P, _P, _L, _P, _P, _P, _P]),
     "ggad_mb_owner_flags": (c_int32, [_P, _P, _L, _P, _P]),
     "ggad_mb_hop2_tiled": (c_int32, [_P, _P, _P, _I, _I, _L, _P, _P, _P, _P, _P, _I, _P, _L, _P, _P]),
     "ggad_mb_hop2_ktile": (c_int32, [_P, _P, _P, _I, _I, _L, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P]),

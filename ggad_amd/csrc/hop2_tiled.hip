@@ -28,14 +28,14 @@ constexpr int H2_W = H2_T / 64;
 constexpr int SHORT_MAX = 4;           // segments up to this length are processed one owner per lane
 
 __global__ void __launch_bounds__(256) k_tile_offsets(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                                      int64_t n_nodes, int n_tiles, int32_t *__restrict__ off) {
+                                                      int64_t n_nodes, int n_tiles, int shift, int32_t *__restrict__ off) {
   const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (u >= n_nodes) return;
   const int s = rowptr[u], e = rowptr[u + 1];
   int32_t *o = off + u * (n_tiles + 1);
   int t = 0;
   for (int i = s; i < e; ++i) {
-    const int tile = col[i] >> TILE_SHIFT;
+    const int tile = col[i] >> shift;
     while (t <= tile) { o[t] = i - s; ++t; }
   }
   while (t <= n_tiles) { o[t] = e - s; ++t; }
@@ -291,18 +291,259 @@ __global__ void __launch_bounds__(256) k_gather2_tile(const int32_t *__restrict_
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// "ldsw": LDS counting, weights through HBM.  Measured facts behind the split (scripts/atomic_bench.hip):
+// device-scope atomics run at ~27 G/s whatever the footprint or clustering, so one global atomic per (u, k) pair
+// cannot beat 10 ms per 277 M pairs; random 4-byte reads run at 50-60 G/s, sequential ones are free.
+//   k_tile_counts : one workgroup per (tile of 32,768 ids, batch).  All pairs of the batch whose k lies in the tile
+//                   are enumerated PAIR-parallel (block scan of the segment lengths + binary search in LDS, so hub
+//                   owners and 1-neighbour owners cost the same per pair), counted with ds_add into 16-bit LDS
+//                   counters, and the final count of every pair is written to pc[] at the pair's position inside
+//                   its owner's CSR row.  No global atomics, no counter arrays in HBM.
+//   k_gather2_w   : one wave per owner, exactly k_gather2's access pattern but the weight comes from the
+//                   SEQUENTIAL pc[] stream instead of a random counter read: one random row per neighbour.
+constexpr int TW_SHIFT = 15;
+constexpr int TW_TILE = 1 << TW_SHIFT;
+constexpr int TW_MAXOWN = 6144;          // owners per batch the LDS arrays hold (falls back to "global" beyond)
+constexpr int TW_T = 1024;
+
+__global__ void __launch_bounds__(256) k_owner_meta(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ own_list,
+                                                    const int32_t *__restrict__ n_own, const int32_t *__restrict__ ent_col,
+                                                    int64_t n_cap, int32_t *__restrict__ own_deg) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_cap) return;
+  if (p >= *n_own) { own_deg[p] = 0; return; }
+  const int u = ent_col[own_list[p]];
+  own_deg[p] = rowptr[u + 1] - rowptr[u];
+}
+
+__device__ __forceinline__ int block_excl_scan_1024(int v, int *warp_buf, int *total) {
+  // exclusive scan over 1024 threads (16 waves); warp_buf: 16 ints of LDS
+  const int lane = lane_id(), wid = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += t;
+  }
+  if (lane == 63) warp_buf[wid] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) { const int sv = warp_buf[w]; if (w < wid) base += sv; tot += sv; }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+__global__ void __launch_bounds__(TW_T) k_tile_counts(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                      const int32_t *__restrict__ tile_off, int n_tiles,
+                                                      const int32_t *__restrict__ own_list, const int32_t *__restrict__ own_pos,
+                                                      const int32_t *__restrict__ batch_ent_ptr,
+                                                      const int32_t *__restrict__ ent_col, const int32_t *__restrict__ pw_base,
+                                                      uint16_t *__restrict__ pc) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
+  uint32_t *cnt = lds_u;                                   // TW_TILE / 2 words
+  int *offs = reinterpret_cast<int *>(lds_u + TW_TILE / 2);  // TW_MAXOWN + 1
+  int *segbeg = offs + TW_MAXOWN + 1;                      // TW_MAXOWN   (index into col[])
+  int *dst = segbeg + TW_MAXOWN;                           // TW_MAXOWN   (index into pc[])
+  __shared__ int wbuf[16];
+  const int t = blockIdx.x, b = blockIdx.y;
+  const int o0 = own_pos[batch_ent_ptr[b]], o1 = own_pos[batch_ent_ptr[b + 1]];
+  const int n_own_all = o1 - o0;
+  const int NT1 = n_tiles + 1;
+  for (int i = threadIdx.x; i < TW_TILE / 2; i += TW_T) cnt[i] = 0u;
+  constexpr int IPT = TW_MAXOWN / TW_T;
+  // batches with more owners than the LDS tables hold are walked in slabs of TW_MAXOWN owners (counts accumulate
+  // over the slabs in pass 0; pass 1 re-derives each slab's tables).  The usual batch is one slab: tables built once.
+  const int n_slabs = (n_own_all + TW_MAXOWN - 1) / TW_MAXOWN;
+  const bool one_slab = n_slabs == 1;
+  constexpr int CACHE_IT = 16;
+  int kc[CACHE_IT], dc[CACHE_IT];
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int slab = 0; slab < n_slabs; ++slab) {
+      const int ob0 = o0 + slab * TW_MAXOWN;
+      const int n_own = min(TW_MAXOWN, o1 - ob0);
+      if (pass == 0 || n_slabs > 1) {
+        // segment of every owner inside this tile; exclusive scan of the lengths (IPT owners per thread)
+        int len[IPT];
+        int mysum = 0;
+#pragma unroll
+        for (int q = 0; q < IPT; ++q) {
+          const int i = threadIdx.x * IPT + q;
+          len[q] = 0;
+          if (i < n_own) {
+            const int u = ent_col[own_list[ob0 + i]];
+            const int64_t ob = (int64_t)u * NT1 + t;
+            const int lo = tile_off[ob], hi = tile_off[ob + 1];
+            len[q] = hi - lo;
+            segbeg[i] = rowptr[u] + lo;
+            dst[i] = pw_base[ob0 + i] + lo;
+          }
+          mysum += len[q];
+        }
+        int P0;
+        int ex = block_excl_scan_1024(mysum, wbuf, &P0);
+#pragma unroll
+        for (int q = 0; q < IPT; ++q) {
+          const int i = threadIdx.x * IPT + q;
+          if (i < n_own) offs[i] = ex;
+          ex += len[q];
+        }
+        if (threadIdx.x == 0) offs[n_own] = P0;               // number of pairs of the slab
+        __syncthreads();
+      }
+      const int P = offs[n_own];
+      if (P > 0) {                                             // uniform
+        // pair p -> owner = last index i with offs[i] <= p.  Branch-free descent over the LDS table, four pairs per
+        // thread in flight (the LDS round trips of one search are dependent; four searches interleave), so a hub
+        // owner and a 1-neighbour owner cost the same per pair.
+        const int s0 = 1 << (31 - __clz(n_own));
+        auto locate = [&](int pp, int &own, int &j) {
+          int lo = 0;
+          for (int st = s0; st > 0; st >>= 1) { const int m = lo + st; lo = (offs[min(m, n_own)] <= pp) ? m : lo; }
+          own = lo; j = pp - offs[lo];
+        };
+        auto locate4 = [&](const int (&pp)[4], int (&own)[4], int (&j)[4]) {
+          int lo[4] = {0, 0, 0, 0};
+          for (int st = s0; st > 0; st >>= 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int m = lo[q] + st; lo[q] = (offs[min(m, n_own)] <= pp[q]) ? m : lo[q]; }
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { own[q] = lo[q]; j[q] = pp[q] - offs[lo[q]]; }
+        };
+        int p_start = 0;
+        if (one_slab) {
+          // the first CACHE_IT * 1024 pairs keep (k, pc index) in registers between the passes: pass 1 is then a
+          // counter read + a 2-byte store
+          if (pass == 0) {
+#pragma unroll
+            for (int g4 = 0; g4 < CACHE_IT; g4 += 4) {
+              int pp[4], own[4], j[4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) pp[q] = min((g4 + q) * TW_T + (int)threadIdx.x, P - 1);
+              if (g4 * TW_T < P) {                             // uniform
+                locate4(pp, own, j);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                  const bool on = (g4 + q) * TW_T + (int)threadIdx.x < P;
+                  const int k = col[segbeg[own[q]] + j[q]];
+                  const int loc = k & (TW_TILE - 1);
+                  kc[g4 + q] = on ? loc : -1;
+                  dc[g4 + q] = dst[own[q]] + j[q];
+                  if (on) atomicAdd(&cnt[loc >> 1], 1u << ((loc & 1) << 4));
+                }
+              } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) kc[g4 + q] = -1;
+              }
+            }
+          } else {
+#pragma unroll
+            for (int it = 0; it < CACHE_IT; ++it)
+              if (kc[it] >= 0) pc[dc[it]] = (uint16_t)((cnt[kc[it] >> 1] >> ((kc[it] & 1) << 4)) & 0xFFFFu);
+          }
+          p_start = CACHE_IT * TW_T;
+        }
+        for (int p0 = p_start; p0 < P; p0 += 4 * TW_T) {
+          int pp[4], own[4], j[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) pp[q] = min(p0 + q * TW_T + (int)threadIdx.x, P - 1);
+          locate4(pp, own, j);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (p0 + q * TW_T + (int)threadIdx.x < P) {
+              const int k = col[segbeg[own[q]] + j[q]];
+              const int loc = k & (TW_TILE - 1);
+              if (pass == 0) atomicAdd(&cnt[loc >> 1], 1u << ((loc & 1) << 4));
+              else pc[(int64_t)dst[own[q]] + j[q]] = (uint16_t)((cnt[loc >> 1] >> ((loc & 1) << 4)) & 0xFFFFu);
+            }
+          }
+        }
+        (void)locate;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_gather2_w(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                   const float *__restrict__ feat, int F, int stride,
+                                                   const int32_t *__restrict__ own_list, const int32_t *__restrict__ n_own,
+                                                   const int32_t *__restrict__ ent_col, const int32_t *__restrict__ pw_base,
+                                                   const uint16_t *__restrict__ pc, float *__restrict__ x2) {
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= *n_own) return;
+  const int lane = lane_id();
+  const int e = own_list[p];
+  const int u = ent_col[e];
+  const int s = rowptr[u];
+  const int deg = rowptr[u + 1] - s;
+  const int64_t pb = pw_base[p];
+  const float inv_sr = 1.0f / sqrtf((float)deg);          // deg = 0 -> inf * 0 = NaN, as the dense 0/0 row (quirk 3)
+  const int rpi = F <= 64 ? 64 / F : 1;
+  const int fchunks = F <= 64 ? 1 : (F + 63) / 64;
+  for (int fc = 0; fc < fchunks; ++fc) {
+    const int fbase = fc * 64;
+    const int fw = F <= 64 ? F : min(64, F - fbase);
+    const int g = lane / fw, f = lane - g * fw;
+    const bool act = g < rpi;
+    float acc = 0.0f;
+    for (int blk = 0; blk < deg; blk += 64) {
+      const int idx = blk + lane;
+      int k = 0; float w = 0.0f;
+      if (idx < deg) { k = col[s + idx]; w = inv_sr / sqrtf((float)pc[pb + idx]); }   // .div(row).div(col)  graphsage.py:348
+      const int count = min(64, deg - blk);
+      const int iters = (count + rpi - 1) / rpi;
+      int tt = 0;
+      for (; tt + 4 <= iters; tt += 4) {
+        float x[4], ww[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int src = (tt + q) * rpi + g;
+          const int kk = __shfl(k, src & 63, GGAD_WAVE);
+          const float ws = __shfl(w, src & 63, GGAD_WAVE);
+          ww[q] = (src < count) ? ws : 0.0f;
+          x[q] = (act && src < count) ? feat[(int64_t)kk * stride + fbase + f] : 0.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = fmaf(ww[q], x[q], acc);
+      }
+      for (; tt < iters; ++tt) {
+        const int src = tt * rpi + g;
+        const int kk = __shfl(k, src & 63, GGAD_WAVE);
+        const float ws = __shfl(w, src & 63, GGAD_WAVE);
+        const float x = (act && src < count) ? feat[(int64_t)kk * stride + fbase + f] : 0.0f;
+        acc = fmaf((src < count) ? ws : 0.0f, x, acc);
+      }
+    }
+    float tot = acc;
+    if (F <= 64)
+      for (int q = 1; q < rpi; ++q) tot += __shfl(acc, (lane + q * fw) & 63, GGAD_WAVE);
+    if (deg == 0) tot = inv_sr * 0.0f;
+    if (lane < fw) x2[(int64_t)e * F + fbase + lane] = tot;
+  }
+}
+
 }  // namespace
 
 extern "C" {
 
 int ggad_mb_tile_size(void) { return TILE; }
-int64_t ggad_mb_tile_offsets_elems(int64_t n_nodes) { return n_nodes * (((n_nodes + TILE - 1) >> TILE_SHIFT) + 1); }
+int ggad_mb_ldsw_tile_shift(void) { return TW_SHIFT; }
+int ggad_mb_ldsw_max_owners(void) { return TW_MAXOWN; }
+int64_t ggad_mb_tile_offsets_elems(int64_t n_nodes, int32_t tile_shift) {
+  return n_nodes * (((n_nodes + (1LL << tile_shift) - 1) >> tile_shift) + 1);
+}
 
-int ggad_mb_tile_offsets(const int32_t *rowptr, const int32_t *col, int64_t n_nodes, int32_t *tile_off, ggad_stream_t stream) {
-  GGAD_REQUIRE(rowptr && col && tile_off && n_nodes >= 0);
+int ggad_mb_tile_offsets(const int32_t *rowptr, const int32_t *col, int64_t n_nodes, int32_t tile_shift, int32_t *tile_off,
+                         ggad_stream_t stream) {
+  GGAD_REQUIRE(rowptr && col && tile_off && n_nodes >= 0 && tile_shift >= 8 && tile_shift <= 24);
   if (n_nodes == 0) return GGAD_OK;
-  const int n_tiles = (int)((n_nodes + TILE - 1) >> TILE_SHIFT);
-  k_tile_offsets<<<dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0, as_stream(stream)>>>(rowptr, col, n_nodes, n_tiles, tile_off);
+  const int n_tiles = (int)((n_nodes + (1LL << tile_shift) - 1) >> tile_shift);
+  k_tile_offsets<<<dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0, as_stream(stream)>>>(rowptr, col, n_nodes, n_tiles,
+                                                                                               tile_shift, tile_off);
   GGAD_CHECK_LAUNCH("mb_tile_offsets");
   return GGAD_OK;
 }
@@ -341,6 +582,49 @@ int ggad_mb_hop2_tiled(const int32_t *rowptr, const int32_t *col, const float *f
                                                              own_pos, batch_ent_ptr, ent_col, x2);
   }
   GGAD_CHECK_LAUNCH("mb_hop2_tiled");
+  return GGAD_OK;
+}
+
+/* "ldsw" 2-hop, stage 1: compact the owners, pw_base = exclusive scan of their degrees, then LDS counting per
+ * (32,768-id tile, batch) writing the per-pair counts pc[] (uint16, one per 2-hop pair, laid out like the owners' CSR rows).
+ * tile_off must be built with shift ggad_mb_ldsw_tile_shift().  own_deg: n_entries_cap ints; pw_base: n_entries_cap + 1;
+ * scan_ws: ggad_scan_workspace_elems(n_entries_cap); pc: >= pw_base[n_entries_cap] elements (sum of the owners' degrees). */
+int ggad_mb_hop2_ldsw_count(const int32_t *rowptr, const int32_t *col, int64_t n_nodes, const int32_t *tile_off,
+                            const int32_t *flags, const int32_t *own_pos, int32_t *own_list, const int32_t *batch_ent_ptr,
+                            int32_t n_batches, const int32_t *ent_col, int64_t n_entries_cap, int32_t *own_deg,
+                            int32_t *pw_base, int32_t *scan_ws, uint16_t *pc, ggad_stream_t stream) {
+  GGAD_REQUIRE(rowptr && col && tile_off && flags && own_pos && own_list && batch_ent_ptr && ent_col && own_deg && pw_base &&
+               scan_ws && pc);
+  GGAD_REQUIRE(n_batches >= 0 && n_entries_cap >= 0 && n_nodes >= 0);
+  if (n_batches == 0 || n_entries_cap == 0) return GGAD_OK;
+  hipStream_t st = as_stream(stream);
+  const int n_tiles = (int)((n_nodes + TW_TILE - 1) >> TW_SHIFT);
+  const unsigned eb = (unsigned)((n_entries_cap + 255) / 256);
+  k_owner_compact<<<dim3(eb), dim3(256), 0, st>>>(flags, own_pos, n_entries_cap, own_list);
+  const int32_t *n_own = own_pos + n_entries_cap;
+  k_owner_meta<<<dim3(eb), dim3(256), 0, st>>>(rowptr, own_list, n_own, ent_col, n_entries_cap, own_deg);
+  int rc = ggad_exclusive_scan_i32(own_deg, pw_base, n_entries_cap, scan_ws, stream);
+  if (rc) return rc;
+  const size_t lds = (size_t)(TW_TILE / 2) * 4 + (size_t)(3 * TW_MAXOWN + 1) * 4;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void *)k_tile_counts, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  k_tile_counts<<<dim3(n_tiles, n_batches), dim3(TW_T), lds, st>>>(rowptr, col, tile_off, n_tiles, own_list, own_pos,
+                                                                   batch_ent_ptr, ent_col, pw_base, pc);
+  GGAD_CHECK_LAUNCH("mb_hop2_ldsw_count");
+  return GGAD_OK;
+}
+
+/* "ldsw" 2-hop, stage 2: x2[owner] = (1/sqrt(deg)) * sum_k x_k / sqrt(pc[..]) -- one wave per owner, streaming col[] and
+ * pc[], one random feature row per neighbour. */
+int ggad_mb_hop2_ldsw_gather(const int32_t *rowptr, const int32_t *col, const float *feat, int32_t feat_dim, int32_t feat_stride,
+                             const int32_t *own_pos, const int32_t *own_list, const int32_t *ent_col, int64_t n_entries_cap,
+                             const int32_t *pw_base, const uint16_t *pc, float *x2, ggad_stream_t stream) {
+  GGAD_REQUIRE(rowptr && col && feat && own_pos && own_list && ent_col && pw_base && pc && x2);
+  GGAD_REQUIRE(feat_dim >= 1 && feat_dim <= GGAD_MAX_F && feat_stride >= feat_dim && n_entries_cap >= 0);
+  if (n_entries_cap == 0) return GGAD_OK;
+  k_gather2_w<<<dim3((unsigned)((n_entries_cap + 3) / 4)), dim3(256), 0, as_stream(stream)>>>(
+      rowptr, col, feat, feat_dim, feat_stride, own_list, own_pos + n_entries_cap, ent_col, pw_base, pc, x2);
+  GGAD_CHECK_LAUNCH("mb_hop2_ldsw_gather");
   return GGAD_OK;
 }
 

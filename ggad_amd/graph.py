@@ -86,16 +86,31 @@ class DeviceGraph:
             self._closed_deg_host = (self.deg_host + 1 - has_self).astype(np.int64)
         return self._closed_deg_host
 
-    def tile_offsets(self) -> torch.Tensor:
-        """Static per-node table of CSR-row offsets at the 65,536-id tile boundaries (LDS-tiled 2-hop kernel)."""
-        t = getattr(self, "_tile_off", None)
+    @property
+    def pair_bound_host(self) -> np.ndarray:
+        """int64[n]: sum of deg(k) over k in N(i) + {i} -- upper bound of the 2-hop pairs row i contributes to a batch."""
+        t = self.__dict__.get("_pair_bound")
+        if t is None:
+            rp = self.rowptr.long()
+            deg = rp[1:] - rp[:-1]
+            rows = torch.repeat_interleave(torch.arange(self.n, device=self.device), deg)
+            acc = deg.clone()
+            acc.index_add_(0, rows, deg[self.col.long()])
+            t = acc.cpu().numpy()
+            self.__dict__["_pair_bound"] = t
+        return t
+
+    def tile_offsets(self, shift: int = 16) -> torch.Tensor:
+        """Static per-node table of CSR-row offsets at the (1 << shift)-id tile boundaries (tiled 2-hop kernels)."""
+        cache = self.__dict__.setdefault("_tile_off", {})
+        t = cache.get(shift)
         if t is None:
             from . import _lib
             lib = _lib.load()
-            t = torch.empty(int(lib.ggad_mb_tile_offsets_elems(self.n)), dtype=torch.int32, device=self.device)
+            t = torch.empty(int(lib.ggad_mb_tile_offsets_elems(self.n, shift)), dtype=torch.int32, device=self.device)
             with torch.cuda.device(self.device):
-                _lib.call("ggad_mb_tile_offsets", self.rowptr.data_ptr(), self.col.data_ptr(), self.n, t.data_ptr())
-            self._tile_off = t
+                _lib.call("ggad_mb_tile_offsets", self.rowptr.data_ptr(), self.col.data_ptr(), self.n, shift, t.data_ptr())
+            cache[shift] = t
         return t
 
     def closed_degrees(self, nodes: np.ndarray) -> np.ndarray:

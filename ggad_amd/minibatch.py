@@ -65,11 +65,14 @@ class BatchChunk:
         self.feat = feat
         self.stride = int(feat.shape[1])
         self.F = int(feat_dim) if feat_dim is not None else self.stride
-        self.packed = self.stride > self.F        # counters of the 2-hop histogram live inside the feature rows
-        # 2-hop mode: "tiled" = LDS-tiled kernel (no counter arrays in HBM); "global" = atomics on per-batch slots
+        # stride > F with hop2 != "ldsw": counters of the 2-hop histogram live inside the feature rows ("packed");
+        # with "ldsw" a wider stride is plain padding (rows aligned to 128 B for the one-random-access gather)
+        self.packed = self.stride > self.F and hop2 != "ldsw"
+        # 2-hop mode: "ldsw" = LDS counting per (tile, batch) + streamed per-pair counts; "global" = atomics on per-batch
+        # slots in HBM; "tiled" / "ktile" = earlier LDS / tile-major variants kept for comparison
         self.hop2 = "global" if self.packed else hop2
-        if self.hop2 not in ("tiled", "ktile", "global"):
-            raise ValueError("hop2 must be 'tiled', 'ktile' or 'global'")
+        if self.hop2 not in ("tiled", "ktile", "global", "ldsw"):
+            raise ValueError("hop2 must be 'ldsw', 'tiled', 'ktile' or 'global'")
         if self.packed and train and max_batches > self.stride - self.F:
             raise ValueError(f"packed feature rows hold {self.stride - self.F} counter slots, chunk wants {max_batches}")
         self.D = int(embed_dim)
@@ -138,9 +141,13 @@ class BatchChunk:
         self.ent_col, self.ent_slot, self.ent_row = _i32(cap, d), _i32(cap, d), _i32(cap, d)
         self.ent_own, self.ent_c1 = _i32(cap, d), _i32(cap, d)
         self.x2 = _f32(cap * self.F, d) if self.train else None
-        if self.train and self.hop2 in ("tiled", "ktile"):
+        if self.train and self.hop2 in ("tiled", "ktile", "ldsw"):
             self.own_flags, self.own_pos, self.own_list = _i32(cap, d), _i32(cap + 1, d), _i32(cap, d)
             self.own_scan_ws = _i32(self.lib.ggad_scan_workspace_elems(cap), d)
+        if self.train and self.hop2 == "ldsw":
+            self.own_deg, self.pw_base = _i32(cap, d), _i32(cap + 1, d)
+            if not hasattr(self, "pc"):
+                self.pc = torch.empty(0, dtype=torch.int16, device=d)      # uint16 per-pair counts (raw storage)
 
     # ---- build
     def build(self, batches: Sequence[np.ndarray], labels: Optional[Sequence[np.ndarray]] = None) -> None:
@@ -231,6 +238,21 @@ class BatchChunk:
                  nb, ptr(self.ent_col), e, ptr(self.x2))
             if self.gather2_events is not None:
                 self.gather2_events[1].record()
+        elif self.train and self._use_ldsw(nodes):
+            tot = self.ent_total_ptr()
+            e = n_ents
+            call("ggad_mb_owner_flags", ptr(self.ent_own), tot, e, ptr(self.own_flags))
+            call("ggad_exclusive_scan_i32", ptr(self.own_flags), ptr(self.own_pos), e, ptr(self.own_scan_ws))
+            call("ggad_mb_hop2_ldsw_count", ptr(g.rowptr), ptr(g.col), g.n,
+                 ptr(g.tile_offsets(self.lib.ggad_mb_ldsw_tile_shift())), ptr(self.own_flags), ptr(self.own_pos),
+                 ptr(self.own_list), ptr(self.batch_ent_ptr), nb, ptr(self.ent_col), e, ptr(self.own_deg), ptr(self.pw_base),
+                 ptr(self.own_scan_ws), ptr(self.pc))
+            if self.gather2_events is not None:
+                self.gather2_events[0].record()
+            call("ggad_mb_hop2_ldsw_gather", ptr(g.rowptr), ptr(g.col), ptr(self.feat), self.F, self.stride, ptr(self.own_pos),
+                 ptr(self.own_list), ptr(self.ent_col), e, ptr(self.pw_base), ptr(self.pc), ptr(self.x2))
+            if self.gather2_events is not None:
+                self.gather2_events[1].record()
         elif self.train and self.hop2 == "ktile" and self.n_ents <= (1 << 22):
             self.last_hop2 = "ktile"
             tot = self.ent_total_ptr()
@@ -270,6 +292,24 @@ class BatchChunk:
         self.last_hop2 = "tiled"
         return True
 
+    def _use_ldsw(self, nodes: np.ndarray) -> bool:
+        """"ldsw" needs < 65,536 owners per batch (16-bit LDS counters), <= 4 Mi entries per chunk (scan) and < 2^31
+        2-hop pairs per chunk (int32 offsets into pc[]).  The pair count is bounded on the host from the static per-node
+        table sum_{k in N(i) + i} deg(k) -- the exact number is only known on the device and reading it back would
+        serialise the host with the GPU."""
+        if self.hop2 != "ldsw":
+            return False
+        per_batch = np.diff(self.ent_ptr_host[self.batch_ptr_host])
+        bound = int(self.g.pair_bound_host[nodes].sum())
+        if per_batch.max() >= 65536 or self.n_ents > (1 << 22) or bound >= (1 << 31) - 1:
+            self.last_hop2 = "global"
+            return False
+        if bound > self.pc.numel():
+            self.pc = torch.empty(int(bound * 1.25) + 1024, dtype=torch.int16, device=self.dev)
+            self.generation += 1
+        self.last_hop2 = "ldsw"
+        return True
+
     def ent_total_ptr(self) -> int:
         return self.ent_ptr.data_ptr() + 4 * self.n_rows
 
@@ -290,7 +330,7 @@ class BatchChunk:
         if not self.dirty:
             return
         g = self.g
-        if self.train and getattr(self, "last_hop2", "global") == "tiled":
+        if self.train and getattr(self, "last_hop2", "global") in ("tiled", "ldsw"):
             # only the small 1-hop slots were touched
             call("ggad_mb_plan_reset", ptr(g.rowptr), ptr(g.col), ptr(self.ent_col), ptr(self.ent_slot), ptr(self.ent_own),
                  self.ent_total_ptr(), self.n_ents, g.n, ptr(self.cnt1), 0, 0, 0, self.F, self.stride)

@@ -69,11 +69,13 @@ class DGraphTrainer:
     def __init__(self, graph: DeviceGraph, feat: torch.Tensor, embed_dim: int, schedule: BatchSchedule,
                  lr: float = 1e-3, weight_decay: float = 0.007, chunk_batches: int = 150, rank: int = 0,
                  world_size: int = 1, allreduce: Optional[Callable[[torch.Tensor], None]] = None,
-                 engine: Optional[MiniBatchEngine] = None, packed: bool = False, hop2: str = "global",
+                 engine: Optional[MiniBatchEngine] = None, packed: bool = False, hop2: str = "ldsw",
                  overlap: bool = False, prefetch: bool = True):
-        """`feat` is the plain (N, F) table.  hop2 = "global" (default, fastest measured): per-batch counter slots in
-        HBM; "tiled" / "ktile": LDS-tiled / tile-ordered variants; with `packed` the global counters
-        live inside a private padded copy of the feature rows (15 slots for F = 17 -> chunks of <= 15 batches).
+        """`feat` is the plain (N, F) table.  hop2 = "ldsw" (default, fastest measured): 2-hop counts in LDS per
+        (tile, batch), per-pair counts streamed to the gather, feature rows padded to one 128-byte line; "global":
+        per-batch counter slots in HBM + device atomics; "tiled" / "ktile": earlier LDS-tiled / tile-ordered variants
+        (DESIGN.md §4c); with `packed` the global counters live inside a private padded copy of the feature rows
+        (15 slots for F = 17 -> chunks of <= 15 batches).
         `overlap`: two chunk buffers; the plan + gather of chunk c+1 runs on a side stream while the dense steps of
         chunk c run on a high-priority stream (measured: no gain on MI355X -- the 900 tiny dependent launches of a
         chunk queue behind the 600k-wave gather launches -- hence off by default).
@@ -91,6 +93,10 @@ class DGraphTrainer:
         if self.packed:
             table = pack_features(feat)
             self.chunk_batches = max(1, min(self.chunk_batches, table.shape[1] - f))
+        elif hop2 == "ldsw" and f <= 32 and (f * 4) % 128 != 0:
+            # one random access per neighbour: keep every feature row inside one 128-byte line
+            table = torch.zeros(feat.shape[0], 32, dtype=torch.float32, device=feat.device)
+            table[:, :f] = feat
         rows = self.chunk_batches * (schedule.bs + schedule.n_pseudo)
         mean_deg = max(1.0, graph.nnz / max(1, graph.n))
         ent_cap = int(rows * (mean_deg + 1) * 1.5) + 1024

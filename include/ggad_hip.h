@@ -117,20 +117,39 @@ int ggad_mb_gather2(const int32_t *rowptr, const int32_t *col, const float *feat
  * per-batch counter array in HBM.  Node ids are cut into tiles of ggad_mb_tile_size() = 65,536 ids; one
  * workgroup per batch walks the tiles, keeps c'_k of the current tile in LDS (16-bit counters, so every batch
  * must have < 65,536 owners) and reads each owner's neighbours of the tile as one contiguous piece of its CSR
- * row through tile_off[n_nodes][n_tiles + 1] (ggad_mb_tile_offsets, built once per graph; int32 x
- * ggad_mb_tile_offsets_elems(n_nodes)).  x2 must be zero on entry.
+ * row through tile_off[n_nodes][n_tiles + 1] (ggad_mb_tile_offsets with tile_shift 16, built once per graph;
+ * int32 x ggad_mb_tile_offsets_elems(n_nodes, 16)).  x2 must be zero on entry.
  *   flags[e]     = 1 if entry e is an owner (ggad_mb_owner_flags)
  *   own_pos[]    = exclusive scan of flags (n_entries_cap + 1 values, ggad_exclusive_scan_i32)
  *   own_list[]   = workspace, n_entries_cap ints;  batch_ent_ptr[g] = first entry of batch g (n_batches + 1). */
 int ggad_mb_tile_size(void);
-int64_t ggad_mb_tile_offsets_elems(int64_t n_nodes);
-int ggad_mb_tile_offsets(const int32_t *rowptr, const int32_t *col, int64_t n_nodes, int32_t *tile_off, ggad_stream_t stream);
+int64_t ggad_mb_tile_offsets_elems(int64_t n_nodes, int32_t tile_shift);     /* tile = 1 << tile_shift node ids */
+int ggad_mb_tile_offsets(const int32_t *rowptr, const int32_t *col, int64_t n_nodes, int32_t tile_shift, int32_t *tile_off,
+                         ggad_stream_t stream);
 int ggad_mb_owner_flags(const int32_t *ent_own, const int32_t *ent_total, int64_t n_entries_cap, int32_t *flags,
                         ggad_stream_t stream);
 int ggad_mb_hop2_tiled(const int32_t *rowptr, const int32_t *col, const float *feat, int32_t feat_dim, int32_t feat_stride,
                        int64_t n_nodes, const int32_t *tile_off, const int32_t *flags, const int32_t *own_pos,
                        int32_t *own_list, const int32_t *batch_ent_ptr, int32_t n_batches, const int32_t *ent_col,
                        int64_t n_entries_cap, float *x2, ggad_stream_t stream);
+
+/* "LDSW" 2-hop (hop2_tiled.hip): device-scope atomics are capped at ~27 G/s on MI355X whatever their locality
+ * (scripts/atomic_bench.hip), so counting goes to LDS: one workgroup per (32,768-id tile, batch) enumerates the
+ * batch's pairs of that tile pair-parallel, counts them in 16-bit LDS counters and writes every pair's final count to
+ * pc[] at the pair's position in its owner's CSR row (pw_base = exclusive scan of the owners' degrees); the gather then
+ * streams pc[] and makes ONE random access per neighbour (the feature row).  tile_off must be built with
+ * tile_shift = ggad_mb_ldsw_tile_shift(); every batch needs <= ggad_mb_ldsw_max_owners() owners.
+ * Workspaces: own_deg[n_entries_cap], pw_base[n_entries_cap + 1], scan_ws[ggad_scan_workspace_elems(n_entries_cap)],
+ * pc[sum of the owners' degrees]. */
+int ggad_mb_ldsw_tile_shift(void);
+int ggad_mb_ldsw_max_owners(void);
+int ggad_mb_hop2_ldsw_count(const int32_t *rowptr, const int32_t *col, int64_t n_nodes, const int32_t *tile_off,
+                            const int32_t *flags, const int32_t *own_pos, int32_t *own_list, const int32_t *batch_ent_ptr,
+                            int32_t n_batches, const int32_t *ent_col, int64_t n_entries_cap, int32_t *own_deg,
+                            int32_t *pw_base, int32_t *scan_ws, uint16_t *pc, ggad_stream_t stream);
+int ggad_mb_hop2_ldsw_gather(const int32_t *rowptr, const int32_t *col, const float *feat, int32_t feat_dim, int32_t feat_stride,
+                             const int32_t *own_pos, const int32_t *own_list, const int32_t *ent_col, int64_t n_entries_cap,
+                             const int32_t *pw_base, const uint16_t *pc, float *x2, ggad_stream_t stream);
 
 /* K-TILE-MAJOR 2-hop: same tables as ggad_mb_hop2_tiled but with the per-batch counters in HBM slots
  * (cnt2[n_slots][n_nodes], zero on entry) and the WORK ordered by tile: launch t touches only the counters and

@@ -79,7 +79,7 @@ def _check_plan_against_oracle(g, ch, batches, feat_np, atol=2e-6):
                                        err_msg=f"x2 batch {b}")
 
 
-@pytest.mark.parametrize("hop2", ["tiled", "ktile", "global"])
+@pytest.mark.parametrize("hop2", ["ldsw", "tiled", "ktile", "global"])
 @pytest.mark.parametrize("name", ["minibatch_small.npz", "minibatch_dense.npz"])
 def test_plan_matches_golden_and_oracle(name, hop2):
     g = load_golden(name)
@@ -193,7 +193,7 @@ def _random_case(n, n_entries, f, d, seed, nb, bsz, n_ano):
     return dict(rowptr=rowptr, col=col, feat=feat, f=f, d=d), batches, labels
 
 
-@pytest.mark.parametrize("hop2", ["tiled", "ktile", "global"])
+@pytest.mark.parametrize("hop2", ["ldsw", "tiled", "ktile", "global"])
 @pytest.mark.parametrize("f,d", [(17, 64), (9, 32), (40, 64), (70, 48)])
 def test_random_graph_vs_oracle(f, d, hop2):
     g, batches, labels = _random_case(n=20000, n_entries=160000, f=f, d=d, seed=21 + f, nb=3, bsz=200, n_ano=50)
@@ -303,12 +303,51 @@ def test_tiled_hop2_many_tiles_and_isolated_owner():
         nodes[0] = hub
         lab = np.zeros(200, dtype=np.int64); lab[150:] = 1
         batches.append(nodes); labels.append(lab)
-    for hop2 in ("tiled", "ktile", "global"):
+    for hop2 in ("ldsw", "tiled", "ktile", "global"):
         graph, ft, ch = _setup(g, max_batches=3, hop2=hop2)
         ch.build(batches, labels)
         torch.cuda.synchronize()
         assert ch.last_hop2 == hop2
         _check_plan_against_oracle(g, ch, batches, feat, atol=3e-6)
+
+
+def test_ldsw_hop2_owner_slabs_and_padded_rows():
+    """"ldsw" with a batch of > 6,144 owners (the LDS tables are walked in slabs), several 32,768-id tiles, and the
+    128-byte padded feature rows the trainer hands it: x2 must equal the global-counter path bit for bit per owner
+    up to summation order, and the oracle within 2e-5 (hub rows)."""
+    n = 120000
+    rowptr, col = synth.make_graph(n, 1200000, 9, kind="powerlaw", max_degree=3000)
+    feat = O.normalize_rows(synth.make_features(n, 17, 9)).astype(np.float32)
+    g = dict(rowptr=rowptr, col=col, feat=feat, f=17, d=64)
+    rng = np.random.default_rng(3)
+    order = np.argsort(-np.diff(rowptr))
+    batches, labels = [], []
+    for b in range(2):
+        nodes = rng.choice(n, size=400, replace=False)
+        nodes[:6] = order[b * 6:(b + 1) * 6]              # a few hubs: > 6,144 distinct owners in the batch
+        lab = np.zeros(400, dtype=np.int64); lab[300:] = 1
+        batches.append(nodes); labels.append(lab)
+    graph = DeviceGraph(rowptr, col, DEV)
+    table = torch.zeros(n, 32, dtype=torch.float32, device=DEV)
+    table[:, :17] = torch.from_numpy(feat).to(DEV)
+    ch = BatchChunk(graph, table, 64, max_batches=2, rows_cap=64, ent_cap=64, train=True, feat_dim=17, hop2="ldsw")
+    ch.build(batches, labels)
+    torch.cuda.synchronize()
+    assert ch.last_hop2 == "ldsw" and not ch.packed
+    n_own = int(ch.own_pos[ch.n_ents].item())
+    per_batch = [int(ch.own_pos[ch.batch_ents(b)[1]].item()) - int(ch.own_pos[ch.batch_ents(b)[0]].item()) for b in range(2)]
+    assert max(per_batch) > _lib.load().ggad_mb_ldsw_max_owners() and sum(per_batch) == n_own
+    _check_plan_against_oracle(g, ch, batches, feat, atol=2e-5)       # 3,000-neighbour hub rows: values up to ~2.5
+    ref = BatchChunk(graph, torch.from_numpy(feat).to(DEV), 64, max_batches=2, rows_cap=64, ent_cap=64, train=True, hop2="global")
+    ref.build(batches, labels)
+    torch.cuda.synchronize()
+    own = ch.own_list[:n_own].long()
+    a = ch.x2.view(-1, 17)[own]
+    b_ = ref.x2.view(-1, 17)[ref.ent_own[own].long()]      # owner election is a race: same column, maybe another entry
+    assert torch.allclose(a, b_, rtol=1e-5, atol=1e-6, equal_nan=True)    # same sums, weights rounded once more or less
+    ch.reset(); ch.build(batches[:1], labels[:1])           # rebuild after reset: counters clean, same rows again
+    torch.cuda.synchronize()
+    _check_plan_against_oracle(g, ch, batches[:1], feat, atol=2e-5)
 
 
 def test_overlapped_chunks_equal_serial_execution():
