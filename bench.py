@@ -49,10 +49,13 @@ def parse():
     ap.add_argument("--chunk", type=int, default=150, help="batches planned per launch group (reference epoch = 150)")
     ap.add_argument("--cpu-batches", type=int, default=3, help="batches timed on the CPU port (0 = skip)")
     ap.add_argument("--no-overlap", action="store_true", help="plan and dense steps on one stream")
+    ap.add_argument("--dense-cus", type=int, default=32, help="CUs reserved for the dense step chain when overlapping "
+                    "(CU-masked streams; 0 = plain streams with priorities)")
     ap.add_argument("--hop2", default="ldsw", choices=["ldsw", "tiled", "ktile", "global", "packed"],
                     help="ldsw: LDS counting per (tile, batch) + streamed per-pair counts (default); tiled / ktile: earlier LDS variants; "
                          "global: atomics on per-batch counter slots in HBM; "
                          "packed: global counters inside 128-byte feature rows (chunk <= 15 batches)")
+    ap.add_argument("--chain", type=int, default=0, choices=[0, 1], help="per-step kernel chain: 0 six launches, 1 row-wise three launches (include/ggad_hip.h: ggad_mb_step.chain)")
     ap.add_argument("--seed", type=int, default=72)
     return ap.parse_args()
 
@@ -99,7 +102,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
     trainer = DGraphTrainer(graph, feat, a.emb, sched, lr=1e-3, weight_decay=0.007, chunk_batches=a.chunk, rank=rank,
                             world_size=world, allreduce=allreduce, packed=(a.hop2 == "packed"),
-                            hop2=(a.hop2 if a.hop2 in ("tiled", "ktile", "ldsw") else "global"), overlap=not a.no_overlap)
+                            hop2=(a.hop2 if a.hop2 in ("tiled", "ktile", "ldsw") else "global"), overlap=not a.no_overlap, chain=a.chain, dense_cus=a.dense_cus)
     torch.manual_seed(a.seed)
     w = torch.nn.init.xavier_uniform_(torch.empty(1, a.emb))
     W = torch.nn.init.xavier_uniform_(torch.empty(a.emb, a.feat))
@@ -182,7 +185,11 @@ def main():
                 "unit": "GB/s", "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": traffic,
                 "launches": len(gather_ms), "avg_launch_ms": float(np.mean(gather_ms)) if gather_ms else None,
                 "alg_bytes_per_launch": float(np.mean(alg_bytes)) if alg_bytes else None, "alg_bytes_per_neighbour": per_nbr,
-                "gather_share_of_step_time": (sum(gather_ms) / 1e3) / elapsed if gather_ms else None}
+                "gather_share_of_step_time": (sum(gather_ms) / 1e3) / elapsed if gather_ms else None,
+                # with overlap the kernel runs on the plan stream's CU partition while the dense chain of the previous
+                # chunk runs on the other CUs; --no-overlap times it alone on the whole chip
+                "concurrent_with_dense_chain": bool(trainer.overlap),
+                "cus": (256 - a.dense_cus) if (trainer.overlap and a.dense_cus > 0) else 256}
 
     # ---------------- CPU baseline: dense-faithful port of the reference's step, bounded sample
     cpu = None
@@ -216,7 +223,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "DGraph-Fin-size synthetic graph, mini-batch GGAD (GCN encoder)", "nodes": a.nodes,
                        "directed_entries": int(graph.nnz), "feat": a.feat, "emb": a.emb, "batch": "150+50",
-                       "graph": f"{a.graph_kind}(alpha=2.1,max_degree={a.max_degree})", "chunk_batches": trainer.chunk_batches, "hop2": a.hop2, "overlap": trainer.overlap,
+                       "graph": f"{a.graph_kind}(alpha=2.1,max_degree={a.max_degree})", "chunk_batches": trainer.chunk_batches, "hop2": a.hop2, "overlap": trainer.overlap, "dense_cus": (a.dense_cus if trainer.overlap else 0), "chain": a.chain,
                        "parallelism": f"dp{world}", "optimizer": "adam(lr=1e-3,wd=0.007)"},
             "roofline": roofline, "cpu_baseline": cpu,
             "gpu_over_cpu": (value / cpu["value"]) if cpu else None,

@@ -45,8 +45,12 @@ SIGNATURES = {
     "ggad_mb_tile_offsets": (c_int32, [_P, _P, _L, _I, _P, _P]),
     "ggad_mb_ldsw_tile_shift": (c_int32, []),
     "ggad_mb_ldsw_max_owners": (c_int32, []),
+    "ggad_mb_dw_part_elems": (c_int64, [_I, _I, _I]),
+    "ggad_stream_create_cu_mask": (c_int32, [_P, _I, _P]),
+    "ggad_stream_destroy": (c_int32, [_P]),
+    "ggad_device_cu_count": (c_int32, [_I, _P]),
     "ggad_mb_hop2_ldsw_count": (c_int32, [_P, _P, _L, _P, _P, _P, _P, _P, _I, _P, _L, _P, _P, _P, _P, _P]),
-    "ggad_mb_hop2_ldsw_gather": (c_int32, [_P, _P, _P, _I, _I, _P, _P, _P, _L, _P, _P, _P, _P]),
+    "ggad_mb_hop2_ldsw_gather": (c_int32, [_P, _P, _P, _I, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P]),
     "ggad_mb_owner_flags": (c_int32, [_P, _P, _L, _P, _P]),
     "ggad_mb_hop2_tiled": (c_int32, [_P, _P, _P, _I, _I, _L, _P, _P, _P, _P, _P, _I, _P, _L, _P, _P]),
     "ggad_mb_hop2_ktile": (c_int32, [_P, _P, _P, _I, _I, _L, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P]),
@@ -98,7 +102,7 @@ class MbStep(ctypes.Structure):
                                          "ent_ptr", "ent_own", "ent_row", "labels", "pos_meta", "row_pos", "h1", "nbar",
                                          "gen", "dz", "coef_a", "coef_g", "h2", "dw_part", "loss_ws", "losses8")]
                 + [(n, c_int32) for n in ("D", "F", "row0", "n_rows", "ent0", "n_ents")]
-                + [("lr", c_float), ("weight_decay", c_float)])
+                + [("lr", c_float), ("weight_decay", c_float), ("chain", c_int32)])
 
 
 _lib = None

@@ -526,6 +526,144 @@ __global__ void __launch_bounds__(256) k_gather2_w(const int32_t *__restrict__ r
   }
 }
 
+// ---- node-major gather: all occurrences of a node in the chunk share ONE pass over its neighbour rows.
+// A node u is an owner in ~ B * deg(u) / N of the batches: the 2,000-neighbour hubs that produce most of the 2-hop
+// pairs recur in ~16 of 150 batches, each time with other weights 1/sqrt(r c') but the SAME neighbour rows.  The owner
+// entries of the chunk are linked per node (atomicExch on node_head[u]: order of the list is irrelevant, every
+// occurrence has its own accumulator and its own fixed summation order), the list is cut into groups of up to 8
+// occurrences and one wave per group walks the node's neighbours: one random 128-byte row fetch per neighbour serves
+// up to 8 (batch, owner) pairs, their counts streaming in from pc[]; the groups of one node run side by side and find
+// each other's rows in L2.  Results are bit-identical to k_gather2_w.
+__global__ void __launch_bounds__(256) k_link_owners(const int32_t *__restrict__ own_list, const int32_t *__restrict__ n_own,
+                                                     const int32_t *__restrict__ ent_col, int32_t *__restrict__ node_head,
+                                                     int32_t *__restrict__ own_next) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= *n_own) return;
+  const int u = ent_col[own_list[p]];
+  own_next[p] = atomicExch(&node_head[u], p + 1);
+}
+
+template <int G>
+__device__ __forceinline__ void gather_occurrences(const int32_t *__restrict__ col, const float *__restrict__ feat, int F,
+                                                   int stride, int s, int deg, float inv_sr, const int (&e)[8],
+                                                   const int64_t (&pb)[8], const uint16_t *__restrict__ pc,
+                                                   float *__restrict__ x2, int lane) {
+  const int rpi = 64 / F;
+  const int g = lane / F, f = lane - g * F;
+  const bool act = g < rpi;
+  float acc[G];
+#pragma unroll
+  for (int j = 0; j < G; ++j) acc[j] = 0.0f;
+  for (int blk = 0; blk < deg; blk += 64) {
+    const int idx = blk + lane;
+    int k = 0;
+    float w[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) w[j] = 0.0f;
+    if (idx < deg) {
+      k = col[s + idx];
+#pragma unroll
+      for (int j = 0; j < G; ++j)
+        if (e[j] >= 0) w[j] = inv_sr / sqrtf((float)pc[pb[j] + idx]);            // .div(row).div(col)  graphsage.py:348
+    }
+    const int count = min(64, deg - blk);
+    const int iters = (count + rpi - 1) / rpi;
+    int tt = 0;
+    for (; tt + 4 <= iters; tt += 4) {
+      float x[4];
+      int src[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        src[q] = (tt + q) * rpi + g;
+        const int kk = __shfl(k, src[q] & 63, GGAD_WAVE);
+        x[q] = (act && src[q] < count) ? feat[(int64_t)kk * stride + f] : 0.0f;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+          const float ws = __shfl(w[j], src[q] & 63, GGAD_WAVE);
+          acc[j] = fmaf((src[q] < count) ? ws : 0.0f, x[q], acc[j]);
+        }
+      }
+    }
+    for (; tt < iters; ++tt) {
+      const int sr = tt * rpi + g;
+      const int kk = __shfl(k, sr & 63, GGAD_WAVE);
+      const float x = (act && sr < count) ? feat[(int64_t)kk * stride + f] : 0.0f;
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const float ws = __shfl(w[j], sr & 63, GGAD_WAVE);
+        acc[j] = fmaf((sr < count) ? ws : 0.0f, x, acc[j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < G; ++j) {
+    float tot = acc[j];
+    for (int q = 1; q < rpi; ++q) tot += __shfl(acc[j], (lane + q * F) & 63, GGAD_WAVE);
+    if (deg == 0) tot = inv_sr * 0.0f;                       // inf * 0 = NaN, as the dense 0/0 row (quirk 3)
+    if (lane < F && e[j] >= 0) x2[(int64_t)e[j] * F + lane] = tot;
+  }
+}
+
+// One thread per owner entry; the entry that was linked last acts for its node: it cuts the node's occurrence list into
+// groups of <= 8 and appends them to the compact group table (all groups of a node adjacent, so that their waves are
+// dispatched together and share the node's neighbour rows in L2), then clears node_head[u] for the next chunk.
+__global__ void __launch_bounds__(256) k_build_groups(const int32_t *__restrict__ own_list, const int32_t *__restrict__ n_own,
+                                                      const int32_t *__restrict__ ent_col, int32_t *__restrict__ node_head,
+                                                      const int32_t *__restrict__ own_next, int32_t *__restrict__ grp_p,
+                                                      int32_t *__restrict__ n_groups) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= *n_own) return;
+  const int u = ent_col[own_list[p]];
+  if (node_head[u] != p + 1) return;
+  int m = 0;
+  for (int cur = p + 1; cur != 0; cur = own_next[cur - 1]) ++m;
+  const int ng = (m + 7) >> 3;
+  const int base = atomicAdd(n_groups, ng);
+  int cur = p + 1;
+  for (int g = 0; g < ng; ++g) {
+    int32_t *dst = grp_p + (int64_t)(base + g) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int v = -1;
+      if (cur != 0) { v = cur - 1; cur = own_next[v]; }
+      dst[j] = v;
+    }
+  }
+  node_head[u] = 0;
+}
+
+__global__ void __launch_bounds__(256) k_gather2_groups(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                        const float *__restrict__ feat, int F, int stride,
+                                                        const int32_t *__restrict__ own_list, const int32_t *__restrict__ ent_col,
+                                                        const int32_t *__restrict__ pw_base, const uint16_t *__restrict__ pc,
+                                                        const int32_t *__restrict__ grp_p, const int32_t *__restrict__ n_groups,
+                                                        float *__restrict__ x2) {
+  const int gi = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (gi >= *n_groups) return;
+  const int lane = lane_id();
+  const int pv = (lane < 8) ? grp_p[(int64_t)gi * 8 + lane] : -1;
+  int e[8];
+  int64_t pb[8];
+  int n = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int pj = __builtin_amdgcn_readlane(pv, j);
+    e[j] = -1; pb[j] = 0;
+    if (pj >= 0) { e[j] = own_list[pj]; pb[j] = pw_base[pj]; ++n; }
+  }
+  const int u = ent_col[e[0]];
+  const int s = rowptr[u];
+  const int deg = rowptr[u + 1] - s;
+  const float inv_sr = 1.0f / sqrtf((float)deg);
+  if (n == 1) gather_occurrences<1>(col, feat, F, stride, s, deg, inv_sr, e, pb, pc, x2, lane);
+  else if (n == 2) gather_occurrences<2>(col, feat, F, stride, s, deg, inv_sr, e, pb, pc, x2, lane);
+  else if (n <= 4) gather_occurrences<4>(col, feat, F, stride, s, deg, inv_sr, e, pb, pc, x2, lane);
+  else gather_occurrences<8>(col, feat, F, stride, s, deg, inv_sr, e, pb, pc, x2, lane);
+}
+
 }  // namespace
 
 extern "C" {
@@ -614,16 +752,33 @@ int ggad_mb_hop2_ldsw_count(const int32_t *rowptr, const int32_t *col, int64_t n
   return GGAD_OK;
 }
 
-/* "ldsw" 2-hop, stage 2: x2[owner] = (1/sqrt(deg)) * sum_k x_k / sqrt(pc[..]) -- one wave per owner, streaming col[] and
- * pc[], one random feature row per neighbour. */
+/* "ldsw" 2-hop, stage 2: x2[owner] = (1/sqrt(deg)) * sum_k x_k / sqrt(pc[..]), streaming col[] and pc[], one random
+ * feature row per neighbour.  With node_head (int32[n_nodes], zero on entry, zero again on return), own_next
+ * (int32[n_entries_cap]), grp (int32[8 * n_entries_cap + 1]: group table, last word = group counter) and feat_dim <= 64:
+ * node-major -- the occurrences of a node in the chunk share the fetch of its neighbour rows, 8 per wave.
+ * node_head == NULL: one wave per owner entry.  Same results either way. */
 int ggad_mb_hop2_ldsw_gather(const int32_t *rowptr, const int32_t *col, const float *feat, int32_t feat_dim, int32_t feat_stride,
                              const int32_t *own_pos, const int32_t *own_list, const int32_t *ent_col, int64_t n_entries_cap,
-                             const int32_t *pw_base, const uint16_t *pc, float *x2, ggad_stream_t stream) {
+                             const int32_t *pw_base, const uint16_t *pc, int32_t *node_head, int32_t *own_next, int32_t *grp,
+                             float *x2, ggad_stream_t stream) {
   GGAD_REQUIRE(rowptr && col && feat && own_pos && own_list && ent_col && pw_base && pc && x2);
   GGAD_REQUIRE(feat_dim >= 1 && feat_dim <= GGAD_MAX_F && feat_stride >= feat_dim && n_entries_cap >= 0);
+  GGAD_REQUIRE((node_head == nullptr) == (own_next == nullptr) && (node_head == nullptr) == (grp == nullptr));
   if (n_entries_cap == 0) return GGAD_OK;
-  k_gather2_w<<<dim3((unsigned)((n_entries_cap + 3) / 4)), dim3(256), 0, as_stream(stream)>>>(
-      rowptr, col, feat, feat_dim, feat_stride, own_list, own_pos + n_entries_cap, ent_col, pw_base, pc, x2);
+  hipStream_t st = as_stream(stream);
+  const int32_t *n_own = own_pos + n_entries_cap;
+  const unsigned wb = (unsigned)((n_entries_cap + 3) / 4);
+  const unsigned tb = (unsigned)((n_entries_cap + 255) / 256);
+  if (node_head != nullptr && feat_dim <= 64) {
+    int32_t *n_groups = grp + 8 * n_entries_cap;
+    if (hipMemsetAsync(n_groups, 0, sizeof(int32_t), st) != hipSuccess) { GGAD_CHECK_LAUNCH("mb_hop2_ldsw_gather(memset)"); }
+    k_link_owners<<<dim3(tb), dim3(256), 0, st>>>(own_list, n_own, ent_col, node_head, own_next);
+    k_build_groups<<<dim3(tb), dim3(256), 0, st>>>(own_list, n_own, ent_col, node_head, own_next, grp, n_groups);
+    k_gather2_groups<<<dim3(wb), dim3(256), 0, st>>>(rowptr, col, feat, feat_dim, feat_stride, own_list, ent_col, pw_base, pc, grp,
+                                                     n_groups, x2);
+  } else {
+    k_gather2_w<<<dim3(wb), dim3(256), 0, st>>>(rowptr, col, feat, feat_dim, feat_stride, own_list, n_own, ent_col, pw_base, pc, x2);
+  }
   GGAD_CHECK_LAUNCH("mb_hop2_ldsw_gather");
   return GGAD_OK;
 }

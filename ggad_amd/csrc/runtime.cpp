@@ -22,6 +22,35 @@ void ggad_set_error(hipError_t e, const char *where) {
   g_last_error = std::string(where) + ": " + hipGetErrorString(e);
 }
 
+// ---- CU-partitioned streams.  The plan of chunk c+1 (two launches that fill the chip for milliseconds) and the dense
+// steps of chunk c (hundreds of dependent launches of a few microseconds) only overlap if they do not compete for
+// the same compute units: a tiny launch queued behind 600k gather waves waits for a free CU.  Two streams with
+// disjoint CU masks give the dense chain its own CUs.
+extern "C" int ggad_stream_create_cu_mask(const uint32_t *mask, int32_t n_words, ggad_stream_t *out) {
+  if (!mask || n_words <= 0 || !out) return GGAD_E_INVALID;
+  hipStream_t st = nullptr;
+  hipError_t e = hipExtStreamCreateWithCUMask(&st, (uint32_t)n_words, mask);
+  if (e != hipSuccess) { ggad_set_error(e, "stream_create_cu_mask"); return GGAD_E_LAUNCH; }
+  *out = reinterpret_cast<ggad_stream_t>(st);
+  return GGAD_OK;
+}
+
+extern "C" int ggad_stream_destroy(ggad_stream_t stream) {
+  if (!stream) return GGAD_OK;
+  hipError_t e = hipStreamDestroy(reinterpret_cast<hipStream_t>(stream));
+  if (e != hipSuccess) { ggad_set_error(e, "stream_destroy"); return GGAD_E_LAUNCH; }
+  return GGAD_OK;
+}
+
+extern "C" int ggad_device_cu_count(int32_t device, int32_t *out) {
+  if (!out) return GGAD_E_INVALID;
+  hipDeviceProp_t prop;
+  hipError_t e = hipGetDeviceProperties(&prop, device);
+  if (e != hipSuccess) { ggad_set_error(e, "device_cu_count"); return GGAD_E_LAUNCH; }
+  *out = prop.multiProcessorCount;
+  return GGAD_OK;
+}
+
 struct ggad_mt19937 {
   uint32_t mt[624];
   int index;

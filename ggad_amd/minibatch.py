@@ -59,8 +59,9 @@ class BatchChunk:
 
     def __init__(self, graph: DeviceGraph, feat: torch.Tensor, embed_dim: int, max_batches: int,
                  rows_cap: int, ent_cap: int, train: bool = True, reset_mode: str = "auto", feat_dim: Optional[int] = None,
-                 hop2: str = "global"):
+                 hop2: str = "global", node_major: bool = True):
         self.lib = _lib.load()
+        self.node_major = bool(node_major)     # "ldsw": one pass over a node's neighbour rows for all its occurrences in the chunk
         self.g = graph
         self.feat = feat
         self.stride = int(feat.shape[1])
@@ -146,6 +147,10 @@ class BatchChunk:
             self.own_scan_ws = _i32(self.lib.ggad_scan_workspace_elems(cap), d)
         if self.train and self.hop2 == "ldsw":
             self.own_deg, self.pw_base = _i32(cap, d), _i32(cap + 1, d)
+            self.own_next = _i32(cap, d)
+            self.grp = _i32(8 * cap + 1, d)        # group table of the node-major gather (+ its counter word)
+            if not hasattr(self, "node_head"):
+                self.node_head = torch.zeros(self.g.n, dtype=torch.int32, device=d)   # zero between gathers (the kernel cleans up)
             if not hasattr(self, "pc"):
                 self.pc = torch.empty(0, dtype=torch.int16, device=d)      # uint16 per-pair counts (raw storage)
 
@@ -249,8 +254,10 @@ class BatchChunk:
                  ptr(self.own_scan_ws), ptr(self.pc))
             if self.gather2_events is not None:
                 self.gather2_events[0].record()
+            nm = self.node_major and self.F <= 64
             call("ggad_mb_hop2_ldsw_gather", ptr(g.rowptr), ptr(g.col), ptr(self.feat), self.F, self.stride, ptr(self.own_pos),
-                 ptr(self.own_list), ptr(self.ent_col), e, ptr(self.pw_base), ptr(self.pc), ptr(self.x2))
+                 ptr(self.own_list), ptr(self.ent_col), e, ptr(self.pw_base), ptr(self.pc),
+                 ptr(self.node_head) if nm else 0, ptr(self.own_next) if nm else 0, self.grp_ptr(e) if nm else 0, ptr(self.x2))
             if self.gather2_events is not None:
                 self.gather2_events[1].record()
         elif self.train and self.hop2 == "ktile" and self.n_ents <= (1 << 22):
@@ -309,6 +316,10 @@ class BatchChunk:
             self.generation += 1
         self.last_hop2 = "ldsw"
         return True
+
+    def grp_ptr(self, e: int) -> int:
+        """The group table is laid out for n_entries_cap = e of THIS build (counter word right behind 8 * e ints)."""
+        return self.grp.data_ptr()
 
     def ent_total_ptr(self) -> int:
         return self.ent_ptr.data_ptr() + 4 * self.n_rows
@@ -376,8 +387,10 @@ def reduce_gradients(grads: torch.Tensor, world_size: int, allreduce: Optional[C
 class MiniBatchEngine:
     """Parameters, optimiser state and the per-batch kernel chain."""
 
-    def __init__(self, feat_dim: int, embed_dim: int, device, lr: float = 1e-3, weight_decay: float = 0.007):
+    def __init__(self, feat_dim: int, embed_dim: int, device, lr: float = 1e-3, weight_decay: float = 0.007,
+                 chain: int = 0):
         self.lib = _lib.load()
+        self.chain = int(chain)          # 0: 6-launch step, 1: row-wise 3-launch step, F == 17 (include/ggad_hip.h)
         self.F, self.D = int(feat_dim), int(embed_dim)
         if self.D > self.lib.ggad_max_embed_dim():
             raise ValueError(f"emb_size {self.D} > {self.lib.ggad_max_embed_dim()} is not supported by the HIP step kernels")
@@ -392,7 +405,7 @@ class MiniBatchEngine:
         self.loss_ws = _f32(self.lib.ggad_mb_loss_workspace_elems(256), self.dev)
         self.step_counter = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self.n_parts = int(self.lib.ggad_mb_bwd_parts())
-        self.dw_part = torch.zeros(self.n_parts * self.F * self.D, dtype=torch.float32, device=self.dev)
+        self.dw_part = torch.zeros(int(self.lib.ggad_mb_dw_part_elems(256, self.D, self.F)), dtype=torch.float32, device=self.dev)
         self.h2 = _f32(1024 * self.D, self.dev)
         self.loss_log = torch.zeros(8 * 256, dtype=torch.float32, device=self.dev)
         D, F = self.D, self.F
@@ -426,6 +439,9 @@ class MiniBatchEngine:
         need = int(self.lib.ggad_mb_loss_workspace_elems(max_rows))
         if self.loss_ws.numel() < need:
             self.loss_ws = _f32(need, self.dev)
+        need = int(self.lib.ggad_mb_dw_part_elems(max_rows, self.D, self.F))
+        if self.dw_part.numel() < need:
+            self.dw_part = torch.zeros(need, dtype=torch.float32, device=self.dev)
         if self.loss_log.numel() < 8 * log_slots:
             new = torch.zeros(8 * max(log_slots, 2 * (self.loss_log.numel() // 8)), dtype=torch.float32, device=self.dev)
             new[:self.loss_log.numel()].copy_(self.loss_log)
@@ -447,6 +463,7 @@ class MiniBatchEngine:
         s.losses8 = self.loss_log.data_ptr() + 32 * log_slot
         s.D, s.F, s.row0, s.n_rows, s.ent0, s.n_ents = self.D, self.F, r0, r1 - r0, e0, e1 - e0
         s.lr, s.weight_decay = self.lr, self.wd
+        s.chain = self.chain
         return s
 
     def loss_and_grads(self, ch: BatchChunk, b: int, log_slot: int = 0) -> None:

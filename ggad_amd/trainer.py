@@ -70,22 +70,24 @@ class DGraphTrainer:
                  lr: float = 1e-3, weight_decay: float = 0.007, chunk_batches: int = 150, rank: int = 0,
                  world_size: int = 1, allreduce: Optional[Callable[[torch.Tensor], None]] = None,
                  engine: Optional[MiniBatchEngine] = None, packed: bool = False, hop2: str = "ldsw",
-                 overlap: bool = False, prefetch: bool = True):
+                 overlap: bool = True, prefetch: bool = True, chain: int = 0, dense_cus: int = 32):
         """`feat` is the plain (N, F) table.  hop2 = "ldsw" (default, fastest measured): 2-hop counts in LDS per
         (tile, batch), per-pair counts streamed to the gather, feature rows padded to one 128-byte line; "global":
         per-batch counter slots in HBM + device atomics; "tiled" / "ktile": earlier LDS-tiled / tile-ordered variants
         (DESIGN.md §4c); with `packed` the global counters live inside a private padded copy of the feature rows
         (15 slots for F = 17 -> chunks of <= 15 batches).
-        `overlap`: two chunk buffers; the plan + gather of chunk c+1 runs on a side stream while the dense steps of
-        chunk c run on a high-priority stream (measured: no gain on MI355X -- the 900 tiny dependent launches of a
-        chunk queue behind the 600k-wave gather launches -- hence off by default).
+        `overlap` (default): two chunk buffers; the plan + gather of chunk c+1 runs on one stream while the dense steps
+        of chunk c run on another, the two streams confined to DISJOINT compute units (`dense_cus` CUs for the dense
+        chain, the rest for the plan; `ggad_stream_create_cu_mask`).  Measured on MI355X: 100 -> 73 us/step.  With
+        plain streams (`dense_cus=0`, dense chain on the high-priority queue) there is no gain: the 900 tiny dependent
+        launches of a chunk queue behind the 600k-wave gather launches.
         `prefetch`: the host sampler (bit-exact CPython shuffle, ~0.6 ms per batch for the 55k pool) runs in a
         background thread one chunk ahead; the C call releases the GIL, so sampling overlaps the GPU work."""
         self.graph, self.feat = graph, feat
         self.schedule = schedule
         self.rank, self.world = int(rank), int(world_size)
         self.allreduce = allreduce if self.world > 1 else None
-        self.engine = engine or MiniBatchEngine(feat.shape[1], embed_dim, feat.device, lr, weight_decay)
+        self.engine = engine or MiniBatchEngine(feat.shape[1], embed_dim, feat.device, lr, weight_decay, chain=chain)
         self.chunk_batches = int(chunk_batches)
         f = int(feat.shape[1])
         self.packed = bool(packed) and f + 1 <= 64
@@ -106,12 +108,46 @@ class DGraphTrainer:
         if self.overlap:
             self.chunks.append(BatchChunk(graph, table, embed_dim, self.chunk_batches, rows, ent_cap, train=True, feat_dim=f,
                                           hop2=hop2))
-            # the dense chain is ~900 tiny dependent launches per chunk: give it the high-priority queue so that its
-            # workgroups are not stuck behind the 600k-wave gather launches of the side stream
-            self.side = torch.cuda.Stream(device=feat.device, priority=0)
-            self.hi = torch.cuda.Stream(device=feat.device, priority=-1)
+            # the dense chain is ~900 tiny dependent launches per chunk; queued on the same CUs as the 600k-wave gather
+            # launches of the side stream they wait for a free CU (measured: no gain, even with a high-priority
+            # queue).  With disjoint CU masks (`dense_cus` CUs for the dense chain, the rest for the plan) both
+            # streams make progress.
+            self.side, self.hi = self._make_streams(feat.device, int(dense_cus))
         self.steps_done = 0
         self.prefetch = bool(prefetch)
+
+    def _make_streams(self, device, dense_cus: int):
+        """(plan stream, dense stream).  dense_cus > 0: CU-masked HIP streams (dense chain on CUs [0, dense_cus), plan on
+        the rest); dense_cus == 0: plain torch streams, dense chain on the high-priority queue."""
+        if dense_cus <= 0:
+            return torch.cuda.Stream(device=device, priority=0), torch.cuda.Stream(device=device, priority=-1)
+        import ctypes
+        from . import _lib
+        lib = _lib.load()
+        n = ctypes.c_int32(0)
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        _lib.check(lib.ggad_device_cu_count(idx, ctypes.byref(n)), "ggad_device_cu_count")
+        n_cu = int(n.value)
+        if not 0 < dense_cus < n_cu:
+            raise ValueError(f"dense_cus must be in (0, {n_cu})")
+        words = (n_cu + 31) // 32
+        self._raw_streams = []
+        out = []
+        with torch.cuda.device(device):
+            # mask bit i = CU i, numbered round-robin over the 8 XCDs (measured: bits 0..31 = 4 CUs on every XCD -> 60 us/step;
+            # every 8th bit = one whole XCD for the dense chain -> 79 us/step), so a contiguous range spreads the dense
+            # chain over all XCDs
+            dense = set(range(dense_cus))
+            for members in (set(range(n_cu)) - dense, dense):
+                mask = (ctypes.c_uint32 * words)()
+                for cu in members:
+                    mask[cu // 32] |= 1 << (cu % 32)
+                h = ctypes.c_void_p()
+                _lib.check(lib.ggad_stream_create_cu_mask(ctypes.cast(mask, ctypes.c_void_p), words, ctypes.byref(h)),
+                           "ggad_stream_create_cu_mask")
+                self._raw_streams.append(h.value)
+                out.append(torch.cuda.ExternalStream(h.value, device=device))
+        return out[0], out[1]
 
     def run_steps(self, n_steps: int, prepared: Optional[Tuple[List[np.ndarray], List[np.ndarray]]] = None,
                   gather_hook=None) -> int:

@@ -147,9 +147,14 @@ int ggad_mb_hop2_ldsw_count(const int32_t *rowptr, const int32_t *col, int64_t n
                             const int32_t *flags, const int32_t *own_pos, int32_t *own_list, const int32_t *batch_ent_ptr,
                             int32_t n_batches, const int32_t *ent_col, int64_t n_entries_cap, int32_t *own_deg,
                             int32_t *pw_base, int32_t *scan_ws, uint16_t *pc, ggad_stream_t stream);
+/* node_head (int32[n_nodes], zero on entry and again on return) + own_next (int32[n_entries_cap]) + grp
+ * (int32[8 * n_entries_cap + 1]): NODE-MAJOR gather -- a node that is an owner in several batches of the chunk (hubs:
+ * ~B deg / N of them) has its neighbour rows fetched once for up to 8 occurrences, each with its own streamed counts
+ * and accumulator; bit-identical to the per-owner kernel that runs when the three are NULL (or feat_dim > 64). */
 int ggad_mb_hop2_ldsw_gather(const int32_t *rowptr, const int32_t *col, const float *feat, int32_t feat_dim, int32_t feat_stride,
                              const int32_t *own_pos, const int32_t *own_list, const int32_t *ent_col, int64_t n_entries_cap,
-                             const int32_t *pw_base, const uint16_t *pc, float *x2, ggad_stream_t stream);
+                             const int32_t *pw_base, const uint16_t *pc, int32_t *node_head, int32_t *own_next, int32_t *grp,
+                             float *x2, ggad_stream_t stream);
 
 /* K-TILE-MAJOR 2-hop: same tables as ggad_mb_hop2_tiled but with the per-batch counters in HBM slots
  * (cnt2[n_slots][n_nodes], zero on entry) and the WORK ordered by tile: launch t touches only the counters and
@@ -234,9 +239,12 @@ int ggad_mb_adam(float *params, float *exp_avg, float *exp_avg_sq, const float *
                  float lr, float weight_decay, float grad_scale, const int32_t *step_counter,
                  ggad_stream_t stream);
 
-/* Whole training step of one batch in one host call: project -> fwd_rows -> loss -> bwd_flat -> grad_reduce,
- * with Adam fused into the last launch when fuse_adam != 0 (single GPU); with fuse_adam == 0 the caller
- * all-reduces `grads` and then calls ggad_mb_adam.  All members are device pointers. */
+/* Whole training step of one batch in one host call.  chain 0 (default): project -> fwd_rows -> loss -> bwd_flat ->
+ * grad_reduce (6 launches).  chain 1 (F == 17): THREE launches, one workgroup per batch row -- k_fwd_rows_x (h2
+ * recomputed per entry), k_loss_bwd_rows (all positions of the batch evaluated from LDS tiles in every workgroup, then
+ * the row's backward coefficients and its dW partial), k_grad_reduce; same results, measured slower (step.hip).
+ * Adam is fused into the last launch when fuse_adam != 0 (single GPU); with fuse_adam == 0 the caller all-reduces
+ * `grads` and then calls ggad_mb_adam.  All members are device pointers. */
 typedef struct ggad_mb_step {
   float *params, *exp_avg, *exp_avg_sq, *grads;
   int32_t *step_counter;
@@ -246,7 +254,10 @@ typedef struct ggad_mb_step {
   float *h2, *dw_part, *loss_ws, *losses8;
   int32_t D, F, row0, n_rows, ent0, n_ents;
   float lr, weight_decay;
+  int32_t chain;          /* 0: 6-launch chain (default); 1: row-wise 3-launch chain, F == 17 only (h2 / coef_* / ent_row unused) */
 } ggad_mb_step;
+/* dw_part must hold ggad_mb_dw_part_elems(n_rows, D, F) floats (one [F][D] partial per row or per bwd_flat part). */
+int64_t ggad_mb_dw_part_elems(int32_t n_rows, int32_t D, int32_t F);
 int ggad_mb_train_step(const ggad_mb_step *step, int32_t fuse_adam, ggad_stream_t stream);
 
 /* Inference embeddings: h[i] = relu(W x1[i])  (GCNEncoder.forward, train_flag False).   graphsage.py:412 */
@@ -256,6 +267,12 @@ int ggad_mb_encode(const float *params, int32_t D, int32_t F, const float *x1, i
 /* Inference: prob[i] = sigmoid(w . relu(W x1[i]))                   graphsage.py:178-181 */
 int ggad_mb_score(const float *params, int32_t D, int32_t F, const float *x1, int32_t n_rows, float *prob,
                   ggad_stream_t stream);
+
+/* Streams restricted to a subset of the compute units (bit i of mask = CU i; n_words 32-bit words).  Used to run the
+ * chunk plan (chip-filling gathers) and the dense step chain (tiny dependent launches) side by side on disjoint CUs. */
+int ggad_stream_create_cu_mask(const uint32_t *mask, int32_t n_words, ggad_stream_t *out);
+int ggad_stream_destroy(ggad_stream_t stream);
+int ggad_device_cu_count(int32_t device, int32_t *out);
 
 /* ------------------------------------------------------------------------------------
  * Full-graph path (run.py + model.py): sparse products over the edges instead of dense N x N matrices

@@ -229,6 +229,43 @@ def test_random_graph_vs_oracle(f, d, hop2):
     np.testing.assert_allclose(eng.weight.cpu().numpy(), p.weight.detach().numpy(), atol=1e-5, rtol=0)
 
 
+@pytest.mark.parametrize("d,bsz,n_ano", [(64, 200, 50), (32, 333, 77), (48, 23, 5)])
+def test_rowwise_chain_equals_six_launch_chain(d, bsz, n_ano):
+    """The 3-launch row-wise step (one workgroup per batch row; F = 17) and the 6-launch step compute the same
+    losses, gradients and Adam trajectory (different summation order only), and both match the oracle."""
+    g, batches, labels = _random_case(n=12000, n_entries=150000, f=17, d=d, seed=31 + d, nb=3, bsz=bsz, n_ano=n_ano)
+    torch.manual_seed(d)
+    w = torch.nn.init.xavier_uniform_(torch.empty(1, d))
+    W = torch.nn.init.xavier_uniform_(torch.empty(d, 17))
+    fc = torch.nn.init.xavier_uniform_(torch.empty(d, d))
+    res = {}
+    for chain in (0, 1):
+        graph, feat, ch = _setup(g, max_batches=3, hop2="ldsw")
+        eng = MiniBatchEngine(17, d, DEV, chain=chain)
+        eng.load_params(w, W, fc)
+        ch.build(batches, labels)
+        grads = []
+        for b in range(3):
+            eng.loss_and_grads(ch, b, b)
+            grads.append(eng.grads.cpu().numpy().copy())
+            eng.adam_step()
+        res[chain] = (np.stack(grads), eng.losses(3).copy(), eng.params.cpu().numpy().copy())
+        eng2 = MiniBatchEngine(17, d, DEV, chain=chain)      # Adam fused into the last launch
+        eng2.load_params(w, W, fc)
+        eng2.train_chunk(ch)
+        np.testing.assert_array_equal(eng2.params.cpu().numpy(), res[chain][2])
+    np.testing.assert_allclose(res[0][0], res[1][0], atol=2e-6, rtol=2e-5)
+    np.testing.assert_allclose(res[0][1], res[1][1], atol=2e-6, rtol=0)
+    np.testing.assert_allclose(res[0][2], res[1][2], atol=2e-6, rtol=0)
+    p = O.MiniParams(w.clone().requires_grad_(), W.clone().requires_grad_(), fc.clone().requires_grad_())
+    agg = O.aggregate_batch(g["rowptr"], g["col"], g["feat"], batches[0], True)
+    tot, cls, mar, rec = O.batch_loss(p, agg, labels[0])
+    tot.backward()
+    ref = np.concatenate([t.grad.numpy().reshape(-1) for t in p.tensors()])
+    np.testing.assert_allclose(res[1][0][0], ref, atol=3e-6, rtol=2e-5)
+    np.testing.assert_allclose(res[1][1][0], [tot.item(), cls.item(), mar.item(), rec.item()], atol=1e-5, rtol=0)
+
+
 def test_rebuild_reuses_clean_slots():
     g, batches, labels = _random_case(n=5000, n_entries=30000, f=17, d=64, seed=4, nb=2, bsz=60, n_ano=10)
     graph, feat, ch = _setup(g, max_batches=2)
@@ -257,7 +294,7 @@ def test_fused_adam_chunk_equals_stepwise():
                 eng.loss_and_grads(ch, b, b)
                 eng.adam_step()
         outs.append((eng.params.cpu().numpy().copy(), eng.losses(4).copy()))
-    for o in outs[1:]:        # side-stream planning and the background sampler thread change nothing
+    for o in outs[1:]:        # side-stream planning (CU-masked or plain streams) and the sampler thread change nothing
         np.testing.assert_array_equal(outs[0][0], o[0])
         np.testing.assert_array_equal(outs[0][1], o[1])
 
@@ -350,6 +387,54 @@ def test_ldsw_hop2_owner_slabs_and_padded_rows():
     _check_plan_against_oracle(g, ch, batches[:1], feat, atol=2e-5)
 
 
+def test_ldsw_node_major_gather_bit_identical():
+    """A hub that is an owner in 11 of 12 batches (two groups: 8 + 3 occurrences), nodes shared by 2 / 4 batches and
+    single occurrences: the node-major gather must equal the per-owner kernel bit for bit, leave node_head clean, and
+    match the oracle."""
+    n = 60000
+    rowptr, col = synth.make_graph(n, 600000, 13, kind="powerlaw", max_degree=900)
+    feat = O.normalize_rows(synth.make_features(n, 17, 13)).astype(np.float32)
+    g = dict(rowptr=rowptr, col=col, feat=feat, f=17, d=64)
+    rng = np.random.default_rng(5)
+    order = np.argsort(-np.diff(rowptr))
+    shared = rng.choice(n, size=40, replace=False)
+    batches, labels = [], []
+    for b in range(12):
+        nodes = rng.choice(n, size=120, replace=False)
+        if b != 4:
+            nodes[0] = order[0]
+        if b % 3 == 0:
+            nodes[1:21] = shared[:20]                    # 4 batches
+        if b in (1, 2):
+            nodes[1:21] = shared[20:]                    # 2 batches
+        lab = np.zeros(120, dtype=np.int64); lab[90:] = 1
+        batches.append(nodes); labels.append(lab)
+    graph = DeviceGraph(rowptr, col, DEV)
+    ft = torch.from_numpy(feat).to(DEV)
+    outs = []
+    for nm in (True, False):
+        ch = BatchChunk(graph, ft, 64, max_batches=12, rows_cap=64, ent_cap=64, train=True, hop2="ldsw", node_major=nm)
+        ch.build(batches, labels)
+        torch.cuda.synchronize()
+        assert ch.last_hop2 == "ldsw"
+        n_own = int(ch.own_pos[ch.n_ents].item())
+        own = ch.own_list[:n_own].long()
+        outs.append((ch.ent_col[own].clone(), torch.div(own, 1, rounding_mode="floor"), ch.x2.view(-1, 17)[own].clone()))
+        if nm:
+            assert int(ch.node_head.abs().sum()) == 0
+            _check_plan_against_oracle(g, ch, batches, feat, atol=5e-6)
+    # owner election is a race between duplicate entries, so compare per (batch, node): sort owners by (entry range, column)
+    def keyed(cols, ents, x, chunk):
+        b = torch.bucketize(ents, torch.as_tensor(chunk.ent_ptr_host[chunk.batch_ptr_host][1:], device=DEV), right=True)
+        k = b * n + cols.long()
+        o = torch.argsort(k)
+        return k[o], x[o]
+    ka, xa = keyed(*outs[0], ch)
+    kb, xb = keyed(*outs[1], ch)
+    assert torch.equal(ka, kb)
+    assert torch.equal(xa.view(torch.int32), xb.view(torch.int32))
+
+
 def test_overlapped_chunks_equal_serial_execution():
     """Plan of chunk c+1 on a side stream while chunk c trains: same weights and losses as the one-stream order."""
     from ggad_amd.sampler import PyCompatRandom
@@ -366,16 +451,16 @@ def test_overlapped_chunks_equal_serial_execution():
     W = torch.nn.init.xavier_uniform_(torch.empty(64, 17))
     fc = torch.nn.init.xavier_uniform_(torch.empty(64, 64))
     outs = []
-    for overlap, prefetch in ((False, False), (True, False), (False, True)):
+    for overlap, prefetch, dense_cus in ((False, False, 32), (True, False, 32), (True, False, 0), (False, True, 32)):
         graph = DeviceGraph(rowptr, col, DEV)
         feat = torch.from_numpy(feat_np).to(DEV)
         sched = BatchSchedule(train.copy(), pool.copy(), labels, 60, PyCompatRandom(72), n_pseudo=20, batches_per_epoch=5)
-        tr = DGraphTrainer(graph, feat, 64, sched, chunk_batches=3, overlap=overlap, prefetch=prefetch)
+        tr = DGraphTrainer(graph, feat, 64, sched, chunk_batches=3, overlap=overlap, prefetch=prefetch, dense_cus=dense_cus)
         assert tr.overlap == overlap
         tr.engine.load_params(w, W, fc)
         tr.run_steps(11)                                   # chunks of 3,3,3,2 -> both buffers reused
         torch.cuda.synchronize()
         outs.append((tr.engine.params.cpu().numpy().copy(), tr.engine.losses(11).copy()))
-    for o in outs[1:]:        # side-stream planning and the background sampler thread change nothing
+    for o in outs[1:]:        # side-stream planning (CU-masked or plain streams) and the sampler thread change nothing
         np.testing.assert_array_equal(outs[0][0], o[0])
         np.testing.assert_array_equal(outs[0][1], o[1])
