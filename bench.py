@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--chunk", type=int, default=150, help="batches planned per launch group (reference epoch = 150)")
     ap.add_argument("--cpu-batches", type=int, default=3, help="batches timed on the CPU port (0 = skip)")
     ap.add_argument("--no-overlap", action="store_true", help="plan and dense steps on one stream")
-    ap.add_argument("--dense-cus", type=int, default=32, help="CUs reserved for the dense step chain when overlapping "
+    ap.add_argument("--dense-cus", type=int, default=64, help="CUs reserved for the dense step chain when overlapping "
                     "(CU-masked streams; 0 = plain streams with priorities)")
     ap.add_argument("--hop2", default="ldsw", choices=["ldsw", "tiled", "ktile", "global", "packed"],
                     help="ldsw: LDS counting per (tile, batch) + streamed per-pair counts (default); tiled / ktile: earlier LDS variants; "

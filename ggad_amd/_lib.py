@@ -49,7 +49,8 @@ SIGNATURES = {
     "ggad_stream_create_cu_mask": (c_int32, [_P, _I, _P]),
     "ggad_stream_destroy": (c_int32, [_P]),
     "ggad_device_cu_count": (c_int32, [_I, _P]),
-    "ggad_mb_hop2_ldsw_count": (c_int32, [_P, _P, _L, _P, _P, _P, _P, _P, _I, _P, _L, _P, _P, _P, _P, _P]),
+    "ggad_mb_ldsw_seg_elems": (c_int64, [_L, _L]),
+    "ggad_mb_hop2_ldsw_count": (c_int32, [_P, _P, _L, _P, _P, _P, _P, _P, _I, _P, _L, _P, _P, _P, _P, _P, _P, _P]),
     "ggad_mb_hop2_ldsw_gather": (c_int32, [_P, _P, _P, _I, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P]),
     "ggad_mb_owner_flags": (c_int32, [_P, _P, _L, _P, _P]),
     "ggad_mb_hop2_tiled": (c_int32, [_P, _P, _P, _I, _I, _L, _P, _P, _P, _P, _P, _I, _P, _L, _P, _P]),

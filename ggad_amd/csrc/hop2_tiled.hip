@@ -309,12 +309,49 @@ constexpr int TW_T = 1024;
 
 __global__ void __launch_bounds__(256) k_owner_meta(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ own_list,
                                                     const int32_t *__restrict__ n_own, const int32_t *__restrict__ ent_col,
-                                                    int64_t n_cap, int32_t *__restrict__ own_deg) {
+                                                    int64_t n_cap, int32_t *__restrict__ own_deg, int32_t *__restrict__ own_rp) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_cap) return;
-  if (p >= *n_own) { own_deg[p] = 0; return; }
+  if (p >= *n_own) { own_deg[p] = 0; own_rp[p] = 0; return; }
   const int u = ent_col[own_list[p]];
-  own_deg[p] = rowptr[u + 1] - rowptr[u];
+  const int rp = rowptr[u];
+  own_rp[p] = rp;
+  own_deg[p] = rowptr[u + 1] - rp;
+}
+
+// seg_t[t][p] = tile_off[node(p)][t]: the per-node table rows of the chunk's owners, transposed to TILE-major so that the
+// workgroup of (tile t, batch b) reads its owners' segment bounds as two contiguous runs.  (Reading tile_off directly
+// costs one random 64-byte sector per (owner, tile): 68 M of them per chunk, 2/3 of k_tile_counts' time.)
+// One workgroup = 64 owners: rows read coalesced (one wave per owner row), transposed through LDS, written as 256-byte runs.
+constexpr int TT_SLAB = 128;
+__global__ void __launch_bounds__(256) k_seg_transpose(const int32_t *__restrict__ tile_off, int n_tiles,
+                                                       const int32_t *__restrict__ own_list, const int32_t *__restrict__ n_own,
+                                                       const int32_t *__restrict__ ent_col, int64_t n_cap,
+                                                       int32_t *__restrict__ seg_t) {
+  __shared__ int tl[TT_SLAB][65];
+  const int p0 = blockIdx.x * 64;
+  const int no = *n_own;
+  if (p0 >= no) return;
+  const int lane = lane_id(), wid = threadIdx.x >> 6;
+  const int NT1 = n_tiles + 1;
+  for (int t0 = 0; t0 < NT1; t0 += TT_SLAB) {
+    for (int j = wid; j < 64; j += 4) {
+      const int p = p0 + j;
+      if (p < no) {
+        const int u = ent_col[own_list[p]];
+        const int32_t *row = tile_off + (int64_t)u * NT1 + t0;
+        if (t0 + lane < NT1) tl[lane][j] = row[lane];
+        if (t0 + 64 + lane < NT1) tl[64 + lane][j] = row[64 + lane];
+      }
+    }
+    __syncthreads();
+    const int nt = min(TT_SLAB, NT1 - t0);
+    for (int idx = threadIdx.x; idx < nt * 64; idx += 256) {
+      const int tt = idx >> 6, j = idx & 63;
+      if (p0 + j < no) seg_t[(int64_t)(t0 + tt) * n_cap + p0 + j] = tl[tt][j];
+    }
+    __syncthreads();
+  }
 }
 
 __device__ __forceinline__ int block_excl_scan_1024(int v, int *warp_buf, int *total) {
@@ -336,12 +373,11 @@ __device__ __forceinline__ int block_excl_scan_1024(int v, int *warp_buf, int *t
   return base + inc - v;
 }
 
-__global__ void __launch_bounds__(TW_T) k_tile_counts(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                                      const int32_t *__restrict__ tile_off, int n_tiles,
-                                                      const int32_t *__restrict__ own_list, const int32_t *__restrict__ own_pos,
+__global__ void __launch_bounds__(TW_T) k_tile_counts(const int32_t *__restrict__ col, const int32_t *__restrict__ seg_t,
+                                                      int64_t n_cap, const int32_t *__restrict__ own_rp,
+                                                      const int32_t *__restrict__ own_pos,
                                                       const int32_t *__restrict__ batch_ent_ptr,
-                                                      const int32_t *__restrict__ ent_col, const int32_t *__restrict__ pw_base,
-                                                      uint16_t *__restrict__ pc) {
+                                                      const int32_t *__restrict__ pw_base, uint16_t *__restrict__ pc) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
   uint32_t *cnt = lds_u;                                   // TW_TILE / 2 words
   int *offs = reinterpret_cast<int *>(lds_u + TW_TILE / 2);  // TW_MAXOWN + 1
@@ -351,7 +387,7 @@ __global__ void __launch_bounds__(TW_T) k_tile_counts(const int32_t *__restrict_
   const int t = blockIdx.x, b = blockIdx.y;
   const int o0 = own_pos[batch_ent_ptr[b]], o1 = own_pos[batch_ent_ptr[b + 1]];
   const int n_own_all = o1 - o0;
-  const int NT1 = n_tiles + 1;
+  const int32_t *seg_lo = seg_t + (int64_t)t * n_cap, *seg_hi = seg_lo + n_cap;
   for (int i = threadIdx.x; i < TW_TILE / 2; i += TW_T) cnt[i] = 0u;
   constexpr int IPT = TW_MAXOWN / TW_T;
   // batches with more owners than the LDS tables hold are walked in slabs of TW_MAXOWN owners (counts accumulate
@@ -365,23 +401,24 @@ __global__ void __launch_bounds__(TW_T) k_tile_counts(const int32_t *__restrict_
       const int ob0 = o0 + slab * TW_MAXOWN;
       const int n_own = min(TW_MAXOWN, o1 - ob0);
       if (pass == 0 || n_slabs > 1) {
-        // segment of every owner inside this tile; exclusive scan of the lengths (IPT owners per thread)
+        // segment of every owner inside this tile; exclusive scan of the lengths (IPT owners per thread).
+        // The four table reads are coalesced (thread-contiguous owners), staged through LDS for the per-thread scan.
+        for (int i = threadIdx.x; i < n_own; i += TW_T) {
+          const int lo = seg_lo[ob0 + i], hi = seg_hi[ob0 + i];
+          offs[i] = hi - lo;
+          segbeg[i] = own_rp[ob0 + i] + lo;
+          dst[i] = pw_base[ob0 + i] + lo;
+        }
+        __syncthreads();
         int len[IPT];
         int mysum = 0;
 #pragma unroll
         for (int q = 0; q < IPT; ++q) {
           const int i = threadIdx.x * IPT + q;
-          len[q] = 0;
-          if (i < n_own) {
-            const int u = ent_col[own_list[ob0 + i]];
-            const int64_t ob = (int64_t)u * NT1 + t;
-            const int lo = tile_off[ob], hi = tile_off[ob + 1];
-            len[q] = hi - lo;
-            segbeg[i] = rowptr[u] + lo;
-            dst[i] = pw_base[ob0 + i] + lo;
-          }
+          len[q] = (i < n_own) ? offs[i] : 0;
           mysum += len[q];
         }
+        __syncthreads();
         int P0;
         int ex = block_excl_scan_1024(mysum, wbuf, &P0);
 #pragma unroll
@@ -725,14 +762,20 @@ int ggad_mb_hop2_tiled(const int32_t *rowptr, const int32_t *col, const float *f
 
 /* "ldsw" 2-hop, stage 1: compact the owners, pw_base = exclusive scan of their degrees, then LDS counting per
  * (32,768-id tile, batch) writing the per-pair counts pc[] (uint16, one per 2-hop pair, laid out like the owners' CSR rows).
- * tile_off must be built with shift ggad_mb_ldsw_tile_shift().  own_deg: n_entries_cap ints; pw_base: n_entries_cap + 1;
- * scan_ws: ggad_scan_workspace_elems(n_entries_cap); pc: >= pw_base[n_entries_cap] elements (sum of the owners' degrees). */
+ * tile_off must be built with shift ggad_mb_ldsw_tile_shift().  own_deg, own_rp: n_entries_cap ints; pw_base:
+ * n_entries_cap + 1; scan_ws: ggad_scan_workspace_elems(n_entries_cap); seg_t: ggad_mb_ldsw_seg_elems(n_nodes,
+ * n_entries_cap) ints (the owners' tile_off rows, transposed tile-major); pc: >= pw_base[n_entries_cap] elements. */
+int64_t ggad_mb_ldsw_seg_elems(int64_t n_nodes, int64_t n_entries_cap) {
+  return (((n_nodes + TW_TILE - 1) >> TW_SHIFT) + 1) * n_entries_cap;
+}
+
 int ggad_mb_hop2_ldsw_count(const int32_t *rowptr, const int32_t *col, int64_t n_nodes, const int32_t *tile_off,
                             const int32_t *flags, const int32_t *own_pos, int32_t *own_list, const int32_t *batch_ent_ptr,
                             int32_t n_batches, const int32_t *ent_col, int64_t n_entries_cap, int32_t *own_deg,
-                            int32_t *pw_base, int32_t *scan_ws, uint16_t *pc, ggad_stream_t stream) {
-  GGAD_REQUIRE(rowptr && col && tile_off && flags && own_pos && own_list && batch_ent_ptr && ent_col && own_deg && pw_base &&
-               scan_ws && pc);
+                            int32_t *own_rp, int32_t *pw_base, int32_t *scan_ws, int32_t *seg_t, uint16_t *pc,
+                            ggad_stream_t stream) {
+  GGAD_REQUIRE(rowptr && col && tile_off && flags && own_pos && own_list && batch_ent_ptr && ent_col && own_deg && own_rp &&
+               pw_base && scan_ws && seg_t && pc);
   GGAD_REQUIRE(n_batches >= 0 && n_entries_cap >= 0 && n_nodes >= 0);
   if (n_batches == 0 || n_entries_cap == 0) return GGAD_OK;
   hipStream_t st = as_stream(stream);
@@ -740,14 +783,16 @@ int ggad_mb_hop2_ldsw_count(const int32_t *rowptr, const int32_t *col, int64_t n
   const unsigned eb = (unsigned)((n_entries_cap + 255) / 256);
   k_owner_compact<<<dim3(eb), dim3(256), 0, st>>>(flags, own_pos, n_entries_cap, own_list);
   const int32_t *n_own = own_pos + n_entries_cap;
-  k_owner_meta<<<dim3(eb), dim3(256), 0, st>>>(rowptr, own_list, n_own, ent_col, n_entries_cap, own_deg);
+  k_owner_meta<<<dim3(eb), dim3(256), 0, st>>>(rowptr, own_list, n_own, ent_col, n_entries_cap, own_deg, own_rp);
   int rc = ggad_exclusive_scan_i32(own_deg, pw_base, n_entries_cap, scan_ws, stream);
   if (rc) return rc;
+  k_seg_transpose<<<dim3((unsigned)((n_entries_cap + 63) / 64)), dim3(256), 0, st>>>(tile_off, n_tiles, own_list, n_own, ent_col,
+                                                                                   n_entries_cap, seg_t);
   const size_t lds = (size_t)(TW_TILE / 2) * 4 + (size_t)(3 * TW_MAXOWN + 1) * 4;
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void *)k_tile_counts, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-  k_tile_counts<<<dim3(n_tiles, n_batches), dim3(TW_T), lds, st>>>(rowptr, col, tile_off, n_tiles, own_list, own_pos,
-                                                                   batch_ent_ptr, ent_col, pw_base, pc);
+  k_tile_counts<<<dim3(n_tiles, n_batches), dim3(TW_T), lds, st>>>(col, seg_t, n_entries_cap, own_rp, own_pos, batch_ent_ptr,
+                                                                   pw_base, pc);
   GGAD_CHECK_LAUNCH("mb_hop2_ldsw_count");
   return GGAD_OK;
 }

@@ -104,11 +104,7 @@ inline uint32_t mt_next(ggad_mt19937 *g) {
   return y;
 }
 
-inline int bit_length_u64(uint64_t n) {
-  int k = 0;
-  while (n) { ++k; n >>= 1; }
-  return k;
-}
+inline int bit_length_u64(uint64_t n) { return n ? 64 - __builtin_clzll(n) : 0; }
 }  // namespace
 
 extern "C" {
@@ -149,14 +145,32 @@ uint32_t ggad_mt_getrandbits32(ggad_mt19937 *g) { return mt_next(g); }
 
 int ggad_mt_shuffle_i64(ggad_mt19937 *g, int64_t *data, int64_t n) {
   if (!g || (!data && n > 0) || n < 0 || n > 0x7fffffffLL) return GGAD_E_INVALID;
-  for (int64_t i = n - 1; i >= 1; --i) {
-    const uint64_t bound = (uint64_t)i + 1;
-    const int k = bit_length_u64(bound);
-    uint32_t r;
-    do { r = mt_next(g) >> (32 - k); } while (r >= bound);
-    const int64_t t = data[i];
-    data[i] = data[r];
-    data[r] = t;
+  // This loop IS the per-batch cost of the reference's schedule (55,275 dependent draws).  CPython's _randbelow redraws
+  // until the value is below the bound (rejected ~28 % of the time, unpredictably); here every MT output is consumed by a
+  // branch-free step instead: an accepted draw swaps data[i] with data[r] and moves on, a rejected one swaps data[i]
+  // with itself and stays.  Same outputs consumed in the same order -> same permutation, same generator state.
+  int64_t i = n - 1;
+  while (i >= 1) {
+    if (g->index >= MT_N) { (void)mt_next(g); g->index = 0; }      // regenerate the block (mt_next twists, we rewind)
+    const int avail = MT_N - g->index;
+    const uint32_t *blk = g->mt + g->index;
+    int used = 0;
+    while (used < avail && i >= 1) {
+      uint32_t y = blk[used++];
+      y ^= (y >> 11);
+      y ^= (y << 7) & 0x9d2c5680u;
+      y ^= (y << 15) & 0xefc60000u;
+      y ^= (y >> 18);
+      const uint32_t bound = (uint32_t)i + 1u;
+      const uint32_t r = y >> __builtin_clz(bound);
+      const bool acc = r < bound;
+      const int64_t j = acc ? (int64_t)r : i;
+      const int64_t t = data[i];
+      data[i] = data[j];
+      data[j] = t;
+      i -= acc ? 1 : 0;
+    }
+    g->index += used;
   }
   return GGAD_OK;
 }

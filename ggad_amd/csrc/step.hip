@@ -129,6 +129,13 @@ __global__ void __launch_bounds__(FWD_NW * 64) k_fwd_rows(const float *__restric
     const int ov = (my < r) ? ent_own[e0 + my] : 0;
     const int cnt = min(64, (r - blk + FWD_NW - 1) / FWD_NW);
     int i = 0;
+    for (; i + 8 <= cnt; i += 8) {                   // hub rows: 8 row loads in flight per wave (same summation order)
+      float a[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) a[q] = h2[(int64_t)(__builtin_amdgcn_readlane(ov, i + q) - ent0) * D + d];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc += a[q];
+    }
     for (; i + 4 <= cnt; i += 4) {
       const int o0 = __builtin_amdgcn_readlane(ov, i), o1 = __builtin_amdgcn_readlane(ov, i + 1);
       const int o2 = __builtin_amdgcn_readlane(ov, i + 2), o3 = __builtin_amdgcn_readlane(ov, i + 3);

@@ -146,7 +146,8 @@ class BatchChunk:
             self.own_flags, self.own_pos, self.own_list = _i32(cap, d), _i32(cap + 1, d), _i32(cap, d)
             self.own_scan_ws = _i32(self.lib.ggad_scan_workspace_elems(cap), d)
         if self.train and self.hop2 == "ldsw":
-            self.own_deg, self.pw_base = _i32(cap, d), _i32(cap + 1, d)
+            self.own_deg, self.own_rp, self.pw_base = _i32(cap, d), _i32(cap, d), _i32(cap + 1, d)
+            self.seg_t = _i32(int(self.lib.ggad_mb_ldsw_seg_elems(self.g.n, cap)), d)
             self.own_next = _i32(cap, d)
             self.grp = _i32(8 * cap + 1, d)        # group table of the node-major gather (+ its counter word)
             if not hasattr(self, "node_head"):
@@ -250,8 +251,8 @@ class BatchChunk:
             call("ggad_exclusive_scan_i32", ptr(self.own_flags), ptr(self.own_pos), e, ptr(self.own_scan_ws))
             call("ggad_mb_hop2_ldsw_count", ptr(g.rowptr), ptr(g.col), g.n,
                  ptr(g.tile_offsets(self.lib.ggad_mb_ldsw_tile_shift())), ptr(self.own_flags), ptr(self.own_pos),
-                 ptr(self.own_list), ptr(self.batch_ent_ptr), nb, ptr(self.ent_col), e, ptr(self.own_deg), ptr(self.pw_base),
-                 ptr(self.own_scan_ws), ptr(self.pc))
+                 ptr(self.own_list), ptr(self.batch_ent_ptr), nb, ptr(self.ent_col), e, ptr(self.own_deg), ptr(self.own_rp),
+                 ptr(self.pw_base), ptr(self.own_scan_ws), ptr(self.seg_t), ptr(self.pc))
             if self.gather2_events is not None:
                 self.gather2_events[0].record()
             nm = self.node_major and self.F <= 64

@@ -70,7 +70,7 @@ class DGraphTrainer:
                  lr: float = 1e-3, weight_decay: float = 0.007, chunk_batches: int = 150, rank: int = 0,
                  world_size: int = 1, allreduce: Optional[Callable[[torch.Tensor], None]] = None,
                  engine: Optional[MiniBatchEngine] = None, packed: bool = False, hop2: str = "ldsw",
-                 overlap: bool = True, prefetch: bool = True, chain: int = 0, dense_cus: int = 32):
+                 overlap: bool = True, prefetch: bool = True, chain: int = 0, dense_cus: int = 64):
         """`feat` is the plain (N, F) table.  hop2 = "ldsw" (default, fastest measured): 2-hop counts in LDS per
         (tile, batch), per-pair counts streamed to the gather, feature rows padded to one 128-byte line; "global":
         per-batch counter slots in HBM + device atomics; "tiled" / "ktile": earlier LDS-tiled / tile-ordered variants

@@ -139,14 +139,18 @@ int ggad_mb_hop2_tiled(const int32_t *rowptr, const int32_t *col, const float *f
  * pc[] at the pair's position in its owner's CSR row (pw_base = exclusive scan of the owners' degrees); the gather then
  * streams pc[] and makes ONE random access per neighbour (the feature row).  tile_off must be built with
  * tile_shift = ggad_mb_ldsw_tile_shift(); every batch needs <= ggad_mb_ldsw_max_owners() owners.
- * Workspaces: own_deg[n_entries_cap], pw_base[n_entries_cap + 1], scan_ws[ggad_scan_workspace_elems(n_entries_cap)],
+ * Workspaces: own_deg[n_entries_cap], own_rp[n_entries_cap], pw_base[n_entries_cap + 1],
+ * scan_ws[ggad_scan_workspace_elems(n_entries_cap)], seg_t[ggad_mb_ldsw_seg_elems(n_nodes, n_entries_cap)] (the owners'
+ * tile_off rows transposed tile-major, so that a (tile, batch) workgroup reads its segment bounds as contiguous runs),
  * pc[sum of the owners' degrees]. */
 int ggad_mb_ldsw_tile_shift(void);
 int ggad_mb_ldsw_max_owners(void);
+int64_t ggad_mb_ldsw_seg_elems(int64_t n_nodes, int64_t n_entries_cap);     /* ints of seg_t */
 int ggad_mb_hop2_ldsw_count(const int32_t *rowptr, const int32_t *col, int64_t n_nodes, const int32_t *tile_off,
                             const int32_t *flags, const int32_t *own_pos, int32_t *own_list, const int32_t *batch_ent_ptr,
                             int32_t n_batches, const int32_t *ent_col, int64_t n_entries_cap, int32_t *own_deg,
-                            int32_t *pw_base, int32_t *scan_ws, uint16_t *pc, ggad_stream_t stream);
+                            int32_t *own_rp, int32_t *pw_base, int32_t *scan_ws, int32_t *seg_t, uint16_t *pc,
+                            ggad_stream_t stream);
 /* node_head (int32[n_nodes], zero on entry and again on return) + own_next (int32[n_entries_cap]) + grp
  * (int32[8 * n_entries_cap + 1]): NODE-MAJOR gather -- a node that is an owner in several batches of the chunk (hubs:
  * ~B deg / N of them) has its neighbour rows fetched once for up to 8 occurrences, each with its own streamed counts
