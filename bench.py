@@ -170,12 +170,12 @@ def main():
     per_nbr = 4 * a.feat + 4 + (2 if mode == "ldsw" else 0)
     alg_bytes = [per_nbr * nb for nb in gather_nbrs]
     ach = (sum(alg_bytes) / 1e9) / (sum(gather_ms) / 1e3) if gather_ms and sum(gather_ms) > 0 else None
-    kname = {"ldsw": "k_gather2_w (2-hop gather-aggregate, streamed pair counts)",
+    kname = {"ldsw": "k_gather2_groups (node-major 2-hop gather-aggregate, streamed pair counts; + k_link_owners, k_build_groups)",
              "tiled": "k_hop2_tiled (LDS-tiled 2-hop count + gather-aggregate)",
              "ktile": "k_count2_tile + k_gather2_tile (k-tile-major 2-hop count + gather-aggregate, all launches)"}.get(
         trainer.chunk.last_hop2, "k_gather2 (2-hop gather-aggregate)")
     traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", {"global": "r01_pmc_gather2.json", "ldsw": "r01_pmc_gather2w.json"}.get(mode, "none"))
+    pmc_path = os.path.join(ROOT, "profiles", {"global": "r01_pmc_gather2.json", "ldsw": "r01_pmc_gather2_groups.json"}.get(mode, "none"))
     if os.path.exists(pmc_path) and gather_nbrs:
         # HBM-side bytes per launch from the rocprofv3 PMC pass of this same command (FETCH_SIZE x 1024, see the json's note),
         # scaled by the neighbours this run's launches gathered
