@@ -70,13 +70,19 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; GGAD_BENCH_BACKEND=gloo lets several ranks share one GPU (tests of the multi-rank path on a 1-GPU box)
+    backend = os.environ.get("GGAD_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from ggad_amd import synth
     from ggad_amd.dgraph import normalize_features, split_dgraphfin

@@ -1,0 +1,109 @@
+"""Data-parallel path on the GPU with 2 ranks sharing ONE device (gloo carries the CUDA tensors): the very code the
+8-GPU run uses -- rank-dealt batches, chunk plans on CU-masked streams, one all-reduce of the packed gradient block
+per step between the backward and the Adam kernel -- checked against a one-process run that averages the two
+gradients itself, and the multi-rank `bench.py` launch line end to end."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _inputs():
+    from ggad_amd import synth
+    from oracle import ggad_oracle as O
+    n = 40000
+    rowptr, col = synth.make_graph(n, 400000, 6, kind="powerlaw", max_degree=500)
+    feat = O.normalize_rows(synth.make_features(n, 17, 6)).astype(np.float32)
+    labels = np.zeros(n, dtype=np.int64)
+    pool = np.arange(500, 1300)
+    labels[pool] = 1
+    train = np.arange(2000, 30000)
+    torch.manual_seed(8)
+    w = torch.nn.init.xavier_uniform_(torch.empty(1, 64))
+    W = torch.nn.init.xavier_uniform_(torch.empty(64, 17))
+    fc = torch.nn.init.xavier_uniform_(torch.empty(64, 64))
+    return rowptr, col, feat, labels, train, pool, (w, W, fc)
+
+
+def _worker(rank, world, port, steps, out_dir):
+    import torch.distributed as dist
+    from ggad_amd.graph import DeviceGraph
+    from ggad_amd.sampler import PyCompatRandom
+    from ggad_amd.trainer import BatchSchedule, DGraphTrainer
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    rowptr, col, feat, labels, train, pool, (w, W, fc) = _inputs()
+    graph = DeviceGraph(rowptr, col, "cuda:0")
+    ft = torch.from_numpy(feat).to("cuda:0")
+    sched = BatchSchedule(train.copy(), pool.copy(), labels, 90, PyCompatRandom(72), n_pseudo=30, batches_per_epoch=7)
+    tr = DGraphTrainer(graph, ft, 64, sched, chunk_batches=3, rank=rank, world_size=world,
+                       allreduce=lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM))
+    assert tr.overlap
+    tr.engine.load_params(w, W, fc)
+    tr.run_steps(steps)
+    torch.cuda.synchronize()
+    np.save(os.path.join(out_dir, f"params_{rank}.npy"), tr.engine.params.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_equal_gradient_averaging(tmp_path):
+    import torch.multiprocessing as mp
+    from ggad_amd.graph import DeviceGraph
+    from ggad_amd.minibatch import BatchChunk, MiniBatchEngine
+    from ggad_amd.sampler import PyCompatRandom
+    from ggad_amd.trainer import BatchSchedule
+    steps, world = 8, 2
+    mp.spawn(_worker, args=(world, _free_port(), steps, str(tmp_path)), nprocs=world, join=True)
+    p0 = np.load(tmp_path / "params_0.npy")
+    p1 = np.load(tmp_path / "params_1.npy")
+    np.testing.assert_array_equal(p0, p1)                       # identical update on every rank
+    # one process, same global batch stream: step s averages the gradients of batches 2s and 2s + 1
+    rowptr, col, feat, labels, train, pool, (w, W, fc) = _inputs()
+    graph = DeviceGraph(rowptr, col, "cuda:0")
+    ft = torch.from_numpy(feat).to("cuda:0")
+    sched = BatchSchedule(train.copy(), pool.copy(), labels, 90, PyCompatRandom(72), n_pseudo=30, batches_per_epoch=7)
+    bn, bl = sched.next_batches(steps * world, 0, 1)
+    eng = MiniBatchEngine(17, 64, "cuda:0")
+    eng.load_params(w, W, fc)
+    ch = BatchChunk(graph, ft, 64, max_batches=world, rows_cap=64, ent_cap=64, train=True, hop2="ldsw")
+    for s in range(steps):
+        ch.build(bn[world * s:world * s + world], bl[world * s:world * s + world])
+        eng.loss_and_grads(ch, 0, 0)
+        g0 = eng.grads.clone()
+        eng.loss_and_grads(ch, 1, 1)
+        eng.step_counter.sub_(1)                                 # two backward passes, ONE optimiser step
+        eng.grads.add_(g0)                                       # what the all-reduce(SUM) leaves on every rank
+        eng.adam_step(1.0 / world)
+    np.testing.assert_allclose(p0, eng.params.cpu().numpy(), atol=1e-6, rtol=1e-5)
+
+
+def test_bench_launch_line_two_ranks_one_gpu():
+    env = dict(os.environ, GGAD_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "60", "--warmup", "30",
+           "--nodes", "200000", "--entries", "4000000", "--chunk", "30"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                       # rank 0 prints ONE json line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 60 and d["scaling"] == "weak" and d["cpu_baseline"] is None
+    assert d["value"] > 0 and np.isfinite(d["last_loss"]) and d["config"]["parallelism"] == "dp2"
