@@ -1,7 +1,8 @@
-"""Evaluation helpers of the DGraph path (reference `src/utils.py:207-260,324-326`), host side.
+"""Evaluation helpers of the DGraph path (reference `src/utils.py:207-260,324-326`).
 
 Scores come from the HIP inference path (`GCN.to_prob` semantics: per-batch normalisation with the
-reference's batch boundaries); the metrics themselves are sklearn's, as in the reference."""
+reference's batch boundaries) and stay on the device; the metrics follow sklearn's definitions (the reference's
+metric library) and are computed on the device too (`ggad_amd/metrics.py`; `device_metrics=False` runs sklearn)."""
 from __future__ import annotations
 
 from typing import Sequence
@@ -24,7 +25,7 @@ def conf_gmean(conf: np.ndarray) -> float:
     return float((tp * tn / ((tp + fn) * (tn + fp))) ** 0.5)
 
 
-def score_nodes(model, test_cases: Sequence[int], batch_size: int, batches_per_launch: int = 2048) -> np.ndarray:
+def score_nodes(model, test_cases: Sequence[int], batch_size: int, batches_per_launch: int = 2048, device: bool = False):
     """Probabilities for `test_cases`, batched EXACTLY like `test_sage` (`src/utils.py:216-230`):
     consecutive slices of `batch_size`; the column counts of the aggregation are per slice (quirk 2).
     Thousands of reference batches are planned and scored per launch group."""
@@ -34,7 +35,7 @@ def score_nodes(model, test_cases: Sequence[int], batch_size: int, batches_per_l
     n = len(cases)
     out = torch.empty(n, dtype=torch.float32, device=eng.dev)
     if n == 0:
-        return out.cpu().numpy()
+        return out if device else out.cpu().numpy()
     from .graphsage import _as_graph
     graph = _as_graph(enc.adj_lists, enc.features.weight.shape[0], eng.dev)
     # slots are N ints per batch: bound the number of batches in flight by memory (<= ~2 GiB of counters)
@@ -55,22 +56,29 @@ def score_nodes(model, test_cases: Sequence[int], batch_size: int, batches_per_l
         ch.build(batches)
         eng.score_chunk(ch, out[s:s + len(part)])
     ch.reset()
-    return out.cpu().numpy()
+    return out if device else out.cpu().numpy()
 
 
-def test_sage(test_cases, labels, model, batch_size, thres=0.5):
+def test_sage(test_cases, labels, model, batch_size, thres=0.5, device_metrics=True):
     """Reference `test_sage` (`src/utils.py:207-247`): same prints, same return tuple."""
-    probs = score_nodes(model, test_cases, batch_size)
-    preds = prob2pred(probs, thres)
-    labels = np.asarray(labels)
-    auc_gnn = roc_auc_score(labels, probs)
-    ap = average_precision_score(labels, probs, average="macro", pos_label=1, sample_weight=None)
-    f1_binary_1 = f1_score(labels, preds, pos_label=1, average="binary")
-    f1_binary_0 = f1_score(labels, preds, pos_label=0, average="binary")
-    f1_macro = f1_score(labels, preds, average="macro")
-    conf = confusion_matrix(labels, preds)
-    tn, fp, fn, tp = conf.ravel()
-    gmean = conf_gmean(conf)
+    if device_metrics:
+        from .metrics import binary_report
+        probs = score_nodes(model, test_cases, batch_size, device=True)
+        r = binary_report(probs, torch.as_tensor(np.asarray(labels), device=probs.device), thres)
+        f1_binary_1, f1_binary_0, f1_macro, auc_gnn, ap, gmean = r["f1_1"], r["f1_0"], r["f1_macro"], r["auc"], r["ap"], r["gmean"]
+        tn, fp, fn, tp = r["tn"], r["fp"], r["fn"], r["tp"]
+    else:
+        probs = score_nodes(model, test_cases, batch_size)
+        preds = prob2pred(probs, thres)
+        labels = np.asarray(labels)
+        auc_gnn = roc_auc_score(labels, probs)
+        ap = average_precision_score(labels, probs, average="macro", pos_label=1, sample_weight=None)
+        f1_binary_1 = f1_score(labels, preds, pos_label=1, average="binary")
+        f1_binary_0 = f1_score(labels, preds, pos_label=0, average="binary")
+        f1_macro = f1_score(labels, preds, average="macro")
+        conf = confusion_matrix(labels, preds)
+        tn, fp, fn, tp = conf.ravel()
+        gmean = conf_gmean(conf)
     print(f"   GNN F1-binary-1: {f1_binary_1:.4f}\tF1-binary-0: {f1_binary_0:.4f}" +
           f"\tF1-macro: {f1_macro:.4f}\tG-Mean: {gmean:.4f}\tAUC: {auc_gnn:.4f}")
     print("Testing AP:", ap)

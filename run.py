@@ -18,11 +18,11 @@ import time
 import numpy as np
 import scipy.sparse as sp
 import torch
-from sklearn.metrics import average_precision_score, roc_auc_score
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from ggad_amd import synth  # noqa: E402
 from ggad_amd.fullgraph import FlatAdam, FullGraphAdj, GgadLossFn  # noqa: E402
+from ggad_amd.metrics import average_precision, roc_auc  # noqa: E402
 from ggad_amd.model import Model  # noqa: E402
 from ggad_amd.utils import load_mat, normalize_adj, preprocess_features, split_nodes  # noqa: E402
 
@@ -95,6 +95,8 @@ def main():
     model = Model(ft_size, args.embedding_dim, "prelu", args.negsamp_ratio, args.readout).to(dev)
     optimiser = FlatAdam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
     ls = full.loss_structs(normal_label_idx, abnormal_label_idx)
+    idx_test_dev = torch.as_tensor(np.asarray(idx_test, dtype=np.int64), device=dev)
+    y_test_dev = torch.as_tensor(np.asarray(ano_label)[np.asarray(idx_test, dtype=np.int64)].astype(np.int64), device=dev)
     total_time = 0.0
     epoch_times = []
     for epoch in range(args.num_epoch):
@@ -120,10 +122,10 @@ def main():
             model.eval()
             with torch.no_grad():
                 _, _, logits_eval, _, _ = model(feats, full, abnormal_label_idx, normal_label_idx, False, args)
-            scores = np.squeeze(logits_eval[:, idx_test, :].cpu().numpy())
-            auc = roc_auc_score(ano_label[idx_test], scores)
+            scores = logits_eval[0, idx_test_dev, 0]                          # stays in HBM: device sort + fp64 prefix sums
+            auc = roc_auc(scores, y_test_dev)                                 # = sklearn roc_auc_score      run.py:236
             print("Testing {} AUC:{:.4f}".format(args.dataset, auc))
-            ap = average_precision_score(ano_label[idx_test], scores, average="macro", pos_label=1, sample_weight=None)
+            ap = average_precision(scores, y_test_dev)                        # = average_precision_score    run.py:238
             print("Testing AP:", ap)
     print("nodes/s (training window, run.py:146->214): {:.1f}".format(nb_nodes * args.num_epoch / total_time))
     med = float(np.median(epoch_times))
