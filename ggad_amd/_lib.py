@@ -46,6 +46,7 @@ SIGNATURES = {
     "ggad_mb_ldsw_tile_shift": (c_int32, []),
     "ggad_mb_ldsw_max_owners": (c_int32, []),
     "ggad_mb_dw_part_elems": (c_int64, [_I, _I, _I]),
+    "ggad_mb_train_chunk": (c_int32, [_P, _I, _P, _P, _P, _P, _I, _I, _P]),
     "ggad_stream_create_cu_mask": (c_int32, [_P, _I, _P]),
     "ggad_stream_destroy": (c_int32, [_P]),
     "ggad_device_cu_count": (c_int32, [_I, _P]),
@@ -103,7 +104,7 @@ class MbStep(ctypes.Structure):
                                          "ent_ptr", "ent_own", "ent_row", "labels", "pos_meta", "row_pos", "h1", "nbar",
                                          "gen", "dz", "coef_a", "coef_g", "h2", "dw_part", "loss_ws", "losses8")]
                 + [(n, c_int32) for n in ("D", "F", "row0", "n_rows", "ent0", "n_ents")]
-                + [("lr", c_float), ("weight_decay", c_float), ("chain", c_int32)])
+                + [("lr", c_float), ("weight_decay", c_float), ("chain", c_int32), ("max_row_entries", c_int32)])
 
 
 _lib = None

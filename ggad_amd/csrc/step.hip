@@ -20,6 +20,8 @@
 // lane = embedding channel d (D <= 64).  The projection uses the f32 VALU: at K = 17 an f32 MFMA tile
 // (32x32x2) has the same FLOP rate and would waste 32/17 of it on padding; MFMA is used for the wide
 // full-graph projections only (gemm.hip).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -411,7 +413,8 @@ __global__ void __launch_bounds__(256) k_bwd_flat(ParamLayout L, const float *__
                                                   const float *__restrict__ h2, const int32_t *__restrict__ ent_own,
                                                   const int32_t *__restrict__ ent_row, int row0, int n_rows, int ent0,
                                                   int n_ents, const float *__restrict__ coef_a,
-                                                  const float *__restrict__ coef_g, float *__restrict__ dw_part) {
+                                                  const float *__restrict__ coef_g, float *__restrict__ dw_part,
+                                                  int h2_by_entry) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // [4][F*D]
   const int D = L.D, F = (FT > 0) ? FT : L.F;
   const int lane = lane_id(), wid = threadIdx.x / 64;
@@ -434,7 +437,7 @@ __global__ void __launch_bounds__(256) k_bwd_flat(ParamLayout L, const float *__
     if (idx < n_ents) {
       const int e = ent0 + idx;
       const int o = ent_own[e];
-      xo = o; ho = o - ent0; co = ent_row[e];
+      xo = o; ho = h2_by_entry ? idx : o - ent0; co = ent_row[e];      // h2 stored per owner (k_project) or per entry (k_fwd_rows_v)
     } else if (idx < n_items) {
       co = row0 + idx - n_ents; xo = -2 - co;
     }
@@ -647,6 +650,99 @@ __global__ void __launch_bounds__(256) k_encode(const float *__restrict__ params
     float acc = 0.0f;
     for (int f = 0; f < F; ++f) acc = fmaf(lds[f * D + d], x[f], acc);
     if (lane < D) h[(int64_t)row * D + lane] = fmaxf(acc, 0.0f);                  // graphsage.py:412
+  }
+}
+
+// ------------------------------------------------------------------ forward rows with the projection fused in
+// k_project + k_fwd_rows in one launch (one launch boundary and one 8 us latency-bound kernel less per step).  The
+// projection h2 = relu(W x2[own(e)]) is computed by the workgroup of the entry's row: the x2 rows are fetched with
+// VECTOR loads, 3 rows per instruction (lane = (row slot g, feature f)), four instructions in flight, and the 17
+// features of a row reach every channel lane through v_readlane (SGPR broadcast) -- a scalar-load version
+// (k_fwd_rows_x) has one dependent scalar-cache round trip per 4 entries and is 2x slower on hub rows.
+// h2 is written per ENTRY (not per owner) for the relu mask of k_bwd_flat.  Same fma / summation order as
+// k_project + k_fwd_rows: bit-identical h1 / nbar / gen.
+template <int FT>
+__global__ void __launch_bounds__(FWD_NW * 64) k_fwd_rows_v(const float *__restrict__ params, ParamLayout L,
+                                                    const float *__restrict__ x1, const float *__restrict__ x2,
+                                                    const int32_t *__restrict__ ent_ptr, const int32_t *__restrict__ ent_own,
+                                                    const int32_t *__restrict__ labels, int row0, int ent0,
+                                                    float *__restrict__ h2, float *__restrict__ h1,
+                                                    float *__restrict__ nbar, float *__restrict__ gen) {
+  static_assert(FT > 0 && FT <= 32, "register-resident W^T column, >= 2 rows per load");
+  constexpr int RPI = 64 / FT;              // x2 rows per load instruction
+  constexpr int U = 4;                      // load instructions in flight
+  __shared__ float part[FWD_NW][64];
+  __shared__ float ns[64];
+  const int D = L.D;
+  const int lane = lane_id(), wid = threadIdx.x / 64, d = lane < D ? lane : D - 1;
+  const int g = lane / FT, f = lane - g * FT;
+  const bool ld_on = g < RPI;
+  const int row = row0 + blockIdx.x;
+  WCol<FT> W;
+  W.load(params + L.o_Wt(), nullptr, D, FT, d, threadIdx.x, blockDim.x);
+  const int e0 = ent_ptr[row], e1 = ent_ptr[row + 1];
+  const int r = e1 - e0;
+  float acc = 0.0f;
+  for (int blk = wid; blk < r; blk += FWD_NW * 64) {
+    const int my = blk + FWD_NW * lane;                 // lane l holds the owner of entry blk + 16 l of the row
+    const int ov = (my < r) ? ent_own[e0 + my] : 0;
+    const int cnt = min(64, (r - blk + FWD_NW - 1) / FWD_NW);
+    for (int i0 = 0; i0 < cnt; i0 += RPI * U) {
+      float xv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int src = i0 + u * RPI + g;
+        const int o = __shfl(ov, src & 63, GGAD_WAVE);
+        xv[u] = (ld_on && src < cnt) ? x2[(int64_t)o * FT + f] : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+#pragma unroll
+        for (int gg = 0; gg < RPI; ++gg) {
+          const int idx = i0 + u * RPI + gg;            // wave-uniform
+          if (idx < cnt) {
+            float h = 0.0f;
+#pragma unroll
+            for (int ff = 0; ff < FT; ++ff)
+              h = fmaf(W.reg[ff], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv[u]), gg * FT + ff)), h);
+            h = fmaxf(h, 0.0f);                                                        // relu(W x2[u])   graphsage.py:419
+            acc += h;
+            if (lane < D) h2[(int64_t)(e0 - ent0 + blk + FWD_NW * idx) * D + lane] = h;
+          }
+        }
+      }
+    }
+  }
+  part[wid][lane] = acc;
+  __syncthreads();
+  const float inv_r = 1.0f / (float)r;                                      // mask_row = mask / rowsum  graphsage.py:317
+  float tot = 0.0f;
+#pragma unroll
+  for (int k = 0; k < FWD_NW; ++k) tot += part[k][lane];                    // fixed order
+  const float nb = inv_r * tot;
+  const int y = labels[row];
+  if (wid == 0) {
+    if (lane < D) nbar[(int64_t)row * D + lane] = nb;                       // mask_row.mm(...)          graphsage.py:421
+    ns[lane] = (lane < D) ? nb : 0.0f;
+  }
+  if (wid == 1) {                                                           // h1 = relu(W x1[row])      graphsage.py:412
+    const float h = fmaxf(W.dot(x1 + (int64_t)row * FT), 0.0f);
+    if (lane < D) h1[(int64_t)row * D + lane] = h;
+  }
+  if (y != 1) return;                                                       // block-uniform exit
+  __syncthreads();
+  const float *fcT = params + L.o_fcT();                                    // gen = relu(fc nbar)   graphsage.py:428-430
+  const int q = (D + FWD_NW - 1) / FWD_NW;
+  float a = 0.0f;
+  for (int d2 = wid * q; d2 < min(D, (wid + 1) * q); ++d2) a = fmaf(fcT[d2 * D + d], ns[d2], a);
+  __syncthreads();
+  part[wid][lane] = a;
+  __syncthreads();
+  if (wid == 0 && lane < D) {
+    float gs = 0.0f;
+#pragma unroll
+    for (int k = 0; k < FWD_NW; ++k) gs += part[k][lane];
+    gen[(int64_t)row * D + lane] = fmaxf(gs, 0.0f);
   }
 }
 
@@ -1009,19 +1105,29 @@ int ggad_mb_row_coefs(const float *params, int32_t D, int32_t F, const int32_t *
   return GGAD_OK;
 }
 
+static int bwd_flat_launch(int32_t D, int32_t F, const float *x1, const float *x2, const float *h2, const int32_t *ent_own,
+                           const int32_t *ent_row, int32_t row0, int32_t n_rows, int32_t ent0, int32_t n_ents,
+                           const float *coef_a, const float *coef_g, float *dw_part, int h2_by_entry, ggad_stream_t stream);
+
 int ggad_mb_bwd_flat(int32_t D, int32_t F, const float *x1, const float *x2, const float *h2, const int32_t *ent_own,
                      const int32_t *ent_row, int32_t row0, int32_t n_rows, int32_t ent0, int32_t n_ents,
                      const float *coef_a, const float *coef_g, float *dw_part, ggad_stream_t stream) {
+  return bwd_flat_launch(D, F, x1, x2, h2, ent_own, ent_row, row0, n_rows, ent0, n_ents, coef_a, coef_g, dw_part, 0, stream);
+}
+
+static int bwd_flat_launch(int32_t D, int32_t F, const float *x1, const float *x2, const float *h2, const int32_t *ent_own,
+                           const int32_t *ent_row, int32_t row0, int32_t n_rows, int32_t ent0, int32_t n_ents,
+                           const float *coef_a, const float *coef_g, float *dw_part, int h2_by_entry, ggad_stream_t stream) {
   GGAD_REQUIRE(x1 && x2 && h2 && ent_own && ent_row && coef_a && coef_g && dw_part && dims_ok(D, F));
   GGAD_REQUIRE(n_rows >= 1 && row0 >= 0 && ent0 >= 0 && n_ents >= 0);
   ParamLayout L{D, F};
   const size_t lds = (size_t)4 * F * D * 4;
   if (F == 17)
     k_bwd_flat<17><<<dim3(BWD_PARTS), dim3(256), lds, as_stream(stream)>>>(L, x1, x2, h2, ent_own, ent_row, row0, n_rows, ent0,
-                                                                           n_ents, coef_a, coef_g, dw_part);
+                                                                           n_ents, coef_a, coef_g, dw_part, h2_by_entry);
   else
     k_bwd_flat<0><<<dim3(BWD_PARTS), dim3(256), lds, as_stream(stream)>>>(L, x1, x2, h2, ent_own, ent_row, row0, n_rows, ent0,
-                                                                          n_ents, coef_a, coef_g, dw_part);
+                                                                          n_ents, coef_a, coef_g, dw_part, h2_by_entry);
   GGAD_CHECK_LAUNCH("mb_bwd_flat");
   return GGAD_OK;
 }
@@ -1073,8 +1179,9 @@ int ggad_mb_encode(const float *params, int32_t D, int32_t F, const float *x1, i
   return GGAD_OK;
 }
 
-/* One whole training step for one batch.  chain 0 (default): project -> fwd_rows -> loss_pos -> loss_rows -> bwd_flat ->
- * grad_reduce; chain 1 (F == 17 only): the row-wise 3-launch chain fwd_rows_x -> loss_bwd_rows -> grad_reduce (measured
+/* One whole training step for one batch.  chain 0 (default): fwd_rows_v (projection fused, F == 17; else project ->
+ * fwd_rows) -> loss_pos -> loss_rows -> bwd_flat -> grad_reduce; chain 2: always project -> fwd_rows -> ...;
+ * chain 1 (F == 17 only): the row-wise 3-launch chain fwd_rows_x -> loss_bwd_rows -> grad_reduce (measured
  * slower: the redundant all-positions pass costs more than the launches it saves; kept as a tested alternative).
  * Adam is fused into the last launch when fuse_adam != 0; otherwise the caller all-reduces s->grads and calls
  * ggad_mb_adam. */
@@ -1115,6 +1222,7 @@ static int train_step_rows(const ggad_mb_step *s, int32_t fuse_adam, ggad_stream
 
 int ggad_mb_train_step(const ggad_mb_step *s, int32_t fuse_adam, ggad_stream_t stream) {
   GGAD_REQUIRE(s && s->params && s->exp_avg && s->exp_avg_sq && s->grads && s->step_counter);
+  GGAD_REQUIRE(s->chain >= 0 && s->chain <= 2);
   const int D = s->D, F = s->F;
   int rc;
   if (s->chain == 1) {
@@ -1123,14 +1231,27 @@ int ggad_mb_train_step(const ggad_mb_step *s, int32_t fuse_adam, ggad_stream_t s
                  s->gen && s->dz && s->dw_part && s->loss_ws && s->losses8 && dims_ok(D, F) && s->n_rows >= 1 && s->row0 >= 0);
     return train_step_rows(s, fuse_adam, stream);
   }
-  if ((rc = ggad_mb_project(s->params, D, F, s->x2, s->ent_own, s->ent0, s->n_ents, s->h2, stream))) return rc;
-  if ((rc = ggad_mb_fwd_rows(s->params, D, F, s->x1, s->h2, s->ent_ptr, s->ent_own, s->labels, s->row0, s->n_rows, s->ent0,
-                             s->h1, s->nbar, s->gen, stream))) return rc;
+  // 5 launches: the projection is done by the forward-rows kernel -- unless the batch holds a hub row (one workgroup would
+  // project thousands of entries while the flat k_project spreads them over the chip)
+  static const int fuse_max_row = [] { const char *e = getenv("GGAD_FUSE_MAX_ROW"); return e ? atoi(e) : 256; }();
+  const bool fused_fwd = s->chain == 0 && F == 17 && s->max_row_entries > 0 && s->max_row_entries <= fuse_max_row;
+  if (fused_fwd) {
+    GGAD_REQUIRE(s->x1 && s->x2 && s->h2 && s->ent_ptr && s->ent_own && s->labels && s->h1 && s->nbar && s->gen && dims_ok(D, F));
+    GGAD_REQUIRE(s->n_rows >= 1 && s->row0 >= 0 && s->ent0 >= 0);
+    ParamLayout L{D, F};
+    k_fwd_rows_v<17><<<dim3(s->n_rows), dim3(FWD_NW * 64), 0, as_stream(stream)>>>(s->params, L, s->x1, s->x2, s->ent_ptr, s->ent_own,
+                                                                                  s->labels, s->row0, s->ent0, s->h2, s->h1, s->nbar,
+                                                                                  s->gen);
+  } else {
+    if ((rc = ggad_mb_project(s->params, D, F, s->x2, s->ent_own, s->ent0, s->n_ents, s->h2, stream))) return rc;
+    if ((rc = ggad_mb_fwd_rows(s->params, D, F, s->x1, s->h2, s->ent_ptr, s->ent_own, s->labels, s->row0, s->n_rows, s->ent0,
+                               s->h1, s->nbar, s->gen, stream))) return rc;
+  }
   if ((rc = ggad_mb_loss(s->params, D, F, s->h1, s->nbar, s->gen, s->labels, s->pos_meta, s->row_pos, s->ent_ptr, s->row0,
                          s->n_rows, s->loss_ws, s->losses8, nullptr, nullptr, nullptr, s->dz, s->coef_a, s->coef_g,
                          s->step_counter, stream))) return rc;
-  if ((rc = ggad_mb_bwd_flat(D, F, s->x1, s->x2, s->h2, s->ent_own, s->ent_row, s->row0, s->n_rows, s->ent0, s->n_ents,
-                             s->coef_a, s->coef_g, s->dw_part, stream))) return rc;
+  if ((rc = bwd_flat_launch(D, F, s->x1, s->x2, s->h2, s->ent_own, s->ent_row, s->row0, s->n_rows, s->ent0, s->n_ents,
+                            s->coef_a, s->coef_g, s->dw_part, fused_fwd ? 1 : 0, stream))) return rc;
   if (!fuse_adam)
     return ggad_mb_grad_reduce(D, F, s->pos_meta, s->row0, s->n_rows, s->losses8, s->nbar, s->dw_part, s->dz, s->loss_ws,
                                s->grads, stream);
@@ -1141,6 +1262,29 @@ int ggad_mb_train_step(const ggad_mb_step *s, int32_t fuse_adam, ggad_stream_t s
       L, s->pos_meta, s->row0, s->losses8, s->nbar, s->dw_part, BWD_PARTS, s->dz, gw_part, nwg, s->grads, s->params,
       s->exp_avg, s->exp_avg_sq, s->lr, s->weight_decay, s->step_counter);
   GGAD_CHECK_LAUNCH("mb_train_step");
+  return GGAD_OK;
+}
+
+/* The dense steps of a whole chunk in ONE host call: step b = batch b of the chunk, rows [batch_ptr[b], batch_ptr[b+1]),
+ * entries [batch_ent_ptr[b], batch_ent_ptr[b+1]) (HOST arrays of n_batches + 1 offsets), loss record of step b at
+ * loss_log + 8 * (log_base + b) (device), largest row of batch b = batch_max_row[b] (host, optional).  Every other member
+ * comes from *tmpl.  The host cost per step drops to the six
+ * launches themselves, so the launch queue stays ahead of the 5-8 us kernels. */
+int ggad_mb_train_chunk(const ggad_mb_step *tmpl, int32_t n_batches, const int32_t *batch_ptr, const int64_t *batch_ent_ptr,
+                        const int32_t *batch_max_row, float *loss_log, int32_t log_base, int32_t fuse_adam,
+                        ggad_stream_t stream) {
+  GGAD_REQUIRE(tmpl && batch_ptr && batch_ent_ptr && loss_log && n_batches >= 0 && log_base >= 0);
+  for (int b = 0; b < n_batches; ++b) {
+    ggad_mb_step s = *tmpl;
+    s.row0 = batch_ptr[b];
+    s.n_rows = batch_ptr[b + 1] - batch_ptr[b];
+    s.ent0 = (int32_t)batch_ent_ptr[b];
+    s.n_ents = (int32_t)(batch_ent_ptr[b + 1] - batch_ent_ptr[b]);
+    s.losses8 = loss_log + (int64_t)8 * (log_base + b);
+    s.max_row_entries = batch_max_row ? batch_max_row[b] : 0;
+    const int rc = ggad_mb_train_step(&s, fuse_adam, stream);
+    if (rc) return rc;
+  }
   return GGAD_OK;
 }
 

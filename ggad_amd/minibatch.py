@@ -100,6 +100,7 @@ class BatchChunk:
         self.n_ents = 0
         self.batch_ptr_host = np.zeros(1, dtype=np.int32)
         self.ent_ptr_host = np.zeros(1, dtype=np.int64)
+        self.batch_max_row = np.zeros(1, dtype=np.int32)
         self.dirty = False
         self.build_count = 0
         self.gather2_events = None      # optional (start, end) torch events recorded around the gather2 launch
@@ -222,6 +223,7 @@ class BatchChunk:
         self.build_count += 1
         self.batch_ptr_host = bp
         self.ent_ptr_host = ent_ptr_host
+        self.batch_max_row = np.maximum.reduceat(r_host, bp[:-1]).astype(np.int32)     # largest closed neighbourhood per batch
         g = self.g
         call("ggad_mb_row_degree", ptr(g.rowptr), ptr(g.col), ptr(self.nodes), ptr(self.batch_ptr), nb, rows,
              ptr(self.row_r), ptr(self.row_slot))
@@ -391,7 +393,7 @@ class MiniBatchEngine:
     def __init__(self, feat_dim: int, embed_dim: int, device, lr: float = 1e-3, weight_decay: float = 0.007,
                  chain: int = 0):
         self.lib = _lib.load()
-        self.chain = int(chain)          # 0: 6-launch step, 1: row-wise 3-launch step, F == 17 (include/ggad_hip.h)
+        self.chain = int(chain)          # 0: fused-forward step (5 launches, F == 17), 1: row-wise 3-launch step, 2: 6 launches
         self.F, self.D = int(feat_dim), int(embed_dim)
         if self.D > self.lib.ggad_max_embed_dim():
             raise ValueError(f"emb_size {self.D} > {self.lib.ggad_max_embed_dim()} is not supported by the HIP step kernels")
@@ -465,6 +467,7 @@ class MiniBatchEngine:
         s.D, s.F, s.row0, s.n_rows, s.ent0, s.n_ents = self.D, self.F, r0, r1 - r0, e0, e1 - e0
         s.lr, s.weight_decay = self.lr, self.wd
         s.chain = self.chain
+        s.max_row_entries = int(ch.batch_max_row[b])
         return s
 
     def loss_and_grads(self, ch: BatchChunk, b: int, log_slot: int = 0) -> None:
@@ -482,6 +485,16 @@ class MiniBatchEngine:
         self.ensure_capacity(ch, log_base + ch.n_batches)
         stream = _lib.current_stream()
         fuse = 1 if (allreduce is None and world_size == 1) else 0
+        if fuse:
+            # single GPU: the whole chunk in one host call (the C loop issues the launches; Python per step costs more
+            # than the 5-8 us kernels it feeds)
+            s = self.step_desc(ch, 0, log_base)
+            bp = np.ascontiguousarray(ch.batch_ptr_host[:ch.n_batches + 1], dtype=np.int32)
+            ep = np.ascontiguousarray(ch.ent_ptr_host[bp], dtype=np.int64)
+            mr = np.ascontiguousarray(ch.batch_max_row, dtype=np.int32)
+            _lib.check(self.lib.ggad_mb_train_chunk(ctypes.byref(s), ch.n_batches, bp.ctypes.data, ep.ctypes.data, mr.ctypes.data,
+                                                    self.loss_log.data_ptr(), log_base, 1, stream), "ggad_mb_train_chunk")
+            return
         for b in range(ch.n_batches):
             s = self.step_desc(ch, b, log_base + b)
             _lib.check(self.lib.ggad_mb_train_step(ctypes.byref(s), fuse, stream), "ggad_mb_train_step")

@@ -243,8 +243,9 @@ int ggad_mb_adam(float *params, float *exp_avg, float *exp_avg_sq, const float *
                  float lr, float weight_decay, float grad_scale, const int32_t *step_counter,
                  ggad_stream_t stream);
 
-/* Whole training step of one batch in one host call.  chain 0 (default): project -> fwd_rows -> loss -> bwd_flat ->
- * grad_reduce (6 launches).  chain 1 (F == 17): THREE launches, one workgroup per batch row -- k_fwd_rows_x (h2
+/* Whole training step of one batch in one host call.  chain 0 (default): fwd_rows_v (h2 = relu(W x2) computed by the
+ * row's workgroup, F == 17) or project -> fwd_rows, then loss_pos -> loss_rows -> bwd_flat -> grad_reduce (5 or 6
+ * launches); chain 2: always 6.  chain 1 (F == 17): THREE launches, one workgroup per batch row -- k_fwd_rows_x (h2
  * recomputed per entry), k_loss_bwd_rows (all positions of the batch evaluated from LDS tiles in every workgroup, then
  * the row's backward coefficients and its dW partial), k_grad_reduce; same results, measured slower (step.hip).
  * Adam is fused into the last launch when fuse_adam != 0 (single GPU); with fuse_adam == 0 the caller all-reduces
@@ -258,11 +259,20 @@ typedef struct ggad_mb_step {
   float *h2, *dw_part, *loss_ws, *losses8;
   int32_t D, F, row0, n_rows, ent0, n_ents;
   float lr, weight_decay;
-  int32_t chain;          /* 0: 6-launch chain (default); 1: row-wise 3-launch chain, F == 17 only (h2 / coef_* / ent_row unused) */
+  int32_t chain;          /* 0 (default): 5 launches when F == 17 and the batch has no hub row (projection fused into the
+                             forward-rows kernel, h2 per ENTRY), else 6; 2: always 6; 1: row-wise 3-launch chain, F == 17 */
+  int32_t max_row_entries; /* largest closed neighbourhood among the batch rows (host knowledge; 0 = unknown -> 6 launches) */
 } ggad_mb_step;
 /* dw_part must hold ggad_mb_dw_part_elems(n_rows, D, F) floats (one [F][D] partial per row or per bwd_flat part). */
 int64_t ggad_mb_dw_part_elems(int32_t n_rows, int32_t D, int32_t F);
 int ggad_mb_train_step(const ggad_mb_step *step, int32_t fuse_adam, ggad_stream_t stream);
+/* All steps of a chunk in one host call (the reference's per-batch loop, src/model_handler.py:330-364): batch b covers rows
+ * [batch_ptr[b], batch_ptr[b+1]) and entries [batch_ent_ptr[b], batch_ent_ptr[b+1]) -- HOST arrays of n_batches + 1
+ * offsets --, its largest row has batch_max_row[b] entries (host, may be NULL), its loss record goes to
+ * loss_log + 8 * (log_base + b) (device); everything else is taken from *tmpl. */
+int ggad_mb_train_chunk(const ggad_mb_step *tmpl, int32_t n_batches, const int32_t *batch_ptr, const int64_t *batch_ent_ptr,
+                        const int32_t *batch_max_row, float *loss_log, int32_t log_base, int32_t fuse_adam,
+                        ggad_stream_t stream);
 
 /* Inference embeddings: h[i] = relu(W x1[i])  (GCNEncoder.forward, train_flag False).   graphsage.py:412 */
 int ggad_mb_encode(const float *params, int32_t D, int32_t F, const float *x1, int32_t n_rows, float *h,

@@ -231,15 +231,15 @@ def test_random_graph_vs_oracle(f, d, hop2):
 
 @pytest.mark.parametrize("d,bsz,n_ano", [(64, 200, 50), (32, 333, 77), (48, 23, 5)])
 def test_rowwise_chain_equals_six_launch_chain(d, bsz, n_ano):
-    """The 3-launch row-wise step (one workgroup per batch row; F = 17) and the 6-launch step compute the same
-    losses, gradients and Adam trajectory (different summation order only), and both match the oracle."""
+    """Chain 0 (projection fused into the forward-rows kernel) is bit-identical to the 6-launch chain 2; the 3-launch
+    row-wise chain 1 computes the same losses, gradients and Adam trajectory up to summation order; oracle check."""
     g, batches, labels = _random_case(n=12000, n_entries=150000, f=17, d=d, seed=31 + d, nb=3, bsz=bsz, n_ano=n_ano)
     torch.manual_seed(d)
     w = torch.nn.init.xavier_uniform_(torch.empty(1, d))
     W = torch.nn.init.xavier_uniform_(torch.empty(d, 17))
     fc = torch.nn.init.xavier_uniform_(torch.empty(d, d))
     res = {}
-    for chain in (0, 1):
+    for chain in (0, 1, 2):
         graph, feat, ch = _setup(g, max_batches=3, hop2="ldsw")
         eng = MiniBatchEngine(17, d, DEV, chain=chain)
         eng.load_params(w, W, fc)
@@ -254,6 +254,8 @@ def test_rowwise_chain_equals_six_launch_chain(d, bsz, n_ano):
         eng2.load_params(w, W, fc)
         eng2.train_chunk(ch)
         np.testing.assert_array_equal(eng2.params.cpu().numpy(), res[chain][2])
+    for k in range(3):                                        # fused forward == project + fwd_rows, bit for bit
+        np.testing.assert_array_equal(res[0][k], res[2][k])
     np.testing.assert_allclose(res[0][0], res[1][0], atol=2e-6, rtol=2e-5)
     np.testing.assert_allclose(res[0][1], res[1][1], atol=2e-6, rtol=0)
     np.testing.assert_allclose(res[0][2], res[1][2], atol=2e-6, rtol=0)
