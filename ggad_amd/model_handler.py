@@ -132,25 +132,31 @@ class ModelHandler(object):
                     print("total_time is", total_time)
                     print("loss_constraint", l[:, 2].mean())
             epoch = last
-            if epoch % args.valid_epochs == 0 and rank == 0:
-                print("Valid at epoch {}".format(epoch))
-                f1_mac_val, f1_1_val, f1_0_val, auc_val, gmean_val = test_sage(idx_valid, y_valid, gnn_model,
-                                                                               args.batch_size, args.thres)
+            if epoch % args.valid_epochs == 0:
+                # the validation sweep is sharded over the ranks (contiguous ranges of the reference's batches, one
+                # all-reduce of the scores); every rank sees the same metrics, rank 0 prints and saves
+                if rank == 0:
+                    print("Valid at epoch {}".format(epoch))
+                f1_mac_val, f1_1_val, f1_0_val, auc_val, gmean_val = test_sage(idx_valid, y_valid, gnn_model, args.batch_size,
+                                                                               args.thres, dist=dist, verbose=rank == 0)
                 if auc_val > auc_best:
                     f1_mac_best, auc_best, ep_best = f1_mac_val, auc_val, epoch
-                    if not os.path.exists(dir_saver):
-                        os.makedirs(dir_saver)
-                    print("  Saving model ...")
-                    torch.save(gnn_model.state_dict(), path_saver)
+                    if rank == 0:
+                        if not os.path.exists(dir_saver):
+                            os.makedirs(dir_saver)
+                        print("  Saving model ...")
+                        torch.save(gnn_model.state_dict(), path_saver)
             if dist:
                 dist.barrier()
             total_time += time.time() - t0
             epoch += 1
         random.setstate(rng.to_python_state())       # hand the stream back to python `random`
-        if rank == 0 and ep_best >= 0:
-            print("Restore model from epoch {}".format(ep_best))
-            print("Model path: {}".format(path_saver))
-            gnn_model.load_state_dict(torch.load(path_saver))
+        if ep_best >= 0:
+            if rank == 0:
+                print("Restore model from epoch {}".format(ep_best))
+                print("Model path: {}".format(path_saver))
+                gnn_model.load_state_dict(torch.load(path_saver))
+            if dist and world > 1:
+                dist.broadcast(engine.params, src=0)          # every rank tests the restored weights
             engine.sync_params()
-        res = test_sage(idx_test, y_test, gnn_model, args.batch_size, args.thres) if rank == 0 else (0, 0, 0, 0, 0)
-        return res
+        return test_sage(idx_test, y_test, gnn_model, args.batch_size, args.thres, dist=dist, verbose=rank == 0)

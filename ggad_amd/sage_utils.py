@@ -25,10 +25,15 @@ def conf_gmean(conf: np.ndarray) -> float:
     return float((tp * tn / ((tp + fn) * (tn + fp))) ** 0.5)
 
 
-def score_nodes(model, test_cases: Sequence[int], batch_size: int, batches_per_launch: int = 2048, device: bool = False):
+def score_nodes(model, test_cases: Sequence[int], batch_size: int, batches_per_launch: int = 2048, device: bool = False,
+                dist=None):
     """Probabilities for `test_cases`, batched EXACTLY like `test_sage` (`src/utils.py:216-230`):
     consecutive slices of `batch_size`; the column counts of the aggregation are per slice (quirk 2).
-    Thousands of reference batches are planned and scored per launch group."""
+    Thousands of reference batches are planned and scored per launch group.
+
+    With an initialised `torch.distributed` module as `dist`, the sweep is sharded: rank r scores a
+    contiguous range of the reference's batches (boundaries unchanged, so the per-batch normalisation is the same)
+    and one all-reduce of the zero-padded score vector hands every rank all scores."""
     enc = model.enc
     eng = enc.engine
     cases = np.asarray(test_cases, dtype=np.int64)
@@ -50,25 +55,35 @@ def score_nodes(model, test_cases: Sequence[int], batch_size: int, batches_per_l
                                      per_launch * batch_size, per_launch * batch_size * 8, train=False)
     eng.sync_params()
     step = per_launch * batch_size
-    for s in range(0, n, step):
-        part = cases[s:s + step]
+    lo, hi = 0, n
+    if dist is not None and dist.get_world_size() > 1:
+        world, rank = dist.get_world_size(), dist.get_rank()
+        nb = (n + batch_size - 1) // batch_size
+        lo = min(n, ((nb * rank) // world) * batch_size)
+        hi = min(n, ((nb * (rank + 1)) // world) * batch_size)
+        out.zero_()
+    for s in range(lo, hi, step):
+        part = cases[s:min(hi, s + step)]
         batches = [part[i:i + batch_size] for i in range(0, len(part), batch_size)]
         ch.build(batches)
         eng.score_chunk(ch, out[s:s + len(part)])
     ch.reset()
+    if dist is not None and dist.get_world_size() > 1:
+        dist.all_reduce(out, op=dist.ReduceOp.SUM)              # disjoint slices, zeros elsewhere
     return out if device else out.cpu().numpy()
 
 
-def test_sage(test_cases, labels, model, batch_size, thres=0.5, device_metrics=True):
-    """Reference `test_sage` (`src/utils.py:207-247`): same prints, same return tuple."""
+def test_sage(test_cases, labels, model, batch_size, thres=0.5, device_metrics=True, dist=None, verbose=True):
+    """Reference `test_sage` (`src/utils.py:207-247`): same prints, same return tuple.  `dist`: shard the sweep over the
+    ranks (every rank returns the same metrics; pass verbose=False on the ranks that must not print)."""
     if device_metrics:
         from .metrics import binary_report
-        probs = score_nodes(model, test_cases, batch_size, device=True)
+        probs = score_nodes(model, test_cases, batch_size, device=True, dist=dist)
         r = binary_report(probs, torch.as_tensor(np.asarray(labels), device=probs.device), thres)
         f1_binary_1, f1_binary_0, f1_macro, auc_gnn, ap, gmean = r["f1_1"], r["f1_0"], r["f1_macro"], r["auc"], r["ap"], r["gmean"]
         tn, fp, fn, tp = r["tn"], r["fp"], r["fn"], r["tp"]
     else:
-        probs = score_nodes(model, test_cases, batch_size)
+        probs = score_nodes(model, test_cases, batch_size, dist=dist)
         preds = prob2pred(probs, thres)
         labels = np.asarray(labels)
         auc_gnn = roc_auc_score(labels, probs)
@@ -79,8 +94,9 @@ def test_sage(test_cases, labels, model, batch_size, thres=0.5, device_metrics=T
         conf = confusion_matrix(labels, preds)
         tn, fp, fn, tp = conf.ravel()
         gmean = conf_gmean(conf)
-    print(f"   GNN F1-binary-1: {f1_binary_1:.4f}\tF1-binary-0: {f1_binary_0:.4f}" +
-          f"\tF1-macro: {f1_macro:.4f}\tG-Mean: {gmean:.4f}\tAUC: {auc_gnn:.4f}")
-    print("Testing AP:", ap)
-    print(f"   GNN TP: {tp}\tTN: {tn}\tFN: {fn}\tFP: {fp}")
+    if verbose:
+        print(f"   GNN F1-binary-1: {f1_binary_1:.4f}\tF1-binary-0: {f1_binary_0:.4f}" +
+              f"\tF1-macro: {f1_macro:.4f}\tG-Mean: {gmean:.4f}\tAUC: {auc_gnn:.4f}")
+        print("Testing AP:", ap)
+        print(f"   GNN TP: {tp}\tTN: {tn}\tFN: {fn}\tFP: {fp}")
     return f1_macro, f1_binary_1, f1_binary_0, auc_gnn, gmean

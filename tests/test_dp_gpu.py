@@ -95,6 +95,44 @@ def test_two_ranks_one_gpu_equal_gradient_averaging(tmp_path):
     np.testing.assert_allclose(p0, eng.params.cpu().numpy(), atol=1e-6, rtol=1e-5)
 
 
+def _score_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    from ggad_amd.graph import DeviceGraph
+    from ggad_amd.graphsage import GCN, FeatureTable, GCNAggregator, GCNEncoder
+    from ggad_amd.sage_utils import score_nodes, test_sage
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    rowptr, col, feat, labels, train, pool, (w, W, fc) = _inputs()
+    graph = DeviceGraph(rowptr, col, "cuda:0")
+    features = FeatureTable(torch.from_numpy(feat))
+    enc = GCNEncoder(features, 17, 64, graph, GCNAggregator(features, cuda=True), gcn=True, cuda=True)
+    model = GCN(2, enc)
+    enc.engine.load_params(w, W, fc)
+    cases = np.arange(1000, 1000 + 7 * 150 + 37)                  # 8 reference batches, the last one ragged
+    full = score_nodes(model, cases, 150)
+    shard = score_nodes(model, cases, 150, dist=dist)
+    np.save(os.path.join(out_dir, f"scores_{rank}.npy"), np.stack([full, shard]))
+    y = (np.arange(len(cases)) % 7 == 0).astype(np.int64)
+    res = test_sage(cases, y, model, 150, 0.4, dist=dist, verbose=False)
+    np.save(os.path.join(out_dir, f"metrics_{rank}.npy"), np.asarray(res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_validation_sweep_two_ranks_one_gpu(tmp_path):
+    """The validation sweep sharded over 2 ranks (contiguous ranges of the reference's batches + one all-reduce) gives
+    every rank exactly the scores and metrics of the one-process sweep."""
+    import torch.multiprocessing as mp
+    mp.spawn(_score_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    s0, s1 = np.load(tmp_path / "scores_0.npy"), np.load(tmp_path / "scores_1.npy")
+    np.testing.assert_array_equal(s0[0], s0[1])
+    np.testing.assert_array_equal(s1[0], s1[1])
+    np.testing.assert_array_equal(s0[0], s1[0])
+    np.testing.assert_array_equal(np.load(tmp_path / "metrics_0.npy"), np.load(tmp_path / "metrics_1.npy"))
+
+
 def test_bench_launch_line_two_ranks_one_gpu():
     env = dict(os.environ, GGAD_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
