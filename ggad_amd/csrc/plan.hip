@@ -211,9 +211,11 @@ __global__ void __launch_bounds__(256) k_gather1(const float *__restrict__ feat,
   }
 }
 
-// out[row] = mean of feat rows over an explicit ragged neighbour list (MeanAggregator, graphsage.py:66-99)
+// out[row] = mean of feat rows over an explicit ragged neighbour list (MeanAggregator, graphsage.py:66-99; IntraAgg 1-hop,
+// layers.py:213-225), or, with seg_w, the weighted sum over it (IntraAgg 2-hop 1/(sqrt r sqrt c) mask, layers.py:227-242)
 __global__ void __launch_bounds__(256) k_seg_mean(const float *__restrict__ feat, int F, const int32_t *__restrict__ seg_ptr,
-                                                  const int32_t *__restrict__ seg_col, int n_rows, float *__restrict__ out) {
+                                                  const int32_t *__restrict__ seg_col, const float *__restrict__ seg_w,
+                                                  int n_rows, float *__restrict__ out) {
   const int row = blockIdx.x * (blockDim.x / GGAD_WAVE) + threadIdx.x / GGAD_WAVE;
   if (row >= n_rows) return;
   const int lane = lane_id();
@@ -231,10 +233,11 @@ __global__ void __launch_bounds__(256) k_seg_mean(const float *__restrict__ feat
     for (int blk = 0; blk < r; blk += GGAD_WAVE) {
       const int idx = blk + lane;
       int j = 0; float w = 0.0f;
-      if (idx < r) { j = seg_col[e0 + idx]; w = inv; }
+      if (idx < r) { j = seg_col[e0 + idx]; w = seg_w ? seg_w[e0 + idx] : inv; }
       gather_block(feat, F, fbase, rpi, g, f, lane_active, j, w, min(GGAD_WAVE, r - blk), acc);
     }
-    const float tot = (F <= 64) ? reduce_groups(acc, fw, rpi) : acc;
+    float tot = (F <= 64) ? reduce_groups(acc, fw, rpi) : acc;
+    if (r == 0) tot = inv * 0.0f;                            // empty list: the dense 0/0 mask row -> NaN (quirk 3)
     if (lane < fw) out[(int64_t)row * F + fbase + lane] = tot;
   }
 }
@@ -446,8 +449,17 @@ int ggad_seg_mean(const float *feat, int32_t feat_dim, const int32_t *seg_ptr, c
                   float *out, ggad_stream_t stream) {
   GGAD_REQUIRE(feat && seg_ptr && seg_col && out && feat_dim >= 1 && feat_dim <= GGAD_MAX_F && n_rows >= 0);
   if (n_rows == 0) return GGAD_OK;
-  k_seg_mean<<<dim3((n_rows + 3) / 4), dim3(256), 0, as_stream(stream)>>>(feat, feat_dim, seg_ptr, seg_col, n_rows, out);
+  k_seg_mean<<<dim3((n_rows + 3) / 4), dim3(256), 0, as_stream(stream)>>>(feat, feat_dim, seg_ptr, seg_col, nullptr, n_rows, out);
   GGAD_CHECK_LAUNCH("seg_mean");
+  return GGAD_OK;
+}
+
+int ggad_seg_wsum(const float *feat, int32_t feat_dim, const int32_t *seg_ptr, const int32_t *seg_col, const float *seg_w,
+                  int32_t n_rows, float *out, ggad_stream_t stream) {
+  GGAD_REQUIRE(feat && seg_ptr && seg_col && seg_w && out && feat_dim >= 1 && feat_dim <= GGAD_MAX_F && n_rows >= 0);
+  if (n_rows == 0) return GGAD_OK;
+  k_seg_mean<<<dim3((n_rows + 3) / 4), dim3(256), 0, as_stream(stream)>>>(feat, feat_dim, seg_ptr, seg_col, seg_w, n_rows, out);
+  GGAD_CHECK_LAUNCH("seg_wsum");
   return GGAD_OK;
 }
 

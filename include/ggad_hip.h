@@ -90,6 +90,10 @@ int ggad_mb_gather1(const float *feat, int32_t feat_dim, int32_t feat_stride, co
  * (MeanAggregator.forward with host-side sampling, graphsage.py:66-99). */
 int ggad_seg_mean(const float *feat, int32_t feat_dim, const int32_t *seg_ptr, const int32_t *seg_col, int32_t n_rows,
                   float *out, ggad_stream_t stream);
+/* Same ragged gather with explicit weights: out[i] = sum_e seg_w[e] * feat[seg_col[e]] -- the 2-hop mask of IntraAgg,
+ * 1 / (sqrt(row sum) sqrt(column sum)) per element (src/layers.py:227-242). */
+int ggad_seg_wsum(const float *feat, int32_t feat_dim, const int32_t *seg_ptr, const int32_t *seg_col, const float *seg_w,
+                  int32_t n_rows, float *out, ggad_stream_t stream);
 
 /* The per-entry kernels below launch one wave per entry for n_entries_cap entries (a host-side
  * upper bound, e.g. sum(deg+1)) and read the true count from *ent_total (= ent_ptr[n_rows]).

@@ -324,6 +324,31 @@ def mean_aggregate(rowptr, col, feat, nodes, gcn: bool) -> np.ndarray:
     return out
 
 
+def intra_aggregate(rowptr, col, feat, nodes, weight):
+    """IntraAgg.forward (`src/layers.py:179-244`): mean over the OPEN neighbourhood + relu(. W); 2-hop rows = the union U of
+    those neighbourhoods (returned sorted -- the reference's order is python-set order), mask 1/(sqrt r sqrt c) over
+    their neighbours + relu(. W).  Returns (to_feats (B, D), to_feats_neigh (U, D), mask (B, U), unique (U,))."""
+    feat = np.asarray(feat, dtype=np.float32)
+    W = np.asarray(weight, dtype=np.float32)
+    nbrs = [col[rowptr[int(v)]:rowptr[int(v) + 1]].astype(np.int64) for v in nodes]
+    unique = np.unique(np.concatenate(nbrs))
+    pos = {int(n): i for i, n in enumerate(unique)}
+    mask = np.zeros((len(nodes), len(unique)), dtype=np.float32)
+    for i, nb in enumerate(nbrs):
+        mask[i, [pos[int(k)] for k in nb]] = 1.0
+    mask = mask / mask.sum(1, keepdims=True)                                   # layers.py:216-217
+    to_feats = np.maximum((mask @ feat[unique]) @ W, 0.0)                      # :224-226
+    nb2 = [col[rowptr[int(u)]:rowptr[int(u) + 1]].astype(np.int64) for u in unique]
+    u2 = np.unique(np.concatenate(nb2))
+    p2 = {int(n): i for i, n in enumerate(u2)}
+    m2 = np.zeros((len(unique), len(u2)), dtype=np.float32)
+    for i, nb in enumerate(nb2):
+        m2[i, [p2[int(k)] for k in nb]] = 1.0
+    m2 = (m2 / np.sqrt(m2.sum(1, keepdims=True))) / np.sqrt(m2.sum(0, keepdims=True))      # :236-238
+    to_feats_neigh = np.maximum((m2 @ feat[u2]) @ W, 0.0)                      # :243-244
+    return to_feats.astype(np.float32), to_feats_neigh.astype(np.float32), mask, unique
+
+
 def make_adam(params: Sequence[torch.Tensor], lr: float, weight_decay: float):
     """The optimiser both entry points use (`run.py:118`, `src/model_handler.py:299-300`)."""
     return torch.optim.Adam(list(params), lr=lr, weight_decay=weight_decay)

@@ -105,6 +105,19 @@ def test_mean_aggregator_and_encoder(g_mini_small):
                                atol=TOL, rtol=0)
 
 
+@pytest.mark.parametrize("name", ["minibatch_small.npz", "minibatch_dense.npz"])
+def test_intra_agg(name):
+    """IntraAgg (src/layers.py:179-244) against what the reference module returned (columns / rows matched by node id:
+    the reference orders them by python-set iteration)."""
+    g = load_golden(name)
+    tf, tfn, mask, unique = O.intra_aggregate(g["rowptr"], g["col"], g["feat"], g["batches"][0], g["intra_weight"])
+    order = np.argsort(g["intra_unique"])
+    assert np.array_equal(g["intra_unique"][order], unique)
+    np.testing.assert_allclose(tf, g["intra_to_feats"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(tfn, g["intra_to_feats_neigh"][order], atol=TOL, rtol=0)
+    np.testing.assert_allclose(mask, g["intra_mask"][:, order], atol=TOL, rtol=0)
+
+
 # ------------------------------------------------------------------ full graph
 def _full_setup(g):
     adjn_rp, adjn_ci, adjn_va, raw_rp, raw_ci, raw_va = O.normalize_adj(g["rowptr"], g["col"])
