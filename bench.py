@@ -56,6 +56,8 @@ def parse():
                          "global: atomics on per-batch counter slots in HBM; "
                          "packed: global counters inside 128-byte feature rows (chunk <= 15 batches)")
     ap.add_argument("--chain", type=int, default=0, choices=[0, 1, 2], help="per-step kernel chain: 0 five launches (projection fused), 1 row-wise three, 2 six (include/ggad_hip.h: ggad_mb_step.chain)")
+    ap.add_argument("--dp-path", action="store_true", help="1 GPU only: run the data-parallel step chain (backward -> exchange -> "
+                    "Adam, Adam not fused) with a no-op exchange, to measure what the multi-GPU step costs without the collective")
     ap.add_argument("--seed", type=int, default=72)
     return ap.parse_args()
 
@@ -109,6 +111,8 @@ def main():
     trainer = DGraphTrainer(graph, feat, a.emb, sched, lr=1e-3, weight_decay=0.007, chunk_batches=a.chunk, rank=rank,
                             world_size=world, allreduce=allreduce, packed=(a.hop2 == "packed"),
                             hop2=(a.hop2 if a.hop2 in ("tiled", "ktile", "ldsw") else "global"), overlap=not a.no_overlap, chain=a.chain, dense_cus=a.dense_cus)
+    if a.dp_path and world == 1:
+        trainer.allreduce = lambda t: None
     torch.manual_seed(a.seed)
     w = torch.nn.init.xavier_uniform_(torch.empty(1, a.emb))
     W = torch.nn.init.xavier_uniform_(torch.empty(a.emb, a.feat))

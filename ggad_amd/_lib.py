@@ -22,6 +22,7 @@ class GgadKernelError(RuntimeError):
 
 
 _P = c_void_p      # device (or host) pointer
+EXCHANGE_CB = ctypes.CFUNCTYPE(c_int32, c_void_p)      # int exchange(void *user): the data-parallel all-reduce hook
 _I = c_int32
 _L = c_int64
 _F = c_float
@@ -47,6 +48,7 @@ SIGNATURES = {
     "ggad_mb_ldsw_max_owners": (c_int32, []),
     "ggad_mb_dw_part_elems": (c_int64, [_I, _I, _I]),
     "ggad_mb_train_chunk": (c_int32, [_P, _I, _P, _P, _P, _P, _I, _I, _P]),
+    "ggad_mb_train_chunk_dp": (c_int32, [_P, _I, _P, _P, _P, _P, _I, c_float, EXCHANGE_CB, _P, _P]),
     "ggad_stream_create_cu_mask": (c_int32, [_P, _I, _P]),
     "ggad_stream_destroy": (c_int32, [_P]),
     "ggad_device_cu_count": (c_int32, [_I, _P]),

@@ -1288,4 +1288,29 @@ int ggad_mb_train_chunk(const ggad_mb_step *tmpl, int32_t n_batches, const int32
   return GGAD_OK;
 }
 
+/* Data-parallel variant of ggad_mb_train_chunk: per batch  backward (grads) -> exchange(user) -> Adam(grad_scale).
+ * `exchange` is the caller's all-reduce of tmpl->grads on `stream` (e.g. torch.distributed / RCCL); it returns 0 on success.
+ * Keeps the per-step host work to the launches plus that one callback. */
+int ggad_mb_train_chunk_dp(const ggad_mb_step *tmpl, int32_t n_batches, const int32_t *batch_ptr, const int64_t *batch_ent_ptr,
+                           const int32_t *batch_max_row, float *loss_log, int32_t log_base, float grad_scale,
+                           int (*exchange)(void *), void *user, ggad_stream_t stream) {
+  GGAD_REQUIRE(tmpl && batch_ptr && batch_ent_ptr && loss_log && exchange && n_batches >= 0 && log_base >= 0);
+  for (int b = 0; b < n_batches; ++b) {
+    ggad_mb_step s = *tmpl;
+    s.row0 = batch_ptr[b];
+    s.n_rows = batch_ptr[b + 1] - batch_ptr[b];
+    s.ent0 = (int32_t)batch_ent_ptr[b];
+    s.n_ents = (int32_t)(batch_ent_ptr[b + 1] - batch_ent_ptr[b]);
+    s.losses8 = loss_log + (int64_t)8 * (log_base + b);
+    s.max_row_entries = batch_max_row ? batch_max_row[b] : 0;
+    int rc = ggad_mb_train_step(&s, 0, stream);
+    if (rc) return rc;
+    if (exchange(user) != 0) return GGAD_E_LAUNCH;
+    rc = ggad_mb_adam(s.params, s.exp_avg, s.exp_avg_sq, s.grads, s.D, s.F, s.lr, s.weight_decay, grad_scale, s.step_counter,
+                      stream);
+    if (rc) return rc;
+  }
+  return GGAD_OK;
+}
+
 }  // extern "C"

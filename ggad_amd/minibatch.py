@@ -495,11 +495,30 @@ class MiniBatchEngine:
             _lib.check(self.lib.ggad_mb_train_chunk(ctypes.byref(s), ch.n_batches, bp.ctypes.data, ep.ctypes.data, mr.ctypes.data,
                                                     self.loss_log.data_ptr(), log_base, 1, stream), "ggad_mb_train_chunk")
             return
-        for b in range(ch.n_batches):
-            s = self.step_desc(ch, b, log_base + b)
-            _lib.check(self.lib.ggad_mb_train_step(ctypes.byref(s), fuse, stream), "ggad_mb_train_step")
-            if not fuse:
-                self.adam_step(reduce_gradients(self.grads, world_size, allreduce))
+        # data parallel: backward -> all-reduce -> Adam per batch; the loop runs in C, Python only serves the exchange
+        scale = 1.0 / world_size
+        if world_size > 1 and allreduce is None:
+            raise ValueError("world_size > 1 needs an all-reduce callable")
+        err = []
+
+        def exchange(_user):
+            try:
+                if allreduce is not None:
+                    allreduce(self.grads)
+                return 0
+            except BaseException as exc:      # never let an exception cross the C frame
+                err.append(exc)
+                return 1
+        cb = _lib.EXCHANGE_CB(exchange)
+        s = self.step_desc(ch, 0, log_base)
+        bp = np.ascontiguousarray(ch.batch_ptr_host[:ch.n_batches + 1], dtype=np.int32)
+        ep = np.ascontiguousarray(ch.ent_ptr_host[bp], dtype=np.int64)
+        mr = np.ascontiguousarray(ch.batch_max_row, dtype=np.int32)
+        rc = self.lib.ggad_mb_train_chunk_dp(ctypes.byref(s), ch.n_batches, bp.ctypes.data, ep.ctypes.data, mr.ctypes.data,
+                                             self.loss_log.data_ptr(), log_base, scale, cb, None, stream)
+        if err:
+            raise err[0]
+        _lib.check(rc, "ggad_mb_train_chunk_dp")
 
     def forward_batch(self, ch: BatchChunk, b: int) -> None:
         """project + fwd_rows only (layered API / tests): fills ch.h1, ch.nbar, ch.gen for batch b."""

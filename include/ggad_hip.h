@@ -277,6 +277,11 @@ int ggad_mb_train_step(const ggad_mb_step *step, int32_t fuse_adam, ggad_stream_
 int ggad_mb_train_chunk(const ggad_mb_step *tmpl, int32_t n_batches, const int32_t *batch_ptr, const int64_t *batch_ent_ptr,
                         const int32_t *batch_max_row, float *loss_log, int32_t log_base, int32_t fuse_adam,
                         ggad_stream_t stream);
+/* Data-parallel form: per batch  backward -> exchange(user) -> Adam with grad_scale (1 / world size).  `exchange` is the
+ * caller's all-reduce(SUM) of tmpl->grads, enqueued on `stream` (torch.distributed / RCCL); non-zero return aborts. */
+int ggad_mb_train_chunk_dp(const ggad_mb_step *tmpl, int32_t n_batches, const int32_t *batch_ptr, const int64_t *batch_ent_ptr,
+                           const int32_t *batch_max_row, float *loss_log, int32_t log_base, float grad_scale,
+                           int (*exchange)(void *), void *user, ggad_stream_t stream);
 
 /* Inference embeddings: h[i] = relu(W x1[i])  (GCNEncoder.forward, train_flag False).   graphsage.py:412 */
 int ggad_mb_encode(const float *params, int32_t D, int32_t F, const float *x1, int32_t n_rows, float *h,
