@@ -38,7 +38,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s me
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1500)
+    ap.add_argument("--steps", type=int, default=4500)
     ap.add_argument("--warmup", type=int, default=150)
     ap.add_argument("--nodes", type=int, default=3_700_550)
     ap.add_argument("--entries", type=int, default=73_105_508)
@@ -129,6 +129,9 @@ def main():
 
     def timed_build(chunk, bn, bl):
         # BatchChunk.build records these two events around its gather2 launch (same stream)
+        if len(ev_pairs) >= 10:           # the first 10 launches of the timed region are instrumented (host-side neighbour
+            chunk.build(bn, bl)           # counting for the roofline costs ~1 s per launch afterwards)
+            return
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         chunk.gather2_events = (e0, e1)
         chunk.build(bn, bl)
@@ -195,7 +198,7 @@ def main():
                 "unit": "GB/s", "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": traffic,
                 "launches": len(gather_ms), "avg_launch_ms": float(np.mean(gather_ms)) if gather_ms else None,
                 "alg_bytes_per_launch": float(np.mean(alg_bytes)) if alg_bytes else None, "alg_bytes_per_neighbour": per_nbr,
-                "gather_share_of_step_time": (sum(gather_ms) / 1e3) / elapsed if gather_ms else None,
+                "gather_share_of_step_time": (float(np.mean(gather_ms)) / 1e3 * ((a.steps + trainer.chunk_batches - 1) // trainer.chunk_batches)) / elapsed if gather_ms else None,
                 # with overlap the kernel runs on the plan stream's CU partition while the dense chain of the previous
                 # chunk runs on the other CUs; --no-overlap times it alone on the whole chip
                 "concurrent_with_dense_chain": bool(trainer.overlap),
