@@ -122,6 +122,10 @@ def load(path: str = LIB_PATH) -> ctypes.CDLL:
         raise GgadLibraryError(
             f"{path} not found: build it with `python -m ggad_amd.build` (hipcc, gfx950). "
             "There is no CPU fallback for the GGAD hot path.")
+    # torch ships its own libamdhip64: it must be in the process BEFORE this library is loaded, otherwise the loader binds
+    # libggad_hip.so to /opt/rocm's copy and its launches run in a second HIP runtime that knows nothing of torch's
+    # device pointers and streams ("no ROCm-capable device is detected" on the first launch)
+    import torch  # noqa: F401
     try:
         lib = ctypes.CDLL(path)
     except OSError as exc:  # missing ROCm runtime etc.
