@@ -28,9 +28,15 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 // Workgroup = 4 waves = a 128 x 64 tile of C; wave (wr, wc) owns rows [64 wr, 64 wr + 64) x cols [32 wc, 32 wc + 32):
 // two 32x32 MFMA accumulators.  K is stepped by 32; the next K-tile is fetched from global memory into registers
 // while the current one is consumed from LDS (global latency hidden behind 32 MFMAs = 2048 cycles per wave).
-__global__ void __launch_bounds__(256) k_gemm_f32(const float *__restrict__ A, const float *__restrict__ B,
-                                                  float *__restrict__ C, int M, int N, int K, int64_t sam, int64_t sak,
-                                                  int64_t sbk, int64_t sbn, int64_t ldc, const float *__restrict__ bias,
+// Register diet (the first version needed 186 VGPRs = 2 waves per SIMD and left the MFMA pipe idle 48 % of the time,
+// rocprofv3 SQ_WAIT_INST_ANY): the operand layouts are template parameters, every thread keeps ONE 32-bit offset per
+// element relative to a wave-uniform tile pointer (SGPR base + VGPR offset addressing), the row / column bounds are
+// folded into those offsets once (out-of-range elements point at element 0 and are zeroed by a mask bit), and only
+// the last K-tile checks k.
+template <bool A_KFAST, bool B_NFAST>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) k_gemm_f32(const float *__restrict__ A, const float *__restrict__ B,
+                                                  float *__restrict__ C, int M, int N, int K, int sam, int sak,
+                                                  int sbk, int sbn, int64_t ldc, const float *__restrict__ bias,
                                                   int relu, int k_per_split, int64_t c_split_stride) {
   __shared__ float As[BK][LDA_S];
   __shared__ float Bs[BK][LDB_S];
@@ -41,35 +47,62 @@ __global__ void __launch_bounds__(256) k_gemm_f32(const float *__restrict__ A, c
   const int k_end = min(K, k_begin + k_per_split);
   floatx16 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   floatx16 acc1 = acc0;
-  // thread -> (row, k) mapping of the global loads: unit stride along the fastest index of each operand
-  const bool a_kfast = (sak == 1);
-  const bool b_nfast = (sbn == 1);
-  float ra[A_PER_T], rb[B_PER_T];
-  auto a_pos = [&](int p, int &m, int &k) {
-    if (a_kfast) { k = tid & 31; m = (tid >> 5) + 8 * p; } else { m = tid & 127; k = (tid >> 7) + 2 * p; }
-  };
-  auto b_pos = [&](int p, int &n, int &k) {
-    if (b_nfast) { n = tid & 63; k = (tid >> 6) + 4 * p; } else { k = tid & 31; n = (tid >> 5) + 8 * p; }
-  };
-  auto fetch = [&](int k0) {
+  // element p of this thread inside a tile: A (m, k), B (n, k); unit stride along the fastest index of each operand
+  int oa[A_PER_T], ob[B_PER_T];          // offsets relative to the tile pointers
+  unsigned amask = 0, bmask = 0;         // bit p: row (column) inside the matrix
+  int ka0, kb0;                          // k of element 0 of this thread; element p adds a constant step
+  constexpr int KA_STEP = A_KFAST ? 0 : 2, KB_STEP = B_NFAST ? 4 : 0;
+  if (A_KFAST) ka0 = tid & 31; else ka0 = tid >> 7;
+  if (B_NFAST) kb0 = tid >> 6; else kb0 = tid & 31;
 #pragma unroll
-    for (int p = 0; p < A_PER_T; ++p) {
-      int m, k; a_pos(p, m, k);
-      const int gm = m0 + m, gk = k0 + k;
-      ra[p] = (gm < M && gk < k_end) ? A[(int64_t)gm * sam + (int64_t)gk * sak] : 0.0f;
+  for (int p = 0; p < A_PER_T; ++p) {
+    const int m = A_KFAST ? (tid >> 5) + 8 * p : (tid & 127);
+    const int k = ka0 + KA_STEP * p;
+    const bool in = m0 + m < M;
+    oa[p] = in ? m * sam + k * sak : 0;
+    amask |= (in ? 1u : 0u) << p;
+  }
+#pragma unroll
+  for (int p = 0; p < B_PER_T; ++p) {
+    const int n = B_NFAST ? (tid & 63) : (tid >> 5) + 8 * p;
+    const int k = kb0 + KB_STEP * p;
+    const bool in = n0 + n < N;
+    ob[p] = in ? k * sbk + n * sbn : 0;
+    bmask |= (in ? 1u : 0u) << p;
+  }
+  const float *At = A + (int64_t)m0 * sam + (int64_t)k_begin * sak;     // wave-uniform tile pointers
+  const float *Bt = B + (int64_t)n0 * sbn + (int64_t)k_begin * sbk;
+  float ra[A_PER_T], rb[B_PER_T];
+  unsigned oka = 0, okb = 0;             // validity of the elements fetched last
+  auto fetch = [&](int k0) {
+    const int klim = k_end - k0;         // elements with k >= klim lie past the end of this split (last K-tile only)
+    oka = 0; okb = 0;
+#pragma unroll
+    for (int p = 0; p < A_PER_T; ++p) {  // branch-free: every load is issued before the first one is consumed
+      const unsigned ok = ((amask >> p) & 1u) & (unsigned)(ka0 + KA_STEP * p < klim);
+      oka |= ok << p;
+      ra[p] = At[ok ? oa[p] : 0];
     }
 #pragma unroll
     for (int p = 0; p < B_PER_T; ++p) {
-      int n, k; b_pos(p, n, k);
-      const int gn = n0 + n, gk = k0 + k;
-      rb[p] = (gn < N && gk < k_end) ? B[(int64_t)gk * sbk + (int64_t)gn * sbn] : 0.0f;
+      const unsigned ok = ((bmask >> p) & 1u) & (unsigned)(kb0 + KB_STEP * p < klim);
+      okb |= ok << p;
+      rb[p] = Bt[ok ? ob[p] : 0];
     }
+    At += (int64_t)BK * sak;             // (the masks are applied in stash(): nothing here waits for the loads)
+    Bt += (int64_t)BK * sbk;
   };
   auto stash = [&]() {
 #pragma unroll
-    for (int p = 0; p < A_PER_T; ++p) { int m, k; a_pos(p, m, k); As[k][m] = ra[p]; }
+    for (int p = 0; p < A_PER_T; ++p) {
+      const int m = A_KFAST ? (tid >> 5) + 8 * p : (tid & 127);
+      As[ka0 + KA_STEP * p][m] = ((oka >> p) & 1u) ? ra[p] : 0.0f;
+    }
 #pragma unroll
-    for (int p = 0; p < B_PER_T; ++p) { int n, k; b_pos(p, n, k); Bs[k][n] = rb[p]; }
+    for (int p = 0; p < B_PER_T; ++p) {
+      const int n = B_NFAST ? (tid & 63) : (tid >> 5) + 8 * p;
+      Bs[kb0 + KB_STEP * p][n] = ((okb >> p) & 1u) ? rb[p] : 0.0f;
+    }
   };
   if (k_begin < k_end) {
     fetch(k_begin);
@@ -129,6 +162,14 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(const float *__restrict__
   C[(int64_t)m * ldc + n] = s;
 }
 
+template <typename... Args>
+static void launch_gemm(bool a_kfast, bool b_nfast, dim3 grid, hipStream_t st, Args... args) {
+  if (a_kfast && b_nfast) k_gemm_f32<true, true><<<grid, dim3(256), 0, st>>>(args...);
+  else if (a_kfast) k_gemm_f32<true, false><<<grid, dim3(256), 0, st>>>(args...);
+  else if (b_nfast) k_gemm_f32<false, true><<<grid, dim3(256), 0, st>>>(args...);
+  else k_gemm_f32<false, false><<<grid, dim3(256), 0, st>>>(args...);
+}
+
 }  // namespace
 
 extern "C" {
@@ -147,18 +188,23 @@ int ggad_gemm_f32(const float *A, const float *B, float *C, int32_t M, int32_t N
                   int64_t sbk, int64_t sbn, int64_t ldc, const float *bias, int32_t relu, float *workspace,
                   ggad_stream_t stream) {
   GGAD_REQUIRE(A && B && C && M >= 0 && N >= 0 && K >= 0 && ldc >= N);
+  // 32-bit element offsets inside a tile row range (BM rows x K) / (K x BN): every stride times its extent must fit
+  GGAD_REQUIRE((sam == 1 || sak == 1) && (sbk == 1 || sbn == 1));
+  GGAD_REQUIRE((int64_t)BM * sam + (int64_t)K * sak < (1LL << 31) && (int64_t)BN * sbn + (int64_t)K * sbk < (1LL << 31));
   if (M == 0 || N == 0) return GGAD_OK;
   hipStream_t st = as_stream(stream);
   const int gx = (N + BN - 1) / BN, gy = (M + BM - 1) / BM;
+  const bool a_kfast = (sak == 1), b_nfast = (sbn == 1);
   const int64_t ws_elems = workspace ? ggad_gemm_workspace_elems(M, N, K) : 0;
   if (ws_elems == 0) {
-    k_gemm_f32<<<dim3(gx, gy, 1), dim3(256), 0, st>>>(A, B, C, M, N, K, sam, sak, sbk, sbn, ldc, bias, relu, K > 0 ? K : 1, 0);
+    launch_gemm(a_kfast, b_nfast, dim3(gx, gy, 1), st, A, B, C, (int)M, (int)N, (int)K, (int)sam, (int)sak, (int)sbk, (int)sbn, ldc,
+                bias, (int)relu, K > 0 ? (int)K : 1, (int64_t)0);
   } else {
     const int splits = (int)(ws_elems / ((int64_t)M * N));
     int kps = (K + splits - 1) / splits;
     kps = (kps + BK - 1) / BK * BK;
-    k_gemm_f32<<<dim3(gx, gy, splits), dim3(256), 0, st>>>(A, B, workspace, M, N, K, sam, sak, sbk, sbn, N, nullptr, 0, kps,
-                                                          (int64_t)M * N);
+    launch_gemm(a_kfast, b_nfast, dim3(gx, gy, splits), st, A, B, workspace, (int)M, (int)N, (int)K, (int)sam, (int)sak, (int)sbk,
+                (int)sbn, (int64_t)N, (const float *)nullptr, 0, kps, (int64_t)M * N);
     const int64_t tot = (int64_t)M * N;
     k_splitk_reduce<<<dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st>>>(workspace, splits, (int64_t)M * N, C, M, N, ldc,
                                                                              bias, relu);
