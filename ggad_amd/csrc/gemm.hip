@@ -18,7 +18,7 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 64, BK = 32;
+constexpr int BM = 128, BN = 64, BK = 32;      // BM: the large row tile; BM / 2 is used when the grid would not fill the chip
 constexpr int LDA_S = BM + 1, LDB_S = BN + 1;       // +1 pad: the transposing LDS store is conflict-free
 constexpr int A_PER_T = BM * BK / 256;              // 16 elements of the A tile per thread
 constexpr int B_PER_T = BN * BK / 256;              // 8 elements of the B tile per thread
@@ -33,30 +33,32 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 // element relative to a wave-uniform tile pointer (SGPR base + VGPR offset addressing), the row / column bounds are
 // folded into those offsets once (out-of-range elements point at element 0 and are zeroed by a mask bit), and only
 // the last K-tile checks k.
-template <bool A_KFAST, bool B_NFAST>
+template <bool A_KFAST, bool B_NFAST, int TM>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) k_gemm_f32(const float *__restrict__ A, const float *__restrict__ B,
                                                   float *__restrict__ C, int M, int N, int K, int sam, int sak,
                                                   int sbk, int sbn, int64_t ldc, const float *__restrict__ bias,
                                                   int relu, int k_per_split, int64_t c_split_stride) {
-  __shared__ float As[BK][LDA_S];
+  constexpr int TA_PER_T = TM * BK / 256;      // A elements per thread
+  constexpr int NACC = TM / 64;                // 32x32 accumulators per wave (rows 32 * NACC)
+  __shared__ float As[BK][TM + 1];
   __shared__ float Bs[BK][LDB_S];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid >> 1, wc = wid & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int m0 = blockIdx.y * TM, n0 = blockIdx.x * BN;
   const int k_begin = blockIdx.z * k_per_split;
   const int k_end = min(K, k_begin + k_per_split);
   floatx16 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   floatx16 acc1 = acc0;
   // element p of this thread inside a tile: A (m, k), B (n, k); unit stride along the fastest index of each operand
-  int oa[A_PER_T], ob[B_PER_T];          // offsets relative to the tile pointers
+  int oa[TA_PER_T], ob[B_PER_T];          // offsets relative to the tile pointers
   unsigned amask = 0, bmask = 0;         // bit p: row (column) inside the matrix
   int ka0, kb0;                          // k of element 0 of this thread; element p adds a constant step
-  constexpr int KA_STEP = A_KFAST ? 0 : 2, KB_STEP = B_NFAST ? 4 : 0;
-  if (A_KFAST) ka0 = tid & 31; else ka0 = tid >> 7;
+  constexpr int KA_STEP = A_KFAST ? 0 : 256 / TM, KB_STEP = B_NFAST ? 4 : 0;
+  if (A_KFAST) ka0 = tid & 31; else ka0 = tid / TM;
   if (B_NFAST) kb0 = tid >> 6; else kb0 = tid & 31;
 #pragma unroll
-  for (int p = 0; p < A_PER_T; ++p) {
-    const int m = A_KFAST ? (tid >> 5) + 8 * p : (tid & 127);
+  for (int p = 0; p < TA_PER_T; ++p) {
+    const int m = A_KFAST ? (tid >> 5) + 8 * p : (tid % TM);
     const int k = ka0 + KA_STEP * p;
     const bool in = m0 + m < M;
     oa[p] = in ? m * sam + k * sak : 0;
@@ -72,13 +74,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
   }
   const float *At = A + (int64_t)m0 * sam + (int64_t)k_begin * sak;     // wave-uniform tile pointers
   const float *Bt = B + (int64_t)n0 * sbn + (int64_t)k_begin * sbk;
-  float ra[A_PER_T], rb[B_PER_T];
+  float ra[TA_PER_T], rb[B_PER_T];
   unsigned oka = 0, okb = 0;             // validity of the elements fetched last
   auto fetch = [&](int k0) {
     const int klim = k_end - k0;         // elements with k >= klim lie past the end of this split (last K-tile only)
     oka = 0; okb = 0;
 #pragma unroll
-    for (int p = 0; p < A_PER_T; ++p) {  // branch-free: every load is issued before the first one is consumed
+    for (int p = 0; p < TA_PER_T; ++p) {  // branch-free: every load is issued before the first one is consumed
       const unsigned ok = ((amask >> p) & 1u) & (unsigned)(ka0 + KA_STEP * p < klim);
       oka |= ok << p;
       ra[p] = At[ok ? oa[p] : 0];
@@ -94,8 +96,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
   };
   auto stash = [&]() {
 #pragma unroll
-    for (int p = 0; p < A_PER_T; ++p) {
-      const int m = A_KFAST ? (tid >> 5) + 8 * p : (tid & 127);
+    for (int p = 0; p < TA_PER_T; ++p) {
+      const int m = A_KFAST ? (tid >> 5) + 8 * p : (tid % TM);
       As[ka0 + KA_STEP * p][m] = ((oka >> p) & 1u) ? ra[p] : 0.0f;
     }
 #pragma unroll
@@ -116,10 +118,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
 #pragma unroll
     for (int ks = 0; ks < BK; ks += 2) {
       const float b = Bs[ks + kk][wc * 32 + i];
-      const float a0 = As[ks + kk][wr * 64 + i];
-      const float a1 = As[ks + kk][wr * 64 + 32 + i];
+      const float a0 = As[ks + kk][wr * 32 * NACC + i];
       acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
+      if constexpr (NACC == 2) {
+        const float a1 = As[ks + kk][wr * 64 + 32 + i];
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
+      }
     }
     __syncthreads();
     if (more) {
@@ -134,13 +138,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
     const float bv = (bias != nullptr) ? bias[col] : 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = m0 + wr * 64 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int row = m0 + wr * 32 * NACC + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
       if (row < M) {
         float v = acc0[r] + bv;
         if (relu) v = fmaxf(v, 0.0f);
         Cout[(int64_t)row * ldc + col] = v;
       }
-      if (row + 32 < M) {
+      if (NACC == 2 && row + 32 < M) {
         float v = acc1[r] + bv;
         if (relu) v = fmaxf(v, 0.0f);
         Cout[(int64_t)(row + 32) * ldc + col] = v;
@@ -162,20 +166,27 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(const float *__restrict__
   C[(int64_t)m * ldc + n] = s;
 }
 
-template <typename... Args>
+template <int TM, typename... Args>
 static void launch_gemm(bool a_kfast, bool b_nfast, dim3 grid, hipStream_t st, Args... args) {
-  if (a_kfast && b_nfast) k_gemm_f32<true, true><<<grid, dim3(256), 0, st>>>(args...);
-  else if (a_kfast) k_gemm_f32<true, false><<<grid, dim3(256), 0, st>>>(args...);
-  else if (b_nfast) k_gemm_f32<false, true><<<grid, dim3(256), 0, st>>>(args...);
-  else k_gemm_f32<false, false><<<grid, dim3(256), 0, st>>>(args...);
+  if (a_kfast && b_nfast) k_gemm_f32<true, true, TM><<<grid, dim3(256), 0, st>>>(args...);
+  else if (a_kfast) k_gemm_f32<true, false, TM><<<grid, dim3(256), 0, st>>>(args...);
+  else if (b_nfast) k_gemm_f32<false, true, TM><<<grid, dim3(256), 0, st>>>(args...);
+  else k_gemm_f32<false, false, TM><<<grid, dim3(256), 0, st>>>(args...);
 }
 
+// Row tile: 128 when that still gives >= 3 workgroups per CU (they hide each other's global-load latency: the kernel has one
+// K-tile of look-ahead), else 64.
+static int pick_tm(int M, int N) {
+  const int64_t tiles128 = (int64_t)((M + 127) / 128) * ((N + BN - 1) / BN);
+  return tiles128 >= 3 * 256 ? 128 : 64;
+}
 }  // namespace
 
 extern "C" {
 
 int64_t ggad_gemm_workspace_elems(int32_t M, int32_t N, int32_t K) {
-  const int64_t tiles = (int64_t)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  const int tm = pick_tm(M, N);
+  const int64_t tiles = (int64_t)((M + tm - 1) / tm) * ((N + BN - 1) / BN);
   if (K < 2048 || tiles >= 256) return 0;
   int splits = (int)((512 + tiles - 1) / tiles);
   const int max_splits = (K + 255) / 256;
@@ -193,18 +204,27 @@ int ggad_gemm_f32(const float *A, const float *B, float *C, int32_t M, int32_t N
   GGAD_REQUIRE((int64_t)BM * sam + (int64_t)K * sak < (1LL << 31) && (int64_t)BN * sbn + (int64_t)K * sbk < (1LL << 31));
   if (M == 0 || N == 0) return GGAD_OK;
   hipStream_t st = as_stream(stream);
-  const int gx = (N + BN - 1) / BN, gy = (M + BM - 1) / BM;
+  const int tm = pick_tm(M, N);
+  const int gx = (N + BN - 1) / BN, gy = (M + tm - 1) / tm;
   const bool a_kfast = (sak == 1), b_nfast = (sbn == 1);
   const int64_t ws_elems = workspace ? ggad_gemm_workspace_elems(M, N, K) : 0;
   if (ws_elems == 0) {
-    launch_gemm(a_kfast, b_nfast, dim3(gx, gy, 1), st, A, B, C, (int)M, (int)N, (int)K, (int)sam, (int)sak, (int)sbk, (int)sbn, ldc,
-                bias, (int)relu, K > 0 ? (int)K : 1, (int64_t)0);
+    if (tm == 128)
+      launch_gemm<128>(a_kfast, b_nfast, dim3(gx, gy, 1), st, A, B, C, (int)M, (int)N, (int)K, (int)sam, (int)sak, (int)sbk, (int)sbn,
+                       ldc, bias, (int)relu, K > 0 ? (int)K : 1, (int64_t)0);
+    else
+      launch_gemm<64>(a_kfast, b_nfast, dim3(gx, gy, 1), st, A, B, C, (int)M, (int)N, (int)K, (int)sam, (int)sak, (int)sbk, (int)sbn,
+                      ldc, bias, (int)relu, K > 0 ? (int)K : 1, (int64_t)0);
   } else {
     const int splits = (int)(ws_elems / ((int64_t)M * N));
     int kps = (K + splits - 1) / splits;
     kps = (kps + BK - 1) / BK * BK;
-    launch_gemm(a_kfast, b_nfast, dim3(gx, gy, splits), st, A, B, workspace, (int)M, (int)N, (int)K, (int)sam, (int)sak, (int)sbk,
-                (int)sbn, (int64_t)N, (const float *)nullptr, 0, kps, (int64_t)M * N);
+    if (tm == 128)
+      launch_gemm<128>(a_kfast, b_nfast, dim3(gx, gy, splits), st, A, B, workspace, (int)M, (int)N, (int)K, (int)sam, (int)sak,
+                       (int)sbk, (int)sbn, (int64_t)N, (const float *)nullptr, 0, kps, (int64_t)M * N);
+    else
+      launch_gemm<64>(a_kfast, b_nfast, dim3(gx, gy, splits), st, A, B, workspace, (int)M, (int)N, (int)K, (int)sam, (int)sak,
+                      (int)sbk, (int)sbn, (int64_t)N, (const float *)nullptr, 0, kps, (int64_t)M * N);
     const int64_t tot = (int64_t)M * N;
     k_splitk_reduce<<<dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st>>>(workspace, splits, (int64_t)M * N, C, M, N, ldc,
                                                                              bias, relu);
