@@ -13,6 +13,7 @@
 // Pinned by tests/golden/sampler_shuffle.npz (captured from CPython 3.10 itself).
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "common.h"
 
@@ -146,31 +147,43 @@ uint32_t ggad_mt_getrandbits32(ggad_mt19937 *g) { return mt_next(g); }
 int ggad_mt_shuffle_i64(ggad_mt19937 *g, int64_t *data, int64_t n) {
   if (!g || (!data && n > 0) || n < 0 || n > 0x7fffffffLL) return GGAD_E_INVALID;
   // This loop IS the per-batch cost of the reference's schedule (55,275 dependent draws).  CPython's _randbelow redraws
-  // until the value is below the bound (rejected ~28 % of the time, unpredictably); here every MT output is consumed by a
-  // branch-free step instead: an accepted draw swaps data[i] with data[r] and moves on, a rejected one swaps data[i]
-  // with itself and stays.  Same outputs consumed in the same order -> same permutation, same generator state.
+  // until the value is below the bound (rejected ~28 % of the time, unpredictably).  Three passes per MT block keep every
+  // loop simple enough for the compiler and the core: (1) temper the block (vectorised), (2) walk the tempered outputs with
+  // a branch-free accept step -- an accepted draw records its swap target for position i and moves on, a rejected one
+  // rewrites the same slot --, (3) apply the recorded swaps in order, prefetching the random targets ahead.  Same outputs
+  // consumed in the same order -> same permutation, same generator state.
+  static thread_local std::vector<int32_t> tgt;
+  if ((int64_t)tgt.size() < n + 1) tgt.resize((size_t)n + 1);
+  int32_t *T = tgt.data();                       // T[i] = swap partner of position i
   int64_t i = n - 1;
+  uint32_t tmp[MT_N];
   while (i >= 1) {
     if (g->index >= MT_N) { (void)mt_next(g); g->index = 0; }      // regenerate the block (mt_next twists, we rewind)
     const int avail = MT_N - g->index;
     const uint32_t *blk = g->mt + g->index;
-    int used = 0;
-    while (used < avail && i >= 1) {
-      uint32_t y = blk[used++];
+    for (int k = 0; k < avail; ++k) {
+      uint32_t y = blk[k];
       y ^= (y >> 11);
       y ^= (y << 7) & 0x9d2c5680u;
       y ^= (y << 15) & 0xefc60000u;
       y ^= (y >> 18);
+      tmp[k] = y;
+    }
+    int used = 0;
+    while (used < avail && i >= 1) {
       const uint32_t bound = (uint32_t)i + 1u;
-      const uint32_t r = y >> __builtin_clz(bound);
-      const bool acc = r < bound;
-      const int64_t j = acc ? (int64_t)r : i;
-      const int64_t t = data[i];
-      data[i] = data[j];
-      data[j] = t;
-      i -= acc ? 1 : 0;
+      const uint32_t r = tmp[used++] >> __builtin_clz(bound);
+      T[i] = (int32_t)r;                         // overwritten by the redraw if rejected
+      i -= (r < bound) ? 1 : 0;
     }
     g->index += used;
+  }
+  for (int64_t k = n - 1; k >= 1; --k) {
+    if (k >= 16) __builtin_prefetch(&data[T[k - 16]], 1, 1);
+    const int64_t j = T[k];
+    const int64_t t = data[k];
+    data[k] = data[j];
+    data[j] = t;
   }
   return GGAD_OK;
 }
