@@ -670,7 +670,7 @@ __global__ void __launch_bounds__(FWD_NW * 64) k_fwd_rows_v(const float *__restr
                                                     float *__restrict__ nbar, float *__restrict__ gen) {
   static_assert(FT > 0 && FT <= 32, "register-resident W^T column, >= 2 rows per load");
   constexpr int RPI = 64 / FT;              // x2 rows per load instruction
-  constexpr int U = 4;                      // load instructions in flight
+  constexpr int U = 8;                      // load instructions in flight (one memory round trip per 24 entries)
   __shared__ float part[FWD_NW][64];
   __shared__ float ns[64];
   const int D = L.D;
