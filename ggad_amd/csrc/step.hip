@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(256) k_project(const float *__restrict__ param
 }
 
 // ------------------------------------------------------------------ forward rows (FWD_NW waves per row)
-constexpr int FWD_NW = 16;     // a hub row (thousands of entries) is the critical path of the launch
+constexpr int FWD_NW = 8;       // waves per row workgroup: 16 gives no gain on hub rows and half the workgroups per CU
 template <int FT>
 __global__ void __launch_bounds__(FWD_NW * 64) k_fwd_rows(const float *__restrict__ params, ParamLayout L,
                                                   const float *__restrict__ x1, const float *__restrict__ h2,
