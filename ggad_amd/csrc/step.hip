@@ -10,7 +10,7 @@
 // through the scalar cache (wave-uniform) or as 256-byte coalesced vector loads; (3) few launches:
 //
 //   project   flat over entries   h2[u] = relu(W x2[u]) at owner entries          graphsage.py:419
-//   fwd_rows  16 waves per row    nbar = mean_{e in row} h2[own(e)], h1 = relu(W x1), gen = relu(fc nbar)
+//   fwd_rows  8 waves per row     nbar = mean_{e in row} h2[own(e)], h1 = relu(W x1), gen = relu(fc nbar)
 //   loss_pos  1 wave / position   scores, BCE, cosine affinity, norms, recon norms + per-workgroup partial sums
 //   loss_rows 1 wave / row        loss scalars, gradients w.r.t. (h1, gen, nbar, w) folded into the per-row
 //                                 backward coefficients
