@@ -816,7 +816,8 @@ int ggad_mb_hop2_ldsw_gather(const int32_t *rowptr, const int32_t *col, const fl
   const unsigned tb = (unsigned)((n_entries_cap + 255) / 256);
   if (node_head != nullptr && feat_dim <= 64) {
     int32_t *n_groups = grp + 8 * n_entries_cap;
-    if (hipMemsetAsync(n_groups, 0, sizeof(int32_t), st) != hipSuccess) { GGAD_CHECK_LAUNCH("mb_hop2_ldsw_gather(memset)"); }
+    const hipError_t me = hipMemsetAsync(n_groups, 0, sizeof(int32_t), st);
+    if (me != hipSuccess) { ggad_set_error(me, "mb_hop2_ldsw_gather(memset)"); return GGAD_E_LAUNCH; }
     k_link_owners<<<dim3(tb), dim3(256), 0, st>>>(own_list, n_own, ent_col, node_head, own_next);
     k_build_groups<<<dim3(tb), dim3(256), 0, st>>>(own_list, n_own, ent_col, node_head, own_next, grp, n_groups);
     k_gather2_groups<<<dim3(wb), dim3(256), 0, st>>>(rowptr, col, feat, feat_dim, feat_stride, own_list, ent_col, pw_base, pc, grp,
