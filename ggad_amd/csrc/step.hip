@@ -10,7 +10,7 @@
 // through the scalar cache (wave-uniform) or as 256-byte coalesced vector loads; (3) few launches:
 //
 //   project   flat over entries   h2[u] = relu(W x2[u]) at owner entries          graphsage.py:419
-//   fwd_rows  8 waves per row     nbar = mean_{e in row} h2[own(e)], h1 = relu(W x1), gen = relu(fc nbar)
+//   fwd_rows  16 waves per row    nbar = mean_{e in row} h2[own(e)], h1 = relu(W x1), gen = relu(fc nbar)
 //   loss_pos  1 wave / position   scores, BCE, cosine affinity, norms, recon norms + per-workgroup partial sums
 //   loss_rows 1 wave / row        loss scalars, gradients w.r.t. (h1, gen, nbar, w) folded into the per-row
 //                                 backward coefficients
@@ -108,7 +108,8 @@ __global__ void __launch_bounds__(256) k_project(const float *__restrict__ param
 }
 
 // ------------------------------------------------------------------ forward rows (FWD_NW waves per row)
-constexpr int FWD_NW = 8;       // waves per row workgroup: 16 gives no gain on hub rows and half the workgroups per CU
+constexpr int FWD_NW = 16;      // waves per row workgroup of k_fwd_rows: a hub row (thousands of entries) is its critical path
+constexpr int FWDV_NW = 8;      // ... of the fused k_fwd_rows_v (only taken by batches WITHOUT hub rows): twice the workgroups per CU
 template <int FT>
 __global__ void __launch_bounds__(FWD_NW * 64) k_fwd_rows(const float *__restrict__ params, ParamLayout L,
                                                   const float *__restrict__ x1, const float *__restrict__ h2,
@@ -662,7 +663,7 @@ __global__ void __launch_bounds__(256) k_encode(const float *__restrict__ params
 // h2 is written per ENTRY (not per owner) for the relu mask of k_bwd_flat.  Same fma / summation order as
 // k_project + k_fwd_rows: bit-identical h1 / nbar / gen.
 template <int FT>
-__global__ void __launch_bounds__(FWD_NW * 64) k_fwd_rows_v(const float *__restrict__ params, ParamLayout L,
+__global__ void __launch_bounds__(FWDV_NW * 64) k_fwd_rows_v(const float *__restrict__ params, ParamLayout L,
                                                     const float *__restrict__ x1, const float *__restrict__ x2,
                                                     const int32_t *__restrict__ ent_ptr, const int32_t *__restrict__ ent_own,
                                                     const int32_t *__restrict__ labels, int row0, int ent0,
@@ -671,7 +672,7 @@ __global__ void __launch_bounds__(FWD_NW * 64) k_fwd_rows_v(const float *__restr
   static_assert(FT > 0 && FT <= 32, "register-resident W^T column, >= 2 rows per load");
   constexpr int RPI = 64 / FT;              // x2 rows per load instruction
   constexpr int U = 8;                      // load instructions in flight (one memory round trip per 24 entries)
-  __shared__ float part[FWD_NW][64];
+  __shared__ float part[FWDV_NW][64];
   __shared__ float ns[64];
   const int D = L.D;
   const int lane = lane_id(), wid = threadIdx.x / 64, d = lane < D ? lane : D - 1;
@@ -683,10 +684,10 @@ __global__ void __launch_bounds__(FWD_NW * 64) k_fwd_rows_v(const float *__restr
   const int e0 = ent_ptr[row], e1 = ent_ptr[row + 1];
   const int r = e1 - e0;
   float acc = 0.0f;
-  for (int blk = wid; blk < r; blk += FWD_NW * 64) {
-    const int my = blk + FWD_NW * lane;                 // lane l holds the owner of entry blk + 16 l of the row
+  for (int blk = wid; blk < r; blk += FWDV_NW * 64) {
+    const int my = blk + FWDV_NW * lane;                 // lane l holds the owner of entry blk + 16 l of the row
     const int ov = (my < r) ? ent_own[e0 + my] : 0;
-    const int cnt = min(64, (r - blk + FWD_NW - 1) / FWD_NW);
+    const int cnt = min(64, (r - blk + FWDV_NW - 1) / FWDV_NW);
     for (int i0 = 0; i0 < cnt; i0 += RPI * U) {
       float xv[U];
 #pragma unroll
@@ -707,7 +708,7 @@ __global__ void __launch_bounds__(FWD_NW * 64) k_fwd_rows_v(const float *__restr
               h = fmaf(W.reg[ff], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv[u]), gg * FT + ff)), h);
             h = fmaxf(h, 0.0f);                                                        // relu(W x2[u])   graphsage.py:419
             acc += h;
-            if (lane < D) h2[(int64_t)(e0 - ent0 + blk + FWD_NW * idx) * D + lane] = h;
+            if (lane < D) h2[(int64_t)(e0 - ent0 + blk + FWDV_NW * idx) * D + lane] = h;
           }
         }
       }
@@ -718,7 +719,7 @@ __global__ void __launch_bounds__(FWD_NW * 64) k_fwd_rows_v(const float *__restr
   const float inv_r = 1.0f / (float)r;                                      // mask_row = mask / rowsum  graphsage.py:317
   float tot = 0.0f;
 #pragma unroll
-  for (int k = 0; k < FWD_NW; ++k) tot += part[k][lane];                    // fixed order
+  for (int k = 0; k < FWDV_NW; ++k) tot += part[k][lane];                    // fixed order
   const float nb = inv_r * tot;
   const int y = labels[row];
   if (wid == 0) {
@@ -732,7 +733,7 @@ __global__ void __launch_bounds__(FWD_NW * 64) k_fwd_rows_v(const float *__restr
   if (y != 1) return;                                                       // block-uniform exit
   __syncthreads();
   const float *fcT = params + L.o_fcT();                                    // gen = relu(fc nbar)   graphsage.py:428-430
-  const int q = (D + FWD_NW - 1) / FWD_NW;
+  const int q = (D + FWDV_NW - 1) / FWDV_NW;
   float a = 0.0f;
   for (int d2 = wid * q; d2 < min(D, (wid + 1) * q); ++d2) a = fmaf(fcT[d2 * D + d], ns[d2], a);
   __syncthreads();
@@ -741,7 +742,7 @@ __global__ void __launch_bounds__(FWD_NW * 64) k_fwd_rows_v(const float *__restr
   if (wid == 0 && lane < D) {
     float gs = 0.0f;
 #pragma unroll
-    for (int k = 0; k < FWD_NW; ++k) gs += part[k][lane];
+    for (int k = 0; k < FWDV_NW; ++k) gs += part[k][lane];
     gen[(int64_t)row * D + lane] = fmaxf(gs, 0.0f);
   }
 }
@@ -1239,7 +1240,7 @@ int ggad_mb_train_step(const ggad_mb_step *s, int32_t fuse_adam, ggad_stream_t s
     GGAD_REQUIRE(s->x1 && s->x2 && s->h2 && s->ent_ptr && s->ent_own && s->labels && s->h1 && s->nbar && s->gen && dims_ok(D, F));
     GGAD_REQUIRE(s->n_rows >= 1 && s->row0 >= 0 && s->ent0 >= 0);
     ParamLayout L{D, F};
-    k_fwd_rows_v<17><<<dim3(s->n_rows), dim3(FWD_NW * 64), 0, as_stream(stream)>>>(s->params, L, s->x1, s->x2, s->ent_ptr, s->ent_own,
+    k_fwd_rows_v<17><<<dim3(s->n_rows), dim3(FWDV_NW * 64), 0, as_stream(stream)>>>(s->params, L, s->x1, s->x2, s->ent_ptr, s->ent_own,
                                                                                   s->labels, s->row0, s->ent0, s->h2, s->h1, s->nbar,
                                                                                   s->gen);
   } else {

@@ -231,8 +231,8 @@ def test_random_graph_vs_oracle(f, d, hop2):
 
 @pytest.mark.parametrize("d,bsz,n_ano", [(64, 200, 50), (32, 333, 77), (48, 23, 5)])
 def test_rowwise_chain_equals_six_launch_chain(d, bsz, n_ano):
-    """Chain 0 (projection fused into the forward-rows kernel) is bit-identical to the 6-launch chain 2; the 3-launch
-    row-wise chain 1 computes the same losses, gradients and Adam trajectory up to summation order; oracle check."""
+    """Chain 0 (projection fused into the forward-rows kernel), the 6-launch chain 2 and the 3-launch row-wise chain 1
+    compute the same losses, gradients and Adam trajectory up to summation order; oracle check."""
     g, batches, labels = _random_case(n=12000, n_entries=150000, f=17, d=d, seed=31 + d, nb=3, bsz=bsz, n_ano=n_ano)
     torch.manual_seed(d)
     w = torch.nn.init.xavier_uniform_(torch.empty(1, d))
@@ -254,8 +254,10 @@ def test_rowwise_chain_equals_six_launch_chain(d, bsz, n_ano):
         eng2.load_params(w, W, fc)
         eng2.train_chunk(ch)
         np.testing.assert_array_equal(eng2.params.cpu().numpy(), res[chain][2])
-    for k in range(3):                                        # fused forward == project + fwd_rows, bit for bit
-        np.testing.assert_array_equal(res[0][k], res[2][k])
+    # fused forward vs project + fwd_rows: same fma order per entry, 8 instead of 16 partial sums per row
+    np.testing.assert_allclose(res[0][0], res[2][0], atol=1e-6, rtol=1e-5)
+    np.testing.assert_allclose(res[0][1], res[2][1], atol=1e-6, rtol=0)
+    np.testing.assert_allclose(res[0][2], res[2][2], atol=1e-6, rtol=0)
     np.testing.assert_allclose(res[0][0], res[1][0], atol=2e-6, rtol=2e-5)
     np.testing.assert_allclose(res[0][1], res[1][1], atol=2e-6, rtol=0)
     np.testing.assert_allclose(res[0][2], res[1][2], atol=2e-6, rtol=0)
