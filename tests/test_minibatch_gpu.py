@@ -391,6 +391,26 @@ def test_ldsw_hop2_owner_slabs_and_padded_rows():
     _check_plan_against_oracle(g, ch, batches[:1], feat, atol=2e-5)
 
 
+def test_ldsw_falls_back_to_global_counters():
+    """A chunk the LDS-counting path cannot take (here: the host bound on the pair count is forced past 2^31) silently uses
+    the device-atomic 2-hop kernels; same results, counters reset, and the next chunk goes back to "ldsw"."""
+    g, batches, labels = _random_case(n=9000, n_entries=70000, f=17, d=64, seed=77, nb=3, bsz=120, n_ano=30)
+    graph, feat, ch = _setup(g, max_batches=3, hop2="ldsw")
+    real = graph.pair_bound_host
+    graph.__dict__["_pair_bound"] = np.full_like(real, 1 << 27)
+    ch.build(batches, labels)
+    torch.cuda.synchronize()
+    assert ch.last_hop2 == "global"
+    _check_plan_against_oracle(g, ch, batches, g["feat"], atol=3e-6)
+    graph.__dict__["_pair_bound"] = real
+    ch.build(batches, labels)                     # build() resets the global counters of the previous plan first
+    torch.cuda.synchronize()
+    assert ch.last_hop2 == "ldsw"
+    _check_plan_against_oracle(g, ch, batches, g["feat"], atol=3e-6)
+    ch.reset()
+    assert int(ch.cnt1.abs().sum()) == 0 and int(ch.cnt2.abs().sum()) == 0
+
+
 def test_ldsw_node_major_gather_bit_identical():
     """A hub that is an owner in 11 of 12 batches (two groups: 8 + 3 occurrences), nodes shared by 2 / 4 batches and
     single occurrences: the node-major gather must equal the per-owner kernel bit for bit, leave node_head clean, and
