@@ -170,9 +170,34 @@ int ggad_mt_shuffle_i64(ggad_mt19937 *g, int64_t *data, int64_t n) {
       tmp[k] = y;
     }
     int used = 0;
+    // Blocks of 8 outputs without the loop-carried chain i -> bound -> clz -> shift -> compare: inside a block the bound can
+    // drop by at most 8, so a draw r <= bound - 8 is accepted and a draw r >= bound is rejected WHATEVER the draws before
+    // it did (the shift is constant while bound and bound - 8 have the same bit length).  Only a draw in the 7-wide
+    // window between the two (probability ~ 8 / 2^k) makes the walk take one exact scalar step instead.
     while (used < avail && i >= 1) {
       const uint32_t bound = (uint32_t)i + 1u;
-      const uint32_t r = tmp[used++] >> __builtin_clz(bound);
+      const int sh = __builtin_clz(bound);
+      if (used + 8 <= avail && i >= 64 && __builtin_clz(bound - 8u) == sh) {
+        const uint32_t lim = bound - 8u;
+        uint32_t r[8];
+        unsigned bad = 0;
+        for (int k = 0; k < 8; ++k) {
+          const uint32_t rk = tmp[used + k] >> sh;
+          r[k] = rk;
+          bad |= (unsigned)(rk > lim) & (unsigned)(rk < bound);
+        }
+        if (!bad) {
+          int64_t pos = i;
+          for (int k = 0; k < 8; ++k) {
+            T[pos] = (int32_t)r[k];              // a rejected draw is overwritten by the next write to the same slot
+            pos -= (r[k] <= lim);
+          }
+          i = pos;
+          used += 8;
+          continue;
+        }
+      }
+      const uint32_t r = tmp[used++] >> sh;      // exact step: block tails, power-of-two crossings, ambiguous blocks
       T[i] = (int32_t)r;                         // overwritten by the redraw if rejected
       i -= (r < bound) ? 1 : 0;
     }
