@@ -309,6 +309,11 @@ class BatchChunk:
         serialise the host with the GPU."""
         if self.hop2 != "ldsw":
             return False
+        # the static tile-offset table is N x (N / 32,768 + 1) ints: fine at DGraph size (1.7 GB), quadratic beyond ~30 M nodes
+        shift = int(self.lib.ggad_mb_ldsw_tile_shift())
+        if 4 * int(self.lib.ggad_mb_tile_offsets_elems(self.g.n, shift)) > (32 << 30):
+            self.last_hop2 = "global"
+            return False
         per_batch = np.diff(self.ent_ptr_host[self.batch_ptr_host])
         bound = int(self.g.pair_bound_host[nodes].sum())
         if per_batch.max() >= 65536 or self.n_ents > (1 << 22) or bound >= (1 << 31) - 1:
