@@ -86,8 +86,23 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", type=str, default="dgraph.yml", help="")
     ap.add_argument("--multi_run", action="store_true", help="flag: multi run")
+    ap.add_argument("--synthetic", action="store_true",
+                    help="no ../data/dgraphfin.npz here: train on a synthetic graph of DGraph-Fin's size (power-law degrees, "
+                         "U[0,1) features, 0.42 %% anomalies) built from the config's seed")
+    ap.add_argument("--synthetic_entries", type=int, default=73105508, help="directed entries of the synthetic graph "
+                    "(73.1 M = BASELINE's figure; 8600000 = the public dataset's average degree 2.3)")
+    ap.add_argument("--num_epochs", type=int, default=None, help="override the config's num_epochs")
     a = ap.parse_args()
     with open(a.config, "r") as fh:
         cfg = yaml.load(fh, Loader=yaml.FullLoader)
+    if a.num_epochs is not None:
+        cfg["num_epochs"] = a.num_epochs
     init_distributed()
+    if a.synthetic:
+        from ggad_amd import synth
+        dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        n = 3700550
+        rowptr, col = synth.make_graph_torch(n, a.synthetic_entries, cfg["seed"], dev, kind="powerlaw", max_degree=2000)
+        cfg["data"] = ((rowptr, col), synth.make_features(n, 17, cfg["seed"]),
+                       synth.make_labels(n, 15509.0 / 3700550.0, cfg["seed"]).astype(np.int32))
     (multi_run_main if a.multi_run else main)(cfg)
