@@ -17,7 +17,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libggad_hip.so")
 STAMP = os.path.join(HERE, ".libggad_hip.stamp")
-SOURCES = ["runtime.cpp", "plan.hip", "hop2_tiled.hip", "step.hip", "fullgraph.hip", "gemm.hip"]
+SOURCES = ["runtime.cpp", "sampler_x86.cpp", "plan.hip", "hop2_tiled.hip", "step.hip", "fullgraph.hip", "gemm.hip"]
+HOST_ONLY = {"sampler_x86.cpp"}          # plain C++ (x86 intrinsics behind a run-time CPU check), no device pass
 HEADERS = ["common.h", os.path.join("..", "..", "include", "ggad_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-fno-fast-math",
          "-Wall", "-Wno-unused-function"]
@@ -52,7 +53,10 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for s in srcs:
         obj = os.path.join(bdir, os.path.splitext(s)[0] + ".o")
         objs.append(obj)
-        cmd = [hipcc] + FLAGS + ["-x", "hip", "-c", os.path.join(CSRC, s), "-o", obj]
+        if s in HOST_ONLY:
+            cmd = [hipcc, "-O3", "-std=c++17", "-fPIC", "-Wall", "-x", "c++", "-c", os.path.join(CSRC, s), "-o", obj]
+        else:
+            cmd = [hipcc] + FLAGS + ["-x", "hip", "-c", os.path.join(CSRC, s), "-o", obj]
         if verbose:
             print("[ggad build]", " ".join(cmd), flush=True)
         procs.append((s, subprocess.Popen(cmd)))

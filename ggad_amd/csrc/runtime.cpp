@@ -19,6 +19,13 @@
 
 static thread_local std::string g_last_error;
 
+extern "C" {          // sampler_x86.cpp
+int ggad_x86_has_avx2(void);
+int ggad_x86_accept8(const uint32_t *y, int sh, uint32_t bound, int32_t *out);
+int ggad_x86_accept_run(const uint32_t *y, int avail, int64_t n, int64_t *c_io, int32_t *T);
+void ggad_x86_temper(const uint32_t *in, uint32_t *out, int n);
+}
+
 void ggad_set_error(hipError_t e, const char *where) {
   g_last_error = std::string(where) + ": " + hipGetErrorString(e);
 }
@@ -153,59 +160,71 @@ int ggad_mt_shuffle_i64(ggad_mt19937 *g, int64_t *data, int64_t n) {
   // rewrites the same slot --, (3) apply the recorded swaps in order, prefetching the random targets ahead.  Same outputs
   // consumed in the same order -> same permutation, same generator state.
   static thread_local std::vector<int32_t> tgt;
-  if ((int64_t)tgt.size() < n + 1) tgt.resize((size_t)n + 1);
-  int32_t *T = tgt.data();                       // T[i] = swap partner of position i
-  int64_t i = n - 1;
-  uint32_t tmp[MT_N];
-  while (i >= 1) {
+  if ((int64_t)tgt.size() < n + 16) tgt.resize((size_t)n + 16);
+  int32_t *T = tgt.data();                       // T[c] = swap partner of position n - 1 - c (c-th accepted draw)
+  static const bool avx2 = ggad_x86_has_avx2() != 0;
+  const int64_t need = n - 1;                    // accepted draws of one shuffle
+  int64_t c = 0;
+  uint32_t tmp[MT_N + 8];
+  while (c < need) {
     if (g->index >= MT_N) { (void)mt_next(g); g->index = 0; }      // regenerate the block (mt_next twists, we rewind)
     const int avail = MT_N - g->index;
     const uint32_t *blk = g->mt + g->index;
-    for (int k = 0; k < avail; ++k) {
-      uint32_t y = blk[k];
-      y ^= (y >> 11);
-      y ^= (y << 7) & 0x9d2c5680u;
-      y ^= (y << 15) & 0xefc60000u;
-      y ^= (y >> 18);
-      tmp[k] = y;
+    if (avx2) {
+      ggad_x86_temper(blk, tmp, avail);
+    } else {
+      for (int k = 0; k < avail; ++k) {
+        uint32_t y = blk[k];
+        y ^= (y >> 11);
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= (y >> 18);
+        tmp[k] = y;
+      }
     }
     int used = 0;
     // Blocks of 8 outputs without the loop-carried chain i -> bound -> clz -> shift -> compare: inside a block the bound can
     // drop by at most 8, so a draw r <= bound - 8 is accepted and a draw r >= bound is rejected WHATEVER the draws before
     // it did (the shift is constant while bound and bound - 8 have the same bit length).  Only a draw in the 7-wide
     // window between the two (probability ~ 8 / 2^k) makes the walk take one exact scalar step instead.
-    while (used < avail && i >= 1) {
+    while (used < avail && c < need) {
+      if (avx2) used += ggad_x86_accept_run(tmp + used, avail - used, n, &c, T);     // as many whole blocks as the rule allows
+      if (used >= avail || c >= need) break;
+      const int64_t i = n - 1 - c;
       const uint32_t bound = (uint32_t)i + 1u;
       const int sh = __builtin_clz(bound);
-      if (used + 8 <= avail && i >= 64 && __builtin_clz(bound - 8u) == sh) {
-        const uint32_t lim = bound - 8u;
-        uint32_t r[8];
-        unsigned bad = 0;
-        for (int k = 0; k < 8; ++k) {
-          const uint32_t rk = tmp[used + k] >> sh;
-          r[k] = rk;
-          bad |= (unsigned)(rk > lim) & (unsigned)(rk < bound);
-        }
-        if (!bad) {
-          int64_t pos = i;
+      if (!avx2 && used + 8 <= avail && i >= 64 && __builtin_clz(bound - 8u) == sh) {
+        {
+          const uint32_t lim = bound - 8u;
+          uint32_t r[8];
+          unsigned bad = 0;
           for (int k = 0; k < 8; ++k) {
-            T[pos] = (int32_t)r[k];              // a rejected draw is overwritten by the next write to the same slot
-            pos -= (r[k] <= lim);
+            const uint32_t rk = tmp[used + k] >> sh;
+            r[k] = rk;
+            bad |= (unsigned)(rk > lim) & (unsigned)(rk < bound);
           }
-          i = pos;
-          used += 8;
-          continue;
+          if (!bad) {
+            int64_t pos = c;
+            for (int k = 0; k < 8; ++k) {
+              T[pos] = (int32_t)r[k];            // a rejected draw is overwritten by the next write to the same slot
+              pos += (r[k] <= lim);
+            }
+            c = pos;
+            used += 8;
+            continue;
+          }
         }
       }
       const uint32_t r = tmp[used++] >> sh;      // exact step: block tails, power-of-two crossings, ambiguous blocks
-      T[i] = (int32_t)r;                         // overwritten by the redraw if rejected
-      i -= (r < bound) ? 1 : 0;
+      T[c] = (int32_t)r;                         // overwritten by the redraw if rejected
+      c += (r < bound) ? 1 : 0;
     }
     g->index += used;
   }
   for (int64_t k = n - 1; k >= 1; --k) {
-    if (k >= 16) __builtin_prefetch(&data[T[k - 16]], 1, 1);
-    const int64_t j = T[k];
+    const int64_t cc = n - 1 - k;
+    if (k >= 16) __builtin_prefetch(&data[T[cc + 16]], 1, 1);
+    const int64_t j = T[cc];
     const int64_t t = data[k];
     data[k] = data[j];
     data[j] = t;
