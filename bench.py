@@ -38,7 +38,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s me
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4500)
+    ap.add_argument("--steps", type=int, default=9000)
     ap.add_argument("--warmup", type=int, default=150)
     ap.add_argument("--nodes", type=int, default=3_700_550)
     ap.add_argument("--entries", type=int, default=73_105_508)
