@@ -66,6 +66,42 @@ class DeviceGraph:
         return cls(m.indptr.astype(np.int32), m.indices.astype(np.int32), device,
                    val=m.data if keep_values else None)
 
+    # ---- cached binary CSR: converting the reference's 3.7 M-key dict of python sets takes minutes, the
+    # cache is two int32 arrays
+    def save_csr(self, path: str) -> None:
+        """Write rowptr / col as an uncompressed .npz (atomic rename), to be reloaded with `load_csr`."""
+        import os
+        tmp = path + ".tmp.npz"
+        np.savez(tmp, rowptr=self.rowptr_host, col=self.col_host, n=np.int64(self.n), nnz=np.int64(self.nnz))
+        os.replace(tmp, path)
+
+    @classmethod
+    def load_csr(cls, path: str, device="cuda") -> "DeviceGraph":
+        with np.load(path) as f:
+            rowptr, col = f["rowptr"], f["col"]
+            if int(f["n"]) != len(rowptr) - 1 or int(f["nnz"]) != len(col) or int(rowptr[-1]) != len(col):
+                raise ValueError(f"{path}: inconsistent CSR cache")
+        return cls(rowptr, col, device)
+
+    @classmethod
+    def from_adj_lists_cached(cls, adj_lists, n: Optional[int], device, cache_path: Optional[str]) -> "DeviceGraph":
+        """`from_adj_lists` through a binary cache: reused when it describes a graph of the same size, else rebuilt."""
+        import os
+        if cache_path and os.path.exists(cache_path):
+            try:
+                g = cls.load_csr(cache_path, device)
+                if n is None or g.n == n:
+                    return g
+            except (ValueError, OSError, KeyError):
+                pass
+        g = cls.from_adj_lists(adj_lists, n, device)
+        if cache_path:
+            try:
+                g.save_csr(cache_path)
+            except OSError:
+                pass                      # read-only data directory: run without the cache
+        return g
+
     def adj_lists(self):
         """Back-conversion (tests / interchange only)."""
         from .synth import csr_to_adj_lists

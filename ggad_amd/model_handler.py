@@ -83,7 +83,11 @@ class ModelHandler(object):
         elif isinstance(adj_lists, tuple):
             graph = DeviceGraph(adj_lists[0], adj_lists[1], dev)
         else:
-            graph = DeviceGraph.from_adj_lists(adj_lists, n, dev)
+            # the reference's pickled dict of sets: converted once, then served from a binary CSR cache beside it
+            cache = None
+            if getattr(args, "data_name", "") == "dgraphfin" and getattr(args, "data", None) is None:
+                cache = os.path.join(args.data_dir, "dgraphfin_adj_list.csr.npz")
+            graph = DeviceGraph.from_adj_lists_cached(adj_lists, n, dev, cache)
         features = FeatureTable(torch.FloatTensor(np.asarray(feat_data, dtype=np.float32)))
         agg_gcn = GCNAggregator(features, cuda=True)
         enc_gcn = GCNEncoder(features, f, args.emb_size, graph, agg_gcn, gcn=True, cuda=True)

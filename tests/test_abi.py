@@ -3,6 +3,8 @@ import ctypes
 import os
 import re
 
+import numpy as np
+
 import pytest
 
 from conftest import ROOT
@@ -49,3 +51,18 @@ def test_argument_validation_without_gpu():
     assert lib.ggad_mb_params_sync(None, 64, 17, None) == -1
     assert lib.ggad_mb_param_count(64, 17) == 5248
     assert lib.ggad_max_embed_dim() == 64
+
+
+def test_csr_cache_round_trip(tmp_path):
+    """Binary CSR cache of the reference's dict-of-sets adjacency (host side; no GPU needed)."""
+    from ggad_amd import synth
+    from ggad_amd.graph import DeviceGraph
+    rowptr, col = synth.make_graph(500, 4000, 3, kind="powerlaw", max_degree=40)
+    adj = synth.csr_to_adj_lists(rowptr, col)
+    path = str(tmp_path / "adj.csr.npz")
+    g1 = DeviceGraph.from_adj_lists_cached(adj, 500, "cpu", path)
+    g2 = DeviceGraph.from_adj_lists_cached(None, 500, "cpu", path)          # served from the cache: the dict is not touched
+    assert np.array_equal(g1.rowptr_host, rowptr) and np.array_equal(g1.col_host, col)
+    assert np.array_equal(g2.rowptr_host, rowptr) and np.array_equal(g2.col_host, col)
+    g3 = DeviceGraph.from_adj_lists_cached(adj, 400 + 100, "cpu", str(tmp_path / "missing" / "x.npz"))   # unwritable: still works
+    assert g3.nnz == g1.nnz
