@@ -33,12 +33,11 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 // element relative to a wave-uniform tile pointer (SGPR base + VGPR offset addressing), the row / column bounds are
 // folded into those offsets once (out-of-range elements point at element 0 and are zeroed by a mask bit), and only
 // the last K-tile checks k.
-template <bool A_KFAST, bool B_NFAST, int TM>
+template <bool A_KFAST, bool B_NFAST, int TM, bool VEC>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) k_gemm_f32(const float *__restrict__ A, const float *__restrict__ B,
                                                   float *__restrict__ C, int M, int N, int K, int sam, int sak,
                                                   int sbk, int sbn, int64_t ldc, const float *__restrict__ bias,
                                                   int relu, int k_per_split, int64_t c_split_stride) {
-  constexpr int TA_PER_T = TM * BK / 256;      // A elements per thread
   constexpr int NACC = TM / 64;                // 32x32 accumulators per wave (rows 32 * NACC)
   __shared__ float As[BK][TM + 1];
   __shared__ float Bs[BK][LDB_S];
@@ -49,61 +48,106 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
   const int k_end = min(K, k_begin + k_per_split);
   floatx16 acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   floatx16 acc1 = acc0;
-  // element p of this thread inside a tile: A (m, k), B (n, k); unit stride along the fastest index of each operand
-  int oa[TA_PER_T], ob[B_PER_T];          // offsets relative to the tile pointers
+  // Thread -> tile elements.  Scalar mode: element p = one float, unit stride across threads along the operand's fastest
+  // index.  VEC mode (extents along the fastest index are multiples of 4, checked by the launcher): element p = one
+  // float4 along the fastest index -- a quarter of the load instructions and of the address arithmetic; the K = 300
+  // projections are bound by exactly that (per K-tile the MFMA phase is 0.4 us, the 24 dword loads per thread were not).
+  constexpr int VW = VEC ? 4 : 1;
+  constexpr int NA = TM * BK / 256 / VW, NB = BN * BK / 256 / VW;      // elements (floats or float4s) per thread
+  int oa[NA], ob[NB];                    // offsets relative to the tile pointers (0 for out-of-range rows / columns)
   unsigned amask = 0, bmask = 0;         // bit p: row (column) inside the matrix
-  int ka0, kb0;                          // k of element 0 of this thread; element p adds a constant step
-  constexpr int KA_STEP = A_KFAST ? 0 : 256 / TM, KB_STEP = B_NFAST ? 4 : 0;
-  if (A_KFAST) ka0 = tid & 31; else ka0 = tid / TM;
-  if (B_NFAST) kb0 = tid >> 6; else kb0 = tid & 31;
+  // A element p -> (m, k) of its first float; B element p -> (n, k)
+  auto a_mk = [&](int p, int &m, int &k) {
+    if constexpr (VEC) {
+      if (A_KFAST) { k = (tid & 7) * 4; m = (tid >> 3) + 32 * p; }
+      else { m = (tid % (TM / 4)) * 4; k = tid / (TM / 4) + (1024 / TM) * p; }
+    } else {
+      if (A_KFAST) { k = tid & 31; m = (tid >> 5) + 8 * p; }
+      else { m = tid % TM; k = tid / TM + (256 / TM) * p; }
+    }
+  };
+  auto b_nk = [&](int p, int &n, int &k) {
+    if constexpr (VEC) {
+      if (B_NFAST) { n = (tid & 15) * 4; k = (tid >> 4) + 16 * p; }
+      else { k = (tid & 7) * 4; n = (tid >> 3) + 32 * p; }
+    } else {
+      if (B_NFAST) { n = tid & 63; k = (tid >> 6) + 4 * p; }
+      else { k = tid & 31; n = (tid >> 5) + 8 * p; }
+    }
+  };
 #pragma unroll
-  for (int p = 0; p < TA_PER_T; ++p) {
-    const int m = A_KFAST ? (tid >> 5) + 8 * p : (tid % TM);
-    const int k = ka0 + KA_STEP * p;
-    const bool in = m0 + m < M;
+  for (int p = 0; p < NA; ++p) {
+    int m, k; a_mk(p, m, k);
+    const bool in = m0 + m < M;          // VEC and m-fast: M % 4 == 0, so a float4 is inside or outside as a whole
     oa[p] = in ? m * sam + k * sak : 0;
     amask |= (in ? 1u : 0u) << p;
   }
 #pragma unroll
-  for (int p = 0; p < B_PER_T; ++p) {
-    const int n = B_NFAST ? (tid & 63) : (tid >> 5) + 8 * p;
-    const int k = kb0 + KB_STEP * p;
+  for (int p = 0; p < NB; ++p) {
+    int n, k; b_nk(p, n, k);
     const bool in = n0 + n < N;
     ob[p] = in ? k * sbk + n * sbn : 0;
     bmask |= (in ? 1u : 0u) << p;
   }
   const float *At = A + (int64_t)m0 * sam + (int64_t)k_begin * sak;     // wave-uniform tile pointers
   const float *Bt = B + (int64_t)n0 * sbn + (int64_t)k_begin * sbk;
-  float ra[TA_PER_T], rb[B_PER_T];
+  typedef float fvec __attribute__((ext_vector_type(4)));
+  float ra[NA * VW], rb[NB * VW];
   unsigned oka = 0, okb = 0;             // validity of the elements fetched last
   auto fetch = [&](int k0) {
-    const int klim = k_end - k0;         // elements with k >= klim lie past the end of this split (last K-tile only)
+    const int klim = k_end - k0;         // k >= klim lies past the end of this split (last K-tile only; multiple of 4 in VEC mode)
     oka = 0; okb = 0;
 #pragma unroll
-    for (int p = 0; p < TA_PER_T; ++p) {  // branch-free: every load is issued before the first one is consumed
-      const unsigned ok = ((amask >> p) & 1u) & (unsigned)(ka0 + KA_STEP * p < klim);
+    for (int p = 0; p < NA; ++p) {       // branch-free: every load is issued before the first one is consumed
+      int m, k; a_mk(p, m, k);
+      const unsigned ok = ((amask >> p) & 1u) & (unsigned)(k < klim);
       oka |= ok << p;
-      ra[p] = At[ok ? oa[p] : 0];
+      const float *src = At + (ok ? oa[p] : 0);
+      if constexpr (VEC) {
+        if (A_KFAST || true) {
+          const fvec v = *reinterpret_cast<const fvec __attribute__((aligned(4))) *>(src);
+          ra[4 * p] = v.x; ra[4 * p + 1] = v.y; ra[4 * p + 2] = v.z; ra[4 * p + 3] = v.w;
+        }
+      } else {
+        ra[p] = *src;
+      }
     }
 #pragma unroll
-    for (int p = 0; p < B_PER_T; ++p) {
-      const unsigned ok = ((bmask >> p) & 1u) & (unsigned)(kb0 + KB_STEP * p < klim);
+    for (int p = 0; p < NB; ++p) {
+      int n, k; b_nk(p, n, k);
+      const unsigned ok = ((bmask >> p) & 1u) & (unsigned)(k < klim);
       okb |= ok << p;
-      rb[p] = Bt[ok ? ob[p] : 0];
+      const float *src = Bt + (ok ? ob[p] : 0);
+      if constexpr (VEC) {
+        const fvec v = *reinterpret_cast<const fvec __attribute__((aligned(4))) *>(src);
+        rb[4 * p] = v.x; rb[4 * p + 1] = v.y; rb[4 * p + 2] = v.z; rb[4 * p + 3] = v.w;
+      } else {
+        rb[p] = *src;
+      }
     }
     At += (int64_t)BK * sak;             // (the masks are applied in stash(): nothing here waits for the loads)
     Bt += (int64_t)BK * sbk;
   };
   auto stash = [&]() {
 #pragma unroll
-    for (int p = 0; p < TA_PER_T; ++p) {
-      const int m = A_KFAST ? (tid >> 5) + 8 * p : (tid % TM);
-      As[ka0 + KA_STEP * p][m] = ((oka >> p) & 1u) ? ra[p] : 0.0f;
+    for (int p = 0; p < NA; ++p) {
+      int m, k; a_mk(p, m, k);
+      const bool ok = (oka >> p) & 1u;
+#pragma unroll
+      for (int j = 0; j < VW; ++j) {
+        const float v = ok ? ra[VW * p + j] : 0.0f;
+        if (A_KFAST) As[k + j][m] = v; else As[k][m + j] = v;
+      }
     }
 #pragma unroll
-    for (int p = 0; p < B_PER_T; ++p) {
-      const int n = B_NFAST ? (tid & 63) : (tid >> 5) + 8 * p;
-      Bs[kb0 + KB_STEP * p][n] = ((okb >> p) & 1u) ? rb[p] : 0.0f;
+    for (int p = 0; p < NB; ++p) {
+      int n, k; b_nk(p, n, k);
+      const bool ok = (okb >> p) & 1u;
+#pragma unroll
+      for (int j = 0; j < VW; ++j) {
+        const float v = ok ? rb[VW * p + j] : 0.0f;
+        if (B_NFAST) Bs[k][n + j] = v; else Bs[k + j][n] = v;
+      }
     }
   };
   if (k_begin < k_end) {
@@ -115,7 +159,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
   for (int k0 = k_begin; k0 < k_end; k0 += BK) {
     const bool more = (k0 + BK) < k_end;
     if (more) fetch(k0 + BK);
-#pragma unroll
+#pragma unroll 4
     for (int ks = 0; ks < BK; ks += 2) {
       const float b = Bs[ks + kk][wc * 32 + i];
       const float a0 = As[ks + kk][wr * 32 * NACC + i];
@@ -166,12 +210,17 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(const float *__restrict__
   C[(int64_t)m * ldc + n] = s;
 }
 
+template <int TM, bool VEC, typename... Args>
+static void launch_gemm2(bool a_kfast, bool b_nfast, dim3 grid, hipStream_t st, Args... args) {
+  if (a_kfast && b_nfast) k_gemm_f32<true, true, TM, VEC><<<grid, dim3(256), 0, st>>>(args...);
+  else if (a_kfast) k_gemm_f32<true, false, TM, VEC><<<grid, dim3(256), 0, st>>>(args...);
+  else if (b_nfast) k_gemm_f32<false, true, TM, VEC><<<grid, dim3(256), 0, st>>>(args...);
+  else k_gemm_f32<false, false, TM, VEC><<<grid, dim3(256), 0, st>>>(args...);
+}
 template <int TM, typename... Args>
-static void launch_gemm(bool a_kfast, bool b_nfast, dim3 grid, hipStream_t st, Args... args) {
-  if (a_kfast && b_nfast) k_gemm_f32<true, true, TM><<<grid, dim3(256), 0, st>>>(args...);
-  else if (a_kfast) k_gemm_f32<true, false, TM><<<grid, dim3(256), 0, st>>>(args...);
-  else if (b_nfast) k_gemm_f32<false, true, TM><<<grid, dim3(256), 0, st>>>(args...);
-  else k_gemm_f32<false, false, TM><<<grid, dim3(256), 0, st>>>(args...);
+static void launch_gemm(bool vec, bool a_kfast, bool b_nfast, dim3 grid, hipStream_t st, Args... args) {
+  if (vec) launch_gemm2<TM, true>(a_kfast, b_nfast, grid, st, args...);
+  else launch_gemm2<TM, false>(a_kfast, b_nfast, grid, st, args...);
 }
 
 // Row tile: 128 when that still gives >= 3 workgroups per CU (they hide each other's global-load latency: the kernel has one
@@ -207,23 +256,26 @@ int ggad_gemm_f32(const float *A, const float *B, float *C, int32_t M, int32_t N
   const int tm = pick_tm(M, N);
   const int gx = (N + BN - 1) / BN, gy = (M + tm - 1) / tm;
   const bool a_kfast = (sak == 1), b_nfast = (sbn == 1);
+  // float4 loads along each operand's fastest index: its extent must be a multiple of 4 (a float4 never straddles the end of
+  // a row, so nothing is read outside the tensors), K-splits are multiples of BK
+  const bool vec = ((a_kfast ? K : M) % 4 == 0) && ((b_nfast ? N : K) % 4 == 0);
   const int64_t ws_elems = workspace ? ggad_gemm_workspace_elems(M, N, K) : 0;
   if (ws_elems == 0) {
     if (tm == 128)
-      launch_gemm<128>(a_kfast, b_nfast, dim3(gx, gy, 1), st, A, B, C, (int)M, (int)N, (int)K, (int)sam, (int)sak, (int)sbk, (int)sbn,
+      launch_gemm<128>(vec, a_kfast, b_nfast, dim3(gx, gy, 1), st, A, B, C, (int)M, (int)N, (int)K, (int)sam, (int)sak, (int)sbk, (int)sbn,
                        ldc, bias, (int)relu, K > 0 ? (int)K : 1, (int64_t)0);
     else
-      launch_gemm<64>(a_kfast, b_nfast, dim3(gx, gy, 1), st, A, B, C, (int)M, (int)N, (int)K, (int)sam, (int)sak, (int)sbk, (int)sbn,
+      launch_gemm<64>(vec, a_kfast, b_nfast, dim3(gx, gy, 1), st, A, B, C, (int)M, (int)N, (int)K, (int)sam, (int)sak, (int)sbk, (int)sbn,
                       ldc, bias, (int)relu, K > 0 ? (int)K : 1, (int64_t)0);
   } else {
     const int splits = (int)(ws_elems / ((int64_t)M * N));
     int kps = (K + splits - 1) / splits;
     kps = (kps + BK - 1) / BK * BK;
     if (tm == 128)
-      launch_gemm<128>(a_kfast, b_nfast, dim3(gx, gy, splits), st, A, B, workspace, (int)M, (int)N, (int)K, (int)sam, (int)sak,
+      launch_gemm<128>(vec, a_kfast, b_nfast, dim3(gx, gy, splits), st, A, B, workspace, (int)M, (int)N, (int)K, (int)sam, (int)sak,
                        (int)sbk, (int)sbn, (int64_t)N, (const float *)nullptr, 0, kps, (int64_t)M * N);
     else
-      launch_gemm<64>(a_kfast, b_nfast, dim3(gx, gy, splits), st, A, B, workspace, (int)M, (int)N, (int)K, (int)sam, (int)sak,
+      launch_gemm<64>(vec, a_kfast, b_nfast, dim3(gx, gy, splits), st, A, B, workspace, (int)M, (int)N, (int)K, (int)sam, (int)sak,
                       (int)sbk, (int)sbn, (int64_t)N, (const float *)nullptr, 0, kps, (int64_t)M * N);
     const int64_t tot = (int64_t)M * N;
     k_splitk_reduce<<<dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st>>>(workspace, splits, (int64_t)M * N, C, M, N, ldc,
