@@ -88,7 +88,8 @@ SIGNATURES = {
     "ggad_rownorm_bwd_f32": (c_int32, [_P, _P, _P, _I, _I, _P, _P]),
     "ggad_rowdot_f32": (c_int32, [_P, _P, _P, _I, _I, _P, _P, _P]),
     "ggad_rows_scale_f32": (c_int32, [_P, _P, _P, _I, _I, _I, _P, _P]),
-    "ggad_full_loss_f32": (c_int32, [_P, _P, _I, _I, _P, _P, _I, _F, _P, _P, _P, _P, _P]),
+    "ggad_full_loss_workspace_elems": (c_int64, [_I, _I]),
+    "ggad_full_loss_f32": (c_int32, [_P, _P, _I, _I, _P, _P, _I, _F, _P, _P, _P, _P, _P, _P]),
     "ggad_adam_f32": (c_int32, [_P, _P, _P, _P, _L, _F, _F, _P, _I, _P]),
     "ggad_mt_new": (c_void_p, []),
     "ggad_mt_free": (None, [c_void_p]),

@@ -267,10 +267,8 @@ __device__ __forceinline__ float block_sum_1024(float v, float *red) {
 //   aff[L]: affinity at normal_idx (first Nn) and abnormal_idx (last A) -> margin(0.7), g_aff[L] = d total / d aff
 //   D = emb_con - emb_abnormal (A x H): rec = mean_h sqrt(sum_a D^2)   (axis quirk, run.py:207-208) -> dD
 __global__ void __launch_bounds__(1024) k_full_loss(const float *__restrict__ logits, const float *__restrict__ aff, int Nn,
-                                                    int A, const float *__restrict__ emb_con,
-                                                    const float *__restrict__ emb_abn, int H, float margin_c,
-                                                    float *__restrict__ losses4, float *__restrict__ d_logits,
-                                                    float *__restrict__ g_aff, float *__restrict__ dD) {
+                                                    int A, float margin_c, float *__restrict__ losses4,
+                                                    float *__restrict__ d_logits, float *__restrict__ g_aff) {
   __shared__ float red[16];
   const int L = Nn + A;
   float s_bce = 0.f, s_n = 0.f, s_a = 0.f;
@@ -287,23 +285,54 @@ __global__ void __launch_bounds__(1024) k_full_loss(const float *__restrict__ lo
   const float m = margin_c - (an - ab);
   const float active = m >= 0.f ? 1.f : 0.f;
   for (int i = threadIdx.x; i < L; i += 1024) g_aff[i] = active * (i < Nn ? -1.0f / (float)Nn : 1.0f / (float)A);
-  // reconstruction: column norms over the A outliers
-  float s_rec = 0.f;
-  for (int h = threadIdx.x; h < H; h += 1024) {
+  if (threadIdx.x == 0) {
+    const float margin = fmaxf(m, 0.f);
+    losses4[0] = margin + bce; losses4[1] = margin; losses4[2] = bce; losses4[3] = 0.f;     // k_rec_apply adds the reconstruction term
+  }
+}
+
+// Reconstruction term rec = mean_h sqrt(sum_a D[a][h]^2), D = emb_con - emb_abn (A x H; the axis quirk of run.py:207-208),
+// and dD = d total / d D = D / (H * colnorm).  A single workgroup walking the A rows for every column took 0.44 ms at
+// T-Finance size (A = 844), 3 % of the epoch; here the rows are cut into blocks of 32:
+//   k_rec_part : partial column sums of squares per row block                       -> ws[block][H]
+//   k_rec_apply: column norms from the partials (block order, identical in every workgroup), dD for the block's rows;
+//                workgroup 0 also reduces rec and adds it to the loss record
+constexpr int REC_ROWS = 32;
+__global__ void __launch_bounds__(256) k_rec_part(const float *__restrict__ emb_con, const float *__restrict__ emb_abn, int A, int H,
+                                                  float *__restrict__ ws) {
+  const int a0 = blockIdx.x * REC_ROWS, a1 = min(A, a0 + REC_ROWS);
+  for (int h = threadIdx.x; h < H; h += 256) {
     float ss = 0.f;
-    for (int a = 0; a < A; ++a) { const float d = emb_con[(int64_t)a * H + h] - emb_abn[(int64_t)a * H + h]; ss = fmaf(d, d, ss); }
+    for (int a = a0; a < a1; ++a) { const float d = emb_con[(int64_t)a * H + h] - emb_abn[(int64_t)a * H + h]; ss = fmaf(d, d, ss); }
+    ws[(int64_t)blockIdx.x * H + h] = ss;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_rec_apply(const float *__restrict__ emb_con, const float *__restrict__ emb_abn, int A, int H,
+                                                   const float *__restrict__ ws, int n_blocks, float *__restrict__ dD,
+                                                   float *__restrict__ losses4) {
+  __shared__ float red[4];
+  const int a0 = blockIdx.x * REC_ROWS, a1 = min(A, a0 + REC_ROWS);
+  float s_rec = 0.f;
+  for (int h = threadIdx.x; h < H; h += 256) {
+    float ss = 0.f;
+    for (int b = 0; b < n_blocks; ++b) ss += ws[(int64_t)b * H + h];          // fixed order
     const float nrm = sqrtf(ss);
     s_rec += nrm;
     const float k = 1.0f / ((float)H * nrm);
-    for (int a = 0; a < A; ++a) {
+    for (int a = a0; a < a1; ++a) {
       const float d = emb_con[(int64_t)a * H + h] - emb_abn[(int64_t)a * H + h];
       dD[(int64_t)a * H + h] = d * k;
     }
   }
-  const float rec = block_sum_1024(s_rec, red) / (float)H;
+  if (blockIdx.x != 0) return;
+  const float w = wave_sum(s_rec);
+  if (lane_id() == 0) red[threadIdx.x >> 6] = w;
+  __syncthreads();
   if (threadIdx.x == 0) {
-    const float margin = fmaxf(m, 0.f);
-    losses4[0] = margin + bce + rec; losses4[1] = margin; losses4[2] = bce; losses4[3] = rec;
+    const float rec = ((red[0] + red[1]) + (red[2] + red[3])) / (float)H;
+    losses4[3] = rec;
+    losses4[0] += rec;                                                         // total = margin + bce + rec  (run.py:210)
   }
 }
 
@@ -414,12 +443,18 @@ int ggad_rows_scale_f32(const float *X, const int32_t *sel, const float *coef, i
   return GGAD_OK;
 }
 
+int64_t ggad_full_loss_workspace_elems(int32_t n_out, int32_t H) { return (int64_t)((n_out + REC_ROWS - 1) / REC_ROWS) * H; }
+
 int ggad_full_loss_f32(const float *logits, const float *aff, int32_t n_normal, int32_t n_out, const float *emb_con,
                        const float *emb_abn, int32_t H, float margin, float *losses4, float *d_logits, float *g_aff,
-                       float *dD, ggad_stream_t stream) {
-  GGAD_REQUIRE(logits && aff && emb_con && emb_abn && losses4 && d_logits && g_aff && dD && n_normal >= 1 && n_out >= 1 && H >= 1);
-  k_full_loss<<<dim3(1), dim3(1024), 0, as_stream(stream)>>>(logits, aff, n_normal, n_out, emb_con, emb_abn, H, margin, losses4,
-                                                            d_logits, g_aff, dD);
+                       float *dD, float *workspace, ggad_stream_t stream) {
+  GGAD_REQUIRE(logits && aff && emb_con && emb_abn && losses4 && d_logits && g_aff && dD && workspace);
+  GGAD_REQUIRE(n_normal >= 1 && n_out >= 1 && H >= 1);
+  hipStream_t st = as_stream(stream);
+  const int nb = (n_out + REC_ROWS - 1) / REC_ROWS;
+  k_full_loss<<<dim3(1), dim3(1024), 0, st>>>(logits, aff, n_normal, n_out, margin, losses4, d_logits, g_aff);
+  k_rec_part<<<dim3(nb), dim3(256), 0, st>>>(emb_con, emb_abn, n_out, H, workspace);
+  k_rec_apply<<<dim3(nb), dim3(256), 0, st>>>(emb_con, emb_abn, n_out, H, workspace, nb, dD, losses4);
   GGAD_CHECK_LAUNCH("full_loss_f32");
   return GGAD_OK;
 }

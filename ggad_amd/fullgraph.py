@@ -264,8 +264,12 @@ class GgadLossFn(torch.autograd.Function):
         g_aff = torch.empty(L, dtype=torch.float32, device=dev)
         emb_con, emb_abn, logits = emb_con.contiguous(), emb_abn.contiguous(), logits.contiguous()
         dD = torch.empty_like(emb_con)
+        ws = ls.get("loss_ws")
+        if ws is None:
+            ws = ls["loss_ws"] = torch.empty(int(_lib.load().ggad_full_loss_workspace_elems(ls["n_out"], h)), dtype=torch.float32,
+                                             device=dev)
         call("ggad_full_loss_f32", ptr(logits), ptr(aff), ls["n_normal"], ls["n_out"], ptr(emb_con), ptr(emb_abn), h,
-             float(margin), ptr(losses), ptr(d_logits), ptr(g_aff), ptr(dD))
+             float(margin), ptr(losses), ptr(d_logits), ptr(g_aff), ptr(dD), ptr(ws))
         ctx.save_for_backward(en, inv, s_j, g_aff, d_logits, dD)
         ctx.adj, ctx.ls = adj, ls
         ctx.affinity = aff

@@ -118,6 +118,16 @@ class Model(nn.Module):
         self.read = {"max": MaxReadout, "min": MinReadout, "avg": AvgReadout, "weighted_sum": WSReadout}[readout]()
         self.disc = Discriminator(n_h, negsamp_round)
 
+    def _index(self, idx, dev):
+        """Device copy of an index list, made once per list object (the lists of run.py never change between epochs;
+        a host -> device copy per forward would also break hipGraph capture of the epoch)."""
+        cache = self.__dict__.setdefault("_idx_cache", {})
+        key = (id(idx), len(idx), str(dev))
+        hit = cache.get(key)
+        if hit is None or hit[0] is not idx:
+            hit = cache[key] = (idx, torch.as_tensor(list(idx), dtype=torch.long, device=dev))
+        return hit[1]
+
     def _score(self, x):
         f = LinearFn.apply(x, self.fc1.weight, True)                       # fc1 + relu     model.py:176-177
         f = LinearFn.apply(f, self.fc2.weight, True)                       # fc2 + relu     :178-179
@@ -129,17 +139,22 @@ class Model(nn.Module):
         x = seq1.reshape(-1, seq1.shape[-1]).to(dev)
         h_1 = GcnLayerFn.apply(x, self.gcn1.fc.weight, self.gcn1.bias, self.gcn1.act.weight, fa)
         emb = GcnLayerFn.apply(h_1, self.gcn2.fc.weight, self.gcn2.bias, self.gcn2.act.weight, fa)      # (N, H)
-        abn = torch.as_tensor(list(sample_abnormal_idx), dtype=torch.long, device=dev)
+        abn = self._index(sample_abnormal_idx, dev)
         emb_abnormal = emb[abn].unsqueeze(0)
-        noise = torch.randn(emb_abnormal.size()) * args.var + args.mean                                 # CPU generator, :143
-        emb_abnormal = emb_abnormal + noise.to(dev)
+        override = self.__dict__.get("noise_override")
+        if override is not None:
+            # captured epoch (run.py): the caller drew the very same CPU noise and copied it into this static device buffer
+            emb_abnormal = emb_abnormal + override
+        else:
+            noise = torch.randn(emb_abnormal.size()) * args.var + args.mean                             # CPU generator, :143
+            emb_abnormal = emb_abnormal + noise.to(dev)
         emb_con = None
         emb_combine = None
         if train_flag:
             rows_sel, sub_t = fa.abn_structs(sample_abnormal_idx)
             emb_con = SpmmRowsFn.apply(emb, fa, rows_sel, sub_t)                                        # :151-155
             emb_con = LinearFn.apply(emb_con, self.fc4.weight, True)                                    # relu(fc4(.))  :156
-            nrm = torch.as_tensor(list(normal_idx), dtype=torch.long, device=dev)
+            nrm = self._index(normal_idx, dev)
             emb_combine = torch.cat((emb[nrm], emb_con), 0)                                             # :159
             f_3 = self._score(emb_combine)
             emb = emb.index_copy(0, abn, emb_con)                                                       # :182 (in-place there)

@@ -347,9 +347,10 @@ int ggad_rows_scale_f32(const float *X, const int32_t *sel, const float *coef, i
 /* The scalar part of the loss block of run.py:165-210 and its gradients: logits[L], aff[L] (L = n_normal + n_out,
  * normal_idx entries first), emb_con / emb_abn (n_out x H).  losses4 = {total, margin, bce, rec};
  * d_logits[L]; g_aff[L] = d total / d aff; dD = d total / d (emb_con - emb_abn). */
+int64_t ggad_full_loss_workspace_elems(int32_t n_out, int32_t H);   /* floats of `workspace` (partial column sums of the recon term) */
 int ggad_full_loss_f32(const float *logits, const float *aff, int32_t n_normal, int32_t n_out, const float *emb_con,
                        const float *emb_abn, int32_t H, float margin, float *losses4, float *d_logits, float *g_aff,
-                       float *dD, ggad_stream_t stream);
+                       float *dD, float *workspace, ggad_stream_t stream);
 
 /* torch.optim.Adam.step on a flat fp32 block; uses step index *step_counter + 1 and (bump_after != 0) advances it. */
 int ggad_adam_f32(float *params, float *exp_avg, float *exp_avg_sq, const float *grads, int64_t n, float lr,

@@ -129,3 +129,21 @@ def test_gcn_layer_accepts_dense_adjacency_like_the_reference(g_full_reddit):
     ref = torch.nn.functional.prelu(torch.bmm(dense, x @ layer.fc.weight.detach().cpu().t()) + layer.bias.detach().cpu(),
                                     layer.act.weight.detach().cpu())
     np.testing.assert_allclose(out.detach().cpu().numpy(), ref.numpy(), atol=3e-6)
+
+
+def test_run_py_captured_epoch_equals_eager():
+    """run.py replays a captured hipGraph of the training epoch after two eager epochs; losses, AUROC and AP printed
+    along the way must be exactly those of the all-eager run (same kernels, same order, noise from the same CPU draws)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for extra in ([], ["--no_graph"]):
+        r = subprocess.run([sys.executable, os.path.join(root, "run.py"), "--dataset", "reddit", "--synthetic", "--num_epoch", "13"] + extra,
+                           capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        keep = [l for l in r.stdout.splitlines() if l.startswith("Epoch:") or l.startswith("Testing")]
+        assert len(keep) >= 7 * 4 + 4
+        outs.append(keep)
+    assert outs[0] == outs[1]
