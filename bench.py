@@ -112,7 +112,16 @@ def main():
                             world_size=world, allreduce=allreduce, packed=(a.hop2 == "packed"),
                             hop2=(a.hop2 if a.hop2 in ("tiled", "ktile", "ldsw") else "global"), overlap=not a.no_overlap, chain=a.chain, dense_cus=a.dense_cus)
     if a.dp_path and world == 1:
-        trainer.allreduce = lambda t: None
+        if os.environ.get("GGAD_BENCH_REAL_ALLREDUCE") == "1":
+            # one-rank RCCL group: exercises ProcessGroupNCCL on the CU-masked dense stream from the C step loop's callback
+            import torch.distributed as dist1
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29577")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist1.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            trainer.allreduce = lambda t: dist1.all_reduce(t, op=dist1.ReduceOp.SUM)
+        else:
+            trainer.allreduce = lambda t: None
     torch.manual_seed(a.seed)
     w = torch.nn.init.xavier_uniform_(torch.empty(1, a.emb))
     W = torch.nn.init.xavier_uniform_(torch.empty(a.emb, a.feat))
@@ -256,9 +265,29 @@ def main():
             "gpu_over_cpu": (value / cpu["value"]) if cpu else None,
             "first_loss": float(losses[0][0]), "last_loss": float(losses[-1][0]), "setup_s": setup_s,
         }
-        print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    else:
+        out = None
+    # The JSON line must be the LAST thing on stdout: RCCL prints its version banner through C stdio (buffered, flushed at
+    # exit, i.e. after a Python print).  Every rank flushes its C streams, all ranks meet, THEN rank 0 prints; the process
+    # group is torn down afterwards.
+    def flush_c():
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        sys.stdout.flush()
+    flush_c()
+    pg = torch.distributed.is_available() and torch.distributed.is_initialized()
+    if pg:
+        torch.distributed.barrier()
+        torch.cuda.synchronize()
+        flush_c()
+    if out is not None:
+        print(json.dumps(out), flush=True)
+    if pg:
+        torch.distributed.destroy_process_group()
+        os._exit(0) if rank != 0 else None       # non-zero ranks leave without running exit-time stdio flushes
 
 
 if __name__ == "__main__":
