@@ -14,6 +14,8 @@
 // B[k = l >> 5][n = l & 31]: 32 consecutive lanes read 32 consecutive words -> conflict-free ds_read_b32.
 // Long-K / few-tile shapes (weight gradients: K = number of nodes) are split along K over gridDim.z into
 // a workspace and summed by a second kernel in a fixed order (deterministic, no float atomics).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -33,7 +35,7 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 // element relative to a wave-uniform tile pointer (SGPR base + VGPR offset addressing), the row / column bounds are
 // folded into those offsets once (out-of-range elements point at element 0 and are zeroed by a mask bit), and only
 // the last K-tile checks k.
-template <bool A_KFAST, bool B_NFAST, int TM, bool VEC>
+template <bool A_KFAST, bool B_NFAST, int TM, bool VEC, bool PART>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) k_gemm_f32(const float *__restrict__ A, const float *__restrict__ B,
                                                   float *__restrict__ C, int M, int N, int K, int sam, int sak,
                                                   int sbk, int sbn, int64_t ldc, const float *__restrict__ bias,
@@ -75,54 +77,87 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
       else { k = tid & 31; n = (tid >> 5) + 8 * p; }
     }
   };
+  // static validity per float of every element along the non-k index (bit VW * p + j); a float4 along m (n) may straddle the
+  // edge of the matrix when M (N) is not a multiple of 4
 #pragma unroll
   for (int p = 0; p < NA; ++p) {
     int m, k; a_mk(p, m, k);
-    const bool in = m0 + m < M;          // VEC and m-fast: M % 4 == 0, so a float4 is inside or outside as a whole
+    const bool in = m0 + m < M;
     oa[p] = in ? m * sam + k * sak : 0;
-    amask |= (in ? 1u : 0u) << p;
+#pragma unroll
+    for (int j = 0; j < VW; ++j) amask |= ((m0 + m + ((VEC && !A_KFAST) ? j : 0) < M) ? 1u : 0u) << (VW * p + j);
   }
 #pragma unroll
   for (int p = 0; p < NB; ++p) {
     int n, k; b_nk(p, n, k);
     const bool in = n0 + n < N;
     ob[p] = in ? k * sbk + n * sbn : 0;
-    bmask |= (in ? 1u : 0u) << p;
+#pragma unroll
+    for (int j = 0; j < VW; ++j) bmask |= ((n0 + n + ((VEC && B_NFAST) ? j : 0) < N) ? 1u : 0u) << (VW * p + j);
   }
+  // can a float4 of this workgroup straddle an edge along m / n?  (uniform; along k it depends on the K-tile, see fetch)
+  const bool a_edge = VEC && PART && !A_KFAST && (m0 + TM > M) && (M & 3);
+  const bool b_edge = VEC && PART && B_NFAST && (n0 + BN > N) && (N & 3);
   const float *At = A + (int64_t)m0 * sam + (int64_t)k_begin * sak;     // wave-uniform tile pointers
   const float *Bt = B + (int64_t)n0 * sbn + (int64_t)k_begin * sbk;
   typedef float fvec __attribute__((ext_vector_type(4)));
   float ra[NA * VW], rb[NB * VW];
   unsigned oka = 0, okb = 0;             // validity of the elements fetched last
   auto fetch = [&](int k0) {
-    const int klim = k_end - k0;         // k >= klim lies past the end of this split (last K-tile only; multiple of 4 in VEC mode)
+    const int klim = k_end - k0;         // k >= klim lies past the end of this split (last K-tile only)
     oka = 0; okb = 0;
+    // VEC: float4 loads unless one of them could straddle an edge in THIS tile (uniform test) -- then the same elements are
+    // fetched float by float with per-float masks (last K-tile when the split length is not a multiple of 4, edge row /
+    // column tiles when M / N are not)
+    // (PART = false is instantiated for shapes whose extents are all multiples of 4: no second code path at all)
+    const bool partial = VEC && PART && (a_edge || b_edge || ((klim < BK) && (klim & 3) && (A_KFAST || !B_NFAST)));
+    if (!partial) {
 #pragma unroll
-    for (int p = 0; p < NA; ++p) {       // branch-free: every load is issued before the first one is consumed
-      int m, k; a_mk(p, m, k);
-      const unsigned ok = ((amask >> p) & 1u) & (unsigned)(k < klim);
-      oka |= ok << p;
-      const float *src = At + (ok ? oa[p] : 0);
-      if constexpr (VEC) {
-        if (A_KFAST || true) {
+      for (int p = 0; p < NA; ++p) {     // branch-free: every load is issued before the first one is consumed
+        int m, k; a_mk(p, m, k);
+        const unsigned ok = ((amask >> (VW * p)) & 1u) & (unsigned)(k < klim);
+        oka |= (ok ? ((1u << VW) - 1u) : 0u) << (VW * p);
+        const float *src = At + (ok ? oa[p] : 0);
+        if constexpr (VEC) {
           const fvec v = *reinterpret_cast<const fvec __attribute__((aligned(4))) *>(src);
           ra[4 * p] = v.x; ra[4 * p + 1] = v.y; ra[4 * p + 2] = v.z; ra[4 * p + 3] = v.w;
+        } else {
+          ra[p] = *src;
         }
-      } else {
-        ra[p] = *src;
       }
-    }
 #pragma unroll
-    for (int p = 0; p < NB; ++p) {
-      int n, k; b_nk(p, n, k);
-      const unsigned ok = ((bmask >> p) & 1u) & (unsigned)(k < klim);
-      okb |= ok << p;
-      const float *src = Bt + (ok ? ob[p] : 0);
-      if constexpr (VEC) {
-        const fvec v = *reinterpret_cast<const fvec __attribute__((aligned(4))) *>(src);
-        rb[4 * p] = v.x; rb[4 * p + 1] = v.y; rb[4 * p + 2] = v.z; rb[4 * p + 3] = v.w;
-      } else {
-        rb[p] = *src;
+      for (int p = 0; p < NB; ++p) {
+        int n, k; b_nk(p, n, k);
+        const unsigned ok = ((bmask >> (VW * p)) & 1u) & (unsigned)(k < klim);
+        okb |= (ok ? ((1u << VW) - 1u) : 0u) << (VW * p);
+        const float *src = Bt + (ok ? ob[p] : 0);
+        if constexpr (VEC) {
+          const fvec v = *reinterpret_cast<const fvec __attribute__((aligned(4))) *>(src);
+          rb[4 * p] = v.x; rb[4 * p + 1] = v.y; rb[4 * p + 2] = v.z; rb[4 * p + 3] = v.w;
+        } else {
+          rb[p] = *src;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < NA; ++p) {
+        int m, k; a_mk(p, m, k);
+#pragma unroll
+        for (int j = 0; j < VW; ++j) {
+          const unsigned ok = ((amask >> (VW * p + j)) & 1u) & (unsigned)(k + (A_KFAST ? j : 0) < klim);
+          oka |= ok << (VW * p + j);
+          ra[VW * p + j] = At[ok ? oa[p] + j : 0];            // the fastest index has unit stride
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < NB; ++p) {
+        int n, k; b_nk(p, n, k);
+#pragma unroll
+        for (int j = 0; j < VW; ++j) {
+          const unsigned ok = ((bmask >> (VW * p + j)) & 1u) & (unsigned)(k + (B_NFAST ? 0 : j) < klim);
+          okb |= ok << (VW * p + j);
+          rb[VW * p + j] = Bt[ok ? ob[p] + j : 0];
+        }
       }
     }
     At += (int64_t)BK * sak;             // (the masks are applied in stash(): nothing here waits for the loads)
@@ -132,20 +167,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
 #pragma unroll
     for (int p = 0; p < NA; ++p) {
       int m, k; a_mk(p, m, k);
-      const bool ok = (oka >> p) & 1u;
 #pragma unroll
       for (int j = 0; j < VW; ++j) {
-        const float v = ok ? ra[VW * p + j] : 0.0f;
+        const float v = ((oka >> (VW * p + j)) & 1u) ? ra[VW * p + j] : 0.0f;
         if (A_KFAST) As[k + j][m] = v; else As[k][m + j] = v;
       }
     }
 #pragma unroll
     for (int p = 0; p < NB; ++p) {
       int n, k; b_nk(p, n, k);
-      const bool ok = (okb >> p) & 1u;
 #pragma unroll
       for (int j = 0; j < VW; ++j) {
-        const float v = ok ? rb[VW * p + j] : 0.0f;
+        const float v = ((okb >> (VW * p + j)) & 1u) ? rb[VW * p + j] : 0.0f;
         if (B_NFAST) Bs[k][n + j] = v; else Bs[k + j][n] = v;
       }
     }
@@ -210,17 +243,20 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(const float *__restrict__
   C[(int64_t)m * ldc + n] = s;
 }
 
-template <int TM, bool VEC, typename... Args>
+template <int TM, bool VEC, bool PART, typename... Args>
 static void launch_gemm2(bool a_kfast, bool b_nfast, dim3 grid, hipStream_t st, Args... args) {
-  if (a_kfast && b_nfast) k_gemm_f32<true, true, TM, VEC><<<grid, dim3(256), 0, st>>>(args...);
-  else if (a_kfast) k_gemm_f32<true, false, TM, VEC><<<grid, dim3(256), 0, st>>>(args...);
-  else if (b_nfast) k_gemm_f32<false, true, TM, VEC><<<grid, dim3(256), 0, st>>>(args...);
-  else k_gemm_f32<false, false, TM, VEC><<<grid, dim3(256), 0, st>>>(args...);
+  if (a_kfast && b_nfast) k_gemm_f32<true, true, TM, VEC, PART><<<grid, dim3(256), 0, st>>>(args...);
+  else if (a_kfast) k_gemm_f32<true, false, TM, VEC, PART><<<grid, dim3(256), 0, st>>>(args...);
+  else if (b_nfast) k_gemm_f32<false, true, TM, VEC, PART><<<grid, dim3(256), 0, st>>>(args...);
+  else k_gemm_f32<false, false, TM, VEC, PART><<<grid, dim3(256), 0, st>>>(args...);
 }
+// mode 0: per-float loads; 1: float4 loads, every extent along a fastest index is a multiple of 4; 2: float4 loads with the
+// per-float path for tiles where a float4 could straddle an edge
 template <int TM, typename... Args>
-static void launch_gemm(bool vec, bool a_kfast, bool b_nfast, dim3 grid, hipStream_t st, Args... args) {
-  if (vec) launch_gemm2<TM, true>(a_kfast, b_nfast, grid, st, args...);
-  else launch_gemm2<TM, false>(a_kfast, b_nfast, grid, st, args...);
+static void launch_gemm(int mode, bool a_kfast, bool b_nfast, dim3 grid, hipStream_t st, Args... args) {
+  if (mode == 1) launch_gemm2<TM, true, false>(a_kfast, b_nfast, grid, st, args...);
+  else if (mode == 2) launch_gemm2<TM, true, true>(a_kfast, b_nfast, grid, st, args...);
+  else launch_gemm2<TM, false, false>(a_kfast, b_nfast, grid, st, args...);
 }
 
 // Row tile: 128 when that still gives >= 3 workgroups per CU (they hide each other's global-load latency: the kernel has one
@@ -256,9 +292,11 @@ int ggad_gemm_f32(const float *A, const float *B, float *C, int32_t M, int32_t N
   const int tm = pick_tm(M, N);
   const int gx = (N + BN - 1) / BN, gy = (M + tm - 1) / tm;
   const bool a_kfast = (sak == 1), b_nfast = (sbn == 1);
-  // float4 loads along each operand's fastest index: its extent must be a multiple of 4 (a float4 never straddles the end of
-  // a row, so nothing is read outside the tensors), K-splits are multiples of BK
-  const bool vec = ((a_kfast ? K : M) % 4 == 0) && ((b_nfast ? N : K) % 4 == 0);
+  // float4 loads along each operand's fastest index; tiles in which a float4 could straddle the end of a row / column / split
+  // fall back to per-float loads inside the kernel, so nothing is read outside the tensors for any M, N, K
+  static const bool force_scalar = [] { const char *e = getenv("GGAD_GEMM_SCALAR"); return e && e[0] == '1'; }();
+  const bool aligned = ((a_kfast ? K : M) % 4 == 0) && ((b_nfast ? N : K) % 4 == 0);
+  const int vec = force_scalar ? 0 : (aligned ? 1 : 2);
   const int64_t ws_elems = workspace ? ggad_gemm_workspace_elems(M, N, K) : 0;
   if (ws_elems == 0) {
     if (tm == 128)

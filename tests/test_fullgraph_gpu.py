@@ -28,7 +28,8 @@ def _adj(g):
     return FG.FullGraphAdj(adj_norm, raw, DEV)
 
 
-@pytest.mark.parametrize("shape", [(70, 50, 33), (300, 300, 7535), (1, 75, 1000), (130, 1, 40), (64, 64, 16), (257, 129, 3000)])
+@pytest.mark.parametrize("shape", [(70, 50, 33), (300, 300, 7535), (1, 75, 1000), (130, 1, 40), (64, 64, 16), (257, 129, 3000),
+                                   (132, 68, 36), (131, 67, 745), (7535, 300, 745), (66, 302, 130)])
 def test_gemm_f32_all_layouts(shape):
     m, n, k = shape
     rng = np.random.default_rng(m + n + k)
