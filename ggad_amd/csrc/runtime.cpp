@@ -14,6 +14,9 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 
 #include "common.h"
 
@@ -151,17 +154,9 @@ int ggad_mt_get_state(const ggad_mt19937 *g, uint32_t *mt624_host, int32_t *inde
 
 uint32_t ggad_mt_getrandbits32(ggad_mt19937 *g) { return mt_next(g); }
 
-int ggad_mt_shuffle_i64(ggad_mt19937 *g, int64_t *data, int64_t n) {
-  if (!g || (!data && n > 0) || n < 0 || n > 0x7fffffffLL) return GGAD_E_INVALID;
-  // This loop IS the per-batch cost of the reference's schedule (55,275 dependent draws).  CPython's _randbelow redraws
-  // until the value is below the bound (rejected ~28 % of the time, unpredictably).  Three passes per MT block keep every
-  // loop simple enough for the compiler and the core: (1) temper the block (vectorised), (2) walk the tempered outputs with
-  // a branch-free accept step -- an accepted draw records its swap target for position i and moves on, a rejected one
-  // rewrites the same slot --, (3) apply the recorded swaps in order, prefetching the random targets ahead.  Same outputs
-  // consumed in the same order -> same permutation, same generator state.
-  static thread_local std::vector<int32_t> tgt;
-  if ((int64_t)tgt.size() < n + 16) tgt.resize((size_t)n + 16);
-  int32_t *T = tgt.data();                       // T[c] = swap partner of position n - 1 - c (c-th accepted draw)
+// ---- the two halves of random.shuffle: (1) consume the generator -> swap targets T[c] (partner of position n - 1 - c);
+// data-independent, so it can run ahead of (2) applying the swaps to a list.  T must hold n + 16 ints.
+static void shuffle_targets(ggad_mt19937 *g, int64_t n, int32_t *T) {
   static const bool avx2 = ggad_x86_has_avx2() != 0;
   const int64_t need = n - 1;                    // accepted draws of one shuffle
   int64_t c = 0;
@@ -221,6 +216,9 @@ int ggad_mt_shuffle_i64(ggad_mt19937 *g, int64_t *data, int64_t n) {
     }
     g->index += used;
   }
+}
+
+static void apply_swaps(int64_t *data, int64_t n, const int32_t *T) {
   for (int64_t k = n - 1; k >= 1; --k) {
     const int64_t cc = n - 1 - k;
     if (k >= 16) __builtin_prefetch(&data[T[cc + 16]], 1, 1);
@@ -229,6 +227,99 @@ int ggad_mt_shuffle_i64(ggad_mt19937 *g, int64_t *data, int64_t n) {
     data[k] = data[j];
     data[j] = t;
   }
+}
+
+int ggad_mt_shuffle_i64(ggad_mt19937 *g, int64_t *data, int64_t n) {
+  if (!g || (!data && n > 0) || n < 0 || n > 0x7fffffffLL) return GGAD_E_INVALID;
+  // This IS the per-batch cost of the reference's schedule (55,275 dependent draws).  CPython's _randbelow redraws
+  // until the value is below the bound (rejected ~28 % of the time, unpredictably).  Passes per MT block: (1) temper the
+  // block (vectorised), (2) walk the tempered outputs, 8 at a time where the accept rule cannot depend on the walk,
+  // (3) apply the recorded swaps in order, prefetching the random targets ahead.  Same outputs consumed in the same
+  // order -> same permutation, same generator state.
+  static thread_local std::vector<int32_t> tgt;
+  if ((int64_t)tgt.size() < n + 16) tgt.resize((size_t)n + 16);
+  if (n >= 2) {
+    shuffle_targets(g, n, tgt.data());
+    apply_swaps(data, n, tgt.data());
+  }
+  return GGAD_OK;
+}
+
+/* The reference's batch stream (src/model_handler.py:310-345) for `count` consecutive batches, two threads deep: a helper
+ * thread walks the generator (targets of the per-epoch shuffle of `train` and of the per-batch shuffle of `pool`), this
+ * thread applies the swaps and copies every batch out: train[i0:i1] ++ pool[:n_pseudo].  *in_epoch_io is the index of the
+ * next batch inside the epoch (>= batches_per_epoch forces the epoch shuffle first).  out_nodes: count x (batch_size +
+ * n_pseudo) int64, out_len[b] = nodes of batch b.  Same permutations and generator state as the one-call-per-shuffle path. */
+int ggad_sched_batches(ggad_mt19937 *g, int64_t *train, int64_t n_train, int64_t *pool, int64_t n_pool, int32_t batch_size,
+                       int32_t n_pseudo, int32_t batches_per_epoch, int32_t *in_epoch_io, int32_t count, int64_t *out_nodes,
+                       int32_t *out_len) {
+  if (!g || !train || !pool || !in_epoch_io || !out_nodes || !out_len) return GGAD_E_INVALID;
+  if (n_train < 1 || n_pool < n_pseudo || batch_size < 1 || n_pseudo < 0 || batches_per_epoch < 1 || count < 0) return GGAD_E_INVALID;
+  if (n_train > 0x7fffffffLL || n_pool > 0x7fffffffLL) return GGAD_E_INVALID;
+  if (count == 0) return GGAD_OK;
+  // work items in stream order: kind 0 = epoch shuffle of train, kind 1 = batch shuffle of pool
+  struct Item { int kind; };
+  std::vector<Item> items;
+  int ie = *in_epoch_io;
+  for (int b = 0; b < count; ++b) {
+    if (ie >= batches_per_epoch) { items.push_back({0}); ie = 0; }
+    items.push_back({1});
+    ++ie;
+  }
+  constexpr int RING = 4;
+  std::vector<int32_t> ring[RING];
+  const int64_t tmax = (n_train > n_pool ? n_train : n_pool) + 16;
+  for (auto &r : ring) r.resize((size_t)tmax);
+  std::mutex mu;
+  std::condition_variable cv;
+  size_t produced = 0, consumed = 0;
+  std::thread producer([&] {
+    for (size_t i = 0; i < items.size(); ++i) {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return produced - consumed < RING; });
+      }
+      const int64_t n = items[i].kind == 0 ? n_train : n_pool;
+      if (n >= 2) shuffle_targets(g, n, ring[i % RING].data());
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        ++produced;
+      }
+      cv.notify_all();
+    }
+  });
+  ie = *in_epoch_io;
+  const int stride = batch_size + n_pseudo;
+  int b = 0;
+  for (size_t i = 0; i < items.size(); ++i) {
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return produced > i; });
+    }
+    if (items[i].kind == 0) {
+      if (n_train >= 2) apply_swaps(train, n_train, ring[i % RING].data());
+      ie = 0;
+    } else {
+      if (n_pool >= 2) apply_swaps(pool, n_pool, ring[i % RING].data());
+      const int64_t i0 = (int64_t)ie * batch_size;
+      int64_t i1 = i0 + batch_size;
+      if (i1 > n_train) i1 = n_train;
+      const int64_t nt = i1 > i0 ? i1 - i0 : 0;
+      int64_t *dst = out_nodes + (int64_t)b * stride;
+      if (nt > 0) std::memcpy(dst, train + i0, (size_t)nt * sizeof(int64_t));
+      std::memcpy(dst + nt, pool, (size_t)n_pseudo * sizeof(int64_t));
+      out_len[b] = (int32_t)(nt + n_pseudo);
+      ++b;
+      ++ie;
+    }
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      ++consumed;
+    }
+    cv.notify_all();
+  }
+  producer.join();
+  *in_epoch_io = ie;
   return GGAD_OK;
 }
 

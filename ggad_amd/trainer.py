@@ -54,14 +54,25 @@ class BatchSchedule:
         return nodes, self.labels[nodes].astype(np.int64)
 
     def next_batches(self, count: int, rank: int = 0, world: int = 1) -> Tuple[List[np.ndarray], List[np.ndarray]]:
-        """`count` optimiser steps worth of batches for this rank (every rank advances the same stream)."""
-        nodes, labs = [], []
-        for s in range(count):
-            for r in range(world):
-                n, l = self.next_batch()
-                if r == rank:
-                    nodes.append(n)
-                    labs.append(l)
+        """`count` optimiser steps worth of batches for this rank (every rank advances the same stream).  One native call:
+        the generator walk of the next shuffle overlaps the swaps of the current one (`ggad_sched_batches`)."""
+        import ctypes
+        total = int(count) * int(world)
+        if total == 0:
+            return [], []
+        lib = self.rng._lib
+        stride = self.bs + self.n_pseudo
+        out = np.empty((total, stride), dtype=np.int64)
+        lens = np.empty(total, dtype=np.int32)
+        ie = ctypes.c_int32(self._in_epoch)
+        from . import _lib
+        _lib.check(lib.ggad_sched_batches(self.rng._h, self.train.ctypes.data, len(self.train), self.pool.ctypes.data, len(self.pool),
+                                          self.bs, self.n_pseudo, self.bpe, ctypes.byref(ie), total, out.ctypes.data,
+                                          lens.ctypes.data), "ggad_sched_batches")
+        self._in_epoch = int(ie.value)
+        self.global_batch += total
+        nodes = [out[s * world + rank, :lens[s * world + rank]].copy() for s in range(count)]
+        labs = [self.labels[n].astype(np.int64) for n in nodes]
         return nodes, labs
 
 

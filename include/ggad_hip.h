@@ -372,6 +372,14 @@ int ggad_mt_get_state(const ggad_mt19937 *, uint32_t *mt624_host, int32_t *index
 /* random.shuffle(list) in place on an int64 array. */
 int ggad_mt_shuffle_i64(ggad_mt19937 *, int64_t *data_host, int64_t n);
 uint32_t ggad_mt_getrandbits32(ggad_mt19937 *);
+/* `count` consecutive batches of the reference's stream (src/model_handler.py:310-345: random.shuffle(train) at every
+ * epoch start, random.shuffle(pool) before every batch, batch = train[i0:i1] ++ pool[:n_pseudo]) in one call, the
+ * generator walk running one shuffle ahead of the swaps in a helper thread.  HOST pointers; train / pool are shuffled in
+ * place exactly as the per-shuffle calls would; *in_epoch_io = index of the next batch in its epoch (>= batches_per_epoch:
+ * shuffle train first).  out_nodes: count x (batch_size + n_pseudo), out_len[count]. */
+int ggad_sched_batches(ggad_mt19937 *, int64_t *train, int64_t n_train, int64_t *pool, int64_t n_pool, int32_t batch_size,
+                       int32_t n_pseudo, int32_t batches_per_epoch, int32_t *in_epoch_io, int32_t count, int64_t *out_nodes,
+                       int32_t *out_len);
 
 #ifdef __cplusplus
 }

@@ -46,3 +46,38 @@ def test_state_exchange_with_cpython():
     # and back
     random.setstate(r.to_python_state())
     assert random.getrandbits(32) == r.getrandbits32()
+
+
+def test_native_batch_stream_equals_per_batch_path():
+    """`BatchSchedule.next_batches` (one native call, generator walk pipelined with the swaps) produces exactly the batches,
+    the list states and the generator state of the batch-by-batch path -- across epoch boundaries, for 1 and 3 ranks."""
+    import numpy as np
+    from ggad_amd.sampler import PyCompatRandom
+    from ggad_amd.trainer import BatchSchedule
+    n = 5000
+    labels = np.zeros(n, dtype=np.int64)
+    pool = np.arange(100, 700)
+    labels[pool] = 1
+    train = np.arange(1000, 4333)
+
+    def make():
+        return BatchSchedule(train.copy(), pool.copy(), labels, 150, PyCompatRandom(72), n_pseudo=50, batches_per_epoch=7)
+    a, b = make(), make()
+    ref = [a.next_batch() for _ in range(40)]
+    got_n, got_l = [], []
+    for k in (1, 5, 13, 21):                              # uneven call sizes: 40 batches in total
+        nn, ll = b.next_batches(k)
+        got_n += nn; got_l += ll
+    assert len(got_n) == 40
+    for (rn, rl), gn, gl in zip(ref, got_n, got_l):
+        assert np.array_equal(rn, gn) and np.array_equal(rl, gl)
+    assert np.array_equal(a.train, b.train) and np.array_equal(a.pool, b.pool)
+    assert a.rng.to_python_state() == b.rng.to_python_state() and a._in_epoch == b._in_epoch
+    # three ranks: rank r of step s gets global batch 3 s + r
+    c = make()
+    ref3 = [c.next_batch() for _ in range(12)]
+    for r in range(3):
+        d = make()
+        nn, _ = d.next_batches(4, rank=r, world=3)
+        for s_ in range(4):
+            assert np.array_equal(nn[s_], ref3[3 * s_ + r][0])
