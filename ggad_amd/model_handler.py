@@ -113,6 +113,7 @@ class ModelHandler(object):
         trainer = DGraphTrainer(graph, features.weight.data, args.emb_size, sched, chunk_batches=steps_per_epoch, rank=rank,
                                 world_size=world, allreduce=allreduce, engine=engine)
         self.trainer, self.model = trainer, gnn_model
+        trainer.start_stream(steps_per_epoch * args.num_epochs)        # sampler thread alive across the validation pauses
         total_time = 0.0
         epoch = 0
         while epoch < args.num_epochs:

@@ -126,6 +126,7 @@ class DGraphTrainer:
             self.side, self.hi = self._make_streams(feat.device, int(dense_cus))
         self.steps_done = 0
         self.prefetch = bool(prefetch)
+        self._stream = None
 
     def _make_streams(self, device, dense_cus: int):
         """(plan stream, dense stream).  dense_cus > 0: CU-masked HIP streams (dense chain on CUs [0, dense_cus), plan on
@@ -167,6 +168,47 @@ class DGraphTrainer:
             warnings.warn(f"CU-masked streams unavailable ({exc}); overlapping with plain streams")
             return torch.cuda.Stream(device=device, priority=0), torch.cuda.Stream(device=device, priority=-1)
 
+    def start_stream(self, total_steps: int) -> None:
+        """Persistent sampler thread for the next `total_steps` optimiser steps: it keeps up to 3 chunks of batches ready
+        ACROSS `run_steps` calls (the reference-exact sampler is the end-to-end bottleneck; a thread per call would sit
+        idle during validation and start every block with an empty queue).  It consumes exactly `total_steps` steps of the
+        stream, never more, so the generator state handed back after training is the reference's."""
+        import queue
+        import threading
+        if getattr(self, "_stream", None) is not None:
+            raise RuntimeError("a batch stream is already running")
+        q = queue.Queue(maxsize=3)
+        sizes = []
+        left = int(total_steps)
+        while left > 0:
+            sizes.append(min(self.chunk_batches, left))
+            left -= sizes[-1]
+
+        def produce():
+            try:
+                for k in sizes:
+                    q.put((k, self.schedule.next_batches(k, self.rank, self.world)))
+            except BaseException as exc:      # surface sampler errors in the consumer
+                q.put((0, exc))
+        th = threading.Thread(target=produce, daemon=True)
+        self._stream = dict(q=q, thread=th, left=int(total_steps))
+        th.start()
+
+    def _stream_take(self, k: int):
+        st = self._stream
+        kk, item = st["q"].get()
+        if isinstance(item, BaseException):
+            self._stream = None
+            raise item
+        if kk != k:
+            raise RuntimeError(f"run_steps asked for a chunk of {k} steps, the stream produced {kk}: call run_steps with "
+                               "multiples of chunk_batches while a stream is running")
+        st["left"] -= k
+        if st["left"] <= 0:
+            st["thread"].join()
+            self._stream = None
+        return item
+
     def run_steps(self, n_steps: int, prepared: Optional[Tuple[List[np.ndarray], List[np.ndarray]]] = None,
                   gather_hook=None) -> int:
         """Run n optimiser steps; returns nodes processed by THIS rank."""
@@ -178,7 +220,10 @@ class DGraphTrainer:
         pos = [0]
 
         producer = None
-        if prepared is None and self.prefetch and len(sizes) > 1:
+        stream = getattr(self, "_stream", None) if prepared is None else None
+        if stream is not None and n_steps > stream["left"]:
+            raise RuntimeError("run_steps beyond the end of the running batch stream")
+        if prepared is None and stream is None and self.prefetch and len(sizes) > 1:
             import queue
             import threading
             q = queue.Queue(maxsize=2)
@@ -197,6 +242,8 @@ class DGraphTrainer:
                 bn, bl = prepared[0][pos[0]:pos[0] + k], prepared[1][pos[0]:pos[0] + k]
                 pos[0] += k
                 return bn, bl
+            if stream is not None:
+                return self._stream_take(k)
             if producer is not None:
                 item = q.get()
                 if isinstance(item, BaseException):
