@@ -84,6 +84,9 @@ def main():
     random.seed(args.seed)
     if not torch.cuda.is_available():
         sys.exit("run.py needs an MI355X: the GGAD hot path has no CPU fallback")
+    # the only host-side tensor work left is the N(mean, var) noise (<= 844 x 300 floats per epoch): torch's default of one
+    # intra-op thread per core (128 on the MI355X box) turns it into a 1-90 ms lottery on a loaded host
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
     dev = torch.device("cuda", args.device)
     adj, features, ano_label, idx_test, normal_label_idx, abnormal_label_idx = load(args)
     if args.dataset in ["Amazon", "tf_finace", "reddit", "elliptic"]:                 # run.py:87 (typo kept: never T-Finance)

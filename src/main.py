@@ -98,6 +98,7 @@ if __name__ == "__main__":
     if a.num_epochs is not None:
         cfg["num_epochs"] = a.num_epochs
     init_distributed()
+    torch.set_num_threads(min(8, os.cpu_count() or 1))        # host tensors are tiny here; 128 intra-op threads only add jitter
     if a.synthetic:
         from ggad_amd import synth
         dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
