@@ -34,8 +34,11 @@ def normalize_features(mx: np.ndarray) -> np.ndarray:
     return r_inv.astype(np.float64)[:, None] * mx.astype(np.float64)
 
 
-def split_dgraphfin(labels: np.ndarray, seed: int, test_ratio: float = 0.67, with_test: bool = True) -> Dict[str, object]:
-    """The 'dgraphfin' branch of ModelHandler.__init__ (`src/model_handler.py:29-30,150-178`).
+def split_dgraphfin(labels: np.ndarray, seed: int, test_ratio: float = 0.67, with_test: bool = True,
+                    real_frac: float = 0.2, pseudo_frac: float = 0.05) -> Dict[str, object]:
+    """The 'dgraphfin' branch of ModelHandler.__init__ (`src/model_handler.py:29-30,150-178`).  The handlers of the
+    comparison models differ only in the two fractions: 0.15 / 0.10 (`src/model_handler_dominate.py:34,43`) and
+    0.15 / 0.05 (`src/model_handler_anomalydae.py:34,43`).
 
     Mutates a COPY of ``labels`` (pseudo anomalies get label 1, :165) and returns the lists the
     training loop uses.  Consumes the global python/numpy RNGs exactly like the reference."""
@@ -46,10 +49,10 @@ def split_dgraphfin(labels: np.ndarray, seed: int, test_ratio: float = 0.67, wit
     index = list(range(len(labels)))
     idx_normal = [i for i in index if labels[i] == 0]
     idx_real_abnormal = [i for i in index if labels[i] == 1]
-    idx_real_abnormal = idx_real_abnormal[0: int(len(idx_real_abnormal) * 0.2)]
+    idx_real_abnormal = idx_real_abnormal[0: int(len(idx_real_abnormal) * real_frac)]
     random.shuffle(idx_normal)
     idx_labeled = idx_normal[0: int(len(idx_normal) * 0.3)]
-    idx_anomaly = idx_labeled[0: int(len(idx_labeled) * 0.05)]
+    idx_anomaly = idx_labeled[0: int(len(idx_labeled) * pseudo_frac)]
     labels[idx_anomaly] = 1
     idx_train = list(set(idx_labeled).difference(set(idx_anomaly)))
     idx_train = idx_train + idx_real_abnormal                       # "contamination"

@@ -100,3 +100,42 @@ def test_sage(test_cases, labels, model, batch_size, thres=0.5, device_metrics=T
         print("Testing AP:", ap)
         print(f"   GNN TP: {tp}\tTN: {tn}\tFN: {fn}\tFP: {fp}")
     return f1_macro, f1_binary_1, f1_binary_0, auc_gnn, gmean
+
+
+def recon_scores(model, test_cases: Sequence[int], batch_size: int, test_attr, batches_per_launch: int = 1024):
+    """Per-node reconstruction error of the DOMINANT / AnomalyDAE baselines, batched EXACTLY like `test_recon`
+    (`src/utils.py:150-159`): consecutive slices of `batch_size` (the aggregation normalises per slice), many slices per
+    plan; the decoder is row-wise, so all rows of a plan go through it at once.  Returns a device tensor."""
+    enc = model.enc
+    dev = enc.weight.device
+    cases = np.asarray(test_cases, dtype=np.int64)
+    out = torch.empty(len(cases), dtype=torch.float32, device=dev)
+    attr = test_attr if isinstance(test_attr, torch.Tensor) else torch.as_tensor(np.asarray(test_attr))
+    attr = attr.to(device=dev, dtype=torch.float32)
+    from ._lib import call, ptr
+    from .graphsage import _as_graph
+    graph = _as_graph(enc.adj_lists, enc.features.weight.shape[0], dev)
+    per_launch = int(max(1, min(batches_per_launch, (1 << 29) // max(1, graph.n))))
+    step = per_launch * batch_size
+    with torch.no_grad():
+        for s in range(0, len(cases), step):
+            part = cases[s:s + step]
+            batches = [part[i:i + batch_size] for i in range(0, len(part), batch_size)]
+            x1, _ = enc.aggregator.aggregate(batches, graph, per_launch)
+            emb = enc.decode(x1).contiguous()
+            tgt = attr[torch.from_numpy(part).to(dev)].contiguous()
+            call("ggad_recon_rows_f32", ptr(emb), ptr(tgt), len(part), emb.shape[1], ptr(out[s:s + len(part)]))
+    return out
+
+
+def test_recon(test_cases, labels, model, batch_size, test_attr, thres=0.5, verbose=True):
+    """Reference `test_recon` (`src/utils.py:140-172`): AUROC / AP of the reconstruction error; same prints.  The
+    reference returns nothing; the two numbers are returned here as well."""
+    from .metrics import average_precision, roc_auc
+    scores = recon_scores(model, test_cases, batch_size, test_attr)
+    y = torch.as_tensor(np.asarray(labels), device=scores.device)
+    auc_gnn, ap = roc_auc(scores, y), average_precision(scores, y)
+    if verbose:
+        print("Testing AUC", auc_gnn)
+        print("Testing AP:", ap)
+    return auc_gnn, ap

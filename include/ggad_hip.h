@@ -95,6 +95,16 @@ int ggad_seg_mean(const float *feat, int32_t feat_dim, const int32_t *seg_ptr, c
 int ggad_seg_wsum(const float *feat, int32_t feat_dim, const int32_t *seg_ptr, const int32_t *seg_col, const float *seg_w,
                   int32_t n_rows, float *out, ggad_stream_t stream);
 
+/* Reconstruction term of the mini-batch DOMINANT / AnomalyDAE comparison models, which run on the same 1-hop batch
+ * aggregate as GGAD (src/graphsage_dominant.py:154-157,167-171; src/graphsage_anomalydae.py:154-162,172-176):
+ *   loss = mean_c sqrt( sum_b w(a[b][c]) * (a[b][c] - t[b][c])^2 ),  w = w_pos where a > 0, else w_neg
+ * -- the inner sum runs over the batch axis, as written there (torch.sum(diff, 0)).  a, t: (n_rows, n_cols) row-major.
+ * loss: 1 float.  col_sum (n_cols floats, the sums under the root) and da (n_rows * n_cols, d loss / d a) may be NULL. */
+int ggad_recon_cols_f32(const float *a, const float *t, int32_t n_rows, int32_t n_cols, float w_pos, float w_neg, float *loss,
+                        float *col_sum, float *da, ggad_stream_t stream);
+/* out[b] = sqrt( sum_c (a[b][c] - t[b][c])^2 ): the per-node anomaly score of test_recon (src/utils.py:158-159). */
+int ggad_recon_rows_f32(const float *a, const float *t, int64_t n_rows, int32_t n_cols, float *out, ggad_stream_t stream);
+
 /* The per-entry kernels below launch one wave per entry for n_entries_cap entries (a host-side
  * upper bound, e.g. sum(deg+1)) and read the true count from *ent_total (= ent_ptr[n_rows]).
  *

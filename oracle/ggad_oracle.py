@@ -349,6 +349,45 @@ def intra_aggregate(rowptr, col, feat, nodes, weight):
     return to_feats.astype(np.float32), to_feats_neigh.astype(np.float32), mask, unique
 
 
+# ----------------------------------------------------------------------------------
+# Mini-batch comparison models on the same 1-hop aggregate (DOMINANT / AnomalyDAE variants)
+# ----------------------------------------------------------------------------------
+def baseline_recon(rec: torch.Tensor, target: torch.Tensor, pos_weight: Optional[float] = None) -> torch.Tensor:
+    """`GCN.reconstruction` of `src/graphsage_dominant.py:154-157` (pos_weight None) and of
+    `src/graphsage_anomalydae.py:154-162` (pos_weight 0.5): mean over columns of sqrt(sum over the BATCH axis)."""
+    diff = torch.pow(rec - target, 2)
+    if pos_weight is not None:
+        diff = torch.where(rec > 0, diff * pos_weight, diff * (1 - pos_weight))
+    return torch.mean(torch.sqrt(torch.sum(diff, 0)))
+
+
+def baseline_decode(weight: torch.Tensor, fc_weight: torch.Tensor, to_feats: torch.Tensor) -> torch.Tensor:
+    """`GCNEncoder.forward` after the aggregation (`src/graphsage_dominant.py:274-276`): relu(fc(relu(W agg^T)^T)), (B, F)."""
+    combined = F.relu(weight.mm(to_feats.t()))
+    return F.relu(F.linear(combined.t(), fc_weight))
+
+
+def baseline_loss(weight, fc_weight, rowptr, col, feat, nodes, target, pos_weight: Optional[float] = None):
+    """`GCN.loss(nodes, features)` (`:167-171`) from the CSR: 1-hop batch aggregate (same closed form as GGAD's, `:194-226`),
+    decode, reconstruction against `target` = the batch rows of the normalised feature table."""
+    agg = aggregate_batch(rowptr, col, feat, nodes, False)
+    rec = baseline_decode(weight, fc_weight, torch.from_numpy(agg.to_feats))
+    return baseline_recon(rec, torch.as_tensor(np.asarray(target), dtype=torch.float32), pos_weight), rec
+
+
+def baseline_scores(weight, fc_weight, rowptr, col, feat, cases, batch_size: int, attr) -> np.ndarray:
+    """Scores of `test_recon` (`src/utils.py:150-159`): per slice of `batch_size`, sqrt(sum_c (rec - attr)^2)."""
+    out = []
+    attr = np.asarray(attr, dtype=np.float32)
+    with torch.no_grad():
+        for s in range(0, len(cases), batch_size):
+            part = np.asarray(cases[s:s + batch_size])
+            agg = aggregate_batch(rowptr, col, feat, part, False)
+            rec = baseline_decode(weight, fc_weight, torch.from_numpy(agg.to_feats))
+            out.append(torch.sqrt(torch.sum(torch.pow(rec - torch.from_numpy(attr[part]), 2), 1)).numpy())
+    return np.concatenate(out) if out else np.zeros(0, dtype=np.float32)
+
+
 def make_adam(params: Sequence[torch.Tensor], lr: float, weight_decay: float):
     """The optimiser both entry points use (`run.py:118`, `src/model_handler.py:299-300`)."""
     return torch.optim.Adam(list(params), lr=lr, weight_decay=weight_decay)

@@ -379,6 +379,69 @@ def handler_case():
     print("wrote", path, "metrics", out["metrics"])
 
 
+def baseline_case():
+    """Mini-batch comparison models that share GGAD's 1-hop aggregate (src/graphsage_dominant.py, src/graphsage_anomalydae.py):
+    module outputs, k training steps of the loop in src/model_handler_dominate.py:133-163, scores of src/utils.py:140-172."""
+    import importlib
+    import torch.nn as nn
+    n, n_entries, f, d, seed, bsz, k_steps = 700, 3600, 17, 64, 21, 48, 5
+    rowptr, col, feat_raw, feat, adj_lists = _mini_setup(n, n_entries, f, seed, "powerlaw", 0.05)
+    feat = np.asarray(feat, dtype=np.float32)
+    out = dict(n=n, f=f, d=d, seed=seed, rowptr=rowptr, col=col, feat_raw=feat_raw, feat=feat,
+               inputs_crc=synth.crc_of(rowptr, col, feat_raw))
+    rng = np.random.default_rng(seed + 1)
+    batches = [rng.choice(n, size=bsz, replace=False).tolist() for _ in range(k_steps)]
+    test_nodes = rng.choice(n, size=95, replace=False).tolist()
+    out["batches"] = np.array(batches, dtype=np.int64)
+    out["test_nodes"] = np.array(test_nodes, dtype=np.int64)
+    out["test_bs"] = 30
+    for tag, modname in (("dominant", "graphsage_dominant"), ("anomalydae", "graphsage_anomalydae")):
+        gs = importlib.import_module(modname)            # /root/reference/src/graphsage_{dominant,anomalydae}.py
+        torch.manual_seed(seed)
+        features = nn.Embedding(n, f)
+        features.weight = nn.Parameter(torch.FloatTensor(feat), requires_grad=False)
+        agg = gs.GCNAggregator(features, cuda=False)
+        enc = gs.GCNEncoder(features, f, d, adj_lists, agg, gcn=True, cuda=False)
+        model = gs.GCN(2, enc)
+        opt = torch.optim.Adam(filter(lambda p: p.requires_grad, model.parameters()), lr=1e-3, weight_decay=0.007)
+        for k, v in model.state_dict().items():
+            if "features" not in k:
+                out[f"{tag}.init.{k}"] = _np(v).copy()
+        losses = []
+        for step, nodes in enumerate(batches):
+            opt.zero_grad()
+            if step == 0:
+                out[f"{tag}.agg_to_feats"] = _np(agg.forward(nodes, [adj_lists[int(x)] for x in nodes]))
+                out[f"{tag}.enc_out"] = _np(enc.forward(nodes))
+            loss = model.loss(nodes, torch.tensor(feat)[nodes])              # model_handler_dominate.py:157
+            loss.backward()
+            if step == 0:
+                out[f"{tag}.grad.enc.weight"] = _np(enc.weight.grad).copy()
+                out[f"{tag}.grad.enc.fc.weight"] = _np(enc.fc.weight.grad).copy()
+                assert model.weight.grad is None
+            losses.append(loss.item())
+            opt.step()
+            if step == 0:
+                out[f"{tag}.step1.enc.weight"] = _np(enc.weight).copy()
+                out[f"{tag}.step1.enc.fc.weight"] = _np(enc.fc.weight).copy()
+        out[f"{tag}.losses"] = np.array(losses, dtype=np.float64)
+        out[f"{tag}.final.enc.weight"] = _np(enc.weight).copy()
+        out[f"{tag}.final.enc.fc.weight"] = _np(enc.fc.weight).copy()
+        # test_recon's score loop (src/utils.py:150-159); the last slice is ragged
+        scores = []
+        attr = torch.tensor(feat)
+        with torch.no_grad():
+            for it in range(int(len(test_nodes) / 30) + 1):
+                chunk = test_nodes[it * 30:(it + 1) * 30]
+                emb = model.to_prob(chunk, None)
+                scores.extend(torch.sqrt(torch.sum(torch.pow(emb - attr[chunk], 2), 1)).numpy().tolist())
+        out[f"{tag}.test_scores"] = np.array(scores, dtype=np.float32)
+        print(tag, "losses", losses)
+    path = os.path.join(HERE, "minibatch_baselines.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path)
+
+
 def part_mini(with_handler: bool):
     _stub_third_party()
     sys.path.insert(0, os.path.join(REF, "src"))
@@ -393,7 +456,7 @@ def part_mini(with_handler: bool):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--part", choices=["all", "full", "mini"], default="all")
+    ap.add_argument("--part", choices=["all", "full", "mini", "baselines"], default="all")
     ap.add_argument("--no-handler", action="store_true", help="skip the slow end-to-end ModelHandler case")
     a = ap.parse_args()
     if not os.path.isdir(REF):
@@ -401,10 +464,14 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     if a.part == "all":
         env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
-        for p in ("full", "mini"):
+        for p in ("full", "mini", "baselines"):
             cmd = [sys.executable, os.path.abspath(__file__), "--part", p] + (["--no-handler"] if a.no_handler else [])
             subprocess.check_call(cmd, env=env)
     elif a.part == "full":
         part_full()
+    elif a.part == "baselines":
+        _stub_third_party()
+        sys.path.insert(0, os.path.join(REF, "src"))
+        baseline_case()
     else:
         part_mini(not a.no_handler)

@@ -177,3 +177,34 @@ def test_full_forward_loss_grads_trajectory(name):
     yt = g["ano"][g["idx_test"]]
     assert abs(roc_auc_score(yt, le.numpy()[g["idx_test"]]) - float(g["eval_auc"])) < 1e-4
     assert abs(average_precision_score(yt, le.numpy()[g["idx_test"]]) - float(g["eval_ap"])) < 1e-4
+
+
+@pytest.mark.parametrize("tag,pw", [("dominant", None), ("anomalydae", 0.5)])
+def test_baseline_models_on_the_1hop_aggregate(tag, pw):
+    """DOMINANT / AnomalyDAE mini-batch variants (src/graphsage_dominant.py, src/graphsage_anomalydae.py): aggregate, decoder
+    output, loss trajectory under Adam(1e-3, wd 0.007), first-step gradients, scores of test_recon."""
+    g = load_golden("minibatch_baselines.npz")
+    assert synth.crc_of(g["rowptr"], g["col"], g["feat_raw"]) == int(g["inputs_crc"])
+    feat = g["feat"]
+    w = torch.tensor(g[f"{tag}.init.enc.weight"], requires_grad=True)
+    fc = torch.tensor(g[f"{tag}.init.enc.fc.weight"], requires_grad=True)
+    opt = torch.optim.Adam([w, fc], lr=1e-3, weight_decay=0.007)
+    for step, nodes in enumerate(g["batches"]):
+        opt.zero_grad()
+        if step == 0:
+            agg = O.aggregate_batch(g["rowptr"], g["col"], feat, nodes, False)
+            np.testing.assert_allclose(agg.to_feats, g[f"{tag}.agg_to_feats"], atol=TOL, rtol=0)
+        loss, rec = O.baseline_loss(w, fc, g["rowptr"], g["col"], feat, nodes, feat[nodes], pw)
+        loss.backward()
+        assert abs(loss.item() - g[f"{tag}.losses"][step]) < 2e-6
+        if step == 0:
+            np.testing.assert_allclose(rec.detach().numpy(), g[f"{tag}.enc_out"], atol=TOL, rtol=0)
+            np.testing.assert_allclose(w.grad.numpy(), g[f"{tag}.grad.enc.weight"], atol=TOL, rtol=0)
+            np.testing.assert_allclose(fc.grad.numpy(), g[f"{tag}.grad.enc.fc.weight"], atol=TOL, rtol=0)
+        opt.step()
+        if step == 0:
+            np.testing.assert_allclose(w.detach().numpy(), g[f"{tag}.step1.enc.weight"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(w.detach().numpy(), g[f"{tag}.final.enc.weight"], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(fc.detach().numpy(), g[f"{tag}.final.enc.fc.weight"], atol=1e-5, rtol=0)
+    sc = O.baseline_scores(w.detach(), fc.detach(), g["rowptr"], g["col"], feat, g["test_nodes"], int(g["test_bs"]), feat)
+    np.testing.assert_allclose(sc, g[f"{tag}.test_scores"], atol=1e-5, rtol=0)
