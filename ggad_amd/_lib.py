@@ -78,6 +78,7 @@ SIGNATURES = {
     "ggad_seg_wsum": (c_int32, [_P, _I, _P, _P, _P, _I, _P, _P]),
     "ggad_recon_cols_f32": (c_int32, [_P, _P, _I, _I, _F, _F, _P, _P, _P, _P]),
     "ggad_recon_rows_f32": (c_int32, [_P, _P, _L, _I, _P, _P]),
+    "ggad_ocgnn_loss_f32": (c_int32, [_P, _P, _L, _I, _P, _F, _F, _P, _P, _P, _P]),
     "ggad_mb_score": (c_int32, [_P, _I, _I, _P, _I, _P, _P]),
     "ggad_gemm_workspace_elems": (c_int64, [_I, _I, _I]),
     "ggad_gemm_f32": (c_int32, [_P, _P, _P, _I, _I, _I, _L, _L, _L, _L, _L, _P, _I, _P, _P]),

@@ -105,6 +105,14 @@ int ggad_recon_cols_f32(const float *a, const float *t, int32_t n_rows, int32_t 
 /* out[b] = sqrt( sum_c (a[b][c] - t[b][c])^2 ): the per-node anomaly score of test_recon (src/utils.py:158-159). */
 int ggad_recon_rows_f32(const float *a, const float *t, int64_t n_rows, int32_t n_cols, float *out, ggad_stream_t stream);
 
+/* One-class hypersphere loss of the full-graph OCGNN comparison model (ocgnn.py:83-118, :180-184) on the rows idx[0..n_idx)
+ * of emb (row-major, h columns; idx NULL = all of the first n_idx rows):
+ *   score[i] = ||emb[idx[i]] - center||^2 - r^2,   loss = r^2 + (1 / beta) * mean_i max(score[i], 0)
+ * center NULL = the origin.  demb (may be NULL): d loss / d emb, written ONLY on the listed rows -- the caller zero-fills the
+ * rest; an index listed twice gets one row's gradient, not the sum (the reference's index lists are duplicate-free). */
+int ggad_ocgnn_loss_f32(const float *emb, const int64_t *idx, int64_t n_idx, int32_t h, const float *center, float r, float beta,
+                        float *loss, float *score, float *demb, ggad_stream_t stream);
+
 /* The per-entry kernels below launch one wave per entry for n_entries_cap entries (a host-side
  * upper bound, e.g. sum(deg+1)) and read the true count from *ent_total (= ent_ptr[n_rows]).
  *

@@ -447,6 +447,23 @@ def full_forward(P: Dict[str, torch.Tensor], feat: torch.Tensor, adjn, abn_idx, 
     return emb2, emb_combine, f3[:, 0], emb_con, emb_abnormal
 
 
+def ocgnn_forward(P: Dict[str, torch.Tensor], feat: torch.Tensor, adjn) -> torch.Tensor:
+    """`model_ocgnn.Model.forward` (`model_ocgnn.py:128-131`): two GCN layers (`:26-35`) on the CSR adjacency."""
+    rp, ci, va = adjn
+
+    def gcn(x, pre):
+        return F.prelu(_spmm(rp, ci, va, x.mm(P[pre + ".fc.weight"].t())) + P[pre + ".bias"], P[pre + ".act.weight"])
+    return gcn(gcn(feat, "gcn1"), "gcn2")
+
+
+def ocgnn_loss(emb: torch.Tensor, r: float = 0.0, beta: float = 0.5):
+    """`loss_func` of `ocgnn.py:83-118`: the centre and radius are rebuilt (zeros, 0) on every call there, so the warm-up
+    branch has no effect.  Returns (loss, score)."""
+    dist = torch.sum(torch.pow(emb, 2), 1)
+    score = dist - r ** 2
+    return r ** 2 + 1 / beta * torch.mean(torch.relu(score)), score
+
+
 def full_loss(emb, logits, emb_con, emb_abnormal, raw, abn_idx, normal_idx, margin_c: float = 0.7):
     """Loss block of `run.py:165-210`, affinity as a per-edge SDDMM over raw_adj + I.
 

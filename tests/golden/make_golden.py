@@ -164,6 +164,73 @@ def full_graph_case(tag, n, n_entries, f, n_h, seed, mean, var, kind, k_steps,
     print("wrote", path, "losses[0]", losses[0], "auc", out["eval_auc"])
 
 
+def ocgnn_case():
+    """Full-graph OCGNN comparison model: the imported `model_ocgnn.Model` driven by the training block of `ocgnn.py`
+    (`:83-118` loss, `:170-186` step; the script itself needs dgl and a dataset file, so its loop is restated here)."""
+    import scipy.sparse as sp
+    from model_ocgnn import Model                # /root/reference/model_ocgnn.py
+    import utils as rutils                       # /root/reference/utils.py
+    n, n_entries, f, n_h, seed, k_steps = 300, 2400, 20, 48, 4, 5
+    rowptr, col = synth.make_graph(n, n_entries, seed, kind="powerlaw", max_degree=n // 4, self_loop_frac=0.05)
+    feat = synth.make_features(n, f, seed)
+    ano = synth.make_labels(n, 0.06, seed)
+    adj_sp = synth.csr_to_scipy(rowptr, col)
+    random.seed(seed)
+    all_idx = list(range(n))
+    random.shuffle(all_idx)
+    idx_train, idx_test = all_idx[:int(n * 0.3)], all_idx[int(n * 0.3) + int(n * 0.1):]
+    all_normal = [i for i in idx_train if ano[i] == 0]
+    normal_idx = all_normal[: int(len(all_normal) * 0.5)]
+    feats_dense, _ = rutils.preprocess_features(sp.lil_matrix(feat))
+    adj_norm = rutils.normalize_adj(adj_sp)
+    features = torch.FloatTensor(np.asarray(feats_dense)[np.newaxis])
+    adj = torch.FloatTensor(np.asarray((adj_norm + sp.eye(n)).todense())[np.newaxis])
+    torch.manual_seed(seed)
+    model = Model(f, n_h, "prelu", 1, "avg")
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=0.0)
+    out = dict(n=n, f=f, n_h=n_h, seed=seed, rowptr=rowptr, col=col, feat_raw=feat, ano=ano,
+               inputs_crc=synth.crc_of(rowptr, col, feat, ano), features=_np(features[0]),
+               idx_test=np.array(idx_test), normal_idx=np.array(normal_idx))
+    for k, v in model.state_dict().items():
+        out["init." + k] = _np(v).copy()
+
+    def loss_func(emb):                          # ocgnn.py:83-118 with its constants
+        r, beta = 0, 0.5
+        c = torch.zeros(n_h)
+        dist = torch.sum(torch.pow(emb - c, 2), 1)
+        score = dist - r ** 2
+        return r ** 2 + 1 / beta * torch.mean(torch.relu(score)), score
+
+    losses = []
+    for step in range(k_steps):
+        model.train()
+        opt.zero_grad()
+        emb = model(features, adj)
+        loss, score = loss_func(torch.squeeze(emb)[normal_idx])
+        loss.backward()
+        if step == 0:
+            out.update(emb=_np(emb[0]), score=_np(score))
+            for k, p in model.named_parameters():
+                if p.grad is not None:
+                    out["grad." + k] = _np(p.grad).copy()
+        losses.append(loss.item())
+        opt.step()
+    out["losses"] = np.array(losses, dtype=np.float64)
+    for k, v in model.state_dict().items():
+        out["final." + k] = _np(v).copy()
+    model.eval()
+    with torch.no_grad():
+        _, score = loss_func(torch.squeeze(model(features, adj)))
+    from sklearn.metrics import roc_auc_score, average_precision_score
+    sc = _np(score)
+    yt = ano[np.array(idx_test)]
+    out.update(eval_score=sc, eval_auc=roc_auc_score(yt, sc[np.array(idx_test)]),
+               eval_ap=average_precision_score(yt, sc[np.array(idx_test)], average="macro", pos_label=1))
+    path = os.path.join(HERE, "fullgraph_ocgnn.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "losses", losses, "auc", out["eval_auc"])
+
+
 def part_full():
     _stub_third_party()
     sys.path.insert(0, REF)
@@ -456,7 +523,7 @@ def part_mini(with_handler: bool):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--part", choices=["all", "full", "mini", "baselines"], default="all")
+    ap.add_argument("--part", choices=["all", "full", "mini", "baselines", "ocgnn"], default="all")
     ap.add_argument("--no-handler", action="store_true", help="skip the slow end-to-end ModelHandler case")
     a = ap.parse_args()
     if not os.path.isdir(REF):
@@ -464,11 +531,15 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     if a.part == "all":
         env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
-        for p in ("full", "mini", "baselines"):
+        for p in ("full", "mini", "baselines", "ocgnn"):
             cmd = [sys.executable, os.path.abspath(__file__), "--part", p] + (["--no-handler"] if a.no_handler else [])
             subprocess.check_call(cmd, env=env)
     elif a.part == "full":
         part_full()
+    elif a.part == "ocgnn":
+        _stub_third_party()
+        sys.path.insert(0, REF)
+        ocgnn_case()
     elif a.part == "baselines":
         _stub_third_party()
         sys.path.insert(0, os.path.join(REF, "src"))

@@ -148,3 +148,84 @@ def test_run_py_captured_epoch_equals_eager():
         assert len(keep) >= 7 * 4 + 4
         outs.append(keep)
     assert outs[0] == outs[1]
+
+
+def test_ocgnn_model_loss_backward_trajectory():
+    """Full-graph OCGNN comparison model (`model_ocgnn.py` + the loss / step of `ocgnn.py`) against the imported reference."""
+    from ggad_amd.model_ocgnn import Model as OcModel, ocgnn_loss
+    g = load_golden("fullgraph_ocgnn.npz")
+    fa = _adj(g)
+    f, h = int(g["f"]), int(g["n_h"])
+    torch.manual_seed(int(g["seed"]))
+    model = OcModel(f, h, "prelu", 1, "avg")
+    sd = {k[len("init."):]: torch.from_numpy(v) for k, v in g.items() if k.startswith("init.")}
+    assert sorted(sd.keys()) == sorted(model.state_dict().keys())        # same parameter names as the reference
+    for k, v in model.state_dict().items():                              # same seed -> same initial weights
+        np.testing.assert_array_equal(v.numpy(), sd[k].numpy(), err_msg=k)
+    model.to(DEV)
+    opt = FG.FlatAdam(model.parameters(), lr=1e-3, weight_decay=0.0)
+    feats = torch.from_numpy(g["features"])[None].to(DEV)
+    nrm = torch.from_numpy(g["normal_idx"]).to(DEV)
+    for step in range(len(g["losses"])):
+        model.train()
+        opt.zero_grad()
+        emb = model(feats, fa)
+        assert emb.shape == (1, int(g["n"]), h)
+        loss, score = ocgnn_loss(emb[0], nrm)
+        loss.backward()
+        assert abs(loss.item() - g["losses"][step]) < 1e-5
+        if step == 0:
+            np.testing.assert_allclose(emb[0].detach().cpu().numpy(), g["emb"], atol=3e-6)
+            np.testing.assert_allclose(score.cpu().numpy(), g["score"], atol=1e-5)
+            for k, p in model.named_parameters():
+                if ("grad." + k) in g:
+                    np.testing.assert_allclose(p.grad.cpu().numpy(), g["grad." + k], atol=4e-6, rtol=2e-4, err_msg=k)
+                else:
+                    assert p.grad is None, k                              # the discriminator is never used
+        opt.step()
+    for k, v in model.state_dict().items():
+        np.testing.assert_allclose(v.cpu().numpy(), g["final." + k], atol=3e-5, err_msg=k)
+    model.eval()
+    with torch.no_grad():
+        _, sc = ocgnn_loss(model(feats, fa)[0])
+    sc = sc.cpu().numpy()
+    np.testing.assert_allclose(sc, g["eval_score"], atol=5e-5)
+    from sklearn.metrics import average_precision_score, roc_auc_score
+    yt = g["ano"][g["idx_test"]]
+    assert abs(roc_auc_score(yt, sc[g["idx_test"]]) - float(g["eval_auc"])) < 1e-4
+    assert abs(average_precision_score(yt, sc[g["idx_test"]]) - float(g["eval_ap"])) < 1e-4
+
+
+def test_ocgnn_loss_kernel_centre_radius_and_duplicates_free_rows():
+    from ggad_amd.model_ocgnn import ocgnn_loss
+    rng = np.random.default_rng(5)
+    emb = torch.from_numpy(rng.standard_normal((500, 77)).astype(np.float32))
+    idx = torch.from_numpy(rng.permutation(500)[:123].astype(np.int64))
+    c = torch.from_numpy(rng.standard_normal(77).astype(np.float32) * 0.3)
+    for r, beta, cc in ((0.0, 0.5, None), (8.5, 0.25, c)):
+        e = emb.clone().requires_grad_(True)
+        d = torch.sum(torch.pow(e[idx] - (cc if cc is not None else 0.0), 2), 1) - r ** 2
+        ref = r ** 2 + torch.mean(torch.relu(d)) / beta
+        ref.backward()
+        ed = emb.to(DEV).requires_grad_(True)
+        loss, score = ocgnn_loss(ed, idx.to(DEV), cc.to(DEV) if cc is not None else None, r, beta)
+        loss.backward()
+        assert abs(loss.item() - ref.item()) < 2e-5 * max(1.0, abs(ref.item()))
+        np.testing.assert_allclose(score.cpu().numpy(), d.detach().numpy(), rtol=2e-6, atol=2e-5)
+        np.testing.assert_allclose(ed.grad.cpu().numpy(), e.grad.numpy(), rtol=2e-5, atol=1e-7)
+
+
+def test_ocgnn_script_captured_epoch_equals_eager():
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for extra in ([], ["--no_graph"]):
+        r = subprocess.run([sys.executable, os.path.join(root, "ocgnn.py"), "--dataset", "reddit", "--synthetic", "--num_epoch", "12"] + extra,
+                           capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        keep = [l for l in r.stdout.splitlines() if l.startswith("Epoch:") or l.startswith("Testing")]
+        assert len(keep) == 3 * 3
+        outs.append(keep)
+    assert outs[0] == outs[1]

@@ -208,3 +208,32 @@ def test_baseline_models_on_the_1hop_aggregate(tag, pw):
     np.testing.assert_allclose(fc.detach().numpy(), g[f"{tag}.final.enc.fc.weight"], atol=1e-5, rtol=0)
     sc = O.baseline_scores(w.detach(), fc.detach(), g["rowptr"], g["col"], feat, g["test_nodes"], int(g["test_bs"]), feat)
     np.testing.assert_allclose(sc, g[f"{tag}.test_scores"], atol=1e-5, rtol=0)
+
+
+def test_ocgnn_forward_loss_trajectory():
+    """Full-graph OCGNN comparison model (`model_ocgnn.py`, loss / step of `ocgnn.py:83-118,170-186`)."""
+    g = load_golden("fullgraph_ocgnn.npz")
+    assert synth.crc_of(g["rowptr"], g["col"], g["feat_raw"], g["ano"]) == int(g["inputs_crc"])
+    adjn, _ = _full_setup(g)
+    keys = ["gcn1.bias", "gcn1.fc.weight", "gcn1.act.weight", "gcn2.bias", "gcn2.fc.weight", "gcn2.act.weight"]
+    P = {k: torch.tensor(g["init." + k], requires_grad=True) for k in keys}
+    opt = O.make_adam(list(P.values()), 1e-3, 0.0)
+    feat = torch.from_numpy(g["features"])
+    nrm = torch.from_numpy(g["normal_idx"]).long()
+    for step in range(len(g["losses"])):
+        opt.zero_grad()
+        emb = O.ocgnn_forward(P, feat, adjn)
+        loss, score = O.ocgnn_loss(emb[nrm])
+        loss.backward()
+        assert abs(loss.item() - g["losses"][step]) < 1e-5
+        if step == 0:
+            np.testing.assert_allclose(emb.detach().numpy(), g["emb"], atol=TOL)
+            np.testing.assert_allclose(score.detach().numpy(), g["score"], atol=1e-5)
+            for k in keys:
+                np.testing.assert_allclose(P[k].grad.numpy(), g["grad." + k], atol=3e-6, rtol=1e-4, err_msg=k)
+        opt.step()
+    for k in keys:
+        np.testing.assert_allclose(P[k].detach().numpy(), g["final." + k], atol=3e-5, err_msg=k)
+    with torch.no_grad():
+        _, sc = O.ocgnn_loss(O.ocgnn_forward(P, feat, adjn))
+    np.testing.assert_allclose(sc.numpy(), g["eval_score"], atol=5e-5)
