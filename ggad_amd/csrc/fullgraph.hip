@@ -107,6 +107,132 @@ __global__ void __launch_bounds__(256) k_spmm_seg(const int32_t *__restrict__ co
   }
 }
 
+// ---- XCD-sliced variant for dense neighbourhoods (T-Finance: 470 neighbours per row, X = 47 MB) -----------------------
+// Measured on MI355X (scripts/spmm_locality_probe.py): the vector-memory path accepts ONE wave-wide load instruction per
+// ~17 clocks per CU whatever its number of active lanes (W = 260 costs what W = 512 costs), and a 47 MB operand that every
+// XCD gathers from misses its 4 MB L2 and comes from the Infinity Cache at ~8 TB/s (2.6 ms per product against 1.3 ms with
+// an L2-resident operand).  So: (1) X is re-laid slice-major, XS[slice][row][8 float4] -- one 128-byte line per (row, slice)
+// -- and a workgroup gathers ONE slice, chosen from blockIdx % 8 (the dispatcher places block b on XCD b % 8), so each L2
+// serves N x 128 B instead of N x 1200 B; (2) the 64 lanes of a load carry 8 neighbours x 8 float4, so a 64-neighbour
+// segment of one slice takes 8 full-width loads (80 per segment for W = 300, against 128 mostly narrow ones).
+// Slices are dealt to the XCDs in rounds of 8; the slices of a last incomplete round (2 for W = 300) are each shared by
+// several XCDs, which split the segments between them.
+constexpr int SPMM_XCDS = 8;
+constexpr int SPMM_SL = 8;                          // float4 lanes per (row, slice): 32 floats = one cache line
+
+__host__ __device__ inline int spmm_n_slices(int W) { return ((W >> 2) + SPMM_SL - 1) / SPMM_SL; }
+
+__global__ void __launch_bounds__(256) k_slice_major(const float *__restrict__ X, int64_t ldx, int n_rows, int W, int n_slices,
+                                                     float4 *__restrict__ XS) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int per_row = n_slices * SPMM_SL;
+  if (t >= (int64_t)n_rows * per_row) return;
+  const int r = (int)(t / per_row), q = (int)(t - (int64_t)r * per_row);       // q = slice * 8 + j = float4 index in the row
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (q < (W >> 2)) v = reinterpret_cast<const float4 *>(X + (int64_t)r * ldx)[q];
+  XS[((int64_t)(q >> 3) * n_rows + r) * SPMM_SL + (q & 7)] = v;
+}
+
+constexpr int SPMM_WSEG = 8;                        // consecutive segments per wave: the seg table -> col -> X latency chain is
+constexpr int SPMM_BSEG = 4 * SPMM_WSEG;            // paid once per 8 segments (one segment per wave was latency-bound: 1.5 ms)
+
+// number of blocks of the sliced launch: full rounds use U = ceil(n_seg / 32) units per XCD, the last incomplete round
+// ceil(U / m) units, m = the smallest number of XCDs sharing one of its slices
+__host__ inline int64_t spmm_sliced_blocks(int n_seg, int n_slices) {
+  const int64_t U = (n_seg + SPMM_BSEG - 1) / SPMM_BSEG;
+  const int full = n_slices / SPMM_XCDS, R = n_slices % SPMM_XCDS;
+  const int m = R ? SPMM_XCDS / R : 1;              // slice r of the round is served by the XCDs x with x % R == r: >= 8 / R of them
+  return SPMM_XCDS * (full * U + (R ? (U + m - 1) / m : 0));
+}
+
+__global__ void __launch_bounds__(256) k_spmm_sliced(const int32_t *__restrict__ col, const float *__restrict__ val,
+                                                     const int32_t *__restrict__ seg_beg, const int32_t *__restrict__ seg_end,
+                                                     const int32_t *__restrict__ seg_out, int n_seg,
+                                                     const float4 *__restrict__ XS, int n_src, int n_slices, int W,
+                                                     const float *__restrict__ bias, const float *__restrict__ prelu_a,
+                                                     float *__restrict__ out, int64_t ldo, float *__restrict__ out_pre,
+                                                     float *__restrict__ part) {
+  const int xcd = blockIdx.x & (SPMM_XCDS - 1);
+  const int64_t unit = blockIdx.x >> 3;
+  const int64_t U = (n_seg + SPMM_BSEG - 1) / SPMM_BSEG;
+  const int full = n_slices / SPMM_XCDS, R = n_slices - full * SPMM_XCDS;
+  int slice; int64_t group;
+  if (unit < (int64_t)full * U) {                   // complete rounds: XCD x owns slice round * 8 + x
+    const int round = (int)(unit / U);
+    slice = round * SPMM_XCDS + xcd;
+    group = unit - (int64_t)round * U;
+  } else {                                          // incomplete round: slice r shared by the XCDs x % R == r
+    const int r = xcd % R, k = xcd / R;
+    const int nx = (SPMM_XCDS - r + R - 1) / R;     // XCDs serving slice r
+    slice = full * SPMM_XCDS + r;
+    group = (unit - (int64_t)full * U) * nx + k;
+  }
+  const int64_t first64 = group * SPMM_BSEG + (int64_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * SPMM_WSEG;
+  if (first64 >= n_seg) return;
+  const int first = (int)first64;
+  const int nq = (n_seg - first) < SPMM_WSEG ? (n_seg - first) : SPMM_WSEG;
+  const int lane = lane_id();
+  const int g = lane >> 3, j = lane & 7;            // 8 neighbours per load instruction, 8 float4 each
+  const float4 *__restrict__ xs = XS + (int64_t)slice * n_src * SPMM_SL + j;
+  const int vi = slice * SPMM_SL + j;
+  const float a = prelu_a ? *prelu_a : 1.0f;
+  // segment bounds / outputs of all 8 segments in one vector load each, then every segment's indices and values: nothing in
+  // the gather loop below waits for an address
+  const int sb_v = lane < nq ? seg_beg[first + lane] : 0;
+  const int se_v = lane < nq ? seg_end[first + lane] : 0;
+  const int so_v = lane < nq ? seg_out[first + lane] : 0;
+  int cvs[SPMM_WSEG]; float vvs[SPMM_WSEG]; int cnts[SPMM_WSEG];
+#pragma unroll
+  for (int q = 0; q < SPMM_WSEG; ++q) {
+    const int sq = __builtin_amdgcn_readlane(sb_v, q), tq = __builtin_amdgcn_readlane(se_v, q);
+    cnts[q] = tq - sq;                                // 0 for q >= nq
+    const bool in = sq + lane < tq;
+    cvs[q] = in ? col[sq + lane] : 0;
+    vvs[q] = in ? (val ? val[sq + lane] : 1.0f) : 0.0f;
+  }
+  // software pipeline over the segments: the 8 loads of segment q + 1 are issued before segment q is reduced and stored
+  float4 xa[8], xb[8]; float va[8], vb[8];
+#define SPMM_ISSUE(X_, V_, Q_)                                                        \
+  _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                     \
+    const int k = u * 8 + g;                                                          \
+    const int c = __shfl(cvs[Q_], k, GGAD_WAVE);       /* 0 past the segment's end: row 0 is a valid address */ \
+    V_[u] = __shfl(vvs[Q_], k, GGAD_WAVE);             /* 0.0f past the end */         \
+    const float4 ld = xs[(int64_t)c * SPMM_SL];        /* unconditional: a guarded load costs a branch + vmcnt(0) each */ \
+    const bool ok = k < cnts[Q_];                                                     \
+    X_[u] = make_float4(ok ? ld.x : 0.f, ok ? ld.y : 0.f, ok ? ld.z : 0.f, ok ? ld.w : 0.f); \
+  }
+#define SPMM_CONSUME(X_, V_, Q_)                                                      \
+  {                                                                                   \
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);                                     \
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                   \
+      acc.x = fmaf(V_[u], X_[u].x, acc.x); acc.y = fmaf(V_[u], X_[u].y, acc.y);       \
+      acc.z = fmaf(V_[u], X_[u].z, acc.z); acc.w = fmaf(V_[u], X_[u].w, acc.w);       \
+    }                                                                                 \
+    _Pragma("unroll") for (int off = 8; off < GGAD_WAVE; off <<= 1) {                 \
+      acc.x += __shfl_xor(acc.x, off, GGAD_WAVE); acc.y += __shfl_xor(acc.y, off, GGAD_WAVE); \
+      acc.z += __shfl_xor(acc.z, off, GGAD_WAVE); acc.w += __shfl_xor(acc.w, off, GGAD_WAVE); \
+    }                                                                                 \
+    if (g == 0 && vi < (W >> 2)) {                                                    \
+      const int orow = __builtin_amdgcn_readlane(so_v, Q_);                           \
+      if (orow >= 0)                                                                  \
+        spmm_epilogue_store(acc, vi, bias, prelu_a, a, out + (int64_t)orow * ldo,     \
+                            out_pre ? out_pre + (int64_t)orow * ldo : nullptr);       \
+      else                                                                            \
+        reinterpret_cast<float4 *>(part + (int64_t)(first + Q_) * W)[vi] = acc;       \
+    }                                                                                 \
+  }
+  SPMM_ISSUE(xa, va, 0)
+#pragma unroll
+  for (int q = 0; q < SPMM_WSEG; q += 2) {
+    if (q + 1 < nq) SPMM_ISSUE(xb, vb, q + 1)
+    if (q < nq) SPMM_CONSUME(xa, va, q)
+    if (q + 2 < nq && q + 2 < SPMM_WSEG) SPMM_ISSUE(xa, va, (q + 2 < SPMM_WSEG ? q + 2 : 0))
+    if (q + 1 < nq) SPMM_CONSUME(xb, vb, q + 1)
+  }
+#undef SPMM_ISSUE
+#undef SPMM_CONSUME
+}
+
 // rows split into several segments: out[row] = epilogue(sum of part[first .. first + count))   (fixed order)
 __global__ void __launch_bounds__(256) k_spmm_combine(const int32_t *__restrict__ multi_row, const int32_t *__restrict__ multi_first,
                                                       const int32_t *__restrict__ multi_count, int n_multi,
@@ -383,6 +509,37 @@ int ggad_spmm_csr_f32(const int32_t *col, const float *val, const int32_t *seg_b
     k_spmm_combine<<<dim3((n_multi + 3) / 4), dim3(256), 0, st>>>(multi_row, multi_first, multi_count, n_multi, part, W, bias,
                                                                  prelu_a, out, ldo, out_pre);
   GGAD_CHECK_LAUNCH("spmm_csr_f32");
+  return GGAD_OK;
+}
+
+int64_t ggad_spmm_sliced_workspace_elems(int64_t n_src_rows, int32_t W) {
+  return n_src_rows * spmm_n_slices(W) * SPMM_SL * 4;
+}
+
+int ggad_spmm_sliced_f32(const int32_t *col, const float *val, const int32_t *seg_beg, const int32_t *seg_end,
+                         const int32_t *seg_out, int32_t n_seg, const int32_t *multi_row, const int32_t *multi_first,
+                         const int32_t *multi_count, int32_t n_multi, const float *X, int64_t ldx, int32_t W, int64_t n_src_rows,
+                         float *xs_workspace, const float *bias, const float *prelu_a, float *out, int64_t ldo, float *out_pre,
+                         float *part, ggad_stream_t stream) {
+  GGAD_REQUIRE(col && seg_beg && seg_end && seg_out && X && out && xs_workspace && W >= 4 && (W & 3) == 0);
+  GGAD_REQUIRE((ldx & 3) == 0 && (ldo & 3) == 0 && ldx >= W && ldo >= W && n_seg >= 0 && n_multi >= 0 && n_src_rows >= 1);
+  GGAD_REQUIRE(n_multi == 0 || (multi_row && multi_first && multi_count && part));
+  const int S = spmm_n_slices(W);
+  GGAD_REQUIRE(n_src_rows * S * SPMM_SL < (1ll << 31));
+  if (n_seg == 0) return GGAD_OK;
+  const int64_t nb = spmm_sliced_blocks(n_seg, S);
+  GGAD_REQUIRE(nb < (1ll << 31));
+  hipStream_t st = as_stream(stream);
+  const int64_t nt = n_src_rows * S * SPMM_SL;
+  k_slice_major<<<dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st>>>(X, ldx, (int)n_src_rows, W, S,
+                                                                        reinterpret_cast<float4 *>(xs_workspace));
+  k_spmm_sliced<<<dim3((unsigned)nb), dim3(256), 0, st>>>(col, val, seg_beg, seg_end, seg_out, n_seg,
+                                                         reinterpret_cast<const float4 *>(xs_workspace), (int)n_src_rows, S, W, bias,
+                                                         prelu_a, out, ldo, out_pre, part);
+  if (n_multi > 0)
+    k_spmm_combine<<<dim3((n_multi + 3) / 4), dim3(256), 0, st>>>(multi_row, multi_first, multi_count, n_multi, part, W, bias,
+                                                                 prelu_a, out, ldo, out_pre);
+  GGAD_CHECK_LAUNCH("spmm_sliced_f32");
   return GGAD_OK;
 }
 

@@ -12,6 +12,8 @@ The reference keeps `adj` and `raw_adj` as dense (1,N,N) tensors and multiplies 
 """
 from __future__ import annotations
 
+import os
+
 from typing import Dict, Optional, Sequence, Tuple
 
 import numpy as np
@@ -71,7 +73,7 @@ class Csr:
         dev = self.dev
         p = dict(seg_beg=_dev_i32(sbeg, dev), seg_end=_dev_i32(send, dev), seg_out=_dev_i32(seg_out, dev), n_seg=total,
                  multi_row=_dev_i32(multi, dev), multi_first=_dev_i32(first[multi], dev), multi_count=_dev_i32(nseg[multi], dev),
-                 n_multi=int(len(multi)), n_out=int(len(rows)), part=None)
+                 n_multi=int(len(multi)), n_out=int(len(rows)), part=None, nnz=int((end - beg).sum()))
         if key is not None:
             self._plans[key] = p
         return p
@@ -156,6 +158,19 @@ def gemm(A: torch.Tensor, B: torch.Tensor, trans_a: bool, trans_b: bool, bias=No
     return C
 
 
+_XS_WORKSPACE = {}
+
+
+def _use_sliced(csr: Csr, p, X: torch.Tensor) -> bool:
+    """Dense neighbourhoods gathered from an operand that does not fit an XCD's L2: the XCD-sliced kernel (fullgraph.hip).
+    GGAD_SPMM_SLICED=0 / 1 forces the choice (A/B measurements)."""
+    force = os.environ.get("GGAD_SPMM_SLICED")
+    if force is not None:
+        return force == "1"
+    w = X.shape[1]
+    return w >= 64 and X.shape[0] * w * 4 >= (6 << 20) and p["n_seg"] > 0 and p.get("nnz", csr.nnz) >= 24 * p["n_seg"]
+
+
 def spmm(csr: Csr, X: torch.Tensor, plan=None, bias=None, prelu_a=None, want_pre=False):
     """out = act(csr[rows] @ X + bias); `plan` = csr.plan(...) selects the rows (default: all)."""
     X = X.contiguous()
@@ -168,6 +183,17 @@ def spmm(csr: Csr, X: torch.Tensor, plan=None, bias=None, prelu_a=None, want_pre
         part = p.get("part")
         if part is None or part.numel() < p["n_seg"] * W:
             part = p["part"] = torch.empty(p["n_seg"] * W, dtype=torch.float32, device=X.device)
+    if _use_sliced(csr, p, X):
+        n_ws = int(_lib.load().ggad_spmm_sliced_workspace_elems(X.shape[0], W))
+        key = (str(X.device), torch.cuda.current_stream(X.device).cuda_stream)
+        xs = _XS_WORKSPACE.get(key)
+        if xs is None or xs.numel() < n_ws:          # one staging buffer per stream: consumed by the launch that follows its fill
+            xs = _XS_WORKSPACE[key] = torch.empty(n_ws, dtype=torch.float32, device=X.device)
+        call("ggad_spmm_sliced_f32", ptr(csr.col), ptr(csr.val), ptr(p["seg_beg"]), ptr(p["seg_end"]), ptr(p["seg_out"]),
+             p["n_seg"], ptr(p["multi_row"]), ptr(p["multi_first"]), ptr(p["multi_count"]), p["n_multi"], ptr(X), W, W, X.shape[0],
+             ptr(xs), ptr(bias) if bias is not None else 0, ptr(prelu_a) if prelu_a is not None else 0, ptr(out), W,
+             ptr(pre) if pre is not None else 0, ptr(part) if part is not None else 0)
+        return (out, pre) if want_pre else out
     call("ggad_spmm_csr_f32", ptr(csr.col), ptr(csr.val), ptr(p["seg_beg"]), ptr(p["seg_end"]), ptr(p["seg_out"]), p["n_seg"],
          ptr(p["multi_row"]), ptr(p["multi_first"]), ptr(p["multi_count"]), p["n_multi"], ptr(X), W, W,
          ptr(bias) if bias is not None else 0, ptr(prelu_a) if prelu_a is not None else 0, ptr(out), W,

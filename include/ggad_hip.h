@@ -343,6 +343,18 @@ int ggad_spmm_csr_f32(const int32_t *col, const float *val, const int32_t *seg_b
                       const int32_t *multi_count, int32_t n_multi, const float *X, int64_t ldx, int32_t W, const float *bias,
                       const float *prelu_a, float *out, int64_t ldo, float *out_pre, float *part, ggad_stream_t stream);
 
+/* Same product for dense neighbourhoods (hundreds of neighbours per row, X larger than an XCD's 4 MB L2): X is first
+ * re-laid slice-major into xs_workspace (ggad_spmm_sliced_workspace_elems(n_src_rows, W) floats; column slices of 32 floats =
+ * one cache line per row), then every workgroup gathers ONE slice, chosen by the XCD it runs on, 8 neighbours per load.  n_src_rows = rows of X.  Same
+ * segment tables, epilogue and outputs as ggad_spmm_csr_f32; the summation order inside a segment differs (lane groups
+ * take every 8th neighbour), so results agree to fp32 round-off, and are deterministic. */
+int64_t ggad_spmm_sliced_workspace_elems(int64_t n_src_rows, int32_t W);
+int ggad_spmm_sliced_f32(const int32_t *col, const float *val, const int32_t *seg_beg, const int32_t *seg_end,
+                         const int32_t *seg_out, int32_t n_seg, const int32_t *multi_row, const int32_t *multi_first,
+                         const int32_t *multi_count, int32_t n_multi, const float *X, int64_t ldx, int32_t W, int64_t n_src_rows,
+                         float *xs_workspace, const float *bias, const float *prelu_a, float *out, int64_t ldo, float *out_pre,
+                         float *part, ggad_stream_t stream);
+
 /* PReLU backward: dz = g * (z > 0 ? 1 : a); db[W] = column sums of dz; *da = sum g * z * [z <= 0].
  * workspace: float[2 * ggad_prelu_bwd_splits(M) * W].  db / da may be NULL. */
 int32_t ggad_prelu_bwd_splits(int32_t M);

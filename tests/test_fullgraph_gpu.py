@@ -229,3 +229,33 @@ def test_ocgnn_script_captured_epoch_equals_eager():
         assert len(keep) == 3 * 3
         outs.append(keep)
     assert outs[0] == outs[1]
+
+
+@pytest.mark.parametrize("w", [300, 64, 256, 28, 4, 512])
+def test_spmm_xcd_sliced_equals_row_major(w, monkeypatch):
+    """The XCD-sliced SpMM (slice-major operand, 64 / L neighbours per load) against the wave-per-segment kernel: whole
+    matrix with bias + PReLU + pre-activation, and a row subset, on a graph with hub rows (multi-segment) and leaves."""
+    import scipy.sparse as sp
+    n = 3000
+    rowptr, col = synth.make_graph(n, 240000, 9, kind="powerlaw", max_degree=n // 3)
+    a = synth.csr_to_scipy(rowptr, col, n)
+    csr = FG.Csr(U.normalize_adj(a) + sp.eye(n), DEV)
+    rng = np.random.default_rng(w)
+    x = torch.from_numpy(rng.standard_normal((n, w)).astype(np.float32)).to(DEV)
+    bias = torch.from_numpy(rng.standard_normal(w).astype(np.float32)).to(DEV)
+    slope = torch.tensor([0.25], device=DEV)
+    rows = rng.permutation(n)[:257]
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("GGAD_SPMM_SLICED", mode)
+        o, pre = FG.spmm(csr, x, bias=bias, prelu_a=slope, want_pre=True)
+        sub = FG.spmm(csr, x, plan=csr.plan(rows, key=("t", w)))
+        outs[mode] = (o.cpu().numpy(), pre.cpu().numpy(), sub.cpu().numpy())
+    ref = (csr.host.astype(np.float64) @ x.cpu().numpy().astype(np.float64))
+    scale = np.abs(ref).max() + 1.0
+    for k in range(3):
+        assert np.abs(outs["0"][k] - outs["1"][k]).max() / scale < 2e-6
+    np.testing.assert_allclose(outs["1"][1], ref + bias.cpu().numpy(), atol=2e-6 * scale)
+    np.testing.assert_allclose(outs["1"][2], ref[rows], atol=2e-6 * scale)
+    monkeypatch.delenv("GGAD_SPMM_SLICED")
+    assert FG._use_sliced(csr, csr.plan(), x) == (w >= 64 and n * w * 4 >= (6 << 20))
