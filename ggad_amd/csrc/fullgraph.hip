@@ -36,7 +36,8 @@ __device__ __forceinline__ void spmm_epilogue_store(float4 z, int vi, const floa
 // One wave per SEGMENT (<= 64 consecutive neighbours of one row): rows are split so that a hub row does not
 // serialise the launch (power-law graphs: max degree ~ N/8).  seg_out[s] >= 0: the row has this single segment,
 // finish it here (bias / PReLU epilogue, write out[seg_out]); seg_out[s] < 0: write the partial sum to
-// part[s]; k_spmm_combine adds the partials of such rows in segment order.
+// part[-seg_out[s] - 1]; k_spmm_combine adds the partials of such rows in slot order (a row's slots are consecutive;
+// the launch order of the segments is free, e.g. grouped by column range).
 __global__ void __launch_bounds__(256) k_spmm_seg(const int32_t *__restrict__ col, const float *__restrict__ val,
                                                   const int32_t *__restrict__ seg_beg, const int32_t *__restrict__ seg_end,
                                                   const int32_t *__restrict__ seg_out, int n_seg,
@@ -102,7 +103,7 @@ __global__ void __launch_bounds__(256) k_spmm_seg(const int32_t *__restrict__ co
       if (orow >= 0)
         spmm_epilogue_store(acc[ch], vi, bias, prelu_a, a, out + (int64_t)orow * ldo, out_pre ? out_pre + (int64_t)orow * ldo : nullptr);
       else
-        reinterpret_cast<float4 *>(part + (int64_t)sidx * W)[vi] = acc[ch];
+        reinterpret_cast<float4 *>(part + (int64_t)(-orow - 1) * W)[vi] = acc[ch];
     }
   }
 }
@@ -133,13 +134,12 @@ __global__ void __launch_bounds__(256) k_slice_major(const float *__restrict__ X
   XS[((int64_t)(q >> 3) * n_rows + r) * SPMM_SL + (q & 7)] = v;
 }
 
-constexpr int SPMM_WSEG = 8;                        // consecutive segments per wave: the seg table -> col -> X latency chain is
-constexpr int SPMM_BSEG = 4 * SPMM_WSEG;            // paid once per 8 segments (one segment per wave was latency-bound: 1.5 ms)
+constexpr int SPMM_LONG_SEG = 512;                  // segment length of the sliced plan: 8 index loads per wave, ONE reduction
 
-// number of blocks of the sliced launch: full rounds use U = ceil(n_seg / 32) units per XCD, the last incomplete round
+// number of blocks of the sliced launch: full rounds use U = ceil(n_seg / 4) units per XCD, the last incomplete round
 // ceil(U / m) units, m = the smallest number of XCDs sharing one of its slices
 __host__ inline int64_t spmm_sliced_blocks(int n_seg, int n_slices) {
-  const int64_t U = (n_seg + SPMM_BSEG - 1) / SPMM_BSEG;
+  const int64_t U = (n_seg + 3) / 4;
   const int full = n_slices / SPMM_XCDS, R = n_slices % SPMM_XCDS;
   const int m = R ? SPMM_XCDS / R : 1;              // slice r of the round is served by the XCDs x with x % R == r: >= 8 / R of them
   return SPMM_XCDS * (full * U + (R ? (U + m - 1) / m : 0));
@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(256) k_spmm_sliced(const int32_t *__restrict__
                                                      float *__restrict__ part) {
   const int xcd = blockIdx.x & (SPMM_XCDS - 1);
   const int64_t unit = blockIdx.x >> 3;
-  const int64_t U = (n_seg + SPMM_BSEG - 1) / SPMM_BSEG;
+  const int64_t U = (n_seg + 3) / 4;
   const int full = n_slices / SPMM_XCDS, R = n_slices - full * SPMM_XCDS;
   int slice; int64_t group;
   if (unit < (int64_t)full * U) {                   // complete rounds: XCD x owns slice round * 8 + x
@@ -167,70 +167,75 @@ __global__ void __launch_bounds__(256) k_spmm_sliced(const int32_t *__restrict__
     slice = full * SPMM_XCDS + r;
     group = (unit - (int64_t)full * U) * nx + k;
   }
-  const int64_t first64 = group * SPMM_BSEG + (int64_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * SPMM_WSEG;
-  if (first64 >= n_seg) return;
-  const int first = (int)first64;
-  const int nq = (n_seg - first) < SPMM_WSEG ? (n_seg - first) : SPMM_WSEG;
+  const int64_t sidx64 = group * 4 + (int64_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (sidx64 >= n_seg) return;
+  const int sidx = (int)sidx64;
   const int lane = lane_id();
   const int g = lane >> 3, j = lane & 7;            // 8 neighbours per load instruction, 8 float4 each
   const float4 *__restrict__ xs = XS + (int64_t)slice * n_src * SPMM_SL + j;
-  const int vi = slice * SPMM_SL + j;
-  const float a = prelu_a ? *prelu_a : 1.0f;
-  // segment bounds / outputs of all 8 segments in one vector load each, then every segment's indices and values: nothing in
-  // the gather loop below waits for an address
-  const int sb_v = lane < nq ? seg_beg[first + lane] : 0;
-  const int se_v = lane < nq ? seg_end[first + lane] : 0;
-  const int so_v = lane < nq ? seg_out[first + lane] : 0;
-  int cvs[SPMM_WSEG]; float vvs[SPMM_WSEG]; int cnts[SPMM_WSEG];
-#pragma unroll
-  for (int q = 0; q < SPMM_WSEG; ++q) {
-    const int sq = __builtin_amdgcn_readlane(sb_v, q), tq = __builtin_amdgcn_readlane(se_v, q);
-    cnts[q] = tq - sq;                                // 0 for q >= nq
-    const bool in = sq + lane < tq;
-    cvs[q] = in ? col[sq + lane] : 0;
-    vvs[q] = in ? (val ? val[sq + lane] : 1.0f) : 0.0f;
-  }
-  // software pipeline over the segments: the 8 loads of segment q + 1 are issued before segment q is reduced and stored
-  float4 xa[8], xb[8]; float va[8], vb[8];
-#define SPMM_ISSUE(X_, V_, Q_)                                                        \
-  _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                     \
-    const int k = u * 8 + g;                                                          \
-    const int c = __shfl(cvs[Q_], k, GGAD_WAVE);       /* 0 past the segment's end: row 0 is a valid address */ \
-    V_[u] = __shfl(vvs[Q_], k, GGAD_WAVE);             /* 0.0f past the end */         \
-    const float4 ld = xs[(int64_t)c * SPMM_SL];        /* unconditional: a guarded load costs a branch + vmcnt(0) each */ \
-    const bool ok = k < cnts[Q_];                                                     \
-    X_[u] = make_float4(ok ? ld.x : 0.f, ok ? ld.y : 0.f, ok ? ld.z : 0.f, ok ? ld.w : 0.f); \
-  }
-#define SPMM_CONSUME(X_, V_, Q_)                                                      \
+  const int s = seg_beg[sidx], t = seg_end[sidx];
+  const int nch = (t - s + GGAD_WAVE - 1) / GGAD_WAVE;           // chunks of 64 neighbours (any segment length)
+  // indices / values of a chunk: one coalesced load each from a clamped (always valid) position; the RAW values stay in
+  // registers and are masked only when the chunk's row loads are issued, so that nothing waits on them inside the pipeline
+  const float *__restrict__ vsrc = val ? val : reinterpret_cast<const float *>(col);
+#define SPMM_IDX(C_, V_, CH_)                                                         \
   {                                                                                   \
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);                                     \
+    const int e_ = s + (CH_) * GGAD_WAVE + lane;                                      \
+    const int ec_ = e_ < t ? e_ : t - 1;                                              \
+    C_ = col[ec_];                                                                    \
+    V_ = vsrc[ec_];                                                                   \
+  }
+  // the 8 row loads of a chunk, unconditional (a guarded load costs a branch + vmcnt(0) each); lanes past the segment's end
+  // gather row 0 with value 0.0f
+#define SPMM_ISSUE(X_, V_, C_, VV_, CH_)                                              \
+  {                                                                                   \
+    const bool in_ = s + (CH_) * GGAD_WAVE + lane < t;                                \
+    const int cm_ = in_ ? C_ : 0;                                                     \
+    const float vm_ = in_ ? (val ? VV_ : 1.0f) : 0.0f;                                \
     _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                   \
-      acc.x = fmaf(V_[u], X_[u].x, acc.x); acc.y = fmaf(V_[u], X_[u].y, acc.y);       \
-      acc.z = fmaf(V_[u], X_[u].z, acc.z); acc.w = fmaf(V_[u], X_[u].w, acc.w);       \
-    }                                                                                 \
-    _Pragma("unroll") for (int off = 8; off < GGAD_WAVE; off <<= 1) {                 \
-      acc.x += __shfl_xor(acc.x, off, GGAD_WAVE); acc.y += __shfl_xor(acc.y, off, GGAD_WAVE); \
-      acc.z += __shfl_xor(acc.z, off, GGAD_WAVE); acc.w += __shfl_xor(acc.w, off, GGAD_WAVE); \
-    }                                                                                 \
-    if (g == 0 && vi < (W >> 2)) {                                                    \
-      const int orow = __builtin_amdgcn_readlane(so_v, Q_);                           \
-      if (orow >= 0)                                                                  \
-        spmm_epilogue_store(acc, vi, bias, prelu_a, a, out + (int64_t)orow * ldo,     \
-                            out_pre ? out_pre + (int64_t)orow * ldo : nullptr);       \
-      else                                                                            \
-        reinterpret_cast<float4 *>(part + (int64_t)(first + Q_) * W)[vi] = acc;       \
+      const int k = u * 8 + g;                                                        \
+      const int c = __shfl(cm_, k, GGAD_WAVE);                                        \
+      V_[u] = __shfl(vm_, k, GGAD_WAVE);                                              \
+      X_[u] = xs[(int64_t)c * SPMM_SL];                                               \
     }                                                                                 \
   }
-  SPMM_ISSUE(xa, va, 0)
-#pragma unroll
-  for (int q = 0; q < SPMM_WSEG; q += 2) {
-    if (q + 1 < nq) SPMM_ISSUE(xb, vb, q + 1)
-    if (q < nq) SPMM_CONSUME(xa, va, q)
-    if (q + 2 < nq && q + 2 < SPMM_WSEG) SPMM_ISSUE(xa, va, (q + 2 < SPMM_WSEG ? q + 2 : 0))
-    if (q + 1 < nq) SPMM_CONSUME(xb, vb, q + 1)
+#define SPMM_CONSUME(X_, V_, CH_)                                                     \
+  _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                     \
+    const bool ok = (CH_) * GGAD_WAVE + u * 8 + g < t - s;   /* lanes past the end loaded row 0: drop it (it may hold NaN) */ \
+    acc.x = fmaf(V_[u], ok ? X_[u].x : 0.f, acc.x); acc.y = fmaf(V_[u], ok ? X_[u].y : 0.f, acc.y); \
+    acc.z = fmaf(V_[u], ok ? X_[u].z : 0.f, acc.z); acc.w = fmaf(V_[u], ok ? X_[u].w : 0.f, acc.w); \
   }
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 xa[8], xb[8]; float va[8], vb[8];
+  int c0 = 0, c1 = 0; float w0 = 0.f, w1 = 0.f;
+  if (nch > 0) SPMM_IDX(c0, w0, 0)                  // (an empty row keeps row 0 / 0.0f: nothing is accumulated)
+  if (nch > 1) SPMM_IDX(c1, w1, 1)
+  SPMM_ISSUE(xa, va, c0, w0, 0)
+  for (int ch = 0; ch < nch; ch += 2) {             // software pipeline: chunk ch + 1 is in flight while chunk ch is accumulated
+    if (ch + 2 < nch) SPMM_IDX(c0, w0, ch + 2)
+    if (ch + 1 < nch) SPMM_ISSUE(xb, vb, c1, w1, ch + 1)
+    SPMM_CONSUME(xa, va, ch)
+    if (ch + 3 < nch) SPMM_IDX(c1, w1, ch + 3)
+    if (ch + 2 < nch) SPMM_ISSUE(xa, va, c0, w0, ch + 2)
+    if (ch + 1 < nch) SPMM_CONSUME(xb, vb, ch + 1)
+  }
+#undef SPMM_IDX
 #undef SPMM_ISSUE
 #undef SPMM_CONSUME
+  // sum of the 8 lane groups (fixed butterfly over lane bits 3..5)
+#pragma unroll
+  for (int off = 8; off < GGAD_WAVE; off <<= 1) {
+    acc.x += __shfl_xor(acc.x, off, GGAD_WAVE); acc.y += __shfl_xor(acc.y, off, GGAD_WAVE);
+    acc.z += __shfl_xor(acc.z, off, GGAD_WAVE); acc.w += __shfl_xor(acc.w, off, GGAD_WAVE);
+  }
+  const int vi = slice * SPMM_SL + j;
+  if (g != 0 || vi >= (W >> 2)) return;
+  const int orow = seg_out[sidx];
+  const float a = prelu_a ? *prelu_a : 1.0f;
+  if (orow >= 0)
+    spmm_epilogue_store(acc, vi, bias, prelu_a, a, out + (int64_t)orow * ldo, out_pre ? out_pre + (int64_t)orow * ldo : nullptr);
+  else
+    reinterpret_cast<float4 *>(part + (int64_t)(-orow - 1) * W)[vi] = acc;
 }
 
 // rows split into several segments: out[row] = epilogue(sum of part[first .. first + count))   (fixed order)
@@ -493,6 +498,7 @@ __global__ void k_bump(int32_t *c) { *c += 1; }
 extern "C" {
 
 int ggad_spmm_seg_len(void) { return SPMM_SEG; }
+int ggad_spmm_sliced_seg_len(void) { return SPMM_LONG_SEG; }
 
 int ggad_spmm_csr_f32(const int32_t *col, const float *val, const int32_t *seg_beg, const int32_t *seg_end,
                       const int32_t *seg_out, int32_t n_seg, const int32_t *multi_row, const int32_t *multi_first,

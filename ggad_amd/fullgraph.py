@@ -49,31 +49,70 @@ class Csr:
         self.dev = dev
         self._plans = {}
 
-    def plan(self, rows_sel: Optional[np.ndarray] = None, key=None):
-        """Segment tables for ggad_spmm_csr_f32 (whole matrix, or the row subset `rows_sel`); cached."""
+    def plan(self, rows_sel: Optional[np.ndarray] = None, key=None, seg: Optional[int] = None, col_ranges: int = 1):
+        """Segment tables for ggad_spmm_csr_f32 / ggad_spmm_sliced_f32 (whole matrix, or the row subset `rows_sel`); cached.
+        `seg`: segment length (default: the 64 of the wave-per-segment kernel).  `col_ranges` > 1: segments never cross
+        the boundaries of that many equal column ranges and are launched range by range (columns are sorted inside a row,
+        so a row is cut where its columns cross a boundary) -- the gathered operand rows of one phase then fit an L2."""
         key = "all" if rows_sel is None else key
+        if key is not None and (seg is not None or col_ranges > 1):
+            key = (key, "seg", seg, col_ranges)
         p = self._plans.get(key) if key is not None else None
         if p is not None:
             return p
-        seg = int(_lib.load().ggad_spmm_seg_len())
+        seg = int(_lib.load().ggad_spmm_seg_len()) if seg is None else int(seg)
         rp = self.host.indptr.astype(np.int64)
         rows = np.arange(self.shape[0], dtype=np.int64) if rows_sel is None else np.asarray(rows_sel, dtype=np.int64)
         beg, end = rp[rows], rp[rows + 1]
-        nseg = np.maximum(1, (end - beg + seg - 1) // seg)
+        if col_ranges > 1:
+            # runs of (row, column range): cut positions inside every selected row
+            width = -(-self.shape[1] // int(col_ranges))
+            bounds = np.arange(1, int(col_ranges), dtype=np.int64) * width
+            cnt = end - beg
+            tot = int(cnt.sum())
+            off = np.zeros(len(rows) + 1, dtype=np.int64)
+            np.cumsum(cnt, out=off[1:])
+            pos = np.repeat(beg - off[:-1], cnt) + np.arange(tot, dtype=np.int64)        # CSR position of every selected entry
+            bucket = np.searchsorted(bounds, self.host.indices[pos], side="right")
+            owner_e = np.repeat(np.arange(len(rows), dtype=np.int64), cnt)
+            keyv = owner_e * int(col_ranges) + bucket
+            start = np.flatnonzero(np.concatenate(([True], keyv[1:] != keyv[:-1]))) if tot else np.zeros(0, dtype=np.int64)
+            run_beg = pos[start] if tot else np.zeros(0, dtype=np.int64)
+            run_len = np.diff(np.concatenate((start, [tot]))) if tot else np.zeros(0, dtype=np.int64)
+            run_row, run_bucket = owner_e[start], bucket[start]
+            empty = np.flatnonzero(cnt == 0)                                              # rows without entries keep one empty segment
+            run_beg = np.concatenate((run_beg, beg[empty]))
+            run_len = np.concatenate((run_len, np.zeros(len(empty), dtype=np.int64)))
+            run_row = np.concatenate((run_row, empty))
+            run_bucket = np.concatenate((run_bucket, np.zeros(len(empty), dtype=np.int64)))
+            o = np.lexsort((run_bucket, run_row))                                         # row-major: slots of a row are consecutive
+            run_beg, run_len, run_row, run_bucket = run_beg[o], run_len[o], run_row[o], run_bucket[o]
+        else:
+            run_beg, run_len, run_row = beg, end - beg, np.arange(len(rows), dtype=np.int64)
+            run_bucket = np.zeros(len(rows), dtype=np.int64)
+        npiece = np.maximum(1, (run_len + seg - 1) // seg)
+        firstp = np.zeros(len(run_beg) + 1, dtype=np.int64)
+        np.cumsum(npiece, out=firstp[1:])
+        total = int(firstp[-1])
+        run_of = np.repeat(np.arange(len(run_beg), dtype=np.int64), npiece)              # run of every segment (slot order)
+        k = np.arange(total, dtype=np.int64) - firstp[run_of]
+        sbeg = run_beg[run_of] + k * seg
+        send = np.minimum(run_beg[run_of] + run_len[run_of], sbeg + seg)
+        owner = run_row[run_of]                                                           # output row of every segment
+        nseg = np.bincount(owner, minlength=len(rows)).astype(np.int64)                  # segments per output row
         first = np.zeros(len(rows) + 1, dtype=np.int64)
-        np.cumsum(nseg, out=first[1:])
-        total = int(first[-1])
-        owner = np.repeat(np.arange(len(rows), dtype=np.int64), nseg)           # output row of every segment
-        k = np.arange(total, dtype=np.int64) - first[owner]                     # index of the segment inside its row
-        sbeg = beg[owner] + k * seg
-        send = np.minimum(end[owner], sbeg + seg)
+        np.cumsum(nseg, out=first[1:])                                                    # slot order == (row, range, piece) order
         single = nseg[owner] == 1
-        seg_out = np.where(single, owner, -1)
+        seg_out = np.where(single, owner, -(np.arange(total, dtype=np.int64) + 1))       # < 0: partial sum slot = -seg_out - 1
+        if col_ranges > 1:
+            launch = np.argsort(run_bucket[run_of], kind="stable")                        # launch order: column range by range
+            sbeg, send, seg_out = sbeg[launch], send[launch], seg_out[launch]
         multi = np.nonzero(nseg > 1)[0]
         dev = self.dev
         p = dict(seg_beg=_dev_i32(sbeg, dev), seg_end=_dev_i32(send, dev), seg_out=_dev_i32(seg_out, dev), n_seg=total,
                  multi_row=_dev_i32(multi, dev), multi_first=_dev_i32(first[multi], dev), multi_count=_dev_i32(nseg[multi], dev),
-                 n_multi=int(len(multi)), n_out=int(len(rows)), part=None, nnz=int((end - beg).sum()))
+                 n_multi=int(len(multi)), n_out=int(len(rows)), part=None, nnz=int((end - beg).sum()),
+                 rows=None if rows_sel is None else rows, long=None)
         if key is not None:
             self._plans[key] = p
         return p
@@ -171,6 +210,16 @@ def _use_sliced(csr: Csr, p, X: torch.Tensor) -> bool:
     return w >= 64 and X.shape[0] * w * 4 >= (6 << 20) and p["n_seg"] > 0 and p.get("nnz", csr.nnz) >= 24 * p["n_seg"]
 
 
+def _part_buffer(p, W: int, dev):
+    """Partial sums of the rows that are split into several segments (cached on the plan)."""
+    if p["n_multi"] == 0:
+        return None
+    part = p.get("part")
+    if part is None or part.numel() < p["n_seg"] * W:
+        part = p["part"] = torch.empty(p["n_seg"] * W, dtype=torch.float32, device=dev)
+    return part
+
+
 def spmm(csr: Csr, X: torch.Tensor, plan=None, bias=None, prelu_a=None, want_pre=False):
     """out = act(csr[rows] @ X + bias); `plan` = csr.plan(...) selects the rows (default: all)."""
     X = X.contiguous()
@@ -178,12 +227,17 @@ def spmm(csr: Csr, X: torch.Tensor, plan=None, bias=None, prelu_a=None, want_pre
     p = plan if plan is not None else csr.plan()
     out = torch.empty(p["n_out"], W, dtype=torch.float32, device=X.device)
     pre = torch.empty_like(out) if want_pre else None
-    part = None
-    if p["n_multi"] > 0:
-        part = p.get("part")
-        if part is None or part.numel() < p["n_seg"] * W:
-            part = p["part"] = torch.empty(p["n_seg"] * W, dtype=torch.float32, device=X.device)
+    opt = (ptr(bias) if bias is not None else 0, ptr(prelu_a) if prelu_a is not None else 0, ptr(out), W,
+           ptr(pre) if pre is not None else 0)
     if _use_sliced(csr, p, X):
+        if p["long"] is None:      # the sliced kernel walks long segments (8 index loads, one reduction and store per wave)
+            # (GGAD_SPMM_COL_RANGES > 1 cuts them at column-range boundaries and launches range by range so that one phase's
+            # operand rows fit an L2 -- measured slower, 1.35 -> 1.67 ms with 2 ranges on T-Finance: the sliced kernel is bound
+            # by the L1 line rate, not by L2 capacity, and shorter segments cost more prologues; kept for experiments)
+            ranges = max(1, int(os.environ.get("GGAD_SPMM_COL_RANGES", 1)))
+            p["long"] = csr.plan(p["rows"], key=None, seg=int(_lib.load().ggad_spmm_sliced_seg_len()), col_ranges=ranges)
+        p = p["long"]
+        part = _part_buffer(p, W, X.device)
         n_ws = int(_lib.load().ggad_spmm_sliced_workspace_elems(X.shape[0], W))
         key = (str(X.device), torch.cuda.current_stream(X.device).cuda_stream)
         xs = _XS_WORKSPACE.get(key)
@@ -191,13 +245,12 @@ def spmm(csr: Csr, X: torch.Tensor, plan=None, bias=None, prelu_a=None, want_pre
             xs = _XS_WORKSPACE[key] = torch.empty(n_ws, dtype=torch.float32, device=X.device)
         call("ggad_spmm_sliced_f32", ptr(csr.col), ptr(csr.val), ptr(p["seg_beg"]), ptr(p["seg_end"]), ptr(p["seg_out"]),
              p["n_seg"], ptr(p["multi_row"]), ptr(p["multi_first"]), ptr(p["multi_count"]), p["n_multi"], ptr(X), W, W, X.shape[0],
-             ptr(xs), ptr(bias) if bias is not None else 0, ptr(prelu_a) if prelu_a is not None else 0, ptr(out), W,
-             ptr(pre) if pre is not None else 0, ptr(part) if part is not None else 0)
-        return (out, pre) if want_pre else out
-    call("ggad_spmm_csr_f32", ptr(csr.col), ptr(csr.val), ptr(p["seg_beg"]), ptr(p["seg_end"]), ptr(p["seg_out"]), p["n_seg"],
-         ptr(p["multi_row"]), ptr(p["multi_first"]), ptr(p["multi_count"]), p["n_multi"], ptr(X), W, W,
-         ptr(bias) if bias is not None else 0, ptr(prelu_a) if prelu_a is not None else 0, ptr(out), W,
-         ptr(pre) if pre is not None else 0, ptr(part) if part is not None else 0)
+             ptr(xs), *opt, ptr(part) if part is not None else 0)
+    else:
+        part = _part_buffer(p, W, X.device)
+        call("ggad_spmm_csr_f32", ptr(csr.col), ptr(csr.val), ptr(p["seg_beg"]), ptr(p["seg_end"]), ptr(p["seg_out"]), p["n_seg"],
+             ptr(p["multi_row"]), ptr(p["multi_first"]), ptr(p["multi_count"]), p["n_multi"], ptr(X), W, W, *opt,
+             ptr(part) if part is not None else 0)
     return (out, pre) if want_pre else out
 
 

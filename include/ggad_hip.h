@@ -331,8 +331,9 @@ int ggad_gemm_f32(const float *A, const float *B, float *C, int32_t M, int32_t N
 /* out[r] = act( sum_e val[e] * X[col[e]] + bias ) over CSR rows cut into SEGMENTS of <= ggad_spmm_seg_len()
  * consecutive entries [seg_beg, seg_end): one wave per segment, so a hub row never serialises the launch.
  * seg_out[s] >= 0: the row consists of this one segment and is finished in place (output row seg_out[s]);
- * seg_out[s] < 0: the partial sum goes to part[s][W] and the row is listed in multi_row / multi_first /
- * multi_count (output row, first segment, number of segments), summed in segment order by a second launch.
+ * seg_out[s] < 0: the partial sum goes to part[-seg_out[s] - 1][W] and the row is listed in multi_row / multi_first /
+ * multi_count (output row, first slot, number of slots), summed in slot order by a second launch; part holds
+ * n_seg x W floats, slots are unique and < n_seg.  The order of the segments in the tables is the launch order and is free.
  * The segment tables are built once per matrix (and per row subset) on the host.
  * act = PReLU with slope *prelu_a if given; out_pre (optional) receives the pre-activation.  W % 4 == 0.
  * Replaces torch.bmm(adj, .) + bias + PReLU (model.py:31-35), adj[0, abn, :] @ emb (model.py:151-155),
@@ -349,6 +350,7 @@ int ggad_spmm_csr_f32(const int32_t *col, const float *val, const int32_t *seg_b
  * segment tables, epilogue and outputs as ggad_spmm_csr_f32; the summation order inside a segment differs (lane groups
  * take every 8th neighbour), so results agree to fp32 round-off, and are deterministic. */
 int64_t ggad_spmm_sliced_workspace_elems(int64_t n_src_rows, int32_t W);
+int ggad_spmm_sliced_seg_len(void); /* recommended segment length of ITS segment tables (any length is accepted; empty segments are not) */
 int ggad_spmm_sliced_f32(const int32_t *col, const float *val, const int32_t *seg_beg, const int32_t *seg_end,
                          const int32_t *seg_out, int32_t n_seg, const int32_t *multi_row, const int32_t *multi_first,
                          const int32_t *multi_count, int32_t n_multi, const float *X, int64_t ldx, int32_t W, int64_t n_src_rows,

@@ -231,6 +231,36 @@ def test_ocgnn_script_captured_epoch_equals_eager():
     assert outs[0] == outs[1]
 
 
+def test_spmm_sliced_column_ranges_and_empty_rows(monkeypatch):
+    """Segments cut at column-range boundaries and launched range by range (3 ranges forced on a small matrix), rows
+    without entries, hub rows longer than one 512-entry segment, a row subset with repeated structure."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(11)
+    n, m, w = 1500, 2100, 300
+    a = sp.random(n, m, density=0.04, random_state=3, format="lil", dtype=np.float32)
+    a[7, :] = 0
+    a[8, :] = 0
+    a[100, :] = rng.standard_normal(m).astype(np.float32)          # 2100 entries: 5 long segments, crosses every range
+    a[n - 1, :] = 0
+    csr = FG.Csr(a.tocsr(), DEV)
+    x = torch.from_numpy(rng.standard_normal((m, w)).astype(np.float32)).to(DEV)
+    ref = csr.host.astype(np.float64) @ x.cpu().numpy().astype(np.float64)
+    scale = np.abs(ref).max() + 1.0
+    rows = np.array([100, 7, 3, 1499, 100 - 1, 8, 640])
+    monkeypatch.setenv("GGAD_SPMM_SLICED", "1")
+    for ranges in ("1", "3", "7"):
+        monkeypatch.setenv("GGAD_SPMM_COL_RANGES", ranges)
+        for p in (csr.plan(), csr.plan(rows, key=("cr", ranges))):
+            p["long"] = None
+        got = FG.spmm(csr, x).cpu().numpy()
+        assert np.abs(got - ref).max() / scale < 2e-6, ranges
+        assert (got[[7, 8, n - 1]] == 0).all()
+        sub = FG.spmm(csr, x, plan=csr.plan(rows, key=("cr", ranges))).cpu().numpy()
+        assert np.abs(sub - ref[rows]).max() / scale < 2e-6, ranges
+    lp = csr.plan()["long"]
+    assert lp["n_multi"] > 0 and int((lp["seg_out"] < 0).sum().item()) > 5
+
+
 @pytest.mark.parametrize("w", [300, 64, 256, 28, 4, 512])
 def test_spmm_xcd_sliced_equals_row_major(w, monkeypatch):
     """The XCD-sliced SpMM (slice-major operand, 64 / L neighbours per load) against the wave-per-segment kernel: whole
