@@ -289,3 +289,28 @@ def test_spmm_xcd_sliced_equals_row_major(w, monkeypatch):
     np.testing.assert_allclose(outs["1"][2], ref[rows], atol=2e-6 * scale)
     monkeypatch.delenv("GGAD_SPMM_SLICED")
     assert FG._use_sliced(csr, csr.plan(), x) == (w >= 64 and n * w * 4 >= (6 << 20))
+
+
+def test_spmm_at_t_finance_size_against_scipy_and_exact_scaling():
+    """BASELINE's largest full-graph config (39,357 nodes, 21.2 M directed entries, H = 300): the automatically chosen
+    (XCD-sliced) product against scipy in float64, exact under a factor 2, deterministic, with bias + PReLU epilogue."""
+    import scipy.sparse as sp
+    n, ne, w = 39357, 21222543, 300
+    rowptr, col = synth.make_graph(n, ne, 0, kind="powerlaw", max_degree=n // 8)
+    a = synth.csr_to_scipy(rowptr, col, n)
+    csr = FG.Csr(U.normalize_adj(a) + sp.eye(n), DEV)
+    rng = np.random.default_rng(1)
+    xh = rng.standard_normal((n, w)).astype(np.float32)
+    x = torch.from_numpy(xh).to(DEV)
+    assert FG._use_sliced(csr, csr.plan(), x)
+    bias = torch.from_numpy(rng.standard_normal(w).astype(np.float32)).to(DEV)
+    slope = torch.tensor([0.1], device=DEV)
+    out, pre = FG.spmm(csr, x, bias=bias, prelu_a=slope, want_pre=True)
+    ref = csr.host.astype(np.float64) @ xh.astype(np.float64) + bias.cpu().numpy().astype(np.float64)
+    scale = np.abs(ref).max()
+    assert np.abs(pre.cpu().numpy() - ref).max() / scale < 2e-6
+    np.testing.assert_allclose(out.cpu().numpy(), np.where(ref > 0, ref, 0.1 * ref), atol=3e-6 * scale)
+    plain = FG.spmm(csr, x)
+    again = FG.spmm(csr, x)
+    assert torch.equal(plain.view(torch.int32), again.view(torch.int32))                      # fixed summation order
+    assert torch.equal((plain * 2.0).view(torch.int32), FG.spmm(csr, x * 2.0).view(torch.int32))
