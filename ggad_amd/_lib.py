@@ -90,6 +90,7 @@ SIGNATURES = {
     "ggad_prelu_bwd_splits": (c_int32, [_I]),
     "ggad_prelu_bwd_f32": (c_int32, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "ggad_relu_bwd_f32": (c_int32, [_P, _P, _L, _P, _P]),
+    "ggad_prelu_fwd_f32": (c_int32, [_P, _P, _L, _P, _P]),
     "ggad_rownorm_f32": (c_int32, [_P, _I, _I, _P, _P, _P]),
     "ggad_rownorm_bwd_f32": (c_int32, [_P, _P, _P, _I, _I, _P, _P]),
     "ggad_rowdot_f32": (c_int32, [_P, _P, _P, _I, _I, _P, _P, _P]),

@@ -319,6 +319,13 @@ __global__ void __launch_bounds__(256) k_relu_bwd(const float *__restrict__ g, c
   if (i < n) dz[i] = y[i] > 0.f ? g[i] : 0.f;
 }
 
+// out = z > 0 ? z : a z  (PReLU forward on its own: the layer whose aggregate A_hat X is cached has no SpMM to fuse it into)
+__global__ void __launch_bounds__(256) k_prelu_fwd(const float *__restrict__ z, const float *__restrict__ prelu_a, int64_t n,
+                                                   float *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { const float v = z[i]; out[i] = v > 0.f ? v : *prelu_a * v; }
+}
+
 // inv[r] = 1/|x_r| (inf -> 0), xn = x * inv                                     run.py:177-180
 __global__ void __launch_bounds__(256) k_rownorm(const float *__restrict__ X, int M, int W, float *__restrict__ inv,
                                                  float *__restrict__ Xn) {
@@ -568,6 +575,14 @@ int ggad_relu_bwd_f32(const float *g, const float *y, int64_t n, float *dz, ggad
   if (n == 0) return GGAD_OK;
   k_relu_bwd<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream)>>>(g, y, n, dz);
   GGAD_CHECK_LAUNCH("relu_bwd_f32");
+  return GGAD_OK;
+}
+
+int ggad_prelu_fwd_f32(const float *z, const float *prelu_a, int64_t n, float *out, ggad_stream_t stream) {
+  GGAD_REQUIRE(z && prelu_a && out && n >= 0);
+  if (n == 0) return GGAD_OK;
+  k_prelu_fwd<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream)>>>(z, prelu_a, n, out);
+  GGAD_CHECK_LAUNCH("prelu_fwd_f32");
   return GGAD_OK;
 }
 

@@ -144,6 +144,7 @@ class FullGraphAdj:
         self.r_inv_host = r_inv
         self._abn: Dict[tuple, tuple] = {}
         self._loss: Dict[tuple, tuple] = {}
+        self._ax: Dict[str, object] = {}                         # cached A_hat X of the constant input layer (`cached_aggregate`)
 
     @classmethod
     def from_dense(cls, adj, raw_adj, device):
@@ -255,14 +256,45 @@ def spmm(csr: Csr, X: torch.Tensor, plan=None, bias=None, prelu_a=None, want_pre
 
 
 # ------------------------------------------------------------------------------------------------ autograd
+def _reorder_layer(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    """A_hat (X W^T) == (A_hat X) W^T: when the layer's input is a constant (the feature matrix: no gradient) narrower than its
+    output, A_hat X is computed once and cached, and the layer needs no SpMM at all -- neither forward nor backward (the weight
+    gradient is dZ^T (A_hat X)).  T-Finance: F = 10 against H = 300, two of the five N x N x 300 products of an epoch go.
+    Same operations, the two products associated the other way round: results agree to fp32 round-off.
+    GGAD_GCN_REORDER=0 keeps the reference's order."""
+    return (not x.requires_grad) and x.shape[1] < weight.shape[0] and os.environ.get("GGAD_GCN_REORDER", "1") != "0"
+
+
+def cached_aggregate(adj: "FullGraphAdj", x: torch.Tensor) -> torch.Tensor:
+    """A_hat X for a constant X (N x F), computed once per (X storage, version) with the SpMM kernel on zero-padded columns."""
+    key = (x.data_ptr(), x._version, tuple(x.shape))
+    hit = adj._ax.get("key") == key
+    if not hit:
+        f = x.shape[1]
+        fp = (f + 3) // 4 * 4
+        xp = x if fp == f else torch.cat((x, torch.zeros(x.shape[0], fp - f, device=x.device)), 1)
+        with torch.no_grad():
+            ax = spmm(adj.A, xp.contiguous())
+        adj._ax = {"key": key, "ax": ax[:, :f].contiguous()}
+    return adj._ax["ax"]
+
+
 class GcnLayerFn(torch.autograd.Function):
     """out = PReLU(A_hat (X W^T) + b)   (reference GCN.forward, `model.py:26-35`)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, prelu_a, adj: FullGraphAdj):
-        t = gemm(x, weight, False, True)                                     # seq_fts = fc(seq)        model.py:27
-        out, z = spmm(adj.A, t, bias=bias, prelu_a=prelu_a, want_pre=True)   # bmm(adj, .) + bias, act  model.py:31-35
-        ctx.save_for_backward(x, weight, z, prelu_a)
+        ctx.reordered = _reorder_layer(x, weight)
+        if ctx.reordered:
+            ax = cached_aggregate(adj, x)
+            z = gemm(ax, weight, False, True, bias=bias)                     # (A_hat X) W^T + b
+            out = torch.empty_like(z)
+            call("ggad_prelu_fwd_f32", ptr(z), ptr(prelu_a), z.numel(), ptr(out))
+            ctx.save_for_backward(ax, weight, z, prelu_a)
+        else:
+            t = gemm(x, weight, False, True)                                     # seq_fts = fc(seq)        model.py:27
+            out, z = spmm(adj.A, t, bias=bias, prelu_a=prelu_a, want_pre=True)   # bmm(adj, .) + bias, act  model.py:31-35
+            ctx.save_for_backward(x, weight, z, prelu_a)
         ctx.adj = adj
         ctx.has_bias = bias is not None
         return out
@@ -280,6 +312,9 @@ class GcnLayerFn(torch.autograd.Function):
         db = torch.empty(W, dtype=torch.float32, device=z.device)
         da = torch.empty(1, dtype=torch.float32, device=z.device)
         call("ggad_prelu_bwd_f32", ptr(g), ptr(z), ptr(prelu_a), M, W, ptr(dz), ptr(db), ptr(da), ptr(ws))
+        if ctx.reordered:                                                    # x holds A_hat X here
+            dw = gemm(dz, x, True, False)                                    # (H x N)(N x F), no transposed product needed
+            return None, dw, (db if ctx.has_bias else None), da.view_as(prelu_a), None
         dt = spmm(adj.At, dz)                                                # A_hat^T dZ
         dw = gemm(dt, x, True, False)                                        # (H x N)(N x F)
         dx = gemm(dt, weight, False, False) if ctx.needs_input_grad[0] else None

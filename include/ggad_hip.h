@@ -362,6 +362,8 @@ int ggad_spmm_sliced_f32(const int32_t *col, const float *val, const int32_t *se
 int32_t ggad_prelu_bwd_splits(int32_t M);
 int ggad_prelu_bwd_f32(const float *g, const float *z, const float *prelu_a, int32_t M, int32_t W, float *dz, float *db,
                        float *da, float *workspace, ggad_stream_t stream);
+/* out = PReLU(z) with slope *prelu_a (model.py:35), for a GCN layer whose aggregate is taken from a cache (no SpMM epilogue) */
+int ggad_prelu_fwd_f32(const float *z, const float *prelu_a, int64_t n, float *out, ggad_stream_t stream);
 /* dz = g * [y > 0] */
 int ggad_relu_bwd_f32(const float *g, const float *y, int64_t n, float *dz, ggad_stream_t stream);
 

@@ -29,7 +29,8 @@ def _adj(g):
 
 
 @pytest.mark.parametrize("shape", [(70, 50, 33), (300, 300, 7535), (1, 75, 1000), (130, 1, 40), (64, 64, 16), (257, 129, 3000),
-                                   (132, 68, 36), (131, 67, 745), (7535, 300, 745), (66, 302, 130)])
+                                   (132, 68, 36), (131, 67, 745), (7535, 300, 745), (66, 302, 130), (500, 300, 10), (257, 64, 3),
+                                   (300, 10, 5000)])
 def test_gemm_f32_all_layouts(shape):
     m, n, k = shape
     rng = np.random.default_rng(m + n + k)
@@ -314,3 +315,40 @@ def test_spmm_at_t_finance_size_against_scipy_and_exact_scaling():
     again = FG.spmm(csr, x)
     assert torch.equal(plain.view(torch.int32), again.view(torch.int32))                      # fixed summation order
     assert torch.equal((plain * 2.0).view(torch.int32), FG.spmm(csr, x * 2.0).view(torch.int32))
+
+
+def test_gcn_layer_cached_aggregate_equals_reference_order(monkeypatch):
+    """Input layer as (A_hat X) W^T with A_hat X cached (no SpMM per epoch, weight gradient dZ^T (A_hat X)) against the
+    reference's order A_hat (X W^T): output, weight / bias / slope gradients; cache invalidated by an in-place change of X."""
+    import scipy.sparse as sp
+    n, f, h = 5000, 10, 300
+    rowptr, col = synth.make_graph(n, 200000, 4, kind="powerlaw", max_degree=n // 8)
+    a = synth.csr_to_scipy(rowptr, col, n)
+    fa = FG.FullGraphAdj(U.normalize_adj(a) + sp.eye(n), a + sp.eye(n), DEV)
+    rng = np.random.default_rng(2)
+    x = torch.from_numpy(rng.random((n, f)).astype(np.float32)).to(DEV)
+    gout = torch.from_numpy(rng.standard_normal((n, h)).astype(np.float32)).to(DEV)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("GGAD_GCN_REORDER", mode)
+        torch.manual_seed(0)
+        layer = GCN(f, h, "prelu").to(DEV)
+        with torch.no_grad():
+            layer.bias.copy_(torch.from_numpy(rng.standard_normal(h).astype(np.float32) * 0.1 if mode == "0" else res["bias"]))
+        res.setdefault("bias", layer.bias.detach().cpu().numpy().copy())
+        out = layer(x[None], fa)
+        (out[0] * gout).sum().backward()
+        res[mode] = (out[0].detach().cpu().numpy(), layer.fc.weight.grad.cpu().numpy(), layer.bias.grad.cpu().numpy(),
+                     layer.act.weight.grad.cpu().numpy())
+    for k in range(4):
+        scale = np.abs(res["0"][k]).max() + 1e-6
+        assert np.abs(res["0"][k] - res["1"][k]).max() / scale < 5e-6, k
+    # second call hits the cache; an in-place update of X must not
+    monkeypatch.setenv("GGAD_GCN_REORDER", "1")
+    with torch.no_grad():
+        o1 = layer(x[None], fa)[0].clone()
+        x.mul_(2.0)
+        o2 = layer(x[None], fa)[0]
+        monkeypatch.setenv("GGAD_GCN_REORDER", "0")
+        o3 = layer(x[None], fa)[0]
+    assert not torch.allclose(o1, o2) and torch.allclose(o2, o3, rtol=1e-5, atol=1e-5)
