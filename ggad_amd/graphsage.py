@@ -21,9 +21,7 @@ Differences that are deliberate and documented:
 """
 from __future__ import annotations
 
-import ctypes
 import random
-from typing import Optional
 
 import numpy as np
 import torch
