@@ -91,7 +91,7 @@ def main():
     for epoch in range(args.num_epoch):
         start_time = time.time()
         model.train()
-        if not args.no_graph and graph is None and epoch == 2 and epoch_times[1] < 5e-3:     # host-bound epoch: capture it (see run.py)
+        if not args.no_graph and graph is None and epoch == 2 and epoch_times[1] < float(os.environ.get("GGAD_CAPTURE_BELOW_S", "20e-3")):     # host-bound epoch: capture it (see run.py)
             loss = None
             optimiser.zero_grad()
             import gc
