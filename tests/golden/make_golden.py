@@ -231,6 +231,45 @@ def ocgnn_case():
     print("wrote", path, "losses", losses, "auc", out["eval_auc"])
 
 
+def ingest_case():
+    """`load_mat` of the reference (utils.py:66-141) on a small .mat written from seeded synthetic data: the index lists the
+    split produces (python `random` driven), for the two outlier-seed fractions ('Amazon' 5 %, every other name 15 %)."""
+    import tempfile
+    import scipy.io as sio
+    import scipy.sparse as sp
+    import utils as rutils                       # /root/reference/utils.py
+    n, ne, f, seed = 400, 3000, 12, 31
+    rowptr, col = synth.make_graph(n, ne, seed, kind="powerlaw", max_degree=60)
+    adj = synth.csr_to_scipy(rowptr, col)
+    feat = synth.make_features(n, f, seed)
+    ano = synth.make_labels(n, 0.08, seed)
+    out = dict(n=n, n_entries=ne, f=f, seed=seed, inputs_crc=synth.crc_of(rowptr, col, feat, ano))
+    tmp = tempfile.mkdtemp(prefix="ggad_ingest_")
+    os.makedirs(os.path.join(tmp, "dataset"))
+    cwd = os.getcwd()
+    os.chdir(tmp)
+    try:
+        for name, keys in (("Amazon", ("Network", "Attributes", "Label")), ("tiny", ("A", "X", "gnd"))):
+            sio.savemat(os.path.join("dataset", name + ".mat"),
+                        {keys[0]: sp.csr_matrix(adj), keys[1]: sp.csr_matrix(feat), keys[2]: ano.reshape(-1, 1)})
+            random.seed(seed)
+            r = rutils.load_mat(name)
+            a, ft = r[0], r[1]
+            assert (abs(a - adj).nnz == 0) and np.allclose(np.asarray(ft.todense()), feat)
+            out[name + ".all_idx"] = np.array(r[3], dtype=np.int64)
+            out[name + ".idx_train"] = np.array(r[4], dtype=np.int64)
+            out[name + ".idx_val"] = np.array(r[5], dtype=np.int64)
+            out[name + ".idx_test"] = np.array(r[6], dtype=np.int64)
+            out[name + ".normal_idx"] = np.array(r[10], dtype=np.int64)
+            out[name + ".abnormal_idx"] = np.array(r[11], dtype=np.int64)
+            out[name + ".tail"] = np.array([random.getrandbits(32) for _ in range(3)], dtype=np.int64)   # RNG consumption
+    finally:
+        os.chdir(cwd)
+    path = os.path.join(HERE, "ingest_mat.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, {k: len(v) for k, v in out.items() if hasattr(v, "__len__") and "idx" in k})
+
+
 def part_full():
     _stub_third_party()
     sys.path.insert(0, REF)
@@ -523,7 +562,7 @@ def part_mini(with_handler: bool):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--part", choices=["all", "full", "mini", "baselines", "ocgnn"], default="all")
+    ap.add_argument("--part", choices=["all", "full", "mini", "baselines", "ocgnn", "ingest"], default="all")
     ap.add_argument("--no-handler", action="store_true", help="skip the slow end-to-end ModelHandler case")
     a = ap.parse_args()
     if not os.path.isdir(REF):
@@ -531,11 +570,15 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     if a.part == "all":
         env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
-        for p in ("full", "mini", "baselines", "ocgnn"):
+        for p in ("full", "mini", "baselines", "ocgnn", "ingest"):
             cmd = [sys.executable, os.path.abspath(__file__), "--part", p] + (["--no-handler"] if a.no_handler else [])
             subprocess.check_call(cmd, env=env)
     elif a.part == "full":
         part_full()
+    elif a.part == "ingest":
+        _stub_third_party()
+        sys.path.insert(0, REF)
+        ingest_case()
     elif a.part == "ocgnn":
         _stub_third_party()
         sys.path.insert(0, REF)

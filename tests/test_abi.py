@@ -66,3 +66,33 @@ def test_csr_cache_round_trip(tmp_path):
     assert np.array_equal(g2.rowptr_host, rowptr) and np.array_equal(g2.col_host, col)
     g3 = DeviceGraph.from_adj_lists_cached(adj, 400 + 100, "cpu", str(tmp_path / "missing" / "x.npz"))   # unwritable: still works
     assert g3.nnz == g1.nnz
+
+
+def test_load_mat_split_equals_reference(tmp_path, capsys):
+    """`load_mat` (reference utils.py:66-141): same index lists and the same consumption of python's `random` stream as the
+    imported reference produced on a .mat written from the same seeded inputs (tests/golden/ingest_mat.npz)."""
+    import random
+
+    import scipy.io as sio
+    import scipy.sparse as sp
+    from conftest import load_golden
+    from ggad_amd import synth
+    from ggad_amd.utils import load_mat
+    g = load_golden("ingest_mat.npz")
+    n, ne, f, seed = int(g["n"]), int(g["n_entries"]), int(g["f"]), int(g["seed"])
+    rowptr, col = synth.make_graph(n, ne, seed, kind="powerlaw", max_degree=60)
+    adj = synth.csr_to_scipy(rowptr, col)
+    feat = synth.make_features(n, f, seed)
+    ano = synth.make_labels(n, 0.08, seed)
+    assert synth.crc_of(rowptr, col, feat, ano) == int(g["inputs_crc"])
+    for name, keys in (("Amazon", ("Network", "Attributes", "Label")), ("tiny", ("A", "X", "gnd"))):
+        path = str(tmp_path / (name + ".mat"))
+        sio.savemat(path, {keys[0]: sp.csr_matrix(adj), keys[1]: sp.csr_matrix(feat), keys[2]: ano.reshape(-1, 1)})
+        random.seed(seed)
+        r = load_mat(name, path=path)
+        assert len(r) == 12 and abs(r[0] - adj).nnz == 0 and np.allclose(np.asarray(r[1].todense()), feat)
+        assert np.array_equal(r[2], ano) and r[8] is None and r[9] is None
+        for k, idx in (("all_idx", 3), ("idx_train", 4), ("idx_val", 5), ("idx_test", 6), ("normal_idx", 10), ("abnormal_idx", 11)):
+            assert np.array_equal(np.asarray(r[idx], dtype=np.int64), g[f"{name}.{k}"]), (name, k)
+        assert [random.getrandbits(32) for _ in range(3)] == g[name + ".tail"].tolist()
+    capsys.readouterr()
