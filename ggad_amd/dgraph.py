@@ -24,6 +24,26 @@ def load_dgraphfin(npz_path: str, adj_path: str):
     return homo, feat, labels
 
 
+def sparse_to_adjlist(sp_matrix, filename=None):
+    """`src/utils.py:96-112` (the definition in effect: no self loops added): scipy sparse matrix -> `defaultdict(set)` with
+    both directions of every stored entry, pickled to `filename` -- the `dgraphfin_adj_list` file `load_dgraphfin` reads.
+    Built from the symmetrised CSR instead of a python loop over the entries (73 M of them on DGraph-Fin)."""
+    from collections import defaultdict
+
+    import scipy.sparse as sp
+    m = sp.csr_matrix(sp_matrix)
+    pat = sp.csr_matrix((np.ones(m.nnz, dtype=np.int8), m.indices, m.indptr), shape=m.shape)
+    sym = (pat + pat.T).tocsr()
+    sym.sort_indices()
+    adj_lists = defaultdict(set)
+    for node in np.flatnonzero(np.diff(sym.indptr)):
+        adj_lists[int(node)] = set(sym.indices[sym.indptr[node]:sym.indptr[node + 1]].tolist())
+    if filename is not None:
+        with open(filename, "wb") as fh:
+            pickle.dump(adj_lists, fh)
+    return adj_lists
+
+
 def normalize_features(mx: np.ndarray) -> np.ndarray:
     """`src/utils.py:74-84`: x / (rowsum + 0.01), inf -> 0; scipy promotes to fp64, caller casts to fp32."""
     mx = np.asarray(mx)

@@ -25,6 +25,33 @@ def conf_gmean(conf: np.ndarray) -> float:
     return float((tp * tn / ((tp + fn) * (tn + fp))) ** 0.5)
 
 
+def pos_neg_split(nodes, labels):
+    """`src/utils.py:115-130`: the nodes with label 1 and the others, both in their original order."""
+    nodes = list(nodes)
+    lab = np.asarray(labels).reshape(-1)
+    pos_nodes = [n for n, l in zip(nodes, lab) if l == 1]
+    if len(set(nodes)) != len(nodes):                 # duplicated ids: keep the reference's `list.remove` semantics
+        return pos_nodes, _remove_first(nodes, pos_nodes)
+    drop = set(pos_nodes)
+    return pos_nodes, [n for n in nodes if n not in drop]
+
+
+def _remove_first(nodes, remove):
+    out = list(nodes)                                 # first occurrence only
+    for r in remove:
+        out.remove(r)
+    return out
+
+
+def pick_step(idx_train, y_train, adj_list, size):
+    """`src/utils.py:133-137`: degree / label-frequency weighted sampling with python's `random.choices` (same RNG stream)."""
+    import random
+    y = np.asarray(y_train)
+    degree = np.array([len(adj_list[node]) for node in idx_train])
+    lf = (y.sum() - len(y)) * y + len(y)
+    return random.choices(idx_train, weights=degree / lf, k=size)
+
+
 def score_nodes(model, test_cases: Sequence[int], batch_size: int, batches_per_launch: int = 2048, device: bool = False,
                 dist=None):
     """Probabilities for `test_cases`, batched EXACTLY like `test_sage` (`src/utils.py:216-230`):

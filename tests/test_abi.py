@@ -96,3 +96,41 @@ def test_load_mat_split_equals_reference(tmp_path, capsys):
             assert np.array_equal(np.asarray(r[idx], dtype=np.int64), g[f"{name}.{k}"]), (name, k)
         assert [random.getrandbits(32) for _ in range(3)] == g[name + ".tail"].tolist()
     capsys.readouterr()
+
+
+def test_host_utilities_of_src_utils(tmp_path):
+    """`sparse_to_adjlist` (src/utils.py:96-112), `pos_neg_split` (:115-130), `pick_step` (:133-137) against their plain
+    python statements."""
+    import pickle
+    import random
+    from collections import defaultdict
+
+    import scipy.sparse as sp
+    from ggad_amd.dgraph import load_dgraphfin, sparse_to_adjlist
+    from ggad_amd.sage_utils import pick_step, pos_neg_split
+    rng = np.random.default_rng(0)
+    m = sp.random(60, 60, density=0.06, random_state=1, format="csr")
+    ref = defaultdict(set)
+    r, c = m.nonzero()
+    for a, b in zip(r, c):
+        ref[a].add(b)
+        ref[b].add(a)
+    path = str(tmp_path / "adj_list")
+    got = sparse_to_adjlist(m, path)
+    assert dict(got) == dict(ref) and isinstance(got, defaultdict)
+    with open(path, "rb") as fh:
+        assert dict(pickle.load(fh)) == dict(ref)
+    np.savez(str(tmp_path / "d.npz"), x=rng.random((60, 3)), y=(np.arange(60) % 7 == 0).astype(np.int64))
+    homo, feat, labels = load_dgraphfin(str(tmp_path / "d.npz"), path)
+    assert dict(homo) == dict(ref) and feat.dtype == np.float32 and labels.sum() == 9
+    nodes = [5, 9, 2, 7, 11]
+    assert pos_neg_split(nodes, [0, 1, 0, 1, 0]) == ([9, 7], [5, 2, 11])
+    assert pos_neg_split([4, 4, 3], [1, 0, 0]) == ([4], [4, 3])
+    adj = {n: set(range(n % 4 + 1)) for n in nodes}
+    y = np.array([0, 1, 0, 0, 1])
+    random.seed(3)
+    a = pick_step(nodes, y, adj, 6)
+    random.seed(3)
+    deg = [len(adj[n]) for n in nodes]
+    lf = (y.sum() - len(y)) * y + len(y)
+    assert a == random.choices(nodes, weights=np.array(deg) / lf, k=6)
