@@ -55,7 +55,7 @@ def parse():
                     help="ldsw: LDS counting per (tile, batch) + streamed per-pair counts (default); tiled / ktile: earlier LDS variants; "
                          "global: atomics on per-batch counter slots in HBM; "
                          "packed: global counters inside 128-byte feature rows (chunk <= 15 batches)")
-    ap.add_argument("--chain", type=int, default=0, choices=[0, 1, 2], help="per-step kernel chain: 0 five launches (projection fused), 1 row-wise three, 2 six (include/ggad_hip.h: ggad_mb_step.chain)")
+    ap.add_argument("--chain", type=int, default=0, choices=[0, 1, 2, 3], help="per-step kernel chain: 0 five launches (projection fused), 1 row-wise three, 2 six (include/ggad_hip.h: ggad_mb_step.chain)")
     ap.add_argument("--dp-path", action="store_true", help="1 GPU only: run the data-parallel step chain (backward -> exchange -> "
                     "Adam, Adam not fused) with a no-op exchange, to measure what the multi-GPU step costs without the collective")
     ap.add_argument("--seed", type=int, default=72)

@@ -49,6 +49,10 @@ SIGNATURES = {
     "ggad_mb_dw_part_elems": (c_int64, [_I, _I, _I]),
     "ggad_mb_train_chunk": (c_int32, [_P, _I, _P, _P, _P, _P, _I, _I, _P]),
     "ggad_mb_train_chunk_dp": (c_int32, [_P, _I, _P, _P, _P, _P, _I, c_float, EXCHANGE_CB, _P, _P]),
+    "ggad_mb_persistent_chunk_len": (c_int32, []),
+    "ggad_mb_persistent_max_rows": (c_int32, []),
+    "ggad_mb_persistent_ws_elems": (c_int64, [_I, _I]),
+    "ggad_mb_train_chunk_persistent": (c_int32, [_P, _I, _P, _P, _I, _I, _I, _P, _I, _P, _P]),
     "ggad_stream_create_cu_mask": (c_int32, [_P, _I, _P]),
     "ggad_stream_destroy": (c_int32, [_P]),
     "ggad_device_cu_count": (c_int32, [_I, _P]),

@@ -398,7 +398,11 @@ class MiniBatchEngine:
     def __init__(self, feat_dim: int, embed_dim: int, device, lr: float = 1e-3, weight_decay: float = 0.007,
                  chain: int = 0):
         self.lib = _lib.load()
-        self.chain = int(chain)          # 0: fused-forward step (5 launches, F == 17), 1: row-wise 3-launch step, 2: 6 launches
+        # 0: fused-forward step (5 launches, F == 17), 1: row-wise 3-launch step, 2: 6 launches,
+        # 3: ONE persistent launch per chunk (single GPU, F == 17, <= 256 rows per batch; else the chain-0 launches)
+        self.chain = int(chain)
+        self.persistent_wgs = 64         # workgroups of the persistent kernel: at most the CUs of the stream it runs on
+        self.ps_ws = None
         self.F, self.D = int(feat_dim), int(embed_dim)
         if self.D > self.lib.ggad_max_embed_dim():
             raise ValueError(f"emb_size {self.D} > {self.lib.ggad_max_embed_dim()} is not supported by the HIP step kernels")
@@ -471,7 +475,7 @@ class MiniBatchEngine:
         s.losses8 = self.loss_log.data_ptr() + 32 * log_slot
         s.D, s.F, s.row0, s.n_rows, s.ent0, s.n_ents = self.D, self.F, r0, r1 - r0, e0, e1 - e0
         s.lr, s.weight_decay = self.lr, self.wd
-        s.chain = self.chain
+        s.chain = self.chain if self.chain != 3 else 0
         s.max_row_entries = int(ch.batch_max_row[b])
         return s
 
@@ -490,6 +494,8 @@ class MiniBatchEngine:
         self.ensure_capacity(ch, log_base + ch.n_batches)
         stream = _lib.current_stream()
         fuse = 1 if (allreduce is None and world_size == 1) else 0
+        if fuse and self.chain == 3 and self._train_chunk_persistent(ch, log_base, stream):
+            return
         if fuse:
             # single GPU: the whole chunk in one host call (the C loop issues the launches; Python per step costs more
             # than the 5-8 us kernels it feeds)
@@ -524,6 +530,25 @@ class MiniBatchEngine:
         if err:
             raise err[0]
         _lib.check(rc, "ggad_mb_train_chunk_dp")
+
+    def _train_chunk_persistent(self, ch: BatchChunk, log_base: int, stream) -> bool:
+        """All steps of the chunk in one persistent launch (`ggad_mb_train_chunk_persistent`); False = not eligible."""
+        bp = ch.batch_ptr_host[:ch.n_batches + 1]
+        max_rows = int(np.diff(bp).max())
+        if self.F != 17 or max_rows > int(self.lib.ggad_mb_persistent_max_rows()) or not ch.train:
+            return False
+        cl = int(self.lib.ggad_mb_persistent_chunk_len())
+        r = np.diff(ch.ent_ptr_host[:ch.n_rows + 1])
+        per_row = (r + cl - 1) // cl
+        max_chunks = int(np.add.reduceat(per_row, bp[:-1].astype(np.int64)).max())
+        need = int(self.lib.ggad_mb_persistent_ws_elems(max_chunks, self.persistent_wgs))
+        if self.ps_ws is None or self.ps_ws.numel() < need:
+            self.ps_ws = _f32(int(need * 1.25), self.dev)
+        s = self.step_desc(ch, 0, log_base)
+        _lib.check(self.lib.ggad_mb_train_chunk_persistent(ctypes.byref(s), ch.n_batches, ptr(ch.batch_ptr), ptr(ch.batch_ent_ptr),
+                                                           max_rows, max_chunks, self.persistent_wgs, self.loss_log.data_ptr(),
+                                                           log_base, ptr(self.ps_ws), stream), "ggad_mb_train_chunk_persistent")
+        return True
 
     def forward_batch(self, ch: BatchChunk, b: int) -> None:
         """project + fwd_rows only (layered API / tests): fills ch.h1, ch.nbar, ch.gen for batch b."""

@@ -161,6 +161,7 @@ class DGraphTrainer:
                     raw.append(h.value)
                     out.append(torch.cuda.ExternalStream(h.value, device=device))
             self._raw_streams = raw
+            self.engine.persistent_wgs = dense_cus        # chain 3: one workgroup of the persistent kernel per dense CU
             return out[0], out[1]
         except ValueError:
             raise

@@ -301,6 +301,24 @@ int ggad_mb_train_chunk_dp(const ggad_mb_step *tmpl, int32_t n_batches, const in
                            const int32_t *batch_max_row, float *loss_log, int32_t log_base, float grad_scale,
                            int (*exchange)(void *), void *user, ggad_stream_t stream);
 
+/* The same per-batch loop as ggad_mb_train_chunk inside ONE persistent launch (single GPU, F == 17, at most
+ * ggad_mb_persistent_max_rows() rows per batch): n_workgroups x 1024 threads loop over the batches, six phases per batch
+ * separated by grid barriers (a relaxed agent-scope atomic add + poll per workgroup); everything a later phase reads from
+ * another wave is exchanged with write-through stores / L1-bypassing loads (step_persistent.hip).  ALL n_workgroups workgroups
+ * must be resident at once: pass at most the number of compute units of `stream` (one workgroup per CU).  Rows are cut into
+ * chunks of ggad_mb_persistent_chunk_len() entries; max_chunks >= the largest per-batch sum of ceil(row entries / that).
+ * batch_ptr_dev / batch_ent_ptr_dev: DEVICE arrays of n_batches + 1 int32 offsets (rows, entries).  tmpl->h2, dw_part, loss_ws
+ * and max_row_entries are not used (the relu mask of the 2-hop projection is recomputed in the backward phase).
+ * workspace: ggad_mb_persistent_ws_elems(max_chunks, n_workgroups) floats.  Deterministic; agrees with the launch chain to
+ * fp32 round-off (other, fixed summation order of the row sums and partial reductions).  Measured SLOWER than the launch
+ * chain on MI355X (55 vs 42 us per step): an opt-in variant (chain 3 of the Python engine), not the default. */
+int32_t ggad_mb_persistent_chunk_len(void);
+int32_t ggad_mb_persistent_max_rows(void);
+int64_t ggad_mb_persistent_ws_elems(int32_t max_chunks, int32_t n_workgroups);
+int ggad_mb_train_chunk_persistent(const ggad_mb_step *tmpl, int32_t n_batches, const int32_t *batch_ptr_dev,
+                                   const int32_t *batch_ent_ptr_dev, int32_t max_rows, int32_t max_chunks, int32_t n_workgroups,
+                                   float *loss_log, int32_t log_base, float *workspace, ggad_stream_t stream);
+
 /* Inference embeddings: h[i] = relu(W x1[i])  (GCNEncoder.forward, train_flag False).   graphsage.py:412 */
 int ggad_mb_encode(const float *params, int32_t D, int32_t F, const float *x1, int32_t n_rows, float *h,
                    ggad_stream_t stream);

@@ -488,3 +488,53 @@ def test_overlapped_chunks_equal_serial_execution():
     for o in outs[1:]:        # side-stream planning (CU-masked or plain streams) and the sampler thread change nothing
         np.testing.assert_array_equal(outs[0][0], o[0])
         np.testing.assert_array_equal(outs[0][1], o[1])
+
+
+@pytest.mark.parametrize("d,bsz,n_ano,wgs", [(64, 200, 50, 64), (32, 150, 40, 7), (48, 23, 5, 64), (64, 256, 64, 16)])
+def test_persistent_chunk_kernel_equals_launch_chain_and_oracle(d, bsz, n_ano, wgs):
+    """chain 3: all optimiser steps of a chunk in ONE persistent launch (grid barriers between the six phases of a step,
+    write-through hand-offs) against the 5/6-launch chain (same results up to the summation order of the row sums) and
+    against the oracle's autograd + torch Adam; hub rows (hundreds of 16-entry chunks), ragged last batch, few / many
+    workgroups, bit-deterministic."""
+    g, batches, labels = _random_case(n=30000, n_entries=300000, f=17, d=d, seed=5 + d, nb=7, bsz=bsz, n_ano=n_ano)
+    order = np.argsort(-np.diff(g["rowptr"]))
+    batches[2][:3] = order[:3]                                  # hub rows in one batch
+    batches[6], labels[6] = batches[6][:bsz - 9], labels[6][:bsz - 9]   # ragged
+    graph, feat, ch = _setup(g, max_batches=8, hop2="ldsw")
+    ch.build(batches, labels)
+    torch.cuda.synchronize()
+    torch.manual_seed(d)
+    w = torch.nn.init.xavier_uniform_(torch.empty(1, d))
+    W = torch.nn.init.xavier_uniform_(torch.empty(d, 17))
+    fc = torch.nn.init.xavier_uniform_(torch.empty(d, d))
+    runs = {}
+    for name, chain in (("launch", 0), ("pers", 3), ("pers2", 3)):
+        eng = MiniBatchEngine(17, d, DEV, lr=1e-3, weight_decay=0.007, chain=chain)
+        eng.persistent_wgs = wgs
+        eng.load_params(w, W, fc)
+        eng.train_chunk(ch)
+        torch.cuda.synchronize()
+        runs[name] = (eng.loss_log[:8 * 7].view(7, 8).cpu().numpy().copy(), eng.params.cpu().numpy().copy(),
+                      eng.exp_avg.cpu().numpy().copy(), eng.exp_avg_sq.cpu().numpy().copy(), int(eng.step_counter.item()),
+                      eng.grads.cpu().numpy().copy())
+    assert runs["pers"][4] == runs["launch"][4] == 7
+    for k in (0, 1, 2, 3, 5):
+        assert np.array_equal(runs["pers"][k], runs["pers2"][k]), k                      # deterministic
+    np.testing.assert_allclose(runs["pers"][0], runs["launch"][0], atol=2e-5, rtol=1e-5)  # all 8 logged scalars per step
+    np.testing.assert_allclose(runs["pers"][1], runs["launch"][1], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(runs["pers"][2], runs["launch"][2], atol=1e-6, rtol=1e-4)
+    np.testing.assert_allclose(runs["pers"][5], runs["launch"][5], atol=3e-6, rtol=1e-4)
+    # the oracle's trajectory
+    p = O.MiniParams(w.clone().requires_grad_(), W.clone().requires_grad_(), fc.clone().requires_grad_())
+    opt = O.make_adam(p.tensors(), 1e-3, 0.007)
+    ref_losses = []
+    for b in range(7):
+        agg = O.aggregate_batch(g["rowptr"], g["col"], g["feat"], batches[b], True)
+        opt.zero_grad()
+        tot, cls, mar, rec = O.batch_loss(p, agg, labels[b])
+        tot.backward()
+        ref_losses.append([tot.item(), cls.item(), mar.item(), rec.item()])
+        opt.step()
+    np.testing.assert_allclose(runs["pers"][0][:, :4], np.array(ref_losses), atol=2e-5, rtol=0)
+    ref_p = np.concatenate([t.detach().numpy().reshape(-1) for t in p.tensors()])
+    np.testing.assert_allclose(runs["pers"][1][:len(ref_p)], ref_p, atol=2e-5, rtol=0)
