@@ -7,7 +7,7 @@
 // atomic stores (write-through) is never read stale by relaxed agent-scope atomic loads on other XCDs (no release fence:
 // buffer_wbl2 would write back the dirty lines of the plan kernels that share the L2s).
 //
-// Six phases per batch, G workgroups x 16 waves, lane = embedding channel d:
+// Six phases per batch, G workgroups x 8 waves, lane = embedding channel d:
 //   P1  entry chunks (<= 16 entries of ONE row): partial sums of relu(W x2[own(e)]);  rows: h1 = relu(W x1)
 //   P2  rows: nbar = (1/r) sum of the row's chunk partials (chunk order), gen = relu(fc nbar) for label-1 rows
 //   P3  positions of combined_all: score, BCE, cosine affinity, norms, reconstruction norm        (graphsage.py:174,234,246)
@@ -33,7 +33,7 @@ struct ParamLayoutP {                                  // same packed block as s
   __host__ __device__ int o_fcT() const { return n_train() + F * D; }
 };
 
-constexpr int PS_WAVES = 16;                           // waves per workgroup
+constexpr int PS_WAVES = 8;                            // waves per workgroup: 217 VGPRs, no spills (16 waves = 128 VGPRs spilled: 55 us per step)
 constexpr int PS_CH = 16;                              // entries per chunk
 constexpr int PS_FT = 17;                              // feature width (DGraph-Fin)
 constexpr int PS_MAXROWS = 256;                        // rows per batch (150 + 50 on DGraph-Fin)
