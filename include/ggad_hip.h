@@ -302,7 +302,7 @@ int ggad_mb_train_chunk_dp(const ggad_mb_step *tmpl, int32_t n_batches, const in
                            int (*exchange)(void *), void *user, ggad_stream_t stream);
 
 /* The same per-batch loop as ggad_mb_train_chunk inside ONE persistent launch (single GPU, F == 17, at most
- * ggad_mb_persistent_max_rows() rows per batch): n_workgroups x 512 threads loop over the batches, six phases per batch
+ * ggad_mb_persistent_max_rows() rows per batch): n_workgroups x 512 threads loop over the batches, five phases per batch
  * separated by grid barriers (a relaxed agent-scope atomic add + poll per workgroup); everything a later phase reads from
  * another wave is exchanged with write-through stores / L1-bypassing loads (step_persistent.hip).  ALL n_workgroups workgroups
  * must be resident at once: pass at most the number of compute units of `stream` (one workgroup per CU).  Rows are cut into
@@ -310,8 +310,8 @@ int ggad_mb_train_chunk_dp(const ggad_mb_step *tmpl, int32_t n_batches, const in
  * batch_ptr_dev / batch_ent_ptr_dev: DEVICE arrays of n_batches + 1 int32 offsets (rows, entries).  tmpl->h2, dw_part, loss_ws
  * and max_row_entries are not used (the relu mask of the 2-hop projection is recomputed in the backward phase).
  * workspace: ggad_mb_persistent_ws_elems(max_chunks, n_workgroups) floats.  Deterministic; agrees with the launch chain to
- * fp32 round-off (other, fixed summation order of the row sums and partial reductions).  Measured SLOWER than the launch
- * chain on MI355X (43.5 vs 42 us per step alone, 52 vs 51 us in bench.py): an opt-in variant (chain 3 of the Python engine), not the default. */
+ * fp32 round-off (other, fixed summation order of the row sums and partial reductions).  Measured against the launch
+ * chain on MI355X at best equal (41.9 vs 42 us per step alone, 51 vs 51-55 us in bench.py, slower on sparse graphs): an opt-in variant (chain 3 of the Python engine), not the default. */
 int32_t ggad_mb_persistent_chunk_len(void);
 int32_t ggad_mb_persistent_max_rows(void);
 int64_t ggad_mb_persistent_ws_elems(int32_t max_chunks, int32_t n_workgroups);
