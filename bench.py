@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--chunk", type=int, default=150, help="batches planned per launch group (reference epoch = 150)")
     ap.add_argument("--cpu-batches", type=int, default=3, help="batches timed on the CPU port (0 = skip)")
     ap.add_argument("--no-overlap", action="store_true", help="plan and dense steps on one stream")
-    ap.add_argument("--dense-cus", type=int, default=64, help="CUs reserved for the dense step chain when overlapping "
+    ap.add_argument("--dense-cus", type=int, default=-1, help="CUs reserved for the dense step chain when overlapping (-1 = by graph density: 32 or 64) "
                     "(CU-masked streams; 0 = plain streams with priorities)")
     ap.add_argument("--hop2", default="ldsw", choices=["ldsw", "tiled", "ktile", "global", "packed"],
                     help="ldsw: LDS counting per (tile, batch) + streamed per-pair counts (default); tiled / ktile: earlier LDS variants; "
@@ -110,7 +110,8 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
     trainer = DGraphTrainer(graph, feat, a.emb, sched, lr=1e-3, weight_decay=0.007, chunk_batches=a.chunk, rank=rank,
                             world_size=world, allreduce=allreduce, packed=(a.hop2 == "packed"),
-                            hop2=(a.hop2 if a.hop2 in ("tiled", "ktile", "ldsw") else "global"), overlap=not a.no_overlap, chain=a.chain, dense_cus=a.dense_cus)
+                            hop2=(a.hop2 if a.hop2 in ("tiled", "ktile", "ldsw") else "global"), overlap=not a.no_overlap, chain=a.chain, dense_cus=(None if a.dense_cus < 0 else a.dense_cus))
+    a.dense_cus = getattr(trainer, "dense_cus", 0 if a.dense_cus < 0 else a.dense_cus)
     if a.dp_path and world == 1:
         if os.environ.get("GGAD_BENCH_REAL_ALLREDUCE") == "1":
             # one-rank RCCL group: exercises ProcessGroupNCCL on the CU-masked dense stream from the C step loop's callback

@@ -78,6 +78,8 @@ SIGNATURES = {
     "ggad_mb_adam": (c_int32, [_P, _P, _P, _P, _I, _I, _F, _F, _F, _P, _P]),
     "ggad_mb_train_step": (c_int32, [_P, _I, _P]),
     "ggad_mb_encode": (c_int32, [_P, _I, _I, _P, _I, _P, _P]),
+    "ggad_mb_chunk_len": (c_int32, []),
+    "ggad_mb_row_chunks": (c_int32, [_P, _I, _P, _P, _P, _P, _P, _P]),
     "ggad_seg_mean": (c_int32, [_P, _I, _P, _P, _I, _P, _P]),
     "ggad_seg_wsum": (c_int32, [_P, _I, _P, _P, _P, _I, _P, _P]),
     "ggad_recon_cols_f32": (c_int32, [_P, _P, _I, _I, _F, _F, _P, _P, _P, _P]),
@@ -121,7 +123,8 @@ class MbStep(ctypes.Structure):
                                          "ent_ptr", "ent_own", "ent_row", "labels", "pos_meta", "row_pos", "h1", "nbar",
                                          "gen", "dz", "coef_a", "coef_g", "h2", "dw_part", "loss_ws", "losses8")]
                 + [(n, c_int32) for n in ("D", "F", "row0", "n_rows", "ent0", "n_ents")]
-                + [("lr", c_float), ("weight_decay", c_float), ("chain", c_int32), ("max_row_entries", c_int32)])
+                + [("lr", c_float), ("weight_decay", c_float), ("chain", c_int32), ("max_row_entries", c_int32)]
+                + [(n, c_void_p) for n in ("row_ck_ptr", "ck_rc", "ck_e0", "chunk_part")])
 
 
 _lib = None

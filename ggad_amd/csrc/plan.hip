@@ -463,6 +463,42 @@ int ggad_seg_wsum(const float *feat, int32_t feat_dim, const int32_t *seg_ptr, c
   return GGAD_OK;
 }
 
+// ---- row chunks: every batch row cut into pieces of <= chunk_len consecutive entries (the unit of work of the chunk-parallel
+// forward kernel of step.hip: a hub row of thousands of entries is hundreds of independent pieces, not one workgroup's loop)
+__global__ void __launch_bounds__(256) k_row_chunk_counts(const int32_t *__restrict__ ent_ptr, int n_rows, int chunk_len,
+                                                          int32_t *__restrict__ nck) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n_rows) nck[i] = (ent_ptr[i + 1] - ent_ptr[i] + chunk_len - 1) / chunk_len;
+}
+__global__ void __launch_bounds__(256) k_fill_chunks(const int32_t *__restrict__ ent_ptr, const int32_t *__restrict__ row_ck_ptr,
+                                                     int n_rows, int chunk_len, int32_t *__restrict__ ck_rc,
+                                                     int32_t *__restrict__ ck_e0) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_rows) return;
+  const int e0 = ent_ptr[i], e1 = ent_ptr[i + 1];
+  int c = row_ck_ptr[i];
+  for (int e = e0; e < e1; e += chunk_len, ++c) {
+    ck_rc[c] = (i << 6) | min(chunk_len, e1 - e);          // row (chunk-relative to the plan) | entries of the piece
+    ck_e0[c] = e;
+  }
+}
+
+int32_t ggad_mb_chunk_len(void) { return 16; }
+
+int ggad_mb_row_chunks(const int32_t *ent_ptr, int32_t n_rows, int32_t *nck_tmp, int32_t *row_ck_ptr, int32_t *ck_rc,
+                       int32_t *ck_e0, int32_t *scan_ws, ggad_stream_t stream) {
+  GGAD_REQUIRE(ent_ptr && nck_tmp && row_ck_ptr && ck_rc && ck_e0 && scan_ws && n_rows >= 0 && n_rows < (1 << 25));
+  if (n_rows == 0) return GGAD_OK;
+  const int cl = ggad_mb_chunk_len();
+  k_row_chunk_counts<<<dim3((n_rows + 255) / 256), dim3(256), 0, as_stream(stream)>>>(ent_ptr, n_rows, cl, nck_tmp);
+  GGAD_CHECK_LAUNCH("mb_row_chunks counts");
+  const int rc = ggad_exclusive_scan_i32(nck_tmp, row_ck_ptr, n_rows, scan_ws, stream);
+  if (rc) return rc;
+  k_fill_chunks<<<dim3((n_rows + 255) / 256), dim3(256), 0, as_stream(stream)>>>(ent_ptr, row_ck_ptr, n_rows, cl, ck_rc, ck_e0);
+  GGAD_CHECK_LAUNCH("mb_row_chunks fill");
+  return GGAD_OK;
+}
+
 int ggad_mb_packed_stride(int32_t feat_dim) { return ((feat_dim + 1 + 31) / 32) * 32; }
 
 int ggad_mb_count2(const int32_t *rowptr, const int32_t *col, const int32_t *ent_col, const int32_t *ent_slot,

@@ -415,12 +415,20 @@ __global__ void __launch_bounds__(256) k_bwd_flat(ParamLayout L, const float *__
                                                   const int32_t *__restrict__ ent_row, int row0, int n_rows, int ent0,
                                                   int n_ents, const float *__restrict__ coef_a,
                                                   const float *__restrict__ coef_g, float *__restrict__ dw_part,
-                                                  int h2_by_entry) {
+                                                  int h2_by_entry, const float *__restrict__ Wt) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // [4][F*D]
   const int D = L.D, F = (FT > 0) ? FT : L.F;
   const int lane = lane_id(), wid = threadIdx.x / 64;
   const bool on = lane < D;
   const int d = on ? lane : D - 1;
+  // h2_by_entry == 2 (FT > 0 only): h2 is not stored anywhere; its sign is recomputed from the feature row of the item
+  float Wc[FT > 0 ? FT : 1];
+  if constexpr (FT > 0) {
+    if (h2_by_entry == 2) {
+#pragma unroll
+      for (int f = 0; f < FT; ++f) Wc[f] = Wt[f * D + d];
+    }
+  }
   float acc[FT > 0 ? FT : 1];
   float *acc_lds = lds + wid * F * D;
   if constexpr (FT > 0) {
@@ -450,9 +458,16 @@ __global__ void __launch_bounds__(256) k_bwd_flat(ParamLayout L, const float *__
       const int sh = __builtin_amdgcn_readlane(ho, i);
       if (sx >= 0) {
         const float g = coef_g[(int64_t)sc * D + d];
-        const float hv = h2[(int64_t)sh * D + d];
-        coef = (on && hv > 0.0f) ? g : 0.0f;
         xr = x2 + (int64_t)sx * F;
+        float hv;
+        if (FT > 0 && h2_by_entry == 2) {
+          hv = 0.0f;
+#pragma unroll
+          for (int f = 0; f < (FT > 0 ? FT : 1); ++f) hv = fmaf(Wc[f], xr[f], hv);      // same fma order as the forward
+        } else {
+          hv = h2[(int64_t)sh * D + d];
+        }
+        coef = (on && hv > 0.0f) ? g : 0.0f;
       } else {
         coef = on ? coef_a[(int64_t)sc * D + d] : 0.0f;
         xr = x1 + (int64_t)(-2 - sx) * F;
@@ -744,6 +759,139 @@ __global__ void __launch_bounds__(FWDV_NW * 64) k_fwd_rows_v(const float *__rest
 #pragma unroll
     for (int k = 0; k < FWDV_NW; ++k) gs += part[k][lane];
     gen[(int64_t)row * D + lane] = fmaxf(gs, 0.0f);
+  }
+}
+
+// ------------------------------------------------------------------ hub batches: chunk-parallel forward (2 launches)
+// A batch with a hub row used to take k_project (owner-parallel) + k_fwd_rows (one 16-wave workgroup per row: the hub row's
+// workgroup sums thousands of h2 rows) + k_loss_pos: 17.5 + 4.8 us.  Here the unit of work is a CHUNK of <= 16 consecutive
+// entries of one row (tables built by the plan, ggad_mb_row_chunks):
+//   k_fwd_chunks    one wave per chunk: partial sum of relu(W x2[own(e)]) -> chunk_part[c];  extra waves: h1 = relu(W x1)
+//   k_loss_pos_ck   k_loss_pos, whose wave first sums the chunk partials of its row (nbar, stored) and, for a column that
+//                   comes from a label-1 row, of that source row too (gen = relu(fc nbar), stored); fc^T staged in LDS
+// h2 is not stored: k_bwd_flat recomputes the relu mask (same fma order, bit-identical) from the feature row it reads anyway.
+// Row sums run in chunk order: deterministic; other order than k_fwd_rows (waves striding by 16), equal to fp32 round-off.
+__global__ void __launch_bounds__(256) k_fwd_chunks(const float *__restrict__ params, ParamLayout L, const float *__restrict__ x1,
+                                                    const float *__restrict__ x2, const int32_t *__restrict__ ent_own,
+                                                    const int32_t *__restrict__ row_ck_ptr, const int32_t *__restrict__ ck_rc,
+                                                    const int32_t *__restrict__ ck_e0, int row0, int n_rows,
+                                                    float *__restrict__ h1, float *__restrict__ chunk_part) {
+  constexpr int FT = 17, CH = 16;
+  const int D = L.D;
+  const int lane = lane_id(), wid = threadIdx.x / 64, d = lane < D ? lane : D - 1;
+  const int fl = lane < FT ? lane : FT - 1;
+  const int w = blockIdx.x * 4 + wid;
+  const int ck0 = row_ck_ptr[row0], nck = row_ck_ptr[row0 + n_rows] - ck0;
+  if (w >= nck + n_rows) return;
+  float Wr[FT];
+  const float *Wt = params + L.o_Wt();
+#pragma unroll
+  for (int f = 0; f < FT; ++f) Wr[f] = Wt[f * D + d];
+  if (w < nck) {
+    const int c = ck0 + w;
+    const int cnt = ck_rc[c] & 63, e0 = ck_e0[c];
+    const int ov = ent_own[e0 + (lane < cnt ? lane : 0)];
+    float xv[CH];
+#pragma unroll
+    for (int k = 0; k < CH; ++k) xv[k] = x2[(int64_t)__builtin_amdgcn_readlane(ov, k < cnt ? k : 0) * FT + fl];
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+      if (k < cnt) {
+        float h = 0.0f;
+#pragma unroll
+        for (int f = 0; f < FT; ++f) h = fmaf(Wr[f], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv[k]), f)), h);
+        acc += fmaxf(h, 0.0f);                                                        // relu(W x2[u])   graphsage.py:419
+      }
+    }
+    chunk_part[(int64_t)c * 64 + lane] = acc;
+  } else {                                                                            // h1 = relu(W x1[row])      graphsage.py:412
+    const int row = row0 + (w - nck);
+    const float xv = x1[(int64_t)row * FT + fl];
+    float h = 0.0f;
+#pragma unroll
+    for (int f = 0; f < FT; ++f) h = fmaf(Wr[f], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv), f)), h);
+    if (lane < D) h1[(int64_t)row * D + lane] = fmaxf(h, 0.0f);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_loss_pos_ck(const float *__restrict__ params, ParamLayout L, const float *__restrict__ h1,
+                                                     float *__restrict__ nbar, float *__restrict__ gen,
+                                                     const int32_t *__restrict__ pos_meta, const int32_t *__restrict__ ent_ptr,
+                                                     const int32_t *__restrict__ row_ck_ptr, const float *__restrict__ chunk_part,
+                                                     int row0, int B, float *__restrict__ pos_scal, float *__restrict__ part) {
+  __shared__ float red[4][8];
+  __shared__ float fct[GGAD_MAX_D * (GGAD_MAX_D + 1)];           // fc^T, rows padded: conflict-free column reads
+  const int D = L.D;
+  const int lane = lane_id(), wid = threadIdx.x / 64;
+  const bool on = lane < D;
+  const int dl = on ? lane : D - 1;
+  const int q = blockIdx.x * 4 + wid;
+  for (int idx = threadIdx.x; idx < D * D; idx += 256) fct[(idx / D) * (GGAD_MAX_D + 1) + idx % D] = params[L.o_fcT() + idx];
+  float o[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int meta = 0, src = row0, qa = 0, qb = 0, sa = 0, sb = 0, rq = 1, rs = 1;
+  float wd_r = 0.f, hs_r = 0.f;
+  const bool act = q < B;
+  if (act) {
+    meta = pos_meta[row0 + q];
+    src = meta >> 2;
+    const int row = row0 + q;
+    qa = row_ck_ptr[row]; qb = row_ck_ptr[row + 1];
+    rq = ent_ptr[row + 1] - ent_ptr[row];
+    if (meta & 2) { sa = row_ck_ptr[src]; sb = row_ck_ptr[src + 1]; rs = ent_ptr[src + 1] - ent_ptr[src]; }
+    wd_r = params[dl];
+    hs_r = h1[(int64_t)src * D + dl];
+  }
+  float totq = 0.0f, tots = 0.0f;
+  for (int c0 = 0; c0 < max(qb - qa, sb - sa); c0 += 8) {        // chunk order, 8 + 8 loads in flight from clamped indices
+    float vq[8], vs[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      vq[k] = chunk_part[(int64_t)min(qa + c0 + k, max(qb - 1, qa)) * 64 + lane];
+      vs[k] = chunk_part[(int64_t)(sb > sa ? min(sa + c0 + k, sb - 1) : qa) * 64 + lane];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      totq += (qa + c0 + k < qb) ? vq[k] : 0.0f;
+      tots += (sa + c0 + k < sb) ? vs[k] : 0.0f;
+    }
+  }
+  __syncthreads();                                               // fct staged
+  if (act) {
+    const int y = meta & 1;
+    const bool from_gen = (meta & 2) != 0;
+    const float nb_r = (1.0f / (float)rq) * totq;                                            // mask_row = mask / rowsum  graphsage.py:317
+    if (on) nbar[(int64_t)(row0 + q) * D + lane] = nb_r;                                     // to_feats_neigh[q, :]
+    float c_r = hs_r;                                                                        // combined_all[:, q] = h1[src] ...
+    if (from_gen) {                                                                          // ... or gen[src] = relu(fc nbar[src])
+      const float nbm = on ? (1.0f / (float)rs) * tots : 0.0f;
+      float a = 0.0f;
+      for (int d2 = 0; d2 < D; ++d2)
+        a = fmaf(fct[d2 * (GGAD_MAX_D + 1) + dl], __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nbm), d2)), a);
+      c_r = fmaxf(a, 0.0f);
+      if (on) gen[(int64_t)src * D + lane] = c_r;
+    }
+    const float wd = on ? wd_r : 0.0f, c = on ? c_r : 0.0f, nb = on ? nb_r : 0.0f;
+    const float hs = (on && from_gen) ? hs_r : 0.0f;
+    const PosVals v = eval_position(wd, c, nb);
+    float recn = 0.0f;
+    if (from_gen) { const float dl2 = hs - c; recn = sqrtf(wave_sum_fast(dl2 * dl2)); }      // recon2   graphsage.py:197-198
+    o[0] = (1.0f - (float)y) * v.s - log_sigmoid(v.s);                   // BCEWithLogits, pos_weight 1 graphsage.py:246
+    o[1] = y == 0 ? v.aff : 0.0f; o[2] = y == 1 ? v.aff : 0.0f; o[3] = recn;
+    o[4] = y == 0 ? 1.0f : 0.0f;  o[5] = y == 1 ? 1.0f : 0.0f;
+    if (lane == 0) {
+      float *ps = pos_scal + (int64_t)q * 8;
+      ps[0] = v.s; ps[1] = v.aff; ps[2] = v.na; ps[3] = v.nbn; ps[4] = recn;
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) red[wid][k] = o[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int k = threadIdx.x;
+    part[(int64_t)blockIdx.x * 8 + k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
   }
 }
 
@@ -1108,7 +1256,8 @@ int ggad_mb_row_coefs(const float *params, int32_t D, int32_t F, const int32_t *
 
 static int bwd_flat_launch(int32_t D, int32_t F, const float *x1, const float *x2, const float *h2, const int32_t *ent_own,
                            const int32_t *ent_row, int32_t row0, int32_t n_rows, int32_t ent0, int32_t n_ents,
-                           const float *coef_a, const float *coef_g, float *dw_part, int h2_by_entry, ggad_stream_t stream);
+                           const float *coef_a, const float *coef_g, float *dw_part, int h2_by_entry, ggad_stream_t stream,
+                           const float *Wt = nullptr);
 
 int ggad_mb_bwd_flat(int32_t D, int32_t F, const float *x1, const float *x2, const float *h2, const int32_t *ent_own,
                      const int32_t *ent_row, int32_t row0, int32_t n_rows, int32_t ent0, int32_t n_ents,
@@ -1118,17 +1267,19 @@ int ggad_mb_bwd_flat(int32_t D, int32_t F, const float *x1, const float *x2, con
 
 static int bwd_flat_launch(int32_t D, int32_t F, const float *x1, const float *x2, const float *h2, const int32_t *ent_own,
                            const int32_t *ent_row, int32_t row0, int32_t n_rows, int32_t ent0, int32_t n_ents,
-                           const float *coef_a, const float *coef_g, float *dw_part, int h2_by_entry, ggad_stream_t stream) {
-  GGAD_REQUIRE(x1 && x2 && h2 && ent_own && ent_row && coef_a && coef_g && dw_part && dims_ok(D, F));
+                           const float *coef_a, const float *coef_g, float *dw_part, int h2_by_entry, ggad_stream_t stream,
+                           const float *Wt) {
+  GGAD_REQUIRE(x1 && x2 && ent_own && ent_row && coef_a && coef_g && dw_part && dims_ok(D, F));
+  GGAD_REQUIRE(h2_by_entry == 2 ? (Wt != nullptr && F == 17) : (h2 != nullptr));
   GGAD_REQUIRE(n_rows >= 1 && row0 >= 0 && ent0 >= 0 && n_ents >= 0);
   ParamLayout L{D, F};
   const size_t lds = (size_t)4 * F * D * 4;
   if (F == 17)
     k_bwd_flat<17><<<dim3(BWD_PARTS), dim3(256), lds, as_stream(stream)>>>(L, x1, x2, h2, ent_own, ent_row, row0, n_rows, ent0,
-                                                                           n_ents, coef_a, coef_g, dw_part, h2_by_entry);
+                                                                           n_ents, coef_a, coef_g, dw_part, h2_by_entry, Wt);
   else
     k_bwd_flat<0><<<dim3(BWD_PARTS), dim3(256), lds, as_stream(stream)>>>(L, x1, x2, h2, ent_own, ent_row, row0, n_rows, ent0,
-                                                                          n_ents, coef_a, coef_g, dw_part, h2_by_entry);
+                                                                          n_ents, coef_a, coef_g, dw_part, h2_by_entry, Wt);
   GGAD_CHECK_LAUNCH("mb_bwd_flat");
   return GGAD_OK;
 }
@@ -1236,7 +1387,31 @@ int ggad_mb_train_step(const ggad_mb_step *s, int32_t fuse_adam, ggad_stream_t s
   // project thousands of entries while the flat k_project spreads them over the chip)
   static const int fuse_max_row = [] { const char *e = getenv("GGAD_FUSE_MAX_ROW"); return e ? atoi(e) : 256; }();
   const bool fused_fwd = s->chain == 0 && F == 17 && s->max_row_entries > 0 && s->max_row_entries <= fuse_max_row;
-  if (fused_fwd) {
+  // hub batches: chunk-parallel forward + position kernel with the row sums folded in (2 launches instead of 3)
+  static const bool chunk_path_on = [] { const char *e = getenv("GGAD_CHUNK_FWD"); return !e || atoi(e) != 0; }();
+  const bool chunk_fwd = chunk_path_on && s->chain == 0 && F == 17 && !fused_fwd && s->row_ck_ptr && s->ck_rc && s->ck_e0 &&
+                         s->chunk_part;
+  if (chunk_fwd) {
+    GGAD_REQUIRE(s->x1 && s->x2 && s->ent_ptr && s->ent_own && s->ent_row && s->labels && s->pos_meta && s->row_pos && s->h1 &&
+                 s->nbar && s->gen && s->dz && s->coef_a && s->coef_g && s->dw_part && s->loss_ws && s->losses8 && dims_ok(D, F));
+    GGAD_REQUIRE(s->n_rows >= 1 && s->row0 >= 0 && s->ent0 >= 0 && s->n_ents >= 0);
+    ParamLayout L{D, F};
+    hipStream_t st = as_stream(stream);
+    const int cl = 16;
+    const int max_waves = (s->n_ents + cl - 1) / cl + 2 * s->n_rows;        // >= chunks of the batch + its rows
+    k_fwd_chunks<<<dim3((max_waves + 3) / 4), dim3(256), 0, st>>>(s->params, L, s->x1, s->x2, s->ent_own, s->row_ck_ptr, s->ck_rc,
+                                                                 s->ck_e0, s->row0, s->n_rows, s->h1, s->chunk_part);
+    const int nwg = loss_nwg(s->n_rows);
+    float *pos_scal = s->loss_ws, *part = s->loss_ws + (int64_t)s->n_rows * 8, *gw_part = part + (int64_t)nwg * 8;
+    k_loss_pos_ck<<<dim3(nwg), dim3(256), 0, st>>>(s->params, L, s->h1, s->nbar, s->gen, s->pos_meta, s->ent_ptr, s->row_ck_ptr,
+                                                  s->chunk_part, s->row0, s->n_rows, pos_scal, part);
+    k_loss_rows<<<dim3(nwg), dim3(256), 0, st>>>(s->params, L, s->h1, s->nbar, s->gen, s->labels, s->pos_meta, s->row_pos,
+                                                s->ent_ptr, s->row0, s->n_rows, pos_scal, part, gw_part, s->losses8, nullptr, nullptr,
+                                                nullptr, s->dz, s->coef_a, s->coef_g, s->step_counter);
+    GGAD_CHECK_LAUNCH("mb_train_step (chunk forward)");
+    if ((rc = bwd_flat_launch(D, F, s->x1, s->x2, nullptr, s->ent_own, s->ent_row, s->row0, s->n_rows, s->ent0, s->n_ents,
+                              s->coef_a, s->coef_g, s->dw_part, 2, stream, s->params + L.o_Wt()))) return rc;
+  } else if (fused_fwd) {
     GGAD_REQUIRE(s->x1 && s->x2 && s->h2 && s->ent_ptr && s->ent_own && s->labels && s->h1 && s->nbar && s->gen && dims_ok(D, F));
     GGAD_REQUIRE(s->n_rows >= 1 && s->row0 >= 0 && s->ent0 >= 0);
     ParamLayout L{D, F};
@@ -1248,11 +1423,13 @@ int ggad_mb_train_step(const ggad_mb_step *s, int32_t fuse_adam, ggad_stream_t s
     if ((rc = ggad_mb_fwd_rows(s->params, D, F, s->x1, s->h2, s->ent_ptr, s->ent_own, s->labels, s->row0, s->n_rows, s->ent0,
                                s->h1, s->nbar, s->gen, stream))) return rc;
   }
-  if ((rc = ggad_mb_loss(s->params, D, F, s->h1, s->nbar, s->gen, s->labels, s->pos_meta, s->row_pos, s->ent_ptr, s->row0,
-                         s->n_rows, s->loss_ws, s->losses8, nullptr, nullptr, nullptr, s->dz, s->coef_a, s->coef_g,
-                         s->step_counter, stream))) return rc;
-  if ((rc = bwd_flat_launch(D, F, s->x1, s->x2, s->h2, s->ent_own, s->ent_row, s->row0, s->n_rows, s->ent0, s->n_ents,
-                            s->coef_a, s->coef_g, s->dw_part, fused_fwd ? 1 : 0, stream))) return rc;
+  if (!chunk_fwd) {
+    if ((rc = ggad_mb_loss(s->params, D, F, s->h1, s->nbar, s->gen, s->labels, s->pos_meta, s->row_pos, s->ent_ptr, s->row0,
+                           s->n_rows, s->loss_ws, s->losses8, nullptr, nullptr, nullptr, s->dz, s->coef_a, s->coef_g,
+                           s->step_counter, stream))) return rc;
+    if ((rc = bwd_flat_launch(D, F, s->x1, s->x2, s->h2, s->ent_own, s->ent_row, s->row0, s->n_rows, s->ent0, s->n_ents,
+                              s->coef_a, s->coef_g, s->dw_part, fused_fwd ? 1 : 0, stream))) return rc;
+  }
   if (!fuse_adam)
     return ggad_mb_grad_reduce(D, F, s->pos_meta, s->row0, s->n_rows, s->losses8, s->nbar, s->dw_part, s->dz, s->loss_ws,
                                s->grads, stream);

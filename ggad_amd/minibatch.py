@@ -134,6 +134,21 @@ class BatchChunk:
             self.h1, self.nbar, self.gen = _f32(n, d), _f32(n, d), _f32(n, d)
             self.dz, self.coef_a, self.coef_g = _f32(n, d), _f32(n, d), _f32(n, d)
             self.d_h1 = self.d_gen = self.d_nbar = None        # raw loss gradients: allocated on demand (debug / tests)
+        if getattr(self, "ent_cap", 0):
+            self._alloc_chunks()
+
+    def _alloc_chunks(self) -> None:
+        """Row-chunk tables of the plan (pieces of <= 16 entries of one row) and their partial-sum buffer: the unit of work
+        of the chunk-parallel forward kernels for batches with hub rows (`ggad_mb_row_chunks`, step.hip)."""
+        if not self.train or self.rows_cap == 0 or self.ent_cap == 0:
+            return
+        cl = int(self.lib.ggad_mb_chunk_len())
+        n = self.ent_cap // cl + self.rows_cap + 8
+        d = self.dev
+        self.ck_cap = n
+        self.row_ck_ptr, self.nck_tmp = _i32(self.rows_cap + 1, d), _i32(self.rows_cap, d)
+        self.ck_rc, self.ck_e0 = _i32(n, d), _i32(n, d)
+        self.chunk_part = _f32(n * 64, d)
 
     def _alloc_ents(self, cap: int) -> None:
         cap = int(cap)
@@ -155,6 +170,7 @@ class BatchChunk:
                 self.node_head = torch.zeros(self.g.n, dtype=torch.int32, device=d)   # zero between gathers (the kernel cleans up)
             if not hasattr(self, "pc"):
                 self.pc = torch.empty(0, dtype=torch.int16, device=d)      # uint16 per-pair counts (raw storage)
+        self._alloc_chunks()
 
     # ---- build
     def build(self, batches: Sequence[np.ndarray], labels: Optional[Sequence[np.ndarray]] = None) -> None:
@@ -233,6 +249,9 @@ class BatchChunk:
         self.dirty = True
         call("ggad_mb_gather1", ptr(self.feat), self.F, self.stride, ptr(self.row_slot), ptr(self.ent_ptr), ptr(self.ent_col), rows,
              g.n, ptr(self.cnt1), ptr(self.own1), ptr(self.ent_own), ptr(self.ent_c1), ptr(self.x1))
+        if self.train:
+            call("ggad_mb_row_chunks", ptr(self.ent_ptr), rows, ptr(self.nck_tmp), ptr(self.row_ck_ptr), ptr(self.ck_rc),
+                 ptr(self.ck_e0), ptr(self.scan_ws))
         if self.train and self._use_tiled():
             tot = self.ent_total_ptr()
             e = n_ents
@@ -477,6 +496,8 @@ class MiniBatchEngine:
         s.lr, s.weight_decay = self.lr, self.wd
         s.chain = self.chain if self.chain != 3 else 0
         s.max_row_entries = int(ch.batch_max_row[b])
+        if ch.train and getattr(ch, "row_ck_ptr", None) is not None:
+            s.row_ck_ptr, s.ck_rc, s.ck_e0, s.chunk_part = ptr(ch.row_ck_ptr), ptr(ch.ck_rc), ptr(ch.ck_e0), ptr(ch.chunk_part)
         return s
 
     def loss_and_grads(self, ch: BatchChunk, b: int, log_slot: int = 0) -> None:

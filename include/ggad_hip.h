@@ -123,6 +123,12 @@ int ggad_ocgnn_loss_f32(const float *emb, const int64_t *idx, int64_t n_idx, int
  * aligned): F features followed by one int32 counter per slot; the counter of (slot, k) is word F + slot of
  * row k.  One random 128-byte line per gathered neighbour then delivers both x_k and c'_k (measured +48 %
  * rows/s over a separate counter array, scripts/gather_bench.hip).  At most stride - F slots per chunk. */
+/* Rows cut into pieces of <= ggad_mb_chunk_len() consecutive entries: row_ck_ptr[i] = first chunk of row i (n_rows + 1
+ * values, exclusive scan), ck_rc[c] = (row << 6) | entries of chunk c, ck_e0[c] = its first entry.  nck_tmp: n_rows ints,
+ * scan_ws: ggad_scan_workspace_elems(n_rows).  Capacity of ck_rc / ck_e0: total entries / chunk_len + n_rows. */
+int32_t ggad_mb_chunk_len(void);
+int ggad_mb_row_chunks(const int32_t *ent_ptr, int32_t n_rows, int32_t *nck_tmp, int32_t *row_ck_ptr, int32_t *ck_rc,
+                       int32_t *ck_e0, int32_t *scan_ws, ggad_stream_t stream);
 int ggad_mb_packed_stride(int32_t feat_dim);
 int ggad_mb_count2(const int32_t *rowptr, const int32_t *col, const int32_t *ent_col, const int32_t *ent_slot,
                    const int32_t *ent_total, int64_t n_entries_cap, int64_t n_nodes, const int32_t *own1,
@@ -284,6 +290,12 @@ typedef struct ggad_mb_step {
   int32_t chain;          /* 0 (default): 5 launches when F == 17 and the batch has no hub row (projection fused into the
                              forward-rows kernel, h2 per ENTRY), else 6; 2: always 6; 1: row-wise 3-launch chain, F == 17 */
   int32_t max_row_entries; /* largest closed neighbourhood among the batch rows (host knowledge; 0 = unknown -> 6 launches) */
+  /* optional (all four or none): row-chunk tables of the PLAN (ggad_mb_row_chunks over all rows of the chunk) and the
+   * partial-sum buffer, float[(chunks of the plan) * 64].  With them a chain-0 batch that holds a hub row takes the
+   * chunk-parallel forward (k_fwd_chunks + k_loss_pos_ck: 5 launches, h2 not stored, relu mask recomputed in bwd_flat) instead
+   * of project -> fwd_rows -> loss_pos (6 launches). */
+  const int32_t *row_ck_ptr, *ck_rc, *ck_e0;
+  float *chunk_part;
 } ggad_mb_step;
 /* dw_part must hold ggad_mb_dw_part_elems(n_rows, D, F) floats (one [F][D] partial per row or per bwd_flat part). */
 int64_t ggad_mb_dw_part_elems(int32_t n_rows, int32_t D, int32_t F);

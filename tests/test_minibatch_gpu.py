@@ -538,3 +538,48 @@ def test_persistent_chunk_kernel_equals_launch_chain_and_oracle(d, bsz, n_ano, w
     np.testing.assert_allclose(runs["pers"][0][:, :4], np.array(ref_losses), atol=2e-5, rtol=0)
     ref_p = np.concatenate([t.detach().numpy().reshape(-1) for t in p.tensors()])
     np.testing.assert_allclose(runs["pers"][1][:len(ref_p)], ref_p, atol=2e-5, rtol=0)
+
+
+def test_chunk_parallel_forward_on_hub_batches_equals_six_launch_chain():
+    """Batches with hub rows (> 256 entries) take the chunk-parallel forward of chain 0 (k_fwd_chunks + k_loss_pos_ck, relu
+    mask recomputed in bwd_flat); chain 2 keeps project -> fwd_rows -> loss_pos.  Same losses / gradients / weights up to the
+    order of the row sums; the row-chunk tables of the plan against their host statement."""
+    g, batches, labels = _random_case(n=40000, n_entries=500000, f=17, d=64, seed=91, nb=5, bsz=200, n_ano=50)
+    order = np.argsort(-np.diff(g["rowptr"]))
+    for b in (0, 2, 3):
+        batches[b][10:13] = order[3 * b:3 * b + 3]               # three hub rows each
+    graph, feat, ch = _setup(g, max_batches=5, hop2="ldsw")
+    ch.build(batches, labels)
+    torch.cuda.synchronize()
+    assert (ch.batch_max_row[[0, 2, 3]] > 256).all()
+    # plan tables: pieces of <= 16 consecutive entries of one row
+    cl = int(_lib.load().ggad_mb_chunk_len())
+    r = np.diff(ch.ent_ptr_host[:ch.n_rows + 1])
+    nck = (r + cl - 1) // cl
+    ptr_ref = np.concatenate([[0], np.cumsum(nck)])
+    assert np.array_equal(ch.row_ck_ptr[:ch.n_rows + 1].cpu().numpy(), ptr_ref)
+    tot = int(ptr_ref[-1])
+    rows_of = np.repeat(np.arange(ch.n_rows), nck)
+    k_in = np.arange(tot) - ptr_ref[rows_of]
+    e0 = ch.ent_ptr_host[rows_of] + k_in * cl
+    cnt = np.minimum(cl, ch.ent_ptr_host[rows_of + 1] - e0)
+    assert np.array_equal(ch.ck_e0[:tot].cpu().numpy(), e0)
+    assert np.array_equal(ch.ck_rc[:tot].cpu().numpy(), (rows_of << 6) | cnt)
+    torch.manual_seed(4)
+    w = torch.nn.init.xavier_uniform_(torch.empty(1, 64))
+    W = torch.nn.init.xavier_uniform_(torch.empty(64, 17))
+    fc = torch.nn.init.xavier_uniform_(torch.empty(64, 64))
+    out = {}
+    for chain in (0, 2):
+        eng = MiniBatchEngine(17, 64, DEV, lr=1e-3, weight_decay=0.007, chain=chain)
+        eng.load_params(w, W, fc)
+        grads = []
+        for b in range(5):
+            eng.loss_and_grads(ch, b, b)
+            grads.append(eng.grads.cpu().numpy().copy())
+            eng.adam_step()
+        torch.cuda.synchronize()
+        out[chain] = (eng.losses(5).copy(), np.stack(grads), eng.params.cpu().numpy().copy())
+    np.testing.assert_allclose(out[0][0], out[2][0], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(out[0][1], out[2][1], atol=3e-6, rtol=1e-4)
+    np.testing.assert_allclose(out[0][2], out[2][2], atol=1e-5, rtol=0)
