@@ -843,15 +843,16 @@ __global__ void __launch_bounds__(256) k_loss_pos_ck(const float *__restrict__ p
     hs_r = h1[(int64_t)src * D + dl];
   }
   float totq = 0.0f, tots = 0.0f;
-  for (int c0 = 0; c0 < max(qb - qa, sb - sa); c0 += 8) {        // chunk order, 8 + 8 loads in flight from clamped indices
-    float vq[8], vs[8];
+  constexpr int PF = 16;                                         // a hub row of 2,000 entries has 125 partials: 8 rounds
+  for (int c0 = 0; c0 < max(qb - qa, sb - sa); c0 += PF) {       // chunk order, 16 + 16 loads in flight from clamped indices
+    float vq[PF], vs[PF];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < PF; ++k) {
       vq[k] = chunk_part[(int64_t)min(qa + c0 + k, max(qb - 1, qa)) * 64 + lane];
       vs[k] = chunk_part[(int64_t)(sb > sa ? min(sa + c0 + k, sb - 1) : qa) * 64 + lane];
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < PF; ++k) {
       totq += (qa + c0 + k < qb) ? vq[k] : 0.0f;
       tots += (sa + c0 + k < sb) ? vs[k] : 0.0f;
     }
