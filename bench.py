@@ -5,18 +5,28 @@ Workload (BASELINE.json metric, configs[4]): synthetic graph of 
 (3,700,550 nodes, 73,105,508 directed entries, 17 features), emb 64, batches of 150 + 50 nodes
 (`src/dgraph.yml`, `src/model_handler.py:317,342`), fp32.  One "step" = one optimiser step = one
 batch of 200 nodes per GPU: batch sub-graph plan + 1-hop/2-hop gather-aggregate + encoder + loss +
-backward + Adam.  Plans are built per chunk of 150 batches (one reference epoch) inside the timed
-region.  Inputs resident in HBM before the timed region: graph CSR, feature table, labels and the
-batch schedule (node ids); the schedule is produced by the reference-exact host sampler beforehand.
+backward + Adam.  Plans are built per chunk of batches INSIDE the timed region (a run starts with
+small chunks so that the dense chain of chunk c overlaps the plan of chunk c+1 from the first
+fraction of a millisecond on; `DGraphTrainer.default_ramp`).  Inputs resident in HBM before the
+timed region: graph CSR, feature table, labels; the batch schedule (node ids, host memory) is
+produced by the reference-exact host sampler beforehand -- `value` is therefore the GPU path's
+throughput; `e2e_with_sampler` (extra key) times the reference's own window
+(`src/model_handler.py:332-365`) with the sampler thread inside it.
 
-    python bench.py --gpus 1 --steps 1500 --warmup 150
+    python bench.py --gpus 1 --steps 20 --warmup 5          # what the round driver runs
+    python bench.py                                          # default: 9000 steps (steady state)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line (rank 0).  `roofline` refers to the 2-hop gather-aggregate kernel
-(`k_gather2`, the HBM-bound kernel of the path): achieved = 72 B per gathered neighbour x
-neighbours per launch / launch time measured with HIP events on the launch stream.
-`cpu_baseline` times the dense-faithful CPU port of the reference's step (oracle/) on a bounded
-sample of the same batches (rank 0, N = 1 only).
+Prints ONE JSON line (rank 0).  `roofline` refers to the 2-hop gather-aggregate
+(`k_build_groups` + `k_gather2_items` + `k_gather2_combine`, the dominant launches of the path):
+`achieved` = ALGORITHMIC bytes (74 B per gathered neighbour of every (batch, owner) occurrence:
+68-byte feature row + 4-byte id + 2-byte streamed pair count) / launch time measured
+with HIP events on the launch stream.  Because occurrences of a node in several batches of a chunk
+share one fetch of its neighbour rows, algorithmic bytes exceed the HBM traffic; `hbm_bytes_per_neighbour`
+/ `hbm_frac` (from the rocprofv3 PMC pass of the same command, profiles/) say what reaches memory.
+Extra keys (single GPU): `steady_state` (long run after the timed region), `e2e_with_sampler`,
+`fullgraph` (epoch times of the four full-graph configs), `cpu_baseline` (dense-faithful CPU port
+of the reference's step on a bounded sample, rank 0).
 """
 from __future__ import annotations
 
@@ -51,11 +61,16 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true", help="plan and dense steps on one stream")
     ap.add_argument("--dense-cus", type=int, default=-1, help="CUs reserved for the dense step chain when overlapping (-1 = by graph density: 32 or 64) "
                     "(CU-masked streams; 0 = plain streams with priorities)")
-    ap.add_argument("--hop2", default="ldsw", choices=["ldsw", "tiled", "ktile", "global", "packed"],
-                    help="ldsw: LDS counting per (tile, batch) + streamed per-pair counts (default); tiled / ktile: earlier LDS variants; "
-                         "global: atomics on per-batch counter slots in HBM; "
-                         "packed: global counters inside 128-byte feature rows (chunk <= 15 batches)")
-    ap.add_argument("--chain", type=int, default=0, choices=[0, 1, 2, 3], help="per-step kernel chain: 0 five launches (projection fused), 1 row-wise three, 2 six (include/ggad_hip.h: ggad_mb_step.chain)")
+    ap.add_argument("--hop2", default="ldsw", choices=["ldsw", "global"],
+                    help="ldsw: LDS counting per (tile, batch) + streamed per-pair counts (default); "
+                         "global: atomics on per-batch counter slots in HBM (the fallback path)")
+    ap.add_argument("--chain", type=int, default=0, choices=[0, 2], help="per-step kernel chain: 0 five launches (projection fused), 2 the generic six (include/ggad_hip.h: ggad_mb_step.chain)")
+    ap.add_argument("--ramp", default="", help="comma-separated sizes of the first chunks of a run (default: DGraphTrainer.default_ramp)")
+    ap.add_argument("--steady-steps", type=int, default=3000, help="extra leg after the timed region: steps of one long run (0 = skip; "
+                    "skipped when --steps is already >= this)")
+    ap.add_argument("--e2e-steps", type=int, default=1500, help="extra leg: steps timed with the reference-exact sampler inside the window (0 = skip)")
+    ap.add_argument("--fullgraph-epochs", type=int, default=30, help="extra leg: epochs timed per full-graph config (0 = skip)")
+    ap.add_argument("--no-extras", action="store_true", help="only the timed region (no steady-state / e2e / full-graph / CPU legs)")
     ap.add_argument("--dp-path", action="store_true", help="1 GPU only: run the data-parallel step chain (backward -> exchange -> "
                     "Adam, Adam not fused) with a no-op exchange, to measure what the multi-GPU step costs without the collective")
     ap.add_argument("--seed", type=int, default=72)
@@ -109,8 +124,9 @@ def main():
         def allreduce(t):
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
     trainer = DGraphTrainer(graph, feat, a.emb, sched, lr=1e-3, weight_decay=0.007, chunk_batches=a.chunk, rank=rank,
-                            world_size=world, allreduce=allreduce, packed=(a.hop2 == "packed"),
-                            hop2=(a.hop2 if a.hop2 in ("tiled", "ktile", "ldsw") else "global"), overlap=not a.no_overlap, chain=a.chain, dense_cus=(None if a.dense_cus < 0 else a.dense_cus))
+                            world_size=world, allreduce=allreduce, hop2=a.hop2, overlap=not a.no_overlap, chain=a.chain,
+                            dense_cus=(None if a.dense_cus < 0 else a.dense_cus),
+                            ramp=([int(x) for x in a.ramp.split(",") if x] if a.ramp else None))
     a.dense_cus = getattr(trainer, "dense_cus", 0 if a.dense_cus < 0 else a.dense_cus)
     if a.dp_path and world == 1:
         if os.environ.get("GGAD_BENCH_REAL_ALLREDUCE") == "1":
@@ -133,16 +149,25 @@ def main():
     timed = sched.next_batches(a.steps, rank, world)
     setup_s = time.time() - t0
 
-    # ---------------- instrumentation of the dominant kernel (gather2) with HIP events on the launch stream
-    gather_ms, gather_nbrs = [], []
+    # ---------------- instrumentation of the dominant launches (2-hop gather) with HIP events on the launch stream
+    import ctypes
+    from ggad_amd import _lib
+    lib = _lib.load()
     ev_pairs = []
 
+    def new_event():
+        h = ctypes.c_void_p()
+        _lib.check(lib.ggad_event_create(1, ctypes.byref(h)), "ggad_event_create")
+        return h
+    ev_pool = [new_event() for _ in range(24)]          # created before the timed region
+
     def timed_build(chunk, bn, bl):
-        # BatchChunk.build records these two events around its gather2 launch (same stream)
-        if len(ev_pairs) >= 10:           # the first 10 launches of the timed region are instrumented (host-side neighbour
-            chunk.build(bn, bl)           # counting for the roofline costs ~1 s per launch afterwards)
+        # ggad_mb_plan_build records these two events around its gather launches (k_build_groups, k_gather2_items,
+        # k_gather2_combine) on the stream they run on
+        if len(ev_pairs) >= 12:           # the first 12 launches of the timed region are instrumented (host-side neighbour
+            chunk.build(bn, bl)           # counting for the roofline costs ~1 s per 150-batch launch afterwards)
             return
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0, e1 = ev_pool[2 * len(ev_pairs)], ev_pool[2 * len(ev_pairs) + 1]
         chunk.gather2_events = (e0, e1)
         chunk.build(bn, bl)
         chunk.gather2_events = None
@@ -184,39 +209,90 @@ def main():
     losses = trainer.engine.losses(a.steps)
 
     # ---------------- roofline of the dominant kernel
+    gather_ms, gather_nbrs, gather_batches = [], [], []
     for e0, e1, bn in ev_pairs:
-        gather_ms.append(e0.elapsed_time(e1))
+        ms = ctypes.c_float()
+        _lib.check(lib.ggad_event_elapsed_ms(e0, e1, ctypes.byref(ms)), "ggad_event_elapsed_ms")
+        gather_ms.append(float(ms.value))
         gather_nbrs.append(hop2_neighbours(bn))
+        gather_batches.append(len(bn))
+    for h in ev_pool:
+        lib.ggad_event_destroy(h)
     mode = trainer.chunk.last_hop2
-    # algorithmic bytes per gathered neighbour: the feature row (4 F) + the column id (4) [+ the streamed 2-byte
-    # pair count in "ldsw"; the counter word of the other variants is charged to the id's 4 bytes as before]
+    sizes = trainer.default_ramp(a.steps)
+    overlapped = bool(trainer.overlap and len(sizes) > 1)
+    # algorithmic bytes per gathered neighbour (per occurrence): the feature row (4 F) + the column id (4) [+ the streamed
+    # 2-byte pair count in "ldsw"]
     per_nbr = 4 * a.feat + 4 + (2 if mode == "ldsw" else 0)
     alg_bytes = [per_nbr * nb for nb in gather_nbrs]
     ach = (sum(alg_bytes) / 1e9) / (sum(gather_ms) / 1e3) if gather_ms and sum(gather_ms) > 0 else None
-    kname = {"ldsw": "k_gather2_groups (node-major 2-hop gather-aggregate, streamed pair counts; + k_link_owners, k_build_groups)",
-             "tiled": "k_hop2_tiled (LDS-tiled 2-hop count + gather-aggregate)",
-             "ktile": "k_count2_tile + k_gather2_tile (k-tile-major 2-hop count + gather-aggregate, all launches)"}.get(
-        trainer.chunk.last_hop2, "k_gather2 (2-hop gather-aggregate)")
-    traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", {"global": "r01_pmc_gather2.json", "ldsw": "r01_pmc_gather2_groups.json"}.get(mode, "none"))
-    if os.path.exists(pmc_path) and gather_nbrs:
-        # HBM-side bytes per launch from the rocprofv3 PMC pass of this same command (FETCH_SIZE x 1024, see the json's note),
-        # scaled by the neighbours this run's launches gathered
+    kname = ("k_build_groups + k_gather2_items + k_gather2_combine (node-major 2-hop gather-aggregate: work items of <= 8 occurrences "
+             "x 256 neighbours, streamed pair counts)") if mode == "ldsw" else "k_gather2 (2-hop gather-aggregate, device-atomic counters)"
+    # HBM-side bytes per gathered neighbour from the rocprofv3 PMC passes of this command (profiles/, FETCH_SIZE doubled as
+    # MI355X_MICROARCH prescribes for gfx950), keyed by batches per launch; nearest measured chunk size, else null
+    traffic = hbm_per_nbr = hbm_src = None
+    pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_gather2_items.json")
+    if mode == "ldsw" and os.path.exists(pmc_path) and gather_nbrs:
         with open(pmc_path) as fh:
-            traffic = json.load(fh)["bytes_per_neighbour"] * float(np.mean(gather_nbrs))
+            table = json.load(fh).get("by_batches_per_launch", {})
+        if table:
+            mean_b = float(np.mean(gather_batches))
+            key = min(table, key=lambda k: abs(float(k) - mean_b))
+            if abs(float(key) - mean_b) <= 0.5 * mean_b:
+                hbm_per_nbr = float(table[key]["hbm_bytes_per_neighbour"])
+                traffic = hbm_per_nbr * float(np.mean(gather_nbrs))
+                hbm_src = f"profiles/r02_pmc_gather2_items.json[{key} batches per launch]"
+    avg_ms = float(np.mean(gather_ms)) if gather_ms else None
     roofline = {"kernel": kname, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": traffic,
-                "launches": len(gather_ms), "avg_launch_ms": float(np.mean(gather_ms)) if gather_ms else None,
+                "achieved_is": "algorithmic bytes / launch time: every (batch, owner) occurrence is charged its neighbours' rows, "
+                               "although occurrences of a node in several batches of a launch share one fetch -- not HBM traffic",
+                "hbm_bytes_per_neighbour": hbm_per_nbr, "hbm_traffic_source": hbm_src,
+                "hbm_frac": (traffic / 1e9 / (avg_ms / 1e3) / HBM_PEAK_GBS) if (traffic and avg_ms) else None,
+                "launches": len(gather_ms), "avg_launch_ms": avg_ms,
+                "batches_per_launch": gather_batches,
                 "alg_bytes_per_launch": float(np.mean(alg_bytes)) if alg_bytes else None, "alg_bytes_per_neighbour": per_nbr,
-                "gather_share_of_step_time": (float(np.mean(gather_ms)) / 1e3 * ((a.steps + trainer.chunk_batches - 1) // trainer.chunk_batches)) / elapsed if gather_ms else None,
-                # with overlap the kernel runs on the plan stream's CU partition while the dense chain of the previous
-                # chunk runs on the other CUs; --no-overlap times it alone on the whole chip
-                "concurrent_with_dense_chain": bool(trainer.overlap),
+                "gather_share_of_timed_region": (sum(gather_ms) / 1e3 * (len(sizes) / max(1, len(gather_ms)))) / elapsed if gather_ms else None,
+                # with overlap the launches run on the plan stream's CU partition while the dense chain of the previous
+                # chunk runs on the other CUs (the first chunk of a run has nothing to overlap with)
+                "concurrent_with_dense_chain": overlapped,
                 "cus": (256 - a.dense_cus) if (trainer.overlap and a.dense_cus > 0) else 256}
+
+    # ---------------- extra legs (single GPU): steady state, end to end with the sampler, the full-graph programs
+    extras = {}
+    if rank == 0 and world == 1 and not a.no_extras and not a.dp_path:
+        if a.steady_steps > a.steps:
+            batch = sched.next_batches(a.steady_steps, rank, world)
+            barrier()
+            ts = time.perf_counter()
+            n_st = trainer.run_steps(a.steady_steps, prepared=batch)
+            barrier()
+            dt = time.perf_counter() - ts
+            extras["steady_state"] = {"steps": a.steady_steps, "value": n_st / dt, "unit": "nodes/s", "ms_per_step": 1e3 * dt / a.steady_steps,
+                                      "note": "one run of this many steps right after the timed region (schedule prepared beforehand, plans inside)"}
+        if a.e2e_steps > 0:
+            # the reference's window (src/model_handler.py:332-365) holds the per-batch random.shuffle of the pseudo-anomaly pool:
+            # here the bit-exact native sampler produces the batches in its own thread INSIDE the window
+            n_e2e = (a.e2e_steps // trainer.chunk_batches) * trainer.chunk_batches or a.e2e_steps
+            barrier()
+            ts = time.perf_counter()
+            trainer.start_stream(n_e2e)
+            n_nodes = trainer.run_steps(n_e2e)
+            barrier()
+            dt = time.perf_counter() - ts
+            extras["e2e_with_sampler"] = {"steps": n_e2e, "value": n_nodes / dt, "unit": "nodes/s", "ms_per_step": 1e3 * dt / n_e2e,
+                                          "note": "batch schedule generated inside the window by the reference-exact sampler thread "
+                                                  "(CPython random.shuffle of the 55k pool per batch, 1.05M train list per epoch)"}
+        if a.fullgraph_epochs > 0:
+            try:
+                from ggad_amd.fullgraph_bench import bench_fullgraph
+                extras["fullgraph"] = bench_fullgraph(dev, a.fullgraph_epochs)
+            except Exception as exc:          # the extra leg must never take the headline line down
+                extras["fullgraph"] = {"error": repr(exc)}
 
     # ---------------- CPU baseline: dense-faithful port of the reference's step, bounded sample
     cpu = None
-    if rank == 0 and world == 1 and a.cpu_batches > 0:
+    if rank == 0 and world == 1 and a.cpu_batches > 0 and not a.no_extras:
         from oracle import ggad_oracle as O
         ncores = os.cpu_count() or 1
         threads = min(24, ncores)                                       # README.md:21 "24-core CPU"
@@ -260,12 +336,16 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "DGraph-Fin-size synthetic graph, mini-batch GGAD (GCN encoder)", "nodes": a.nodes,
                        "directed_entries": int(graph.nnz), "feat": a.feat, "emb": a.emb, "batch": "150+50",
-                       "graph": f"{a.graph_kind}(alpha=2.1,max_degree={a.max_degree})", "chunk_batches": trainer.chunk_batches, "hop2": a.hop2, "overlap": trainer.overlap, "dense_cus": (a.dense_cus if trainer.overlap else 0), "chain": a.chain,
+                       "graph": f"{a.graph_kind}(alpha=2.1,max_degree={a.max_degree})", "chunk_batches": trainer.chunk_batches,
+                       "chunks_of_timed_region": sizes[:16], "hop2": a.hop2, "overlap": overlapped,
+                       "dense_cus": (a.dense_cus if overlapped else 0), "chain": a.chain,
                        "parallelism": f"dp{world}", "optimizer": "adam(lr=1e-3,wd=0.007)"},
+            "value_is": "GPU path (plans + dense steps inside the window; batch schedule prepared by the host sampler beforehand)",
             "roofline": roofline, "cpu_baseline": cpu,
             "gpu_over_cpu": (value / cpu["value"]) if cpu else None,
             "first_loss": float(losses[0][0]), "last_loss": float(losses[-1][0]), "setup_s": setup_s,
         }
+        out.update(extras)
     else:
         out = None
     # The JSON line must be the LAST thing on stdout: RCCL prints its version banner through C stdio (buffered, flushed at

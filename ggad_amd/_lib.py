@@ -35,35 +35,29 @@ SIGNATURES = {
     "ggad_max_feat_dim": (c_int32, []),
     "ggad_scan_workspace_elems": (c_int64, [_L]),
     "ggad_exclusive_scan_i32": (c_int32, [_P, _P, _L, _P, _P]),
-    "ggad_mb_row_degree": (c_int32, [_P, _P, _P, _P, _I, _I, _P, _P, _P]),
-    "ggad_mb_expand1": (c_int32, [_P, _P, _P, _P, _P, _I, _L, _P, _P, _P, _P, _P, _P]),
-    "ggad_mb_gather1": (c_int32, [_P, _I, _I, _P, _P, _P, _I, _L, _P, _P, _P, _P, _P, _P]),
-    "ggad_mb_packed_stride": (c_int32, [_I]),
-    "ggad_mb_count2": (c_int32, [_P, _P, _P, _P, _P, _L, _L, _P, _P, _P, _I, _I, _P]),
+    "ggad_mb_chunk_len": (c_int32, []),
+    "ggad_mb_slice_len": (c_int32, []),
+    "ggad_mb_group_words": (c_int32, []),
+    "ggad_mb_plan_build": (c_int32, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
+    "ggad_event_create": (c_int32, [_I, _P]),
+    "ggad_event_destroy": (c_int32, [_P]),
+    "ggad_event_record": (c_int32, [_P, _P]),
+    "ggad_event_synchronize": (c_int32, [_P]),
+    "ggad_event_elapsed_ms": (c_int32, [_P, _P, _P]),
+    "ggad_mb_count2": (c_int32, [_P, _P, _P, _P, _P, _L, _L, _P, _P, _P]),
     "ggad_mb_gather2": (c_int32, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _L, _L, _P, _P, _P]),
-    "ggad_mb_tile_size": (c_int32, []),
+    "ggad_mb_plan_reset": (c_int32, [_P, _P, _P, _P, _P, _P, _L, _L, _P, _P, _I, _P]),
     "ggad_mb_tile_offsets_elems": (c_int64, [_L, _I]),
     "ggad_mb_tile_offsets": (c_int32, [_P, _P, _L, _I, _P, _P]),
     "ggad_mb_ldsw_tile_shift": (c_int32, []),
     "ggad_mb_ldsw_max_owners": (c_int32, []),
+    "ggad_mb_ldsw_seg_elems": (c_int64, [_L, _L]),
     "ggad_mb_dw_part_elems": (c_int64, [_I, _I, _I]),
     "ggad_mb_train_chunk": (c_int32, [_P, _I, _P, _P, _P, _P, _I, _I, _P]),
     "ggad_mb_train_chunk_dp": (c_int32, [_P, _I, _P, _P, _P, _P, _I, c_float, EXCHANGE_CB, _P, _P]),
-    "ggad_mb_persistent_chunk_len": (c_int32, []),
-    "ggad_mb_persistent_max_rows": (c_int32, []),
-    "ggad_mb_persistent_ws_elems": (c_int64, [_I, _I]),
-    "ggad_mb_train_chunk_persistent": (c_int32, [_P, _I, _P, _P, _I, _I, _I, _P, _I, _P, _P]),
     "ggad_stream_create_cu_mask": (c_int32, [_P, _I, _P]),
     "ggad_stream_destroy": (c_int32, [_P]),
     "ggad_device_cu_count": (c_int32, [_I, _P]),
-    "ggad_mb_ldsw_seg_elems": (c_int64, [_L, _L]),
-    "ggad_mb_hop2_ldsw_count": (c_int32, [_P, _P, _L, _P, _P, _P, _P, _P, _I, _P, _L, _P, _P, _P, _P, _P, _P, _P]),
-    "ggad_mb_hop2_ldsw_gather": (c_int32, [_P, _P, _P, _I, _I, _P, _P, _P, _L, _P, _P, _P, _P, _P, _P, _P]),
-    "ggad_mb_owner_flags": (c_int32, [_P, _P, _L, _P, _P]),
-    "ggad_mb_hop2_tiled": (c_int32, [_P, _P, _P, _I, _I, _L, _P, _P, _P, _P, _P, _I, _P, _L, _P, _P]),
-    "ggad_mb_hop2_ktile": (c_int32, [_P, _P, _P, _I, _I, _L, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P]),
-    "ggad_mb_reset_packed": (c_int32, [_P, _L, _I, _I, _I, _P]),
-    "ggad_mb_plan_reset": (c_int32, [_P, _P, _P, _P, _P, _P, _L, _L, _P, _P, _I, _P, _I, _I, _P]),
     "ggad_mb_param_count": (c_int64, [_I, _I]),
     "ggad_mb_param_block_elems": (c_int64, [_I, _I]),
     "ggad_mb_params_sync": (c_int32, [_P, _I, _I, _P]),
@@ -78,8 +72,6 @@ SIGNATURES = {
     "ggad_mb_adam": (c_int32, [_P, _P, _P, _P, _I, _I, _F, _F, _F, _P, _P]),
     "ggad_mb_train_step": (c_int32, [_P, _I, _P]),
     "ggad_mb_encode": (c_int32, [_P, _I, _I, _P, _I, _P, _P]),
-    "ggad_mb_chunk_len": (c_int32, []),
-    "ggad_mb_row_chunks": (c_int32, [_P, _I, _P, _P, _P, _P, _P, _P]),
     "ggad_seg_mean": (c_int32, [_P, _I, _P, _P, _I, _P, _P]),
     "ggad_seg_wsum": (c_int32, [_P, _I, _P, _P, _P, _I, _P, _P]),
     "ggad_recon_cols_f32": (c_int32, [_P, _P, _I, _I, _F, _F, _P, _P, _P, _P]),
@@ -125,6 +117,29 @@ class MbStep(ctypes.Structure):
                 + [(n, c_int32) for n in ("D", "F", "row0", "n_rows", "ent0", "n_ents")]
                 + [("lr", c_float), ("weight_decay", c_float), ("chain", c_int32), ("max_row_entries", c_int32)]
                 + [(n, c_void_p) for n in ("row_ck_ptr", "ck_rc", "ck_e0", "chunk_part")])
+
+
+class MbPlan(ctypes.Structure):
+    """Mirror of `ggad_mb_plan` (include/ggad_hip.h)."""
+    _fields_ = ([(n, c_void_p) for n in ("rowptr", "col", "feat", "tile_off", "closed_deg_host", "pair_bound_host", "stage_host",
+                                         "stage", "stage_event", "cnt1", "own1", "cnt2", "ent_col", "ent_slot", "ent_row",
+                                         "ent_own", "ent_c1", "x1", "x2", "ck_part", "own_deg", "own_rp", "pw_base", "seg_t",
+                                         "node_head", "own_next", "grp", "items", "counters", "pc", "part2", "ev_gather0",
+                                         "ev_gather1")]
+                + [(n, c_int64) for n in ("n_nodes", "ent_cap", "ck_cap", "pair_cap", "item_cap", "part2_cap", "stage_cap",
+                                          "seg_cap")]
+                + [(n, c_int32) for n in ("feat_dim", "feat_stride", "max_batches", "rows_cap", "ck_part_stride", "train", "hop2",
+                                          "node_major")]
+                + [("mean_nbr_deg", c_float)])
+
+
+class MbPlanInfo(ctypes.Structure):
+    """Mirror of `ggad_mb_plan_info`."""
+    _fields_ = ([(n, c_int64) for n in ("pair_bound", "off_batch_ptr", "off_batch_ent_ptr", "off_nodes", "off_labels",
+                                        "off_pos_meta", "off_row_pos", "off_row_slot", "off_ent_ptr", "off_row_ck_ptr",
+                                        "off_ck_rc", "off_ck_e0", "need_rows", "need_ents", "need_chunks", "need_pairs",
+                                        "need_items", "need_part2", "need_stage", "need_seg")]
+                + [(n, c_int32) for n in ("n_batches", "n_rows", "n_ents", "n_chunks", "mode", "need_cnt2")])
 
 
 _lib = None

@@ -49,3 +49,13 @@ __device__ __forceinline__ int lower_bound_i32(const int32_t *__restrict__ a, in
   }
   return lo;
 }
+
+// ---- internal (C++ linkage) pieces of ggad_mb_plan_build, shared between plan_build.cpp, plan.hip and hop2_ldsw.hip
+struct ggad_plan_view {      // device views into the staging block of ONE build + its exact sizes (known on the host)
+  const int32_t *batch_ptr, *batch_ent_ptr, *nodes, *row_slot, *ent_ptr, *row_ck_ptr, *ck_rc, *ck_e0;
+  int32_t n_batches, n_rows, n_ents, n_chunks;
+  int32_t seg_stride;        // entries per tile row of seg_t (n_ents rounded up to 64)
+};
+int ggad_int_hop1(const ggad_mb_plan *P, const ggad_plan_view &V, int ldsw, int reset_now, hipStream_t st);
+int ggad_int_global_hop2(const ggad_mb_plan *P, const ggad_plan_view &V, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
+int ggad_int_ldsw_hop2(const ggad_mb_plan *P, const ggad_plan_view &V, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);

@@ -1,0 +1,606 @@
+// LDS-counting 2-hop aggregation of the DGraph mini-batch path (gfx950): the second half of ggad_mb_plan_build.
+//
+// Computes, for every owner entry e of a batch (column u = ent_col[e]; the owners are the reference's deduplicated
+// `unique_nodes_list`, graphsage.py:306),
+//     x2[e] = sum_{k in N(u)} feat[k] / (sqrt(|N(u)|) sqrt(c'_k)),     c'_k = #{owners u' of the batch : k in N(u')}
+// i.e. mask_neigh.mm(embed_matrix_expand) with the batch-dependent column normalisation of graphsage.py:335-355.
+//
+// What the hardware allows (measured, scripts/atomic_bench.hip, scripts/gather_bench.hip): device-scope atomics run at
+// ~27 G/s whatever their footprint or clustering, random 4-byte reads at 50-60 G/s, sequential streams are nearly free.
+// So (a) the counts c'_k are taken in LDS, (b) they reach the gather as a SEQUENTIAL stream (pc[], one uint16 per
+// (owner, neighbour) pair, laid out like the owner's CSR row), which leaves the feature row as the only random access,
+// (c) a node that is an owner in several batches of the chunk has its neighbour rows fetched once for up to 8 occurrences.
+//
+// Every entry of the chunk is an "owner slot" (97 % of the entries ARE owners; the others carry an empty neighbour
+// list), so there is no compaction pass and no prefix sum: the per-owner tables are indexed by entry, pc[] storage is
+// handed out by k_gather1c with one atomic per wave.
+//   k_seg_transpose   tile_off rows of the owners, transposed tile-major (contiguous runs for the counting workgroups)
+//   k_tile_counts     one workgroup per (tile of 32,768 ids, batch): pair-parallel LDS counting, writes pc[]
+//   k_build_groups    per-node owner lists -> groups of <= 8 occurrences x SLICES of <= 256 neighbours = work items
+//   k_gather2_items   one wave per work item, dealt dynamically: every row of a 64-neighbour block in flight at once
+//   k_gather2_combine partial sums of multi-slice owners, slices in order
+// A hub of 2,000 neighbours is 8 independent work items per group instead of one wave's 32 dependent blocks (that single
+// wave WAS the gather's fixed 0.35 ms on small chunks).  Summation order per owner: slices ascending, inside a slice the
+// CSR order -- independent of grouping, chunk composition and launch geometry: bit-reproducible.
+#include <algorithm>
+
+#include "common.h"
+
+namespace {
+
+constexpr int SLICE = 256;              // neighbours per work item
+constexpr int GRP_W = 10;               // ints per group record: 8 owner entries (-1 = empty), partial-slot base, slices
+constexpr int ITEM_GRAB = 4;            // work items a WAVE takes from the cursor at a time
+
+__global__ void __launch_bounds__(256) k_tile_offsets(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                      int64_t n_nodes, int n_tiles, int shift, int32_t *__restrict__ off) {
+  const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= n_nodes) return;
+  const int s = rowptr[u], e = rowptr[u + 1];
+  int32_t *o = off + u * (n_tiles + 1);
+  int t = 0;
+  for (int i = s; i < e; ++i) {
+    const int tile = col[i] >> shift;
+    while (t <= tile) { o[t] = i - s; ++t; }
+  }
+  while (t <= n_tiles) { o[t] = e - s; ++t; }
+}
+
+constexpr int TW_SHIFT = 15;
+constexpr int TW_TILE = 1 << TW_SHIFT;
+constexpr int TW_MAXOWN = 6144;          // owner slots (entries) per batch the LDS arrays hold; larger batches: slabs
+constexpr int TW_T = 1024;
+
+// seg_t[t][e] = tile_off[ent_col[e]][t] for owner entries (0 for the others: empty segments), tile-major so that the
+// workgroup of (tile t, batch b) reads its owners' segment bounds as two contiguous runs.  (Reading tile_off directly
+// costs one random 64-byte sector per (owner, tile).)  One workgroup = 64 entries: table rows read coalesced (one wave per
+// row), transposed through LDS, written as 256-byte runs.
+constexpr int TT_SLAB = 128;
+__global__ void __launch_bounds__(256) k_seg_transpose(const int32_t *__restrict__ tile_off, int n_tiles,
+                                                       const int32_t *__restrict__ ent_own, const int32_t *__restrict__ ent_col,
+                                                       int n_ents, int64_t seg_stride, int32_t *__restrict__ seg_t) {
+  __shared__ int tl[TT_SLAB][65];
+  const int p0 = blockIdx.x * 64;
+  if (p0 >= n_ents) return;
+  const int lane = lane_id(), wid = threadIdx.x >> 6;
+  const int NT1 = n_tiles + 1;
+  for (int t0 = 0; t0 < NT1; t0 += TT_SLAB) {
+    for (int j = wid; j < 64; j += 4) {
+      const int p = p0 + j;
+      if (p < n_ents) {
+        const bool own = ent_own[p] == p;
+        const int u = ent_col[p];
+        const int32_t *row = tile_off + (int64_t)u * NT1 + t0;
+        if (t0 + lane < NT1) tl[lane][j] = own ? row[lane] : 0;
+        if (t0 + 64 + lane < NT1) tl[64 + lane][j] = own ? row[64 + lane] : 0;
+      }
+    }
+    __syncthreads();
+    const int nt = min(TT_SLAB, NT1 - t0);
+    for (int idx = threadIdx.x; idx < nt * 64; idx += 256) {
+      const int tt = idx >> 6, j = idx & 63;
+      if (p0 + j < n_ents) seg_t[(int64_t)(t0 + tt) * seg_stride + p0 + j] = tl[tt][j];
+    }
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ int block_excl_scan_1024(int v, int *warp_buf, int *total) {
+  // exclusive scan over 1024 threads (16 waves); warp_buf: 16 ints of LDS
+  const int lane = lane_id(), wid = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += t;
+  }
+  if (lane == 63) warp_buf[wid] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) { const int sv = warp_buf[w]; if (w < wid) base += sv; tot += sv; }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+__global__ void __launch_bounds__(TW_T) k_tile_counts(const int32_t *__restrict__ col, const int32_t *__restrict__ seg_t,
+                                                      int64_t n_cap, const int32_t *__restrict__ own_rp,
+                                                      const int32_t *__restrict__ batch_ent_ptr,
+                                                      const int32_t *__restrict__ pw_base, uint16_t *__restrict__ pc) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
+  uint32_t *cnt = lds_u;                                   // TW_TILE / 2 words
+  int *offs = reinterpret_cast<int *>(lds_u + TW_TILE / 2);  // TW_MAXOWN + 1
+  int *segbeg = offs + TW_MAXOWN + 1;                      // TW_MAXOWN   (index into col[])
+  int *dst = segbeg + TW_MAXOWN;                           // TW_MAXOWN   (index into pc[])
+  __shared__ int wbuf[16];
+  const int t = blockIdx.x, b = blockIdx.y;
+  const int o0 = batch_ent_ptr[b], o1 = batch_ent_ptr[b + 1];      // "owner slots" = the entries of batch b
+  const int n_own_all = o1 - o0;
+  const int32_t *seg_lo = seg_t + (int64_t)t * n_cap, *seg_hi = seg_lo + n_cap;
+  for (int i = threadIdx.x; i < TW_TILE / 2; i += TW_T) cnt[i] = 0u;
+  constexpr int IPT = TW_MAXOWN / TW_T;
+  // batches with more owners than the LDS tables hold are walked in slabs of TW_MAXOWN owners (counts accumulate
+  // over the slabs in pass 0; pass 1 re-derives each slab's tables).  The usual batch is one slab: tables built once.
+  const int n_slabs = (n_own_all + TW_MAXOWN - 1) / TW_MAXOWN;
+  const bool one_slab = n_slabs == 1;
+  constexpr int CACHE_IT = 16;
+  int kc[CACHE_IT], dc[CACHE_IT];
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int slab = 0; slab < n_slabs; ++slab) {
+      const int ob0 = o0 + slab * TW_MAXOWN;
+      const int n_own = min(TW_MAXOWN, o1 - ob0);
+      if (pass == 0 || n_slabs > 1) {
+        // segment of every owner inside this tile; exclusive scan of the lengths (IPT owners per thread).
+        // The four table reads are coalesced (thread-contiguous owners), staged through LDS for the per-thread scan.
+        for (int i = threadIdx.x; i < n_own; i += TW_T) {
+          const int lo = seg_lo[ob0 + i], hi = seg_hi[ob0 + i];
+          offs[i] = hi - lo;
+          segbeg[i] = own_rp[ob0 + i] + lo;
+          dst[i] = pw_base[ob0 + i] + lo;
+        }
+        __syncthreads();
+        int len[IPT];
+        int mysum = 0;
+#pragma unroll
+        for (int q = 0; q < IPT; ++q) {
+          const int i = threadIdx.x * IPT + q;
+          len[q] = (i < n_own) ? offs[i] : 0;
+          mysum += len[q];
+        }
+        __syncthreads();
+        int P0;
+        int ex = block_excl_scan_1024(mysum, wbuf, &P0);
+#pragma unroll
+        for (int q = 0; q < IPT; ++q) {
+          const int i = threadIdx.x * IPT + q;
+          if (i < n_own) offs[i] = ex;
+          ex += len[q];
+        }
+        if (threadIdx.x == 0) offs[n_own] = P0;               // number of pairs of the slab
+        __syncthreads();
+      }
+      const int P = offs[n_own];
+      if (P > 0) {                                             // uniform
+        // pair p -> owner = last index i with offs[i] <= p.  Branch-free descent over the LDS table, four pairs per
+        // thread in flight (the LDS round trips of one search are dependent; four searches interleave), so a hub
+        // owner and a 1-neighbour owner cost the same per pair.
+        const int s0 = 1 << (31 - __clz(n_own));
+        auto locate = [&](int pp, int &own, int &j) {
+          int lo = 0;
+          for (int st = s0; st > 0; st >>= 1) { const int m = lo + st; lo = (offs[min(m, n_own)] <= pp) ? m : lo; }
+          own = lo; j = pp - offs[lo];
+        };
+        auto locate4 = [&](const int (&pp)[4], int (&own)[4], int (&j)[4]) {
+          int lo[4] = {0, 0, 0, 0};
+          for (int st = s0; st > 0; st >>= 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int m = lo[q] + st; lo[q] = (offs[min(m, n_own)] <= pp[q]) ? m : lo[q]; }
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { own[q] = lo[q]; j[q] = pp[q] - offs[lo[q]]; }
+        };
+        int p_start = 0;
+        if (one_slab) {
+          // the first CACHE_IT * 1024 pairs keep (k, pc index) in registers between the passes: pass 1 is then a
+          // counter read + a 2-byte store
+          if (pass == 0) {
+            // phase A: locate all CACHE_IT pairs of this thread (LDS only); phase B: ALL their column loads in flight at once
+            // (pairs clamped to P - 1, so every load is unconditional); phase C: the LDS counts
+#pragma unroll
+            for (int g4 = 0; g4 < CACHE_IT; g4 += 4) {
+              int pp[4], own[4], j[4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) pp[q] = min((g4 + q) * TW_T + (int)threadIdx.x, P - 1);
+              locate4(pp, own, j);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                kc[g4 + q] = segbeg[own[q]] + j[q];             // index into col[] for now
+                dc[g4 + q] = dst[own[q]] + j[q];
+              }
+            }
+#pragma unroll
+            for (int it = 0; it < CACHE_IT; ++it) kc[it] = col[kc[it]];
+#pragma unroll
+            for (int it = 0; it < CACHE_IT; ++it) {
+              const bool on = it * TW_T + (int)threadIdx.x < P;
+              const int loc = kc[it] & (TW_TILE - 1);
+              if (on) atomicAdd(&cnt[loc >> 1], 1u << ((loc & 1) << 4));
+              kc[it] = on ? loc : -1;
+            }
+          } else {
+#pragma unroll
+            for (int it = 0; it < CACHE_IT; ++it)
+              if (kc[it] >= 0) pc[dc[it]] = (uint16_t)((cnt[kc[it] >> 1] >> ((kc[it] & 1) << 4)) & 0xFFFFu);
+          }
+          p_start = CACHE_IT * TW_T;
+        }
+        for (int p0 = p_start; p0 < P; p0 += 4 * TW_T) {
+          int pp[4], own[4], j[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) pp[q] = min(p0 + q * TW_T + (int)threadIdx.x, P - 1);
+          locate4(pp, own, j);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (p0 + q * TW_T + (int)threadIdx.x < P) {
+              const int k = col[segbeg[own[q]] + j[q]];
+              const int loc = k & (TW_TILE - 1);
+              if (pass == 0) atomicAdd(&cnt[loc >> 1], 1u << ((loc & 1) << 4));
+              else pc[(int64_t)dst[own[q]] + j[q]] = (uint16_t)((cnt[loc >> 1] >> ((loc & 1) << 4)) & 0xFFFFu);
+            }
+          }
+        }
+        (void)locate;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ---- the gather.  One SLICE of one owner group: neighbours [n0, n1) of node u (CSR row start s), weights
+// 1 / (sqrt deg(u) sqrt c') from the streamed counts of up to G occurrences, rpi = 64 / F rows per load instruction.
+// All row loads of a 64-neighbour block are issued before the first is used (FT = 17: 22 loads in flight per wave); the
+// fma order per accumulator is t ascending, blocks ascending, whatever the batching of the loads.
+template <int G, int FT>
+__device__ __forceinline__ void gather_slice(const int32_t *__restrict__ col, const float *__restrict__ feat, int F_rt, int stride,
+                                             int s, int n0, int n1, float inv_sr, int n_occ, const int (&pb)[8],
+                                             const uint16_t *__restrict__ pc, int lane, float (&tot)[G]) {
+  const int F = FT ? FT : F_rt;
+  const int rpi = 64 / F;
+  const int g = lane / F, f = lane - g * F;
+  const bool act = g < rpi;
+  const int gl = act ? g : rpi - 1;      // padding lanes (64 - rpi F of them) re-read the last group's row: the vector L1 works per
+                                         // 128-byte line (~3.8 clocks each), a 4th line per load instruction costs a third more
+  // the table is < 4 GB (checked on the host): a row load is "uniform base + 32-bit byte offset", one address VGPR per load
+  const char *fb = reinterpret_cast<const char *>(feat);
+  const uint32_t rs = (uint32_t)stride * 4u, fo = (uint32_t)f * 4u;
+  auto row_elem = [&](int kk) -> float { return *reinterpret_cast<const float *>(fb + ((uint32_t)kk * rs + fo)); };
+  float acc[G];
+#pragma unroll
+  for (int j = 0; j < G; ++j) acc[j] = 0.0f;
+  // ids and streamed counts of block b + 1 are requested while the rows of block b are in flight (one memory round trip per
+  // 64 neighbours instead of two); the weights of a block are formed from its counts before the request for the next block
+  // re-uses their registers.  EVERY load is unconditional (indices clamped into the slice, node 0 for padding lanes, weight
+  // 0 for what must not count): a guarded load compiles to a branch + s_waitcnt each and serialises the wave.
+  const int last = max(n1 - 1, 0);
+  int k_nx;
+  uint32_t c_nx[G];
+  {
+    const int ix = min(n0 + lane, last);
+    k_nx = col[s + ix];
+#pragma unroll
+    for (int j = 0; j < G; ++j) c_nx[j] = pc[pb[j] + ix];
+  }
+  for (int blk = n0; blk < n1; blk += 64) {
+    const bool mine = blk + lane < n1;
+    const int k = mine ? k_nx : 0;
+    const int count = min(64, n1 - blk);
+    float w[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) w[j] = (j < n_occ && mine) ? inv_sr / sqrtf((float)c_nx[j]) : 0.0f;   // .div(row).div(col)  graphsage.py:348
+    if (FT == 17) {
+      constexpr int IT = 22;                                   // ceil(64 / 3)
+      float x[IT];
+#pragma unroll
+      for (int t = 0; t < IT; ++t) {
+        const int kk = __shfl(k, (t * 3 + gl) & 63, GGAD_WAVE);   // a valid id or 0: always a readable row
+        x[t] = row_elem(kk);
+      }
+      {
+        const int ix = min(blk + 64 + lane, last);
+        k_nx = col[s + ix];
+#pragma unroll
+        for (int j = 0; j < G; ++j) c_nx[j] = pc[pb[j] + ix];
+      }
+#pragma unroll
+      for (int t = 0; t < IT; ++t) {
+        const int src = t * 3 + g;
+        const float xv = (act && src < count) ? x[t] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+          const float ws = __shfl(w[j], src & 63, GGAD_WAVE);
+          acc[j] = fmaf((src < count) ? ws : 0.0f, xv, acc[j]);
+        }
+      }
+    } else {
+      const int iters = (count + rpi - 1) / rpi;
+      int tt = 0;
+      for (; tt + 8 <= iters; tt += 8) {
+        float x[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int kk = __shfl(k, ((tt + q) * rpi + gl) & 63, GGAD_WAVE);
+          x[q] = row_elem(kk);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int src = (tt + q) * rpi + g;
+          const float xv = (act && src < count) ? x[q] : 0.0f;
+#pragma unroll
+          for (int j = 0; j < G; ++j) {
+            const float ws = __shfl(w[j], src & 63, GGAD_WAVE);
+            acc[j] = fmaf((src < count) ? ws : 0.0f, xv, acc[j]);
+          }
+        }
+      }
+      for (; tt < iters; ++tt) {
+        const int src = tt * rpi + g;
+        const int kk = __shfl(k, (tt * rpi + gl) & 63, GGAD_WAVE);
+        const float xr = row_elem(kk);
+        const float xv = (act && src < count) ? xr : 0.0f;
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+          const float ws = __shfl(w[j], src & 63, GGAD_WAVE);
+          acc[j] = fmaf((src < count) ? ws : 0.0f, xv, acc[j]);
+        }
+      }
+      const int ix = min(blk + 64 + lane, last);
+      k_nx = col[s + ix];
+#pragma unroll
+      for (int j = 0; j < G; ++j) c_nx[j] = pc[pb[j] + ix];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < G; ++j) {
+    float t = acc[j];
+    for (int q = 1; q < rpi; ++q) t += __shfl(acc[j], (lane + q * F) & 63, GGAD_WAVE);
+    tot[j] = t;
+  }
+}
+
+// One thread per entry.  The owner entry that was linked LAST into its node's list (k_gather1c) acts for the node: it cuts
+// the list into groups of <= 8 occurrences, every group into ceil(deg / SLICE) work items, and reserves the partial-sum
+// slots of multi-slice owners; the three cursors are bumped once per WAVE (prefix sums over the lanes).  Groups and items
+// of one node are adjacent (their waves run side by side and find each other's rows in L2).  Clears node_head[u].
+__global__ void __launch_bounds__(256) k_build_groups(const int32_t *__restrict__ ent_own, const int32_t *__restrict__ ent_col,
+                                                      const int32_t *__restrict__ own_deg, int n_ents,
+                                                      int32_t *__restrict__ node_head, const int32_t *__restrict__ own_next,
+                                                      int32_t *__restrict__ grp, int32_t *__restrict__ items,
+                                                      int32_t *__restrict__ counters) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int lane = lane_id();
+  int u = 0, m = 0, ng = 0, ns = 0;
+  if (e < n_ents && ent_own[e] == e) {
+    u = ent_col[e];
+    if (node_head[u] == e + 1) {
+      for (int cur = e + 1; cur != 0; cur = own_next[cur - 1]) ++m;
+      ng = (m + 7) >> 3;
+      const int deg = own_deg[e];
+      ns = deg > SLICE ? (deg + SLICE - 1) / SLICE : 1;
+    }
+  }
+  int v0 = ng, v1 = ng * ns, v2 = ns > 1 ? m * ns : 0;        // inclusive prefix sums over the wave
+#pragma unroll
+  for (int off = 1; off < GGAD_WAVE; off <<= 1) {
+    const int t0 = __shfl_up(v0, off, GGAD_WAVE), t1 = __shfl_up(v1, off, GGAD_WAVE), t2 = __shfl_up(v2, off, GGAD_WAVE);
+    if (lane >= off) { v0 += t0; v1 += t1; v2 += t2; }
+  }
+  int b0 = 0, b1 = 0, b2 = 0;
+  if (lane == GGAD_WAVE - 1) {
+    if (v0 > 0) { b0 = atomicAdd(&counters[0], v0); b1 = atomicAdd(&counters[1], v1); }
+    if (v2 > 0) b2 = atomicAdd(&counters[2], v2);
+  }
+  b0 = __shfl(b0, GGAD_WAVE - 1, GGAD_WAVE);
+  b1 = __shfl(b1, GGAD_WAVE - 1, GGAD_WAVE);
+  b2 = __shfl(b2, GGAD_WAVE - 1, GGAD_WAVE);
+  if (ng == 0) return;
+  const int gbase = b0 + v0 - ng, ibase = b1 + v1 - ng * ns, pbase = b2 + v2 - (ns > 1 ? m * ns : 0);
+  int cur = e + 1;
+  for (int g = 0; g < ng; ++g) {
+    int32_t *rec = grp + (int64_t)(gbase + g) * GRP_W;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int v = -1;
+      if (cur != 0) { v = cur - 1; cur = own_next[v]; }
+      rec[j] = v;
+    }
+    rec[8] = pbase + g * 8 * ns;
+    rec[9] = ns;
+    for (int sl = 0; sl < ns; ++sl) {        // slice-major: consecutive items = the same neighbour rows for the node's groups
+      int32_t *it = items + (int64_t)(ibase + sl * ng + g) * 2;
+      it[0] = gbase + g;
+      it[1] = sl;
+    }
+  }
+  node_head[u] = 0;
+}
+
+template <int FT>
+__global__ void __launch_bounds__(256) k_gather2_items(const int32_t *__restrict__ col, const float *__restrict__ feat, int F_rt,
+                                                       int stride, const int32_t *__restrict__ own_rp,
+                                                       const int32_t *__restrict__ own_deg, const int32_t *__restrict__ pw_base,
+                                                       const uint16_t *__restrict__ pc, const int32_t *__restrict__ grp,
+                                                       const int32_t *__restrict__ items, int32_t *__restrict__ counters,
+                                                       float *__restrict__ x2, float *__restrict__ part2) {
+  static_assert(ITEM_GRAB == 4 && GRP_W <= 16, "lane layout of the metadata loads: 16 lanes per item of a grab");
+  const int F = FT ? FT : F_rt;
+  const int lane = lane_id();
+  const int n_items = counters[1];
+  const int q_l = lane >> 4, r_l = lane & 15;                 // metadata phase: lane = (item of the grab, word)
+  for (;;) {
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&counters[3], ITEM_GRAB);
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (base >= n_items) break;
+    // three dependent loads for the FOUR items of the grab (item -> group record -> owner metadata) instead of three per item
+    const bool it_ok = base + q_l < n_items;
+    const int iv = (it_ok && r_l < 2) ? items[(int64_t)(base + q_l) * 2 + r_l] : 0;           // r 0: group, r 1: slice
+    const int gi_l = __shfl(iv, q_l * 16, GGAD_WAVE);
+    const int rv = (it_ok && r_l < GRP_W) ? grp[(int64_t)gi_l * GRP_W + r_l] : -1;
+    const int pbv = (r_l < 8 && rv >= 0) ? pw_base[rv] : 0;
+    const int rpv = (it_ok && r_l == 0) ? own_rp[rv] : 0;
+    const int dgv = (it_ok && r_l == 0) ? own_deg[rv] : 0;
+#pragma unroll 1
+    for (int q = 0; q < ITEM_GRAB; ++q) {
+      if (base + q >= n_items) break;
+      int e[8], pb[8];
+      int n = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        e[j] = __builtin_amdgcn_readlane(rv, q * 16 + j);
+        pb[j] = __builtin_amdgcn_readlane(pbv, q * 16 + j);
+        n += e[j] >= 0 ? 1 : 0;
+      }
+      const int pbase = __builtin_amdgcn_readlane(rv, q * 16 + 8), ns = __builtin_amdgcn_readlane(rv, q * 16 + 9);
+      const int sl = __builtin_amdgcn_readlane(iv, q * 16 + 1);
+      const int s = __builtin_amdgcn_readlane(rpv, q * 16);
+      const int deg = __builtin_amdgcn_readlane(dgv, q * 16);
+      const float inv_sr = 1.0f / sqrtf((float)deg);        // deg = 0 -> inf * 0 = NaN, as the dense 0/0 row (quirk 3)
+      const int n0 = sl * SLICE, n1 = min(deg, n0 + SLICE);
+      float tot[8];
+      if (n == 1) { float t1[1]; gather_slice<1, FT>(col, feat, F, stride, s, n0, n1, inv_sr, n, pb, pc, lane, t1); tot[0] = t1[0]; }
+      else if (n == 2) { float t2[2]; gather_slice<2, FT>(col, feat, F, stride, s, n0, n1, inv_sr, n, pb, pc, lane, t2); tot[0] = t2[0]; tot[1] = t2[1]; }
+      else if (n <= 4) { float t4[4]; gather_slice<4, FT>(col, feat, F, stride, s, n0, n1, inv_sr, n, pb, pc, lane, t4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tot[j] = t4[j]; }
+      else gather_slice<8, FT>(col, feat, F, stride, s, n0, n1, inv_sr, n, pb, pc, lane, tot);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (j < n && lane < F) {
+          if (ns == 1) x2[(int64_t)e[j] * F + lane] = (deg == 0) ? inv_sr * 0.0f : tot[j];
+          else part2[((int64_t)pbase + (int64_t)j * ns + sl) * F + lane] = tot[j];
+        }
+      }
+    }
+  }
+}
+
+// x2 of multi-slice owners: slices in order (0 + P_0 + P_1 + ...), the per-owner kernel's order.
+__global__ void __launch_bounds__(256) k_gather2_combine(const int32_t *__restrict__ grp, const int32_t *__restrict__ counters,
+                                                         const float *__restrict__ part2, int F, float *__restrict__ x2) {
+  const int lane = lane_id();
+  const int n_groups = counters[0];
+  const int rpi = 64 / F;
+  const int g = lane / F, f = lane - g * F;
+  for (int gi = blockIdx.x * 4 + (threadIdx.x >> 6); gi < n_groups; gi += gridDim.x * 4) {
+    const int rv = (lane < GRP_W) ? grp[(int64_t)gi * GRP_W + lane] : -1;
+    const int ns = __builtin_amdgcn_readlane(rv, 9);
+    if (ns <= 1) continue;
+    const int pbase = __builtin_amdgcn_readlane(rv, 8);
+    for (int j0 = 0; j0 < 8; j0 += rpi) {
+      const int j = j0 + g;
+      const int ej = __shfl(rv, j & 7, GGAD_WAVE);
+      if (g < rpi && j < 8 && ej >= 0) {
+        float acc = 0.0f;
+        for (int sl = 0; sl < ns; ++sl) acc += part2[((int64_t)pbase + (int64_t)j * ns + sl) * F + f];
+        x2[(int64_t)ej * F + f] = acc;
+      }
+    }
+  }
+}
+
+// One wave per owner entry (feat_dim > 64, or node_major off): same slices, same order, no sharing of row fetches.
+__global__ void __launch_bounds__(256) k_gather2_w(const int32_t *__restrict__ col, const float *__restrict__ feat, int F, int stride,
+                                                   const int32_t *__restrict__ ent_own, int n_ents,
+                                                   const int32_t *__restrict__ own_rp, const int32_t *__restrict__ own_deg,
+                                                   const int32_t *__restrict__ pw_base, const uint16_t *__restrict__ pc,
+                                                   float *__restrict__ x2) {
+  const int e0 = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (e0 >= n_ents || ent_own[e0] != e0) return;
+  const int lane = lane_id();
+  const int s = own_rp[e0];
+  const int deg = own_deg[e0];
+  const int pb0 = pw_base[e0];
+  const float inv_sr = 1.0f / sqrtf((float)deg);
+  if (F <= 64) {
+    const int pb[8] = {pb0, 0, 0, 0, 0, 0, 0, 0};
+    float total = 0.0f;
+    for (int n0 = 0; n0 < deg; n0 += SLICE) {
+      float t1[1];
+      if (F == 17) gather_slice<1, 17>(col, feat, F, stride, s, n0, min(deg, n0 + SLICE), inv_sr, 1, pb, pc, lane, t1);
+      else gather_slice<1, 0>(col, feat, F, stride, s, n0, min(deg, n0 + SLICE), inv_sr, 1, pb, pc, lane, t1);
+      total += t1[0];
+    }
+    if (deg == 0) total = inv_sr * 0.0f;
+    if (lane < F) x2[(int64_t)e0 * F + lane] = total;
+    return;
+  }
+  for (int fbase = 0; fbase < F; fbase += 64) {               // wide rows: lane = feature, one row per load instruction
+    const int fw = min(64, F - fbase);
+    float total = 0.0f;
+    for (int n0 = 0; n0 < deg; n0 += SLICE) {
+      const int n1 = min(deg, n0 + SLICE);
+      float acc = 0.0f;
+      for (int blk = n0; blk < n1; blk += 64) {
+        const int idx = blk + lane;
+        int k = 0;
+        float w = 0.0f;
+        if (idx < n1) { k = col[s + idx]; w = inv_sr / sqrtf((float)pc[pb0 + idx]); }
+        const int count = min(64, n1 - blk);
+        for (int t = 0; t < count; ++t) {
+          const int kk = __shfl(k, t, GGAD_WAVE);
+          const float ws = __shfl(w, t, GGAD_WAVE);
+          const float x = lane < fw ? feat[(int64_t)kk * stride + fbase + lane] : 0.0f;
+          acc = fmaf(ws, x, acc);
+        }
+      }
+      total += acc;
+    }
+    if (deg == 0) total = inv_sr * 0.0f;
+    if (lane < fw) x2[(int64_t)e0 * F + fbase + lane] = total;
+  }
+}
+
+}  // namespace
+
+int ggad_int_ldsw_hop2(const ggad_mb_plan *P, const ggad_plan_view &V, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+  if (V.n_ents == 0 || V.n_batches == 0) return GGAD_OK;
+  const int n_tiles = (int)((P->n_nodes + TW_TILE - 1) >> TW_SHIFT);
+  k_seg_transpose<<<dim3((unsigned)((V.n_ents + 63) / 64)), dim3(256), 0, st>>>(P->tile_off, n_tiles, P->ent_own, P->ent_col, V.n_ents,
+                                                                                V.seg_stride, P->seg_t);
+  const size_t lds = (size_t)(TW_TILE / 2) * 4 + (size_t)(3 * TW_MAXOWN + 1) * 4;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void *)k_tile_counts, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  k_tile_counts<<<dim3(n_tiles, V.n_batches), dim3(TW_T), lds, st>>>(P->col, P->seg_t, V.seg_stride, P->own_rp, V.batch_ent_ptr,
+                                                                     P->pw_base, P->pc);
+  if (ev0) (void)hipEventRecord(ev0, st);
+  const int F = P->feat_dim;
+  if (P->node_major && F <= 64) {
+    k_build_groups<<<dim3((unsigned)((V.n_ents + 255) / 256)), dim3(256), 0, st>>>(P->ent_own, P->ent_col, P->own_deg, V.n_ents,
+                                                                                   P->node_head, P->own_next, P->grp, P->items,
+                                                                                   P->counters);
+    // waves take ITEM_GRAB work items at a time from a cursor: enough workgroups to fill the chip, no more than there can be items
+    const int64_t max_items = (int64_t)V.n_ents + P->pair_cap / SLICE;
+    const unsigned wgs = (unsigned)std::min<int64_t>((max_items + 4 * ITEM_GRAB - 1) / (4 * ITEM_GRAB), 256 * 8);
+    if (F == 17)
+      k_gather2_items<17><<<dim3(wgs), dim3(256), 0, st>>>(P->col, P->feat, F, P->feat_stride, P->own_rp, P->own_deg, P->pw_base,
+                                                           P->pc, P->grp, P->items, P->counters, P->x2, P->part2);
+    else
+      k_gather2_items<0><<<dim3(wgs), dim3(256), 0, st>>>(P->col, P->feat, F, P->feat_stride, P->own_rp, P->own_deg, P->pw_base,
+                                                          P->pc, P->grp, P->items, P->counters, P->x2, P->part2);
+    const unsigned cg = (unsigned)std::min<int64_t>(((int64_t)V.n_ents + 3) / 4, 1024);
+    k_gather2_combine<<<dim3(cg), dim3(256), 0, st>>>(P->grp, P->counters, P->part2, F, P->x2);
+  } else {
+    k_gather2_w<<<dim3((unsigned)((V.n_ents + 3) / 4)), dim3(256), 0, st>>>(P->col, P->feat, F, P->feat_stride, P->ent_own, V.n_ents,
+                                                                           P->own_rp, P->own_deg, P->pw_base, P->pc, P->x2);
+  }
+  if (ev1) (void)hipEventRecord(ev1, st);
+  GGAD_CHECK_LAUNCH("mb_plan_build (ldsw 2-hop)");
+  return GGAD_OK;
+}
+
+extern "C" {
+
+int ggad_mb_ldsw_tile_shift(void) { return TW_SHIFT; }
+int ggad_mb_ldsw_max_owners(void) { return TW_MAXOWN; }
+int32_t ggad_mb_slice_len(void) { return SLICE; }
+int32_t ggad_mb_group_words(void) { return GRP_W; }
+int64_t ggad_mb_tile_offsets_elems(int64_t n_nodes, int32_t tile_shift) {
+  return n_nodes * (((n_nodes + (1LL << tile_shift) - 1) >> tile_shift) + 1);
+}
+int64_t ggad_mb_ldsw_seg_elems(int64_t n_nodes, int64_t n_entries_cap) {
+  return (((n_nodes + TW_TILE - 1) >> TW_SHIFT) + 1) * ((n_entries_cap + 63) / 64 * 64);
+}
+
+int ggad_mb_tile_offsets(const int32_t *rowptr, const int32_t *col, int64_t n_nodes, int32_t tile_shift, int32_t *tile_off,
+                         ggad_stream_t stream) {
+  GGAD_REQUIRE(rowptr && col && tile_off && n_nodes >= 0 && tile_shift >= 8 && tile_shift <= 24);
+  if (n_nodes == 0) return GGAD_OK;
+  const int n_tiles = (int)((n_nodes + (1LL << tile_shift) - 1) >> tile_shift);
+  k_tile_offsets<<<dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0, as_stream(stream)>>>(rowptr, col, n_nodes, n_tiles,
+                                                                                               tile_shift, tile_off);
+  GGAD_CHECK_LAUNCH("mb_tile_offsets");
+  return GGAD_OK;
+}
+
+}  // extern "C"

@@ -1,19 +1,22 @@
-// Batch sub-graph plan + gather-aggregate kernels of the DGraph mini-batch path (gfx950).
+// Batch sub-graph plan + 1-hop gather-aggregate kernels of the DGraph mini-batch path (gfx950), and the device-atomic
+// fallback of the 2-hop stage.
 //
-// Replaces GCNAggregator.forward of the reference (src/graphsage.py:295-360): python set
-// unions, a dense B x U and a dense U x U2 0/1 mask, their row/column sums, and two dense
-// mask.mm(feature) products -- by CSR walks, per-batch integer histograms in HBM-resident
-// counter slots and wave-level gathers of feature rows.
+// Replaces GCNAggregator.forward of the reference (src/graphsage.py:295-360): python set unions, a dense B x U and a
+// dense U x U2 0/1 mask, their row/column sums, and two dense mask.mm(feature) products -- by CSR walks, per-batch
+// integer histograms in HBM-resident counter slots and wave-level gathers of feature rows.
 //
-// Work decomposition (wave = 64 lanes):
-//   row_degree     1 thread / batch row
-//   expand1        1 wave   / batch row      (entries of N(i)+{i}, histogram c_j, owner election)
-//   gather1        1 wave   / batch row      (1-hop aggregate, 4F+8 B per entry)
-//   count2         1 wave   / entry          (histogram c'_k over N(u), owners only)
-//   gather2        1 wave   / entry          (2-hop aggregate, owners only)  <- HBM-bound, dominant
-//   plan_reset     1 wave   / entry
-// Feature rows are F consecutive floats; a wave reads floor(64/F) rows per load instruction
-// (3 rows of 17 floats: 51 active lanes, each instruction touches 3 x 68 contiguous bytes).
+// Unit of work = a PIECE of <= 16 consecutive entries of one batch row (tables built on the host by ggad_mb_plan_build:
+// closed degrees are known there, so the entry offsets need no device scan).  16 lanes own one piece, a wave four of them:
+//   k_expand          1 lane / entry : the entry's column (closed neighbourhood N(i)+{i}, ascending), histogram c_j,
+//                                      owner election
+//   k_gather1c        1 lane / entry : c_j, owner, weight; owner metadata + pair-count storage + per-node owner lists for the
+//                                      2-hop stage; then the wave gathers the feature rows of its four pieces
+//                                      (3 rows of 17 floats per load instruction, all loads of a piece in flight)
+//   k_combine1_reset  1 wave / row   : x1 of rows made of several pieces (fixed order); 1 lane / entry: c_j slots back to zero
+// A 2,000-neighbour hub row is 125 independent pieces instead of one wave's 32 dependent 64-entry blocks (that loop was
+// a fixed 200 us of every plan, whatever its size).
+// Fallback 2-hop (chunks the LDS-counting stage of hop2_ldsw.hip cannot take):
+//   k_count2 / k_gather2 / k_plan_reset   1 wave / entry, device atomics on per-batch counter slots
 #include "common.h"
 
 namespace {
@@ -84,58 +87,6 @@ __global__ void __launch_bounds__(SCAN_T) scan_apply(const int32_t *__restrict__
   for (int i = 0; i < SCAN_ITEMS; ++i) { if (base + i < n) out[base + i] = ex; ex += v[i]; }
 }
 
-// ------------------------------------------------------------------ plan kernels
-__global__ void __launch_bounds__(256) k_row_degree(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                                    const int32_t *__restrict__ nodes, const int32_t *__restrict__ batch_ptr,
-                                                    int n_batches, int n_rows, int32_t *__restrict__ row_r,
-                                                    int32_t *__restrict__ row_slot) {
-  const int row = blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= n_rows) return;
-  const int v = nodes[row];
-  const int s = rowptr[v], e = rowptr[v + 1];
-  const int p = lower_bound_i32(col, s, e, v);
-  const int self_in = (p < e && col[p] == v) ? 1 : 0;
-  row_r[row] = (e - s) + (1 - self_in);
-  // slot = last g with batch_ptr[g] <= row
-  int lo = 0, hi = n_batches;  // invariant: batch_ptr[lo] <= row < batch_ptr[hi]
-  while (hi - lo > 1) {
-    int mid = (lo + hi) >> 1;
-    if (batch_ptr[mid] <= row) lo = mid; else hi = mid;
-  }
-  row_slot[row] = lo;
-}
-
-__global__ void __launch_bounds__(256) k_expand1(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                                 const int32_t *__restrict__ nodes, const int32_t *__restrict__ row_slot,
-                                                 const int32_t *__restrict__ ent_ptr, int n_rows, int64_t n_nodes,
-                                                 int32_t *__restrict__ ent_col, int32_t *__restrict__ ent_slot,
-                                                 int32_t *__restrict__ ent_row, int32_t *__restrict__ cnt1,
-                                                 int32_t *__restrict__ own1) {
-  const int row = blockIdx.x * (blockDim.x / GGAD_WAVE) + threadIdx.x / GGAD_WAVE;
-  if (row >= n_rows) return;
-  const int lane = lane_id();
-  const int v = nodes[row];
-  const int s = rowptr[v], e = rowptr[v + 1];
-  const int p = lower_bound_i32(col, s, e, v);
-  const bool self_in = (p < e && col[p] == v);
-  const int pself = p - s;
-  const int r = (e - s) + (self_in ? 0 : 1);
-  const int base = ent_ptr[row];
-  const int slot = row_slot[row];
-  const int64_t soff = (int64_t)slot * n_nodes;
-  for (int idx = lane; idx < r; idx += GGAD_WAVE) {
-    int j;
-    if (self_in || idx < pself) j = col[s + idx];
-    else if (idx == pself) j = v;
-    else j = col[s + idx - 1];
-    ent_col[base + idx] = j;
-    ent_slot[base + idx] = slot;
-    ent_row[base + idx] = row;
-    const int old = atomicAdd(&cnt1[soff + j], 1);
-    if (old == 0) own1[soff + j] = base + idx;   // first arrival owns (batch, j)
-  }
-}
-
 // Weighted gather of feature rows for up to 64 neighbours held one per lane (ids in `j`, weights in `w`,
 // w = 0 for padding lanes).  Lane layout: g = lane / F selects one of `rpi` neighbours per instruction,
 // f = lane % F the feature.  Accumulates into acc (per lane partial for (g, f)).
@@ -175,37 +126,193 @@ __device__ __forceinline__ float reduce_groups(float acc, int F, int rpi) {
   return tot;
 }
 
-__global__ void __launch_bounds__(256) k_gather1(const float *__restrict__ feat, int F, int stride, const int32_t *__restrict__ row_slot,
-                                                 const int32_t *__restrict__ ent_ptr, const int32_t *__restrict__ ent_col,
-                                                 int n_rows, int64_t n_nodes, const int32_t *__restrict__ cnt1,
-                                                 const int32_t *__restrict__ own1, int32_t *__restrict__ ent_own,
-                                                 int32_t *__restrict__ ent_c1, float *__restrict__ x1) {
-  const int row = blockIdx.x * (blockDim.x / GGAD_WAVE) + threadIdx.x / GGAD_WAVE;
-  if (row >= n_rows) return;
+// ------------------------------------------------------------------ plan kernels
+// counters[] of a plan (int32[8], zeroed by k_expand): 0 groups, 1 work items, 2 partial slots of the 2-hop gather,
+// 3 its work cursor, 4 pair-count storage cursor (pc[] allocation of k_gather1c)
+__global__ void __launch_bounds__(256) k_expand(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                const int32_t *__restrict__ nodes, const int32_t *__restrict__ row_slot,
+                                                const int32_t *__restrict__ ent_ptr, const int32_t *__restrict__ ck_rc,
+                                                const int32_t *__restrict__ ck_e0, int n_chunks, int64_t n_nodes,
+                                                int32_t *__restrict__ ent_col, int32_t *__restrict__ ent_slot,
+                                                int32_t *__restrict__ ent_row, int32_t *__restrict__ cnt1,
+                                                int32_t *__restrict__ own1, int32_t *__restrict__ counters) {
+  if (blockIdx.x == 0 && threadIdx.x < 8 && counters != nullptr) counters[threadIdx.x] = 0;
+  const int ck = (int)((blockIdx.x * 256u + threadIdx.x) >> 4);
+  const int i = threadIdx.x & 15;
+  if (ck >= n_chunks) return;
+  const int rc = ck_rc[ck];
+  if (i >= (rc & 63)) return;
+  const int row = rc >> 6;
+  const int e = ck_e0[ck] + i;
+  const int e_row = ent_ptr[row];
+  const int r = ent_ptr[row + 1] - e_row;                 // |N(v) + {v}| (exact, from the host)
+  const int idx = e - e_row;
+  const int v = nodes[row];
+  const int s = rowptr[v];
+  const int deg = rowptr[v + 1] - s;
+  // element idx of the sorted closed neighbourhood, decided from the two CSR neighbours around it (no search):
+  // col[0..p), v, col[p..deg) with p = #{neighbours < v}; r == deg means v is its own neighbour already
+  int j;
+  if (r == deg) {
+    j = col[s + idx];
+  } else {
+    const int a = idx > 0 ? col[s + idx - 1] : -1;
+    const int b = idx < deg ? col[s + idx] : 0x7fffffff;
+    j = (b < v) ? b : (a < v ? v : a);
+  }
+  const int slot = row_slot[row];
+  ent_col[e] = j;
+  ent_slot[e] = slot;
+  ent_row[e] = row;
+  const int64_t soff = (int64_t)slot * n_nodes;
+  const int old = atomicAdd(&cnt1[soff + j], 1);            // c_j: column sums of the dense B x U mask   graphsage.py:315
+  if (old == 0) own1[soff + j] = e;                         // first arrival owns (batch, j)
+}
+
+// 1-hop aggregate.  Scalar phase (lane = entry): c_j, owner, weight 1 / (sqrt r_i sqrt c_j) (graphsage.py:314-318); for
+// train plans with the LDS-counting 2-hop stage also the owner's CSR row start / degree, the storage of its pair counts in
+// pc[] (one atomic per WAVE on the cursor: the layout of pc[] is free, only sequential per owner) and the per-node list of
+// owner entries (atomicExch on node_head: order of the list is irrelevant).  Vector phase: the wave gathers the feature
+// rows of each of its four pieces, rpi = 64 / F rows per load instruction, and leaves the piece's partial sum in
+// part1[piece] -- or directly in x1 when the row is that single piece.
+__global__ void __launch_bounds__(256) k_gather1c(const float *__restrict__ feat, int F, int stride,
+                                                  const int32_t *__restrict__ row_slot, const int32_t *__restrict__ ent_ptr,
+                                                  const int32_t *__restrict__ row_ck_ptr, const int32_t *__restrict__ ck_rc,
+                                                  const int32_t *__restrict__ ck_e0, int n_chunks, int64_t n_nodes,
+                                                  const int32_t *__restrict__ cnt1, const int32_t *__restrict__ own1,
+                                                  const int32_t *__restrict__ ent_col, int32_t *__restrict__ ent_own,
+                                                  int32_t *__restrict__ ent_c1, float *__restrict__ part1, int pstride,
+                                                  float *__restrict__ x1, const int32_t *__restrict__ rowptr,
+                                                  int32_t *__restrict__ own_deg, int32_t *__restrict__ own_rp,
+                                                  int32_t *__restrict__ pw_base, int32_t *__restrict__ node_head,
+                                                  int32_t *__restrict__ own_next, int32_t *__restrict__ counters, int ldsw) {
+  const int wave = (int)((blockIdx.x * 256u + threadIdx.x) >> 6);
   const int lane = lane_id();
-  const int e0 = ent_ptr[row], e1 = ent_ptr[row + 1];
-  const int r = e1 - e0;
-  const int64_t soff = (int64_t)row_slot[row] * n_nodes;
-  const float inv_sr = 1.0f / sqrtf((float)r);           // mask.div(row_normalized)   graphsage.py:318
+  const int ck = wave * 4 + (lane >> 4), i = lane & 15;
+  int len = 0, row = 0, e = 0;
+  if (ck < n_chunks) {
+    const int rc = ck_rc[ck];
+    len = rc & 63;
+    row = rc >> 6;
+    e = ck_e0[ck] + i;
+  }
+  const bool valid = i < len;
+  int j = 0, deg = 0;
+  float w = 0.0f;
+  if (valid) {
+    j = ent_col[e];
+    const int64_t soff = (int64_t)row_slot[row] * n_nodes;
+    const int c = cnt1[soff + j];
+    const int own = own1[soff + j];
+    ent_own[e] = own;
+    ent_c1[e] = c;
+    const int r = ent_ptr[row + 1] - ent_ptr[row];
+    const float inv_sr = 1.0f / sqrtf((float)r);           // mask.div(row_normalized)   graphsage.py:318
+    w = inv_sr / sqrtf((float)c);                          // .div(col_normalized)
+    if (ldsw) {
+      int rp = 0;
+      if (own == e) {
+        rp = rowptr[j];
+        deg = rowptr[j + 1] - rp;
+        own_next[e] = atomicExch(&node_head[j], e + 1);
+      }
+      own_rp[e] = rp;
+      own_deg[e] = deg;
+    }
+  }
+  if (ldsw) {   // wave-uniform: storage for the owners' per-pair counts, deg(u) uint16 each
+    int inc = deg;
+#pragma unroll
+    for (int off = 1; off < GGAD_WAVE; off <<= 1) {
+      const int t = __shfl_up(inc, off, GGAD_WAVE);
+      if (lane >= off) inc += t;
+    }
+    const int total = __shfl(inc, GGAD_WAVE - 1, GGAD_WAVE);
+    int base = 0;
+    if (lane == GGAD_WAVE - 1 && total > 0) base = atomicAdd(&counters[4], total);
+    base = __shfl(base, GGAD_WAVE - 1, GGAD_WAVE);
+    if (valid) pw_base[e] = base + inc - deg;
+  }
+  const int rpi = F <= 64 ? 64 / F : 1;
+  const int fchunks = F <= 64 ? 1 : (F + 63) / 64;
+  for (int c4 = 0; c4 < 4; ++c4) {
+    const int len_c = __shfl(len, c4 * 16, GGAD_WAVE);      // lane c4*16 holds the piece's length (0: no such piece)
+    if (len_c == 0) continue;                               // wave-uniform
+    const int row_c = __shfl(row, c4 * 16, GGAD_WAVE);
+    const bool single = (row_ck_ptr[row_c + 1] - row_ck_ptr[row_c]) == 1;
+    const int iters = (len_c + rpi - 1) / rpi;              // <= 6 for F = 17
+    for (int fc = 0; fc < fchunks; ++fc) {
+      const int fbase = fc * 64;
+      const int fw = F <= 64 ? F : min(64, F - fbase);
+      const int g = lane / fw, f = lane - g * fw;
+      const bool act = g < rpi;
+      const int gl = act ? g : rpi - 1;                       // padding lanes re-read the last group's row (no extra cache line)
+      const int fo = act ? f : 0;
+      float acc = 0.0f;
+      int t = 0;
+      // unconditional loads: ids of padding / out-of-piece lanes are 0 or a neighbour of the wave (readable rows), their
+      // weight is 0 -- a guarded load costs a branch and a full wait each
+      for (; t + 6 <= iters; t += 6) {                      // every row of a 16-entry piece in flight at once (F = 17: 6 loads)
+        float x[6], ww[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          const int si = (t + q) * rpi + g;
+          const int jj = __shfl(j, (c4 * 16 + (t + q) * rpi + gl) & 63, GGAD_WAVE);
+          const float ws = __shfl(w, (c4 * 16 + si) & 63, GGAD_WAVE);
+          ww[q] = (act && si < len_c) ? ws : 0.0f;
+          x[q] = feat[(int64_t)jj * stride + fbase + fo];
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) acc = fmaf(ww[q], ww[q] != 0.0f ? x[q] : 0.0f, acc);
+      }
+      for (; t < iters; ++t) {
+        const int si = t * rpi + g;
+        const int jj = __shfl(j, (c4 * 16 + t * rpi + gl) & 63, GGAD_WAVE);
+        const float ws = __shfl(w, (c4 * 16 + si) & 63, GGAD_WAVE);
+        const float wv = (act && si < len_c) ? ws : 0.0f;
+        const float x = feat[(int64_t)jj * stride + fbase + fo];
+        acc = fmaf(wv, wv != 0.0f ? x : 0.0f, acc);
+      }
+      const float tot = (F <= 64) ? reduce_groups(acc, fw, rpi) : acc;
+      if (lane < fw) {
+        if (single) x1[(int64_t)row_c * F + fbase + lane] = tot;
+        else part1[(int64_t)(wave * 4 + c4) * pstride + fbase + lane] = tot;
+      }
+    }
+  }
+}
+
+// Two roles in one launch (both only need k_gather1c to have finished): blocks [0, row_blocks) sum the piece partials of
+// multi-piece rows into x1 -- lane group g takes pieces g, g + rpi, ..., the groups are added in order: a fixed order per
+// row -- ; the remaining blocks put the c_j counter of every entry's (batch, column) back to zero, so the slots are clean
+// for the next plan (the device-atomic 2-hop fallback still needs own1 / the slots and resets later).
+__global__ void __launch_bounds__(256) k_combine1_reset(int row_blocks, int n_rows, const int32_t *__restrict__ row_ck_ptr,
+                                                        const float *__restrict__ part1, int pstride, int F,
+                                                        float *__restrict__ x1, int do_reset, int n_ents,
+                                                        const int32_t *__restrict__ ent_col,
+                                                        const int32_t *__restrict__ ent_slot, int64_t n_nodes,
+                                                        int32_t *__restrict__ cnt1) {
+  if ((int)blockIdx.x >= row_blocks) {
+    if (!do_reset) return;
+    const int e = (blockIdx.x - row_blocks) * 256 + threadIdx.x;
+    if (e < n_ents) cnt1[(int64_t)ent_slot[e] * n_nodes + ent_col[e]] = 0;
+    return;
+  }
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_rows) return;
+  const int c0 = row_ck_ptr[row];
+  const int nck = row_ck_ptr[row + 1] - c0;
+  if (nck <= 1) return;
+  const int lane = lane_id();
   const int rpi = F <= 64 ? 64 / F : 1;
   const int fchunks = F <= 64 ? 1 : (F + 63) / 64;
   for (int fc = 0; fc < fchunks; ++fc) {
     const int fbase = fc * 64;
     const int fw = F <= 64 ? F : min(64, F - fbase);
     const int g = lane / fw, f = lane - g * fw;
-    const bool lane_active = g < rpi;
     float acc = 0.0f;
-    for (int blk = 0; blk < r; blk += GGAD_WAVE) {
-      const int idx = blk + lane;
-      int j = 0; float w = 0.0f;
-      if (idx < r) {
-        j = ent_col[e0 + idx];
-        const int c = cnt1[soff + j];
-        if (fc == 0) { ent_own[e0 + idx] = own1[soff + j]; ent_c1[e0 + idx] = c; }
-        w = inv_sr / sqrtf((float)c);                      // .div(col_normalized)
-      }
-      gather_block(feat, stride, fbase, rpi, g, f, lane_active, j, w, min(GGAD_WAVE, r - blk), acc);
-    }
+    if (g < rpi)
+      for (int c = g; c < nck; c += rpi) acc += part1[(int64_t)(c0 + c) * pstride + fbase + f];
     const float tot = (F <= 64) ? reduce_groups(acc, fw, rpi) : acc;
     if (lane < fw) x1[(int64_t)row * F + fbase + lane] = tot;
   }
@@ -245,89 +352,14 @@ __global__ void __launch_bounds__(256) k_seg_mean(const float *__restrict__ feat
 __global__ void __launch_bounds__(256) k_count2(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                 const int32_t *__restrict__ ent_col, const int32_t *__restrict__ ent_slot,
                                                 const int32_t *__restrict__ ent_total, int64_t n_nodes,
-                                                const int32_t *__restrict__ own1, int32_t *__restrict__ cnt2,
-                                                float *__restrict__ featp, int stride, int F) {
+                                                const int32_t *__restrict__ own1, int32_t *__restrict__ cnt2) {
   const int e = blockIdx.x * (blockDim.x / GGAD_WAVE) + threadIdx.x / GGAD_WAVE;
   if (e >= *ent_total) return;
   const int u = ent_col[e];
-  const int slot = ent_slot[e];
-  const int64_t soff = (int64_t)slot * n_nodes;
+  const int64_t soff = (int64_t)ent_slot[e] * n_nodes;
   if (own1[soff + u] != e) return;                         // each distinct u of the batch once (set semantics)
   const int s = rowptr[u], t = rowptr[u + 1];
-  if (cnt2 != nullptr) {
-    for (int i = s + lane_id(); i < t; i += GGAD_WAVE) atomicAdd(&cnt2[soff + col[i]], 1);
-  } else {   // packed layout: the counter of (slot, k) lives in k's feature row, word F + slot
-    int32_t *base = reinterpret_cast<int32_t *>(featp) + F + slot;
-    for (int i = s + lane_id(); i < t; i += GGAD_WAVE) atomicAdd(base + (int64_t)col[i] * stride, 1);
-  }
-}
-
-// Packed layout (row = F features + per-slot int32 counters, 128-byte aligned): ONE random line per gathered
-// neighbour delivers both x_k and c'_k.  Lanes per row = F + 1 (the extra lane fetches the counter word).
-__global__ void __launch_bounds__(256) k_gather2_packed(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
-                                                        const float *__restrict__ featp, int F, int stride,
-                                                        const int32_t *__restrict__ ent_col, const int32_t *__restrict__ ent_slot,
-                                                        const int32_t *__restrict__ ent_own, const int32_t *__restrict__ ent_total,
-                                                        float *__restrict__ x2) {
-  const int e = blockIdx.x * (blockDim.x / GGAD_WAVE) + threadIdx.x / GGAD_WAVE;
-  if (e >= *ent_total) return;
-  if (ent_own[e] != e) return;
-  const int lane = lane_id();
-  const int u = ent_col[e];
-  const int slot = ent_slot[e];
-  const int s = rowptr[u], t = rowptr[u + 1];
-  const int deg = t - s;
-  const float inv_sr = 1.0f / sqrtf((float)deg);
-  const int lpr = F + 1, rpi = 64 / lpr;
-  const int g = lane / lpr, f = lane - g * lpr;
-  const bool lane_active = g < rpi;
-  const int foff = (f < F) ? f : F + slot;                 // word inside the row this lane fetches
-  float acc = 0.0f;
-  for (int blk = 0; blk < deg; blk += GGAD_WAVE) {
-    const int idx = blk + lane;
-    const int k = (idx < deg) ? col[s + idx] : 0;
-    const int count = min(GGAD_WAVE, deg - blk);
-    const int iters = (count + rpi - 1) / rpi;
-    int tt = 0;
-    for (; tt + 4 <= iters; tt += 4) {
-      float x[4]; bool ok[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int src = (tt + q) * rpi + g;
-        const int kk = __shfl(k, src & 63, GGAD_WAVE);
-        ok[q] = lane_active && src < count;
-        x[q] = ok[q] ? featp[(int64_t)kk * stride + foff] : 0.0f;
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float cw = __shfl(x[q], (g * lpr + F) & 63, GGAD_WAVE);        // counter word of this lane's group
-        const float w = inv_sr / sqrtf((float)__float_as_int(cw));
-        acc = ok[q] ? fmaf(w, x[q], acc) : acc;
-      }
-    }
-    for (; tt < iters; ++tt) {
-      const int src = tt * rpi + g;
-      const int kk = __shfl(k, src & 63, GGAD_WAVE);
-      const bool ok = lane_active && src < count;
-      const float x = ok ? featp[(int64_t)kk * stride + foff] : 0.0f;
-      const float cw = __shfl(x, (g * lpr + F) & 63, GGAD_WAVE);
-      const float w = inv_sr / sqrtf((float)__float_as_int(cw));
-      acc = ok ? fmaf(w, x, acc) : acc;
-    }
-  }
-  // sum the rpi group partials of feature f into lanes [0, F)
-  float tot = acc;
-  for (int gg = 1; gg < rpi; ++gg) tot += __shfl(acc, (lane + gg * lpr) & 63, GGAD_WAVE);
-  if (deg == 0) tot = inv_sr * 0.0f;
-  if (lane < F) x2[(int64_t)e * F + lane] = tot;
-}
-
-__global__ void __launch_bounds__(256) k_reset_packed(float *__restrict__ featp, int64_t n_nodes, int stride, int F, int n_slots) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_nodes * n_slots) return;
-  const int64_t node = i / n_slots;
-  const int sl = (int)(i - node * n_slots);
-  reinterpret_cast<int32_t *>(featp)[node * stride + F + sl] = 0;
+  for (int i = s + lane_id(); i < t; i += GGAD_WAVE) atomicAdd(&cnt2[soff + col[i]], 1);
 }
 
 __global__ void __launch_bounds__(256) k_gather2(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
@@ -371,24 +403,60 @@ __global__ void __launch_bounds__(256) k_plan_reset(const int32_t *__restrict__ 
                                                     const int32_t *__restrict__ ent_col, const int32_t *__restrict__ ent_slot,
                                                     const int32_t *__restrict__ ent_own, const int32_t *__restrict__ ent_total,
                                                     int64_t n_nodes, int32_t *__restrict__ cnt1, int32_t *__restrict__ cnt2,
-                                                    int with_hop2, float *__restrict__ featp, int stride, int F) {
+                                                    int with_hop2) {
   const int e = blockIdx.x * (blockDim.x / GGAD_WAVE) + threadIdx.x / GGAD_WAVE;
   if (e >= *ent_total) return;
   const int u = ent_col[e];
-  const int slot = ent_slot[e];
-  const int64_t soff = (int64_t)slot * n_nodes;
+  const int64_t soff = (int64_t)ent_slot[e] * n_nodes;
   if (lane_id() == 0) cnt1[soff + u] = 0;
   if (!with_hop2 || ent_own[e] != e) return;
   const int s = rowptr[u], t = rowptr[u + 1];
-  if (cnt2 != nullptr) {
-    for (int i = s + lane_id(); i < t; i += GGAD_WAVE) cnt2[soff + col[i]] = 0;
-  } else {
-    int32_t *base = reinterpret_cast<int32_t *>(featp) + F + slot;
-    for (int i = s + lane_id(); i < t; i += GGAD_WAVE) base[(int64_t)col[i] * stride] = 0;
-  }
+  for (int i = s + lane_id(); i < t; i += GGAD_WAVE) cnt2[soff + col[i]] = 0;
 }
 
 }  // namespace
+
+// ------------------------------------------------------------------ launchers used by ggad_mb_plan_build (plan_build.cpp)
+int ggad_int_hop1(const ggad_mb_plan *P, const ggad_plan_view &V, int ldsw, int reset_now, hipStream_t st) {
+  if (V.n_chunks == 0) return GGAD_OK;
+  const unsigned eb = (unsigned)((V.n_chunks + 15) / 16);       // 16 pieces (4 waves x 4) per workgroup
+  k_expand<<<dim3(eb), dim3(256), 0, st>>>(P->rowptr, P->col, V.nodes, V.row_slot, V.ent_ptr, V.ck_rc, V.ck_e0, V.n_chunks,
+                                            P->n_nodes, P->ent_col, P->ent_slot, P->ent_row, P->cnt1, P->own1, P->counters);
+  k_gather1c<<<dim3(eb), dim3(256), 0, st>>>(P->feat, P->feat_dim, P->feat_stride, V.row_slot, V.ent_ptr, V.row_ck_ptr, V.ck_rc,
+                                              V.ck_e0, V.n_chunks, P->n_nodes, P->cnt1, P->own1, P->ent_col, P->ent_own, P->ent_c1,
+                                              P->ck_part, P->ck_part_stride, P->x1, P->rowptr, P->own_deg, P->own_rp, P->pw_base,
+                                              P->node_head, P->own_next, P->counters, ldsw);
+  const int row_blocks = (V.n_rows + 3) / 4;
+  const int ent_blocks = reset_now ? (V.n_ents + 255) / 256 : 0;
+  k_combine1_reset<<<dim3((unsigned)(row_blocks + ent_blocks)), dim3(256), 0, st>>>(
+      row_blocks, V.n_rows, V.row_ck_ptr, P->ck_part, P->ck_part_stride, P->feat_dim, P->x1, reset_now, V.n_ents, P->ent_col,
+      P->ent_slot, P->n_nodes, P->cnt1);
+  GGAD_CHECK_LAUNCH("mb_plan_build (1-hop)");
+  return GGAD_OK;
+}
+
+// device-atomic 2-hop stage + reset of both counter families (chunks the LDS-counting stage cannot take)
+int ggad_int_global_hop2(const ggad_mb_plan *P, const ggad_plan_view &V, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+  if (V.n_ents == 0) return GGAD_OK;
+  const int32_t *tot = V.ent_ptr + V.n_rows;
+  ggad_stream_t s = reinterpret_cast<ggad_stream_t>(st);
+  int rc = ggad_mb_count2(P->rowptr, P->col, P->ent_col, P->ent_slot, tot, V.n_ents, P->n_nodes, P->own1, P->cnt2, s);
+  if (rc) return rc;
+  if (ev0) (void)hipEventRecord(ev0, st);
+  rc = ggad_mb_gather2(P->rowptr, P->col, P->feat, P->feat_dim, P->feat_stride, P->ent_col, P->ent_slot, P->ent_own, tot, V.n_ents,
+                       P->n_nodes, P->cnt2, P->x2, s);
+  if (rc) return rc;
+  if (ev1) (void)hipEventRecord(ev1, st);
+  // zeroing whole slots streams 4 n bytes per batch; walking touches one 64-byte sector per counted 2-hop neighbour
+  const double walk_bytes = (double)V.n_ents * (double)P->mean_nbr_deg * 64.0;
+  const bool memset_cnt2 = walk_bytes > (double)V.n_batches * (double)P->n_nodes * 8.0;
+  if (memset_cnt2) {
+    const hipError_t me = hipMemsetAsync(P->cnt2, 0, (size_t)V.n_batches * (size_t)P->n_nodes * sizeof(int32_t), st);
+    if (me != hipSuccess) { ggad_set_error(me, "mb_plan_build (memset cnt2)"); return GGAD_E_LAUNCH; }
+  }
+  return ggad_mb_plan_reset(P->rowptr, P->col, P->ent_col, P->ent_slot, P->ent_own, tot, V.n_ents, P->n_nodes, P->cnt1, P->cnt2,
+                            memset_cnt2 ? 0 : 1, s);
+}
 
 // ------------------------------------------------------------------ C ABI
 extern "C" {
@@ -412,38 +480,7 @@ int ggad_exclusive_scan_i32(const int32_t *in, int32_t *out, int64_t n, int32_t 
   return GGAD_OK;
 }
 
-int ggad_mb_row_degree(const int32_t *rowptr, const int32_t *col, const int32_t *nodes, const int32_t *batch_ptr,
-                       int32_t n_batches, int32_t n_rows, int32_t *row_r, int32_t *row_slot, ggad_stream_t stream) {
-  GGAD_REQUIRE(rowptr && col && nodes && batch_ptr && row_r && row_slot && n_batches > 0 && n_rows >= 0);
-  if (n_rows == 0) return GGAD_OK;
-  k_row_degree<<<dim3((n_rows + 255) / 256), dim3(256), 0, as_stream(stream)>>>(rowptr, col, nodes, batch_ptr, n_batches,
-                                                                               n_rows, row_r, row_slot);
-  GGAD_CHECK_LAUNCH("mb_row_degree");
-  return GGAD_OK;
-}
-
-int ggad_mb_expand1(const int32_t *rowptr, const int32_t *col, const int32_t *nodes, const int32_t *row_slot,
-                    const int32_t *ent_ptr, int32_t n_rows, int64_t n_nodes, int32_t *ent_col, int32_t *ent_slot,
-                    int32_t *ent_row, int32_t *cnt1, int32_t *own1, ggad_stream_t stream) {
-  GGAD_REQUIRE(rowptr && col && nodes && row_slot && ent_ptr && ent_col && ent_slot && ent_row && cnt1 && own1 && n_rows >= 0);
-  if (n_rows == 0) return GGAD_OK;
-  k_expand1<<<dim3((n_rows + 3) / 4), dim3(256), 0, as_stream(stream)>>>(rowptr, col, nodes, row_slot, ent_ptr, n_rows,
-                                                                         n_nodes, ent_col, ent_slot, ent_row, cnt1, own1);
-  GGAD_CHECK_LAUNCH("mb_expand1");
-  return GGAD_OK;
-}
-
-int ggad_mb_gather1(const float *feat, int32_t feat_dim, int32_t feat_stride, const int32_t *row_slot, const int32_t *ent_ptr,
-                    const int32_t *ent_col, int32_t n_rows, int64_t n_nodes, const int32_t *cnt1,
-                    const int32_t *own1, int32_t *ent_own, int32_t *ent_c1, float *x1, ggad_stream_t stream) {
-  GGAD_REQUIRE(feat && row_slot && ent_ptr && ent_col && cnt1 && own1 && ent_own && ent_c1 && x1);
-  GGAD_REQUIRE(feat_dim >= 1 && feat_dim <= GGAD_MAX_F && feat_stride >= feat_dim && n_rows >= 0);
-  if (n_rows == 0) return GGAD_OK;
-  k_gather1<<<dim3((n_rows + 3) / 4), dim3(256), 0, as_stream(stream)>>>(feat, feat_dim, feat_stride, row_slot, ent_ptr, ent_col, n_rows,
-                                                                         n_nodes, cnt1, own1, ent_own, ent_c1, x1);
-  GGAD_CHECK_LAUNCH("mb_gather1");
-  return GGAD_OK;
-}
+int32_t ggad_mb_chunk_len(void) { return 16; }
 
 int ggad_seg_mean(const float *feat, int32_t feat_dim, const int32_t *seg_ptr, const int32_t *seg_col, int32_t n_rows,
                   float *out, ggad_stream_t stream) {
@@ -463,52 +500,13 @@ int ggad_seg_wsum(const float *feat, int32_t feat_dim, const int32_t *seg_ptr, c
   return GGAD_OK;
 }
 
-// ---- row chunks: every batch row cut into pieces of <= chunk_len consecutive entries (the unit of work of the chunk-parallel
-// forward kernel of step.hip: a hub row of thousands of entries is hundreds of independent pieces, not one workgroup's loop)
-__global__ void __launch_bounds__(256) k_row_chunk_counts(const int32_t *__restrict__ ent_ptr, int n_rows, int chunk_len,
-                                                          int32_t *__restrict__ nck) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n_rows) nck[i] = (ent_ptr[i + 1] - ent_ptr[i] + chunk_len - 1) / chunk_len;
-}
-__global__ void __launch_bounds__(256) k_fill_chunks(const int32_t *__restrict__ ent_ptr, const int32_t *__restrict__ row_ck_ptr,
-                                                     int n_rows, int chunk_len, int32_t *__restrict__ ck_rc,
-                                                     int32_t *__restrict__ ck_e0) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n_rows) return;
-  const int e0 = ent_ptr[i], e1 = ent_ptr[i + 1];
-  int c = row_ck_ptr[i];
-  for (int e = e0; e < e1; e += chunk_len, ++c) {
-    ck_rc[c] = (i << 6) | min(chunk_len, e1 - e);          // row (chunk-relative to the plan) | entries of the piece
-    ck_e0[c] = e;
-  }
-}
-
-int32_t ggad_mb_chunk_len(void) { return 16; }
-
-int ggad_mb_row_chunks(const int32_t *ent_ptr, int32_t n_rows, int32_t *nck_tmp, int32_t *row_ck_ptr, int32_t *ck_rc,
-                       int32_t *ck_e0, int32_t *scan_ws, ggad_stream_t stream) {
-  GGAD_REQUIRE(ent_ptr && nck_tmp && row_ck_ptr && ck_rc && ck_e0 && scan_ws && n_rows >= 0 && n_rows < (1 << 25));
-  if (n_rows == 0) return GGAD_OK;
-  const int cl = ggad_mb_chunk_len();
-  k_row_chunk_counts<<<dim3((n_rows + 255) / 256), dim3(256), 0, as_stream(stream)>>>(ent_ptr, n_rows, cl, nck_tmp);
-  GGAD_CHECK_LAUNCH("mb_row_chunks counts");
-  const int rc = ggad_exclusive_scan_i32(nck_tmp, row_ck_ptr, n_rows, scan_ws, stream);
-  if (rc) return rc;
-  k_fill_chunks<<<dim3((n_rows + 255) / 256), dim3(256), 0, as_stream(stream)>>>(ent_ptr, row_ck_ptr, n_rows, cl, ck_rc, ck_e0);
-  GGAD_CHECK_LAUNCH("mb_row_chunks fill");
-  return GGAD_OK;
-}
-
-int ggad_mb_packed_stride(int32_t feat_dim) { return ((feat_dim + 1 + 31) / 32) * 32; }
-
 int ggad_mb_count2(const int32_t *rowptr, const int32_t *col, const int32_t *ent_col, const int32_t *ent_slot,
                    const int32_t *ent_total, int64_t n_entries_cap, int64_t n_nodes, const int32_t *own1,
-                   int32_t *cnt2, float *feat_packed, int32_t feat_dim, int32_t feat_stride, ggad_stream_t stream) {
-  GGAD_REQUIRE(rowptr && col && ent_col && ent_slot && ent_total && own1 && n_entries_cap >= 0);
-  GGAD_REQUIRE(cnt2 || (feat_packed && feat_stride > feat_dim && feat_dim >= 1));
+                   int32_t *cnt2, ggad_stream_t stream) {
+  GGAD_REQUIRE(rowptr && col && ent_col && ent_slot && ent_total && own1 && cnt2 && n_entries_cap >= 0);
   if (n_entries_cap == 0) return GGAD_OK;
-  k_count2<<<dim3((unsigned)((n_entries_cap + 3) / 4)), dim3(256), 0, as_stream(stream)>>>(
-      rowptr, col, ent_col, ent_slot, ent_total, n_nodes, own1, cnt2, feat_packed, feat_stride, feat_dim);
+  k_count2<<<dim3((unsigned)((n_entries_cap + 3) / 4)), dim3(256), 0, as_stream(stream)>>>(rowptr, col, ent_col, ent_slot, ent_total,
+                                                                                          n_nodes, own1, cnt2);
   GGAD_CHECK_LAUNCH("mb_count2");
   return GGAD_OK;
 }
@@ -516,40 +514,22 @@ int ggad_mb_count2(const int32_t *rowptr, const int32_t *col, const int32_t *ent
 int ggad_mb_gather2(const int32_t *rowptr, const int32_t *col, const float *feat, int32_t feat_dim, int32_t feat_stride,
                     const int32_t *ent_col, const int32_t *ent_slot, const int32_t *ent_own, const int32_t *ent_total,
                     int64_t n_entries_cap, int64_t n_nodes, const int32_t *cnt2, float *x2, ggad_stream_t stream) {
-  GGAD_REQUIRE(rowptr && col && feat && ent_col && ent_slot && ent_own && ent_total && x2);
+  GGAD_REQUIRE(rowptr && col && feat && ent_col && ent_slot && ent_own && ent_total && cnt2 && x2);
   GGAD_REQUIRE(feat_dim >= 1 && feat_dim <= GGAD_MAX_F && feat_stride >= feat_dim && n_entries_cap >= 0);
-  GGAD_REQUIRE(cnt2 || (feat_stride > feat_dim && feat_dim + 1 <= 64));
   if (n_entries_cap == 0) return GGAD_OK;
-  if (cnt2 == nullptr)
-    k_gather2_packed<<<dim3((unsigned)((n_entries_cap + 3) / 4)), dim3(256), 0, as_stream(stream)>>>(
-        rowptr, col, feat, feat_dim, feat_stride, ent_col, ent_slot, ent_own, ent_total, x2);
-  else
-    k_gather2<<<dim3((unsigned)((n_entries_cap + 3) / 4)), dim3(256), 0, as_stream(stream)>>>(
-        rowptr, col, feat, feat_dim, feat_stride, ent_col, ent_slot, ent_own, ent_total, n_nodes, cnt2, x2);
+  k_gather2<<<dim3((unsigned)((n_entries_cap + 3) / 4)), dim3(256), 0, as_stream(stream)>>>(
+      rowptr, col, feat, feat_dim, feat_stride, ent_col, ent_slot, ent_own, ent_total, n_nodes, cnt2, x2);
   GGAD_CHECK_LAUNCH("mb_gather2");
-  return GGAD_OK;
-}
-
-int ggad_mb_reset_packed(float *feat_packed, int64_t n_nodes, int32_t feat_dim, int32_t feat_stride, int32_t n_slots,
-                         ggad_stream_t stream) {
-  GGAD_REQUIRE(feat_packed && n_nodes >= 0 && feat_dim >= 1 && n_slots >= 0 && feat_dim + n_slots <= feat_stride);
-  const int64_t tot = n_nodes * n_slots;
-  if (tot == 0) return GGAD_OK;
-  k_reset_packed<<<dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, as_stream(stream)>>>(feat_packed, n_nodes, feat_stride,
-                                                                                           feat_dim, n_slots);
-  GGAD_CHECK_LAUNCH("mb_reset_packed");
   return GGAD_OK;
 }
 
 int ggad_mb_plan_reset(const int32_t *rowptr, const int32_t *col, const int32_t *ent_col, const int32_t *ent_slot,
                        const int32_t *ent_own, const int32_t *ent_total, int64_t n_entries_cap, int64_t n_nodes,
-                       int32_t *cnt1, int32_t *cnt2, int32_t with_hop2, float *feat_packed, int32_t feat_dim,
-                       int32_t feat_stride, ggad_stream_t stream) {
-  GGAD_REQUIRE(rowptr && col && ent_col && ent_slot && ent_own && ent_total && cnt1);
-  GGAD_REQUIRE(!with_hop2 || cnt2 || (feat_packed && feat_stride > feat_dim));
+                       int32_t *cnt1, int32_t *cnt2, int32_t with_hop2, ggad_stream_t stream) {
+  GGAD_REQUIRE(rowptr && col && ent_col && ent_slot && ent_own && ent_total && cnt1 && (!with_hop2 || cnt2));
   if (n_entries_cap == 0) return GGAD_OK;
   k_plan_reset<<<dim3((unsigned)((n_entries_cap + 3) / 4)), dim3(256), 0, as_stream(stream)>>>(
-      rowptr, col, ent_col, ent_slot, ent_own, ent_total, n_nodes, cnt1, cnt2, with_hop2, feat_packed, feat_stride, feat_dim);
+      rowptr, col, ent_col, ent_slot, ent_own, ent_total, n_nodes, cnt1, cnt2, with_hop2);
   GGAD_CHECK_LAUNCH("mb_plan_reset");
   return GGAD_OK;
 }

@@ -120,7 +120,7 @@ inline int bit_length_u64(uint64_t n) { return n ? 64 - __builtin_clzll(n) : 0; 
 
 extern "C" {
 
-int ggad_abi_version(void) { return 1; }
+int ggad_abi_version(void) { return 2; }
 const char *ggad_last_error(void) { return g_last_error.c_str(); }
 
 ggad_mt19937 *ggad_mt_new(void) {

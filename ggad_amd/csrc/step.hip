@@ -673,8 +673,8 @@ __global__ void __launch_bounds__(256) k_encode(const float *__restrict__ params
 // k_project + k_fwd_rows in one launch (one launch boundary and one 8 us latency-bound kernel less per step).  The
 // projection h2 = relu(W x2[own(e)]) is computed by the workgroup of the entry's row: the x2 rows are fetched with
 // VECTOR loads, 3 rows per instruction (lane = (row slot g, feature f)), four instructions in flight, and the 17
-// features of a row reach every channel lane through v_readlane (SGPR broadcast) -- a scalar-load version
-// (k_fwd_rows_x) has one dependent scalar-cache round trip per 4 entries and is 2x slower on hub rows.
+// features of a row reach every channel lane through v_readlane (SGPR broadcast) (a scalar-load version has
+// one dependent scalar-cache round trip per 4 entries and measured 2x slower on hub rows).
 // h2 is written per ENTRY (not per owner) for the relu mask of k_bwd_flat.  Same fma / summation order as
 // k_project + k_fwd_rows: bit-identical h1 / nbar / gen.
 template <int FT>
@@ -896,275 +896,6 @@ __global__ void __launch_bounds__(256) k_loss_pos_ck(const float *__restrict__ p
   }
 }
 
-// ------------------------------------------------------------------ row-wise chain: 3 launches per step
-// (chain 1, opt-in.)  The 6-launch chain above is latency-bound: every launch costs 4-9 us although its work is a few
-// hundred nanoseconds.  Here everything that is local to a batch row is done by ONE workgroup per row (16 waves),
-// which leaves three grid-wide dependencies:
-//   k_fwd_rows_x     rows need the weights          : h2 = relu(W x2) is recomputed per entry instead of stored,
-//                                                     nbar / h1 / gen as in k_fwd_rows (same summation order)
-//   k_loss_bwd_rows  rows need all rows' embeddings : every workgroup evaluates ALL positions of the batch from
-//                                                     LDS tiles (the loss scalars decide `active`, and this row's
-//                                                     two positions give its gradient), then its backward
-//                                                     coefficients, then dW over its own entries -> one partial
-//                                                     [F][D] per row (the relu mask of h2 is recomputed)
-//   k_grad_reduce    parameters need all partials   : unchanged, n_parts = n_gw = number of rows
-// Redundant work: B workgroups x B positions x 5 wave reductions, 100 KB of L2 reads each.  MEASURED (MI355X, B = 200):
-// k_fwd_rows_x 4.8 us (vs project 5.2 + fwd_rows 4.3) but k_loss_bwd_rows 37 us (vs loss_pos 4.1 + loss_rows 6.1 +
-// bwd_flat 4.2) and grad_reduce over 200 partials 14 us (vs 8.5): 64 us per step against 48 -> not the default.
-constexpr int LB_PT = 128;     // positions per LDS tile of k_loss_bwd_rows
-
-template <int FT>
-__global__ void __launch_bounds__(FWD_NW * 64) k_fwd_rows_x(const float *__restrict__ params, ParamLayout L,
-                                                    const float *__restrict__ x1, const float *__restrict__ x2,
-                                                    const int32_t *__restrict__ ent_ptr, const int32_t *__restrict__ ent_own,
-                                                    const int32_t *__restrict__ labels, int row0,
-                                                    float *__restrict__ h1, float *__restrict__ nbar, float *__restrict__ gen) {
-  static_assert(FT > 0, "row-wise chain keeps W^T in registers");
-  __shared__ float part[FWD_NW][64];
-  __shared__ float ns[64];
-  const int D = L.D;
-  const int lane = lane_id(), wid = threadIdx.x / 64, d = lane < D ? lane : D - 1;
-  const int row = row0 + blockIdx.x;
-  WCol<FT> W;
-  W.load(params + L.o_Wt(), nullptr, D, FT, d, threadIdx.x, blockDim.x);
-  const int e0 = ent_ptr[row], e1 = ent_ptr[row + 1];
-  const int r = e1 - e0;
-  float acc = 0.0f;
-  for (int blk = wid; blk < r; blk += FWD_NW * 64) {
-    const int my = blk + FWD_NW * lane;
-    const int ov = (my < r) ? ent_own[e0 + my] : 0;
-    const int cnt = min(64, (r - blk + FWD_NW - 1) / FWD_NW);
-    int i = 0;
-    for (; i + 4 <= cnt; i += 4) {
-      const int o0 = __builtin_amdgcn_readlane(ov, i), o1 = __builtin_amdgcn_readlane(ov, i + 1);
-      const int o2 = __builtin_amdgcn_readlane(ov, i + 2), o3 = __builtin_amdgcn_readlane(ov, i + 3);
-      const float a0 = fmaxf(W.dot(x2 + (int64_t)o0 * FT), 0.0f), a1 = fmaxf(W.dot(x2 + (int64_t)o1 * FT), 0.0f);   // graphsage.py:419
-      const float a2 = fmaxf(W.dot(x2 + (int64_t)o2 * FT), 0.0f), a3 = fmaxf(W.dot(x2 + (int64_t)o3 * FT), 0.0f);
-      acc += a0; acc += a1; acc += a2; acc += a3;
-    }
-    for (; i < cnt; ++i) {
-      const int o = __builtin_amdgcn_readlane(ov, i);
-      acc += fmaxf(W.dot(x2 + (int64_t)o * FT), 0.0f);
-    }
-  }
-  part[wid][lane] = acc;
-  __syncthreads();
-  const float inv_r = 1.0f / (float)r;                                      // mask_row = mask / rowsum  graphsage.py:317
-  float tot = 0.0f;
-#pragma unroll
-  for (int k = 0; k < FWD_NW; ++k) tot += part[k][lane];                    // fixed order
-  const float nb = inv_r * tot;
-  const int y = labels[row];
-  if (wid == 0) {
-    if (lane < D) nbar[(int64_t)row * D + lane] = nb;                       // mask_row.mm(...)          graphsage.py:421
-    ns[lane] = (lane < D) ? nb : 0.0f;
-  }
-  if (wid == 1) {                                                           // h1 = relu(W x1[row])      graphsage.py:412
-    const float h = fmaxf(W.dot(x1 + (int64_t)row * FT), 0.0f);
-    if (lane < D) h1[(int64_t)row * D + lane] = h;
-  }
-  if (y != 1) return;                                                       // block-uniform exit
-  __syncthreads();
-  const float *fcT = params + L.o_fcT();                                    // gen = relu(fc nbar)   graphsage.py:428-430
-  const int q = (D + FWD_NW - 1) / FWD_NW;
-  float a = 0.0f;
-  for (int d2 = wid * q; d2 < min(D, (wid + 1) * q); ++d2) a = fmaf(fcT[d2 * D + d], ns[d2], a);
-  __syncthreads();
-  part[wid][lane] = a;
-  __syncthreads();
-  if (wid == 0 && lane < D) {
-    float g = 0.0f;
-#pragma unroll
-    for (int k = 0; k < FWD_NW; ++k) g += part[k][lane];
-    gen[(int64_t)row * D + lane] = fmaxf(g, 0.0f);
-  }
-}
-
-template <int FT>
-__global__ void __launch_bounds__(FWD_NW * 64) k_loss_bwd_rows(const float *__restrict__ params, ParamLayout L,
-                                                       const float *__restrict__ x1, const float *__restrict__ x2,
-                                                       const float *__restrict__ h1, const float *__restrict__ nbar,
-                                                       const float *__restrict__ gen, const int32_t *__restrict__ labels,
-                                                       const int32_t *__restrict__ pos_meta, const int32_t *__restrict__ row_pos,
-                                                       const int32_t *__restrict__ ent_ptr, const int32_t *__restrict__ ent_own,
-                                                       int row0, int B, float *__restrict__ gw_rows,
-                                                       float *__restrict__ losses8, float *__restrict__ dz,
-                                                       float *__restrict__ dw_part, int32_t *__restrict__ step_counter) {
-  static_assert(FT > 0, "row-wise chain keeps W^T in registers");
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  // phase 1: cT | nT | hT tiles [LB_PT][64]; phase 3: dW accumulators [FWD_NW][FT * D]   (same storage)
-  float *cT = lds, *nT = lds + LB_PT * 64, *hT = lds + 2 * LB_PT * 64;
-  __shared__ int mT[LB_PT];
-  __shared__ float fc_lds[GGAD_MAX_D * GGAD_MAX_D];
-  __shared__ float red[FWD_NW][8];
-  __shared__ float psave[2][8];
-  __shared__ float zs[64];
-  __shared__ float cg[64];
-  const int D = L.D;
-  const int lane = lane_id(), wid = threadIdx.x / 64;
-  const bool on = lane < D;
-  const int d = on ? lane : D - 1;
-  const int i = blockIdx.x;
-  const int row = row0 + i;
-  for (int k = threadIdx.x; k < D * D; k += FWD_NW * 64) fc_lds[k] = params[L.o_fc() + k];
-  const int q1 = row_pos[row];
-  const float wd = on ? params[lane] : 0.0f;
-  // ---- phase 1: every position of the batch (k_loss_pos), tile by tile through LDS
-  float osum[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int t0 = 0; t0 < B; t0 += LB_PT) {
-    const int nt = min(LB_PT, B - t0);
-    for (int idx = threadIdx.x; idx < nt * 64; idx += FWD_NW * 64) {
-      const int p = idx >> 6, ch = idx & 63;
-      const int meta = pos_meta[row0 + t0 + p];
-      const int src = meta >> 2;
-      const bool from_gen = (meta & 2) != 0;
-      const bool chon = ch < D;
-      const float hv = chon ? h1[(int64_t)src * D + ch] : 0.0f;
-      const float gv = (chon && from_gen) ? gen[(int64_t)src * D + ch] : 0.0f;
-      cT[idx] = from_gen ? gv : hv;                                                  // combined_all[:, q]
-      nT[idx] = chon ? nbar[(int64_t)(row0 + t0 + p) * D + ch] : 0.0f;                // to_feats_neigh[q, :]
-      hT[idx] = from_gen ? hv : 0.0f;
-      if (ch == 0) mT[p] = meta;
-    }
-    __syncthreads();
-    for (int p = wid; p < nt; p += FWD_NW) {
-      const int q = t0 + p;
-      const int meta = mT[p];
-      const int y = meta & 1;
-      const bool from_gen = (meta & 2) != 0;
-      const float c = cT[p * 64 + lane], nb = nT[p * 64 + lane];
-      const PosVals v = eval_position(wd, c, nb);
-      float recn = 0.0f;
-      if (from_gen) { const float dl = hT[p * 64 + lane] - c; recn = sqrtf(wave_sum_fast(dl * dl)); }   // recon2  graphsage.py:197-198
-      osum[0] += (1.0f - (float)y) * v.s - log_sigmoid(v.s);                        // BCEWithLogits      graphsage.py:246
-      osum[1] += y == 0 ? v.aff : 0.0f; osum[2] += y == 1 ? v.aff : 0.0f; osum[3] += recn;
-      osum[4] += y == 0 ? 1.0f : 0.0f;  osum[5] += y == 1 ? 1.0f : 0.0f;
-      if (lane == 0) {
-        if (q == q1) { psave[0][0] = v.s; psave[0][1] = v.aff; psave[0][2] = v.na; psave[0][3] = v.nbn; psave[0][4] = recn; }
-        if (q == i)  { psave[1][0] = v.s; psave[1][1] = v.aff; psave[1][2] = v.na; psave[1][3] = v.nbn; psave[1][4] = recn; }
-      }
-    }
-    __syncthreads();
-  }
-  if (lane == 0) {
-#pragma unroll
-    for (int k = 0; k < 6; ++k) red[wid][k] = osum[k];
-  }
-  __syncthreads();
-  float t[6];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    float v = 0.0f;
-#pragma unroll
-    for (int w = 0; w < FWD_NW; ++w) v += red[w][k];                                 // fixed order, identical in every workgroup
-    t[k] = v;
-  }
-  const float fB = (float)B;
-  const float cls = t[0] / fB;
-  const float an = t[1] / t[4], ab = t[2] / t[5];
-  const float mg = 1.0f - (an - ab);                                     // confidence_margin = 1      graphsage.py:236-240
-  const float active = (mg >= 0.0f) ? 1.0f : 0.0f;                       // clamp_min backward: pass where x >= min
-  const float rec_coef = 0.1f / t[5];
-  if (i == 0 && threadIdx.x == 0) {
-    const float margin = fmaxf(mg, 0.0f), rec = t[3] / t[5];
-    losses8[0] = cls + margin + 0.1f * rec;                              // graphsage.py:258
-    losses8[1] = cls; losses8[2] = margin; losses8[3] = rec;
-    losses8[4] = rec_coef; losses8[5] = active; losses8[6] = t[4]; losses8[7] = t[5];
-    if (step_counter) *step_counter += 1;
-  }
-  // ---- phase 2 (wave 0): gradients w.r.t. this row's h1 / gen / nbar -> backward coefficients (k_loss_rows)
-  const int y = labels[row];
-  const int e0 = ent_ptr[row], e1 = ent_ptr[row + 1];
-  const int r = e1 - e0;
-  float coef_a = 0.0f;
-  if (wid == 0) {
-    const int64_t off = (int64_t)row * D + d;
-    const float H1 = h1[off];
-    const float NB = nbar[off];
-    const float G = (y == 1) ? gen[off] : 0.0f;
-    const float C = (y == 1) ? G : H1;                                   // this row's column of combined_all
-    const float s1 = psave[0][0], aff1 = psave[0][1], na1 = psave[0][2], nbn1 = psave[0][3], recn = psave[0][4];
-    const int y1 = pos_meta[row0 + q1] & 1;
-    const float nbq = nbar[(int64_t)(row0 + q1) * D + d];
-    const float nac1 = fmaxf(na1, 1e-8f), nbc1 = fmaxf(nbn1, 1e-8f);
-    const float ds = (1.0f / (1.0f + expf(-s1)) - (float)y1) / fB;
-    const float gq1 = active * (y1 == 0 ? -1.0f / t[4] : 1.0f / t[5]);
-    const float ca = na1 > 0.0f ? C / na1 : 0.0f;
-    const float dC = ds * wd + gq1 * ((nbq / nbc1) / nac1 - (aff1 / nac1) * ca);
-    float gH = dC, gG = 0.0f;
-    if (y == 1) {                                                        // recon term 0.1 * mean_i |h1_i - gen_i|  graphsage.py:258
-      const float tt = rec_coef * ((H1 - G) / recn);
-      gH = tt; gG = dC - tt;
-    }
-    gw_rows[(int64_t)i * 64 + lane] = on ? ds * C : 0.0f;                // d w = sum_q ds_q * combined_all[:, q]
-    const float aff2 = psave[1][1], na2 = psave[1][2], nbn2 = psave[1][3];
-    const int m2 = pos_meta[row0 + i];
-    const int src2 = m2 >> 2;
-    const float c2 = (m2 & 2) ? gen[(int64_t)src2 * D + d] : h1[(int64_t)src2 * D + d];
-    const float nac2 = fmaxf(na2, 1e-8f), nbc2 = fmaxf(nbn2, 1e-8f);
-    const float gq2 = active * (y == 0 ? -1.0f / t[4] : 1.0f / t[5]);
-    const float cb = nbn2 > 0.0f ? NB / nbn2 : 0.0f;
-    float dNb = gq2 * ((c2 / nac2) / nbc2 - (aff2 / nbc2) * cb);
-    if (y == 1) {
-      const float dZ = (G > 0.0f) ? gG : 0.0f;                           // relu(fc(.))
-      if (on) dz[off] = dZ;
-      zs[lane] = on ? dZ : 0.0f;                                         // same wave reads it back
-      float a = 0.0f;
-      for (int dd = 0; dd < D; ++dd) a = fmaf(fc_lds[dd * D + d], zs[dd], a);   // fc^T dZ
-      dNb += a;
-    }
-    coef_a = (on && H1 > 0.0f) ? gH : 0.0f;
-    cg[lane] = on ? dNb * (1.0f / (float)r) : 0.0f;
-  }
-  __syncthreads();           // cg ready; tiles dead -> the storage becomes the dW accumulators
-  // ---- phase 3: dW[d][f] += coef_d * x_f over this row's entries (+ the row's own x1 term), 16 waves
-  WCol<FT> W;
-  W.load(params + L.o_Wt(), nullptr, D, FT, d, threadIdx.x, blockDim.x);
-  const float cgv = cg[lane];
-  float acc[FT];
-#pragma unroll
-  for (int f = 0; f < FT; ++f) acc[f] = 0.0f;
-  for (int blk = wid; blk < r; blk += FWD_NW * 64) {
-    const int my = blk + FWD_NW * lane;
-    const int ov = (my < r) ? ent_own[e0 + my] : 0;
-    const int cnt = min(64, (r - blk + FWD_NW - 1) / FWD_NW);
-    int k = 0;
-    for (; k + 2 <= cnt; k += 2) {
-      const int o0 = __builtin_amdgcn_readlane(ov, k), o1 = __builtin_amdgcn_readlane(ov, k + 1);
-      const float *xa = x2 + (int64_t)o0 * FT, *xb = x2 + (int64_t)o1 * FT;
-      const float ca = (W.dot(xa) > 0.0f) ? cgv : 0.0f;                  // relu mask of h2 = relu(W x2)
-      const float cb = (W.dot(xb) > 0.0f) ? cgv : 0.0f;
-#pragma unroll
-      for (int f = 0; f < FT; ++f) { acc[f] = fmaf(ca, xa[f], acc[f]); acc[f] = fmaf(cb, xb[f], acc[f]); }
-    }
-    for (; k < cnt; ++k) {
-      const int o = __builtin_amdgcn_readlane(ov, k);
-      const float *xr = x2 + (int64_t)o * FT;
-      const float cc = (W.dot(xr) > 0.0f) ? cgv : 0.0f;
-#pragma unroll
-      for (int f = 0; f < FT; ++f) acc[f] = fmaf(cc, xr[f], acc[f]);
-    }
-  }
-  if (wid == 0) {
-    const float *xr = x1 + (int64_t)row * FT;
-#pragma unroll
-    for (int f = 0; f < FT; ++f) acc[f] = fmaf(coef_a, xr[f], acc[f]);
-  }
-  float *mine = lds + wid * FT * D;
-  if (on) {
-#pragma unroll
-    for (int f = 0; f < FT; ++f) mine[f * D + d] = acc[f];
-  }
-  __syncthreads();
-  float *out = dw_part + (int64_t)i * FT * D;
-  for (int k = threadIdx.x; k < FT * D; k += FWD_NW * 64) {
-    float v = 0.0f;
-#pragma unroll
-    for (int w = 0; w < FWD_NW; ++w) v += lds[w * FT * D + k];            // fixed order
-    out[k] = v;
-  }
-}
-
 bool dims_ok(int D, int F) { return D >= 1 && D <= GGAD_MAX_D && F >= 1 && (size_t)(4 * F * D + 512) * 4 <= 150 * 1024; }
 
 }  // namespace
@@ -1218,7 +949,7 @@ int ggad_mb_fwd_rows(const float *params, int32_t D, int32_t F, const float *x1,
 }
 
 int64_t ggad_mb_loss_workspace_elems(int32_t n_rows) {
-  // pos_scal[n_rows][8] | part[nwg][8] | gw: [nwg][64] (6-launch chain) or [n_rows][64] (row-wise chain)
+  // pos_scal[n_rows][8] | part[nwg][8] | gw: [nwg][64] (sized for n_rows workgroups)
   return (int64_t)n_rows * 8 + (int64_t)loss_nwg(n_rows) * 8 + (int64_t)n_rows * 64;
 }
 
@@ -1333,57 +1064,19 @@ int ggad_mb_encode(const float *params, int32_t D, int32_t F, const float *x1, i
 }
 
 /* One whole training step for one batch.  chain 0 (default): fwd_rows_v (projection fused, F == 17; else project ->
- * fwd_rows) -> loss_pos -> loss_rows -> bwd_flat -> grad_reduce; chain 2: always project -> fwd_rows -> ...;
- * chain 1 (F == 17 only): the row-wise 3-launch chain fwd_rows_x -> loss_bwd_rows -> grad_reduce (measured
- * slower: the redundant all-positions pass costs more than the launches it saves; kept as a tested alternative).
+ * fwd_rows) -> loss_pos -> loss_rows -> bwd_flat -> grad_reduce; chain 2: always project -> fwd_rows -> ...
+ * (the generic layered chain).
  * Adam is fused into the last launch when fuse_adam != 0; otherwise the caller all-reduces s->grads and calls
  * ggad_mb_adam. */
 int64_t ggad_mb_dw_part_elems(int32_t n_rows, int32_t D, int32_t F) {
   return (int64_t)(n_rows > BWD_PARTS ? n_rows : BWD_PARTS) * F * D;
 }
 
-static int train_step_rows(const ggad_mb_step *s, int32_t fuse_adam, ggad_stream_t stream) {
-  const int D = s->D, B = s->n_rows;
-  constexpr int FT = 17;
-  ParamLayout L{D, FT};
-  hipStream_t st = as_stream(stream);
-  const int nwg = loss_nwg(B);
-  float *gw_rows = s->loss_ws + (int64_t)B * 8 + (int64_t)nwg * 8;
-  k_fwd_rows_x<FT><<<dim3(B), dim3(FWD_NW * 64), 0, st>>>(s->params, L, s->x1, s->x2, s->ent_ptr, s->ent_own, s->labels, s->row0,
-                                                         s->h1, s->nbar, s->gen);
-  const size_t tile = (size_t)3 * LB_PT * 64 * 4, accs = (size_t)FWD_NW * FT * D * 4;
-  const size_t lds = tile > accs ? tile : accs;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute((const void *)k_loss_bwd_rows<FT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(tile > 80 * 1024 ? tile : 80 * 1024));
-    attr = true;
-  }
-  k_loss_bwd_rows<FT><<<dim3(B), dim3(FWD_NW * 64), lds, st>>>(s->params, L, s->x1, s->x2, s->h1, s->nbar, s->gen, s->labels,
-                                                              s->pos_meta, s->row_pos, s->ent_ptr, s->ent_own, s->row0, B,
-                                                              gw_rows, s->losses8, s->dz, s->dw_part, s->step_counter);
-  if (fuse_adam)
-    k_grad_reduce<true><<<dim3((L.n_train() + 63) / 64), dim3(64, GR_SUB), 0, st>>>(
-        L, s->pos_meta, s->row0, s->losses8, s->nbar, s->dw_part, B, s->dz, gw_rows, B, s->grads, s->params, s->exp_avg,
-        s->exp_avg_sq, s->lr, s->weight_decay, s->step_counter);
-  else
-    k_grad_reduce<false><<<dim3((L.n_train() + 63) / 64), dim3(64, GR_SUB), 0, st>>>(
-        L, s->pos_meta, s->row0, s->losses8, s->nbar, s->dw_part, B, s->dz, gw_rows, B, s->grads, nullptr, nullptr, nullptr,
-        0.f, 0.f, nullptr);
-  GGAD_CHECK_LAUNCH("mb_train_step(rows)");
-  return GGAD_OK;
-}
-
 int ggad_mb_train_step(const ggad_mb_step *s, int32_t fuse_adam, ggad_stream_t stream) {
   GGAD_REQUIRE(s && s->params && s->exp_avg && s->exp_avg_sq && s->grads && s->step_counter);
-  GGAD_REQUIRE(s->chain >= 0 && s->chain <= 2);
+  GGAD_REQUIRE(s->chain == 0 || s->chain == 2);
   const int D = s->D, F = s->F;
   int rc;
-  if (s->chain == 1) {
-    GGAD_REQUIRE(F == 17);
-    GGAD_REQUIRE(s->x1 && s->x2 && s->ent_ptr && s->ent_own && s->labels && s->pos_meta && s->row_pos && s->h1 && s->nbar &&
-                 s->gen && s->dz && s->dw_part && s->loss_ws && s->losses8 && dims_ok(D, F) && s->n_rows >= 1 && s->row0 >= 0);
-    return train_step_rows(s, fuse_adam, stream);
-  }
   // 5 launches: the projection is done by the forward-rows kernel -- unless the batch holds a hub row (one workgroup would
   // project thousands of entries while the flat k_project spreads them over the chip)
   static const int fuse_max_row = [] { const char *e = getenv("GGAD_FUSE_MAX_ROW"); return e ? atoi(e) : 256; }();

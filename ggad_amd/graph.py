@@ -68,36 +68,58 @@ class DeviceGraph:
 
     # ---- cached binary CSR: converting the reference's 3.7 M-key dict of python sets takes minutes, the
     # cache is two int32 arrays
-    def save_csr(self, path: str) -> None:
-        """Write rowptr / col as an uncompressed .npz (atomic rename), to be reloaded with `load_csr`."""
+    def save_csr(self, path: str, fingerprint: str = "") -> None:
+        """Write rowptr / col as an uncompressed .npz (per-process temporary name + atomic rename, so that ranks converting
+        the same pickle at the same time never replace each other's half-written file), to be reloaded with `load_csr`.
+        `fingerprint` identifies the source the CSR was converted from (`source_fingerprint`)."""
         import os
-        tmp = path + ".tmp.npz"
-        np.savez(tmp, rowptr=self.rowptr_host, col=self.col_host, n=np.int64(self.n), nnz=np.int64(self.nnz))
+        tmp = f"{path}.{os.getpid()}.tmp.npz"
+        np.savez(tmp, rowptr=self.rowptr_host, col=self.col_host, n=np.int64(self.n), nnz=np.int64(self.nnz),
+                 fingerprint=np.array(fingerprint))
         os.replace(tmp, path)
 
+    @staticmethod
+    def source_fingerprint(source_path: Optional[str], adj_lists=None) -> str:
+        """Identity of the adjacency the cache was built from: size + mtime of the source file when there is one, else the
+        number of keys and directed entries of the dict (a regenerated graph of the same node count changes either)."""
+        import os
+        if source_path and os.path.exists(source_path):
+            s = os.stat(source_path)
+            return f"file:{s.st_size}:{int(s.st_mtime)}"
+        if adj_lists is not None:
+            return f"dict:{len(adj_lists)}:{sum(len(v) for v in adj_lists.values())}"
+        return ""
+
     @classmethod
-    def load_csr(cls, path: str, device="cuda") -> "DeviceGraph":
+    def load_csr(cls, path: str, device="cuda", fingerprint: Optional[str] = None) -> "DeviceGraph":
         with np.load(path) as f:
             rowptr, col = f["rowptr"], f["col"]
             if int(f["n"]) != len(rowptr) - 1 or int(f["nnz"]) != len(col) or int(rowptr[-1]) != len(col):
                 raise ValueError(f"{path}: inconsistent CSR cache")
+            if fingerprint is not None and str(f["fingerprint"]) != fingerprint:
+                raise ValueError(f"{path}: CSR cache was built from another source")
         return cls(rowptr, col, device)
 
     @classmethod
-    def from_adj_lists_cached(cls, adj_lists, n: Optional[int], device, cache_path: Optional[str]) -> "DeviceGraph":
-        """`from_adj_lists` through a binary cache: reused when it describes a graph of the same size, else rebuilt."""
+    def from_adj_lists_cached(cls, adj_lists, n: Optional[int], device, cache_path: Optional[str],
+                              source_path: Optional[str] = None) -> "DeviceGraph":
+        """`from_adj_lists` through a binary cache: reused when it was built from the same source (fingerprint: size + mtime of
+        `source_path`, else key / entry counts of the dict) and describes a graph of the same size; else rebuilt.  A truncated
+        or foreign cache file is ignored, never fatal."""
         import os
+        import zipfile
+        fp = cls.source_fingerprint(source_path, adj_lists)
         if cache_path and os.path.exists(cache_path):
             try:
-                g = cls.load_csr(cache_path, device)
+                g = cls.load_csr(cache_path, device, fingerprint=fp)
                 if n is None or g.n == n:
                     return g
-            except (ValueError, OSError, KeyError):
+            except (ValueError, OSError, KeyError, EOFError, zipfile.BadZipFile):
                 pass
         g = cls.from_adj_lists(adj_lists, n, device)
         if cache_path:
             try:
-                g.save_csr(cache_path)
+                g.save_csr(cache_path, fp)
             except OSError:
                 pass                      # read-only data directory: run without the cache
         return g
@@ -123,6 +145,25 @@ class DeviceGraph:
         return self._closed_deg_host
 
     @property
+    def closed_deg_i32(self) -> np.ndarray:
+        """`closed_deg_host` as the contiguous int32 table the native plan builder reads."""
+        t = self.__dict__.get("_closed_deg_i32")
+        if t is None:
+            t = np.ascontiguousarray(self.closed_deg_host, dtype=np.int32)
+            self.__dict__["_closed_deg_i32"] = t
+        return t
+
+    @property
+    def mean_nbr_deg(self) -> float:
+        """sum deg^2 / sum deg: the expected degree of a random neighbour (size of a 2-hop walk per entry)."""
+        t = self.__dict__.get("_mean_nbr_deg")
+        if t is None:
+            d = self.deg_host.astype(np.float64)
+            t = float((d * d).sum() / max(1.0, d.sum()))
+            self.__dict__["_mean_nbr_deg"] = t
+        return t
+
+    @property
     def pair_bound_host(self) -> np.ndarray:
         """int64[n]: sum of deg(k) over k in N(i) + {i} -- upper bound of the 2-hop pairs row i contributes to a batch."""
         t = self.__dict__.get("_pair_bound")
@@ -132,7 +173,7 @@ class DeviceGraph:
             rows = torch.repeat_interleave(torch.arange(self.n, device=self.device), deg)
             acc = deg.clone()
             acc.index_add_(0, rows, deg[self.col.long()])
-            t = acc.cpu().numpy()
+            t = np.ascontiguousarray(acc.cpu().numpy(), dtype=np.int64)
             self.__dict__["_pair_bound"] = t
         return t
 

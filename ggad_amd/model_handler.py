@@ -84,10 +84,12 @@ class ModelHandler(object):
             graph = DeviceGraph(adj_lists[0], adj_lists[1], dev)
         else:
             # the reference's pickled dict of sets: converted once, then served from a binary CSR cache beside it
-            cache = None
+            # (keyed by size + mtime of the pickle; written under a per-process temporary name: ranks may convert concurrently)
+            cache = src = None
             if getattr(args, "data_name", "") == "dgraphfin" and getattr(args, "data", None) is None:
+                src = args.data_dir + "dgraphfin_adj_list"
                 cache = os.path.join(args.data_dir, "dgraphfin_adj_list.csr.npz")
-            graph = DeviceGraph.from_adj_lists_cached(adj_lists, n, dev, cache)
+            graph = DeviceGraph.from_adj_lists_cached(adj_lists, n, dev, cache, source_path=src)
         features = FeatureTable(torch.FloatTensor(np.asarray(feat_data, dtype=np.float32)))
         agg_gcn = GCNAggregator(features, cuda=True)
         enc_gcn = GCNEncoder(features, f, args.emb_size, graph, agg_gcn, gcn=True, cuda=True)

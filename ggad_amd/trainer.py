@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 from .graph import DeviceGraph
-from .minibatch import BatchChunk, MiniBatchEngine, pack_features, reduce_gradients  # noqa: F401 (re-exported)
+from .minibatch import BatchChunk, MiniBatchEngine, reduce_gradients  # noqa: F401 (re-exported)
 from .sampler import PyCompatRandom
 
 
@@ -80,21 +80,22 @@ class DGraphTrainer:
     def __init__(self, graph: DeviceGraph, feat: torch.Tensor, embed_dim: int, schedule: BatchSchedule,
                  lr: float = 1e-3, weight_decay: float = 0.007, chunk_batches: int = 150, rank: int = 0,
                  world_size: int = 1, allreduce: Optional[Callable[[torch.Tensor], None]] = None,
-                 engine: Optional[MiniBatchEngine] = None, packed: bool = False, hop2: str = "ldsw",
-                 overlap: bool = True, prefetch: bool = True, chain: int = 0, dense_cus: Optional[int] = None):
-        """`feat` is the plain (N, F) table.  hop2 = "ldsw" (default, fastest measured): 2-hop counts in LDS per
-        (tile, batch), per-pair counts streamed to the gather, feature rows padded to one 128-byte line; "global":
-        per-batch counter slots in HBM + device atomics; "tiled" / "ktile": earlier LDS-tiled / tile-ordered variants
-        (DESIGN.md §4c); with `packed` the global counters live inside a private padded copy of the feature rows
-        (15 slots for F = 17 -> chunks of <= 15 batches).
+                 engine: Optional[MiniBatchEngine] = None, hop2: str = "ldsw",
+                 overlap: bool = True, prefetch: bool = True, chain: int = 0, dense_cus: Optional[int] = None,
+                 ramp: Optional[Sequence[int]] = None):
+        """`feat` is the plain (N, F) table.  hop2 = "ldsw" (default): 2-hop counts in LDS per (tile, batch), per-pair
+        counts streamed to the gather, feature rows padded to one 128-byte line; "global": per-batch counter slots in HBM +
+        device atomics (the fallback the LDS path takes by itself when a chunk exceeds its limits).
         `overlap` (default): two chunk buffers; the plan + gather of chunk c+1 runs on one stream while the dense steps
         of chunk c run on another, the two streams confined to DISJOINT compute units (`dense_cus` CUs for the dense
-        chain, the rest for the plan; `ggad_stream_create_cu_mask`).  Measured on MI355X: 100 -> 73 us/step.  `dense_cus`
-        None = by graph density: 32 when the plan is the longer stream (average degree >= 8: DGraph-size 47.3 vs 50.6 us per
-        step with 64), 64 when the step chain is (average degree 2.3: 31.8 vs 37.3 us with 32).  With
-        plain streams (`dense_cus=0`, dense chain on the high-priority queue) there is no gain: the 900 tiny dependent
-        launches of a chunk queue behind the 600k-wave gather launches.
-        `prefetch`: the host sampler (bit-exact CPython shuffle, ~0.6 ms per batch for the 55k pool) runs in a
+        chain, the rest for the plan; `ggad_stream_create_cu_mask`).  `dense_cus` None = by graph density: 32 when the plan
+        is the longer stream (average degree >= 8), 64 when the step chain is (average degree 2.3).  With plain streams
+        (`dense_cus=0`) there is no gain: the tiny dependent launches of the dense chain queue behind the chip-filling
+        gather launches.
+        `ramp`: sizes (batches) of the FIRST chunks of a `run_steps` call.  The plan of the first chunk cannot overlap
+        anything, so a run starts with small chunks (the dense chain starts after a fraction of a millisecond instead of
+        after a 150-batch plan) and grows to `chunk_batches`; None = `default_ramp`.
+        `prefetch`: the host sampler (bit-exact CPython shuffle, ~0.1 ms per batch for the 55k pool) runs in a
         background thread one chunk ahead; the C call releases the GIL, so sampling overlaps the GPU work."""
         self.graph, self.feat = graph, feat
         self.schedule = schedule
@@ -102,13 +103,10 @@ class DGraphTrainer:
         self.allreduce = allreduce if self.world > 1 else None
         self.engine = engine or MiniBatchEngine(feat.shape[1], embed_dim, feat.device, lr, weight_decay, chain=chain)
         self.chunk_batches = int(chunk_batches)
+        self.ramp = None if ramp is None else [int(k) for k in ramp]
         f = int(feat.shape[1])
-        self.packed = bool(packed) and f + 1 <= 64
         table = feat
-        if self.packed:
-            table = pack_features(feat)
-            self.chunk_batches = max(1, min(self.chunk_batches, table.shape[1] - f))
-        elif hop2 == "ldsw" and f <= 32 and (f * 4) % 128 != 0:
+        if hop2 == "ldsw" and f <= 32 and (f * 4) % 128 != 0:
             # one random access per neighbour: keep every feature row inside one 128-byte line
             table = torch.zeros(feat.shape[0], 32, dtype=torch.float32, device=feat.device)
             table[:, :f] = feat
@@ -116,15 +114,11 @@ class DGraphTrainer:
         mean_deg = max(1.0, graph.nnz / max(1, graph.n))
         ent_cap = int(rows * (mean_deg + 1) * 1.5) + 1024
         self.chunk = BatchChunk(graph, table, embed_dim, self.chunk_batches, rows, ent_cap, train=True, feat_dim=f, hop2=hop2)
-        self.overlap = bool(overlap) and feat.device.type == "cuda" and not self.packed
+        self.overlap = bool(overlap) and feat.device.type == "cuda"
         self.chunks = [self.chunk]
         if self.overlap:
             self.chunks.append(BatchChunk(graph, table, embed_dim, self.chunk_batches, rows, ent_cap, train=True, feat_dim=f,
                                           hop2=hop2))
-            # the dense chain is ~900 tiny dependent launches per chunk; queued on the same CUs as the 600k-wave gather
-            # launches of the side stream they wait for a free CU (measured: no gain, even with a high-priority
-            # queue).  With disjoint CU masks (`dense_cus` CUs for the dense chain, the rest for the plan) both
-            # streams make progress.
             if dense_cus is None:
                 dense_cus = 32 if graph.nnz >= 8 * graph.n else 64
             self.dense_cus = int(dense_cus)
@@ -132,6 +126,32 @@ class DGraphTrainer:
         self.steps_done = 0
         self.prefetch = bool(prefetch)
         self._stream = None
+        self._pending = ([], [])        # batches taken from the sampler stream but not consumed yet
+
+    def default_ramp(self, n_steps: int) -> List[int]:
+        """Chunk sizes of a run of n optimiser steps.  With overlap the first plan is exposed and the last chunk's dense steps
+        are: start small, grow geometrically to `chunk_batches`, and keep the tail chunk short when the run itself is short."""
+        import os
+        env = os.environ.get("GGAD_RAMP")
+        if self.ramp is not None or env:
+            head = list(self.ramp) if self.ramp is not None else [int(x) for x in env.split(",") if x]
+        elif not self.overlap:
+            head = []
+        elif n_steps <= 3 * 8:
+            k = max(1, (n_steps + 2) // 3)           # short run: three chunks of about equal size
+            head = [k, k]
+        else:
+            head = [8, 16, 32, 64]
+        sizes, left = [], int(n_steps)
+        for k in head:
+            if left <= 0 or k >= self.chunk_batches:
+                break
+            sizes.append(min(k, left))
+            left -= sizes[-1]
+        while left > 0:
+            sizes.append(min(self.chunk_batches, left))
+            left -= sizes[-1]
+        return sizes
 
     def _make_streams(self, device, dense_cus: int):
         """(plan stream, dense stream).  dense_cus > 0: CU-masked HIP streams (dense chain on CUs [0, dense_cus), plan on
@@ -166,7 +186,6 @@ class DGraphTrainer:
                     raw.append(h.value)
                     out.append(torch.cuda.ExternalStream(h.value, device=device))
             self._raw_streams = raw
-            self.engine.persistent_wgs = dense_cus        # chain 3: one workgroup of the persistent kernel per dense CU
             return out[0], out[1]
         except ValueError:
             raise
@@ -201,28 +220,28 @@ class DGraphTrainer:
         th.start()
 
     def _stream_take(self, k: int):
+        """k batches of the running sampler stream (the producer delivers whole chunks; what a shorter request leaves over
+        is kept for the next one)."""
         st = self._stream
-        kk, item = st["q"].get()
-        if isinstance(item, BaseException):
-            self._stream = None
-            raise item
-        if kk != k:
-            raise RuntimeError(f"run_steps asked for a chunk of {k} steps, the stream produced {kk}: call run_steps with "
-                               "multiples of chunk_batches while a stream is running")
+        bn, bl = self._pending
+        while len(bn) < k:
+            kk, item = st["q"].get()
+            if isinstance(item, BaseException):
+                self._stream = None
+                raise item
+            bn = bn + item[0]
+            bl = bl + item[1]
+        self._pending = (bn[k:], bl[k:])
         st["left"] -= k
         if st["left"] <= 0:
             st["thread"].join()
             self._stream = None
-        return item
+        return bn[:k], bl[:k]
 
     def run_steps(self, n_steps: int, prepared: Optional[Tuple[List[np.ndarray], List[np.ndarray]]] = None,
                   gather_hook=None) -> int:
         """Run n optimiser steps; returns nodes processed by THIS rank."""
-        sizes = []
-        left = n_steps
-        while left > 0:
-            sizes.append(min(self.chunk_batches, left))
-            left -= sizes[-1]
+        sizes = self.default_ramp(n_steps)
         pos = [0]
 
         producer = None

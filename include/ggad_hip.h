@@ -59,8 +59,8 @@ int ggad_exclusive_scan_i32(const int32_t *in, int32_t *out, int64_t n, int32_t 
  *
  * A "chunk" is G batches processed together; rows = all batch nodes of the chunk
  * (batch g owns rows [batch_ptr[g], batch_ptr[g+1])).  Batch g uses counter slot g:
- * slot arrays are int32[G * n_nodes], must be all-zero on entry and are all-zero again
- * after ggad_mb_plan_reset.
+ * slot arrays are int32[G * n_nodes], all-zero on entry and all-zero again when
+ * ggad_mb_plan_build returns.
  *
  * Entry e (0 <= e < E) is one element j of the closed neighbourhood N(i)+{i} of row i
  * (graphsage.py:305), rows in order, columns ascending.  The "owner" entry of (batch, j)
@@ -68,23 +68,84 @@ int ggad_exclusive_scan_i32(const int32_t *in, int32_t *out, int64_t n, int32_t 
  * the deduplicated set U of graphsage.py:306 is { e : ent_own[e] == e }.
  * ---------------------------------------------------------------------------------- */
 
-/* row_r[i] = |N(i) + {i}|, row_slot[i] = batch (slot) of row i.          graphsage.py:305 */
-int ggad_mb_row_degree(const int32_t *rowptr, const int32_t *col, const int32_t *nodes, const int32_t *batch_ptr,
-                       int32_t n_batches, int32_t n_rows, int32_t *row_r, int32_t *row_slot, ggad_stream_t stream);
+/* ---- one chunk plan in ONE host call ------------------------------------------------------------------------------
+ * ggad_mb_plan_build replaces, for all batches of a chunk, what GCNAggregator.forward does per batch
+ * (src/graphsage.py:295-360): the closed-neighbourhood entry lists (:305-311), the column sums c_j / c'_k of the dense
+ * B x U and U x U2 masks (:315,:342), the set of distinct columns U (owner entries), the 1-hop aggregate
+ *   x1[i] = sum_{j in N(i)+{i}} feat[j] / (sqrt(r_i) sqrt(c_j))                                              (:314-326)
+ * and (train plans) the 2-hop aggregate at owner entries
+ *   x2[e] = sum_{k in N(u)} feat[k] / (sqrt(|N(u)|) sqrt(c'_k)),  u = ent_col[e]                              (:335-355).
+ * Host part (no device round trip): closed degrees -> entry offsets, the pieces of <= ggad_mb_chunk_len() consecutive
+ * entries every row is cut into (the unit of work of the entry-parallel kernels: a 2,000-neighbour hub row is 125
+ * independent pieces, not one wave's loop), the permutation "label-0 rows first" of graphsage.py:450 (pos_meta / row_pos,
+ * see ggad_mb_loss), all packed into ONE pinned staging block and uploaded with one copy.  Device part: k_expand
+ * (entries, c_j histogram, owner election) -> k_gather1c (x1 partials per piece, owner metadata, pair-count storage,
+ * per-node owner lists) -> k_combine1_reset (x1 of multi-piece rows; 1-hop counter slots back to zero) and, for train plans,
+ * the LDS-counting 2-hop stage: k_seg_transpose -> k_tile_counts -> k_build_groups -> k_gather2_items -> k_gather2_combine
+ * (hop2_ldsw.hip), or the device-atomic fallback k_count2 -> k_gather2 -> reset when a chunk exceeds the LDS path's limits
+ * (>= 65,536 entries in a batch, >= 2^31 2-hop pairs).  Every floating-point sum has a fixed order; which duplicate entry of
+ * (batch, column) becomes the owner is a race, owners are storage locations only (read through ent_own).
+ *
+ * All buffers are the caller's.  Slot arrays cnt1 / own1 (/ cnt2): int32[max_batches * n_nodes], cnt1 / cnt2 zero on entry
+ * and zero again on return.  Counters: int32[8].  The staging block holds, at the element offsets returned in the info
+ * struct: batch_ptr[nb+1], batch_ent_ptr[nb+1], nodes[R], labels[R], pos_meta[R], row_pos[R], row_slot[R], ent_ptr[R+1],
+ * row_ck_ptr[R+1], ck_rc[C], ck_e0[C]   (ck_rc[c] = (row << 6) | entries of piece c, ck_e0[c] = its first entry). */
+typedef struct ggad_mb_plan {
+  /* graph on the device: CSR, feature table (rows feat_stride floats apart), ldsw tile table (ggad_mb_tile_offsets) */
+  const int32_t *rowptr, *col;
+  const float *feat;
+  const int32_t *tile_off;
+  /* graph on the host: |N(i) + {i}| per node; sum_{k in N(i)+{i}} deg(k) per node (upper bound of the 2-hop pairs) */
+  const int32_t *closed_deg_host;
+  const int64_t *pair_bound_host;
+  /* staging: pinned host block, its device twin, an event of ggad_event_create guarding the host block */
+  int32_t *stage_host, *stage;
+  void *stage_event;
+  /* per-batch counter slots */
+  int32_t *cnt1, *own1, *cnt2;
+  /* per entry (ent_cap) */
+  int32_t *ent_col, *ent_slot, *ent_row, *ent_own, *ent_c1;
+  float *x1, *x2;
+  float *ck_part;            /* float[ck_cap * ck_part_stride]: per-piece partial sums (shared with the step kernels) */
+  /* LDS-counting 2-hop stage (train plans) */
+  int32_t *own_deg, *own_rp, *pw_base, *seg_t, *node_head, *own_next, *grp, *items, *counters;
+  uint16_t *pc;
+  float *part2;
+  void *ev_gather0, *ev_gather1; /* optional events recorded around the 2-hop gather launches (roofline timing) */
+  int64_t n_nodes, ent_cap, ck_cap, pair_cap, item_cap, part2_cap, stage_cap, seg_cap;
+  int32_t feat_dim, feat_stride, max_batches, rows_cap, ck_part_stride;
+  int32_t train;             /* 0: inference plan (1-hop only) */
+  int32_t hop2;              /* 1: LDS counting ("ldsw"), 2: device atomics ("global") */
+  int32_t node_major;        /* ldsw gather: occurrences of a node in the chunk share the fetch of its neighbour rows */
+  float mean_nbr_deg;        /* sum deg^2 / sum deg (memset vs walk when the global counters are cleared) */
+} ggad_mb_plan;
 
-/* Materialise entries (ent_ptr = exclusive scan of row_r), count c_j = number of rows of the
- * batch whose closed neighbourhood holds j (column sums of the dense mask, graphsage.py:315)
- * into cnt1[slot][j], elect owners into own1[slot][j]; ent_slot[e] = slot, ent_row[e] = row.   graphsage.py:305-311 */
-int ggad_mb_expand1(const int32_t *rowptr, const int32_t *col, const int32_t *nodes, const int32_t *row_slot,
-                    const int32_t *ent_ptr, int32_t n_rows, int64_t n_nodes, int32_t *ent_col, int32_t *ent_slot,
-                    int32_t *ent_row, int32_t *cnt1, int32_t *own1, ggad_stream_t stream);
+typedef struct ggad_mb_plan_info {
+  int64_t pair_bound;
+  int64_t off_batch_ptr, off_batch_ent_ptr, off_nodes, off_labels, off_pos_meta, off_row_pos, off_row_slot, off_ent_ptr,
+      off_row_ck_ptr, off_ck_rc, off_ck_e0;
+  /* capacities this chunk needs (also filled when the call returns GGAD_E_CAPACITY: grow and call again) */
+  int64_t need_rows, need_ents, need_chunks, need_pairs, need_items, need_part2, need_stage, need_seg;
+  int32_t n_batches, n_rows, n_ents, n_chunks;
+  int32_t mode;              /* 0 inference, 1 ldsw, 2 global */
+  int32_t need_cnt2;
+} ggad_mb_plan_info;
 
-/* ent_own[e], ent_c1[e] from the slot arrays, and the 1-hop aggregate
- * x1[i] = sum_j feat[j] / (sqrt(r_i) sqrt(c_j)).                        graphsage.py:314-326
- * feat rows are feat_stride floats apart (feat_stride == feat_dim for a plain table). */
-int ggad_mb_gather1(const float *feat, int32_t feat_dim, int32_t feat_stride, const int32_t *row_slot, const int32_t *ent_ptr,
-                    const int32_t *ent_col, int32_t n_rows, int64_t n_nodes, const int32_t *cnt1,
-                    const int32_t *own1, int32_t *ent_own, int32_t *ent_c1, float *x1, ggad_stream_t stream);
+int32_t ggad_mb_chunk_len(void);          /* 16 */
+int32_t ggad_mb_slice_len(void);          /* neighbours per work item of the 2-hop gather */
+int32_t ggad_mb_group_words(void);        /* ints per record of grp[] */
+/* nodes_host: the batches back to back; batch_ptr_host[nb+1]; labels_host (0/1, NULL for inference plans).  Host outputs
+ * (each may be NULL): ent_ptr_host_out[R+1], batch_ent_ptr_host_out[nb+1], batch_max_row_host_out[nb]. */
+int ggad_mb_plan_build(const ggad_mb_plan *plan, const int64_t *nodes_host, const int32_t *batch_ptr_host, int32_t n_batches,
+                       const int64_t *labels_host, ggad_mb_plan_info *info, int64_t *ent_ptr_host_out,
+                       int64_t *batch_ent_ptr_host_out, int32_t *batch_max_row_host_out, ggad_stream_t stream);
+
+/* HIP events through the C-ABI (timing of single launches on the stream they run on; guards of pinned staging memory). */
+int ggad_event_create(int32_t timing, void **out);
+int ggad_event_destroy(void *event);
+int ggad_event_record(void *event, ggad_stream_t stream);
+int ggad_event_synchronize(void *event);
+int ggad_event_elapsed_ms(void *start, void *stop, float *ms_host);
 
 /* out[i] = mean of feat rows over the explicit ragged list seg_col[seg_ptr[i] .. seg_ptr[i+1])
  * (MeanAggregator.forward with host-side sampling, graphsage.py:66-99). */
@@ -113,97 +174,31 @@ int ggad_recon_rows_f32(const float *a, const float *t, int64_t n_rows, int32_t 
 int ggad_ocgnn_loss_f32(const float *emb, const int64_t *idx, int64_t n_idx, int32_t h, const float *center, float r, float beta,
                         float *loss, float *score, float *demb, ggad_stream_t stream);
 
-/* The per-entry kernels below launch one wave per entry for n_entries_cap entries (a host-side
- * upper bound, e.g. sum(deg+1)) and read the true count from *ent_total (= ent_ptr[n_rows]).
- *
+/* Device-atomic 2-hop stage (fallback of ggad_mb_plan_build, exported for completeness).  One wave per entry for
+ * n_entries_cap entries (a host-side upper bound), true count read from *ent_total (= ent_ptr[n_rows]).
  * cnt2[slot][k] += 1 for every k in N(u), u an owner entry: column sums of the U x U2 mask
- * (graphsage.py:335-348; rows are adj_list.get(u) WITHOUT self union).
- *
- * PACKED layout (cnt2 == NULL): the feature table has rows of ggad_mb_packed_stride(F) floats (128-byte
- * aligned): F features followed by one int32 counter per slot; the counter of (slot, k) is word F + slot of
- * row k.  One random 128-byte line per gathered neighbour then delivers both x_k and c'_k (measured +48 %
- * rows/s over a separate counter array, scripts/gather_bench.hip).  At most stride - F slots per chunk. */
-/* Rows cut into pieces of <= ggad_mb_chunk_len() consecutive entries: row_ck_ptr[i] = first chunk of row i (n_rows + 1
- * values, exclusive scan), ck_rc[c] = (row << 6) | entries of chunk c, ck_e0[c] = its first entry.  nck_tmp: n_rows ints,
- * scan_ws: ggad_scan_workspace_elems(n_rows).  Capacity of ck_rc / ck_e0: total entries / chunk_len + n_rows. */
-int32_t ggad_mb_chunk_len(void);
-int ggad_mb_row_chunks(const int32_t *ent_ptr, int32_t n_rows, int32_t *nck_tmp, int32_t *row_ck_ptr, int32_t *ck_rc,
-                       int32_t *ck_e0, int32_t *scan_ws, ggad_stream_t stream);
-int ggad_mb_packed_stride(int32_t feat_dim);
+ * (graphsage.py:335-348; rows are adj_list.get(u) WITHOUT self union). */
 int ggad_mb_count2(const int32_t *rowptr, const int32_t *col, const int32_t *ent_col, const int32_t *ent_slot,
                    const int32_t *ent_total, int64_t n_entries_cap, int64_t n_nodes, const int32_t *own1,
-                   int32_t *cnt2, float *feat_packed, int32_t feat_dim, int32_t feat_stride, ggad_stream_t stream);
-
-/* 2-hop aggregate at owner entries:
- * x2[e] = sum_{k in N(u)} feat[k] / (sqrt(|N(u)|) sqrt(c'_k)).          graphsage.py:346-355
- * Dominant kernel of the path: HBM gather of feat rows, 4*F+8 algorithmic bytes per neighbour. */
+                   int32_t *cnt2, ggad_stream_t stream);
+/* x2[e] = sum_{k in N(u)} feat[k] / (sqrt(|N(u)|) sqrt(c'_k)) at owner entries.          graphsage.py:346-355 */
 int ggad_mb_gather2(const int32_t *rowptr, const int32_t *col, const float *feat, int32_t feat_dim, int32_t feat_stride,
                     const int32_t *ent_col, const int32_t *ent_slot, const int32_t *ent_own, const int32_t *ent_total,
                     int64_t n_entries_cap, int64_t n_nodes, const int32_t *cnt2, float *x2, ggad_stream_t stream);
-
-/* LDS-TILED 2-hop aggregation (hop2_tiled.hip): same result as ggad_mb_count2 + ggad_mb_gather2 without any
- * per-batch counter array in HBM.  Node ids are cut into tiles of ggad_mb_tile_size() = 65,536 ids; one
- * workgroup per batch walks the tiles, keeps c'_k of the current tile in LDS (16-bit counters, so every batch
- * must have < 65,536 owners) and reads each owner's neighbours of the tile as one contiguous piece of its CSR
- * row through tile_off[n_nodes][n_tiles + 1] (ggad_mb_tile_offsets with tile_shift 16, built once per graph;
- * int32 x ggad_mb_tile_offsets_elems(n_nodes, 16)).  x2 must be zero on entry.
- *   flags[e]     = 1 if entry e is an owner (ggad_mb_owner_flags)
- *   own_pos[]    = exclusive scan of flags (n_entries_cap + 1 values, ggad_exclusive_scan_i32)
- *   own_list[]   = workspace, n_entries_cap ints;  batch_ent_ptr[g] = first entry of batch g (n_batches + 1). */
-int ggad_mb_tile_size(void);
-int64_t ggad_mb_tile_offsets_elems(int64_t n_nodes, int32_t tile_shift);     /* tile = 1 << tile_shift node ids */
-int ggad_mb_tile_offsets(const int32_t *rowptr, const int32_t *col, int64_t n_nodes, int32_t tile_shift, int32_t *tile_off,
-                         ggad_stream_t stream);
-int ggad_mb_owner_flags(const int32_t *ent_own, const int32_t *ent_total, int64_t n_entries_cap, int32_t *flags,
-                        ggad_stream_t stream);
-int ggad_mb_hop2_tiled(const int32_t *rowptr, const int32_t *col, const float *feat, int32_t feat_dim, int32_t feat_stride,
-                       int64_t n_nodes, const int32_t *tile_off, const int32_t *flags, const int32_t *own_pos,
-                       int32_t *own_list, const int32_t *batch_ent_ptr, int32_t n_batches, const int32_t *ent_col,
-                       int64_t n_entries_cap, float *x2, ggad_stream_t stream);
-
-/* "LDSW" 2-hop (hop2_tiled.hip): device-scope atomics are capped at ~27 G/s on MI355X whatever their locality
- * (scripts/atomic_bench.hip), so counting goes to LDS: one workgroup per (32,768-id tile, batch) enumerates the
- * batch's pairs of that tile pair-parallel, counts them in 16-bit LDS counters and writes every pair's final count to
- * pc[] at the pair's position in its owner's CSR row (pw_base = exclusive scan of the owners' degrees); the gather then
- * streams pc[] and makes ONE random access per neighbour (the feature row).  tile_off must be built with
- * tile_shift = ggad_mb_ldsw_tile_shift(); every batch needs <= ggad_mb_ldsw_max_owners() owners.
- * Workspaces: own_deg[n_entries_cap], own_rp[n_entries_cap], pw_base[n_entries_cap + 1],
- * scan_ws[ggad_scan_workspace_elems(n_entries_cap)], seg_t[ggad_mb_ldsw_seg_elems(n_nodes, n_entries_cap)] (the owners'
- * tile_off rows transposed tile-major, so that a (tile, batch) workgroup reads its segment bounds as contiguous runs),
- * pc[sum of the owners' degrees]. */
-int ggad_mb_ldsw_tile_shift(void);
-int ggad_mb_ldsw_max_owners(void);
-int64_t ggad_mb_ldsw_seg_elems(int64_t n_nodes, int64_t n_entries_cap);     /* ints of seg_t */
-int ggad_mb_hop2_ldsw_count(const int32_t *rowptr, const int32_t *col, int64_t n_nodes, const int32_t *tile_off,
-                            const int32_t *flags, const int32_t *own_pos, int32_t *own_list, const int32_t *batch_ent_ptr,
-                            int32_t n_batches, const int32_t *ent_col, int64_t n_entries_cap, int32_t *own_deg,
-                            int32_t *own_rp, int32_t *pw_base, int32_t *scan_ws, int32_t *seg_t, uint16_t *pc,
-                            ggad_stream_t stream);
-/* node_head (int32[n_nodes], zero on entry and again on return) + own_next (int32[n_entries_cap]) + grp
- * (int32[8 * n_entries_cap + 1]): NODE-MAJOR gather -- a node that is an owner in several batches of the chunk (hubs:
- * ~B deg / N of them) has its neighbour rows fetched once for up to 8 occurrences, each with its own streamed counts
- * and accumulator; bit-identical to the per-owner kernel that runs when the three are NULL (or feat_dim > 64). */
-int ggad_mb_hop2_ldsw_gather(const int32_t *rowptr, const int32_t *col, const float *feat, int32_t feat_dim, int32_t feat_stride,
-                             const int32_t *own_pos, const int32_t *own_list, const int32_t *ent_col, int64_t n_entries_cap,
-                             const int32_t *pw_base, const uint16_t *pc, int32_t *node_head, int32_t *own_next, int32_t *grp,
-                             float *x2, ggad_stream_t stream);
-
-/* K-TILE-MAJOR 2-hop: same tables as ggad_mb_hop2_tiled but with the per-batch counters in HBM slots
- * (cnt2[n_slots][n_nodes], zero on entry) and the WORK ordered by tile: launch t touches only the counters and
- * feature rows of ids [t*65536, (t+1)*65536), so the working set of a launch stays in L2 / Infinity Cache. */
-int ggad_mb_hop2_ktile(const int32_t *rowptr, const int32_t *col, const float *feat, int32_t feat_dim, int32_t feat_stride,
-                       int64_t n_nodes, const int32_t *tile_off, const int32_t *flags, const int32_t *own_pos,
-                       int32_t *own_list, const int32_t *ent_col, const int32_t *ent_slot, int64_t n_entries_cap,
-                       int32_t *cnt2, float *x2, ggad_stream_t stream);
-
-/* Packed layout: zero the first n_slots counters of every feature row (streaming pass). */
-int ggad_mb_reset_packed(float *feat_packed, int64_t n_nodes, int32_t feat_dim, int32_t feat_stride, int32_t n_slots,
-                         ggad_stream_t stream);
-/* Restore the counter slots to zero by re-walking the chunk (with_hop2 = 0 for inference plans). */
+/* Restore the counter slots to zero by re-walking the chunk (with_hop2 = 0: only cnt1). */
 int ggad_mb_plan_reset(const int32_t *rowptr, const int32_t *col, const int32_t *ent_col, const int32_t *ent_slot,
                        const int32_t *ent_own, const int32_t *ent_total, int64_t n_entries_cap, int64_t n_nodes,
-                       int32_t *cnt1, int32_t *cnt2, int32_t with_hop2, float *feat_packed, int32_t feat_dim,
-                       int32_t feat_stride, ggad_stream_t stream);
+                       int32_t *cnt1, int32_t *cnt2, int32_t with_hop2, ggad_stream_t stream);
+
+/* Static per-node table of the LDS-counting 2-hop stage: tile_off[u][t] = offset inside u's sorted CSR row of its first
+ * neighbour with id >= t << ggad_mb_ldsw_tile_shift() (t = 0 .. n_tiles): the neighbours of u inside a tile of 32,768 ids are
+ * one contiguous piece of its row.  int32 x ggad_mb_tile_offsets_elems(n_nodes, shift), built once per graph. */
+int ggad_mb_ldsw_tile_shift(void);
+int ggad_mb_ldsw_max_owners(void);          /* entries of a batch one pass of the LDS tables holds (more: walked in slabs) */
+int64_t ggad_mb_tile_offsets_elems(int64_t n_nodes, int32_t tile_shift);
+int ggad_mb_tile_offsets(const int32_t *rowptr, const int32_t *col, int64_t n_nodes, int32_t tile_shift, int32_t *tile_off,
+                         ggad_stream_t stream);
+int64_t ggad_mb_ldsw_seg_elems(int64_t n_nodes, int64_t n_entries_cap);     /* ints of seg_t */
 
 /* ------------------------------------------------------------------------------------
  * Mini-batch path: dense step = GCNEncoder.forward + GCN.loss + backward + Adam
@@ -273,9 +268,7 @@ int ggad_mb_adam(float *params, float *exp_avg, float *exp_avg_sq, const float *
 
 /* Whole training step of one batch in one host call.  chain 0 (default): fwd_rows_v (h2 = relu(W x2) computed by the
  * row's workgroup, F == 17) or project -> fwd_rows, then loss_pos -> loss_rows -> bwd_flat -> grad_reduce (5 or 6
- * launches); chain 2: always 6.  chain 1 (F == 17): THREE launches, one workgroup per batch row -- k_fwd_rows_x (h2
- * recomputed per entry), k_loss_bwd_rows (all positions of the batch evaluated from LDS tiles in every workgroup, then
- * the row's backward coefficients and its dW partial), k_grad_reduce; same results, measured slower (step.hip).
+ * launches); chain 2: always 6.
  * Adam is fused into the last launch when fuse_adam != 0 (single GPU); with fuse_adam == 0 the caller all-reduces
  * `grads` and then calls ggad_mb_adam.  All members are device pointers. */
 typedef struct ggad_mb_step {
@@ -288,9 +281,9 @@ typedef struct ggad_mb_step {
   int32_t D, F, row0, n_rows, ent0, n_ents;
   float lr, weight_decay;
   int32_t chain;          /* 0 (default): 5 launches when F == 17 and the batch has no hub row (projection fused into the
-                             forward-rows kernel, h2 per ENTRY), else 6; 2: always 6; 1: row-wise 3-launch chain, F == 17 */
+                             forward-rows kernel, h2 per ENTRY), else 6; 2: always 6 */
   int32_t max_row_entries; /* largest closed neighbourhood among the batch rows (host knowledge; 0 = unknown -> 6 launches) */
-  /* optional (all four or none): row-chunk tables of the PLAN (ggad_mb_row_chunks over all rows of the chunk) and the
+  /* optional (all four or none): row-piece tables of the PLAN (staging block of ggad_mb_plan_build) and the
    * partial-sum buffer, float[(chunks of the plan) * 64].  With them a chain-0 batch that holds a hub row takes the
    * chunk-parallel forward (k_fwd_chunks + k_loss_pos_ck: 5 launches, h2 not stored, relu mask recomputed in bwd_flat) instead
    * of project -> fwd_rows -> loss_pos (6 launches). */
@@ -312,24 +305,6 @@ int ggad_mb_train_chunk(const ggad_mb_step *tmpl, int32_t n_batches, const int32
 int ggad_mb_train_chunk_dp(const ggad_mb_step *tmpl, int32_t n_batches, const int32_t *batch_ptr, const int64_t *batch_ent_ptr,
                            const int32_t *batch_max_row, float *loss_log, int32_t log_base, float grad_scale,
                            int (*exchange)(void *), void *user, ggad_stream_t stream);
-
-/* The same per-batch loop as ggad_mb_train_chunk inside ONE persistent launch (single GPU, F == 17, at most
- * ggad_mb_persistent_max_rows() rows per batch): n_workgroups x 512 threads loop over the batches, five phases per batch
- * separated by grid barriers (a relaxed agent-scope atomic add + poll per workgroup); everything a later phase reads from
- * another wave is exchanged with write-through stores / L1-bypassing loads (step_persistent.hip).  ALL n_workgroups workgroups
- * must be resident at once: pass at most the number of compute units of `stream` (one workgroup per CU).  Rows are cut into
- * chunks of ggad_mb_persistent_chunk_len() entries; max_chunks >= the largest per-batch sum of ceil(row entries / that).
- * batch_ptr_dev / batch_ent_ptr_dev: DEVICE arrays of n_batches + 1 int32 offsets (rows, entries).  tmpl->h2, dw_part, loss_ws
- * and max_row_entries are not used (the relu mask of the 2-hop projection is recomputed in the backward phase).
- * workspace: ggad_mb_persistent_ws_elems(max_chunks, n_workgroups) floats.  Deterministic; agrees with the launch chain to
- * fp32 round-off (other, fixed summation order of the row sums and partial reductions).  Measured against the launch
- * chain on MI355X at best equal (41.9 vs 42 us per step alone, 51 vs 51-55 us in bench.py, slower on sparse graphs): an opt-in variant (chain 3 of the Python engine), not the default. */
-int32_t ggad_mb_persistent_chunk_len(void);
-int32_t ggad_mb_persistent_max_rows(void);
-int64_t ggad_mb_persistent_ws_elems(int32_t max_chunks, int32_t n_workgroups);
-int ggad_mb_train_chunk_persistent(const ggad_mb_step *tmpl, int32_t n_batches, const int32_t *batch_ptr_dev,
-                                   const int32_t *batch_ent_ptr_dev, int32_t max_rows, int32_t max_chunks, int32_t n_workgroups,
-                                   float *loss_log, int32_t log_base, float *workspace, ggad_stream_t stream);
 
 /* Inference embeddings: h[i] = relu(W x1[i])  (GCNEncoder.forward, train_flag False).   graphsage.py:412 */
 int ggad_mb_encode(const float *params, int32_t D, int32_t F, const float *x1, int32_t n_rows, float *h,

@@ -1,0 +1,36 @@
+"""Plan kernels alone on the chip at several chunk sizes (run under rocprofv3 --kernel-trace; scripts/rocpd_stats.py reduces the
+trace).  Usage: python scripts/plan_kernel_times.py 7,20,150 [reps]"""
+import random
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, __file__.rsplit('/', 2)[0])
+from ggad_amd import synth  # noqa: E402
+from ggad_amd.dgraph import normalize_features, split_dgraphfin  # noqa: E402
+from ggad_amd.graph import DeviceGraph  # noqa: E402
+from ggad_amd.minibatch import BatchChunk  # noqa: E402
+from ggad_amd.sampler import PyCompatRandom  # noqa: E402
+from ggad_amd.trainer import BatchSchedule  # noqa: E402
+
+sizes = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "7,20,150").split(",")]
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+dev = torch.device('cuda:0')
+n, ne = 3_700_550, 73_105_508
+rp, ci = synth.make_graph_torch(n, ne, 72, dev, max_degree=2000)
+g = DeviceGraph(rp, ci, dev)
+feat = torch.from_numpy(normalize_features(synth.make_features(n, 17, 72)).astype(np.float32)).to(dev)
+table = torch.zeros(n, 32, dtype=torch.float32, device=dev)
+table[:, :17] = feat
+lab = synth.make_labels(n, 15509.0 / 3700550.0, 72).astype(np.int32)
+sp = split_dgraphfin(lab, 72, with_test=False)
+sched = BatchSchedule(sp['idx_train'], sp['idx_anomaly'], sp['labels'], 150, PyCompatRandom.from_python_state(random.getstate()))
+ch = BatchChunk(g, table, 64, 150, 150 * 200, 1 << 20, train=True, feat_dim=17, hop2="ldsw")
+for k in sizes:
+    for rep in range(reps):
+        bn, bl = sched.next_batches(k)
+        ch.build(bn, bl)
+        torch.cuda.synchronize()
+        print("chunk", k, "rows", ch.n_rows, "entries", ch.n_ents, "items", int(ch.counters[1]), "groups", int(ch.counters[0]),
+              "partial slots", int(ch.counters[2]), "pairs", int(ch.counters[4]), flush=True)

@@ -60,12 +60,26 @@ def test_csr_cache_round_trip(tmp_path):
     rowptr, col = synth.make_graph(500, 4000, 3, kind="powerlaw", max_degree=40)
     adj = synth.csr_to_adj_lists(rowptr, col)
     path = str(tmp_path / "adj.csr.npz")
-    g1 = DeviceGraph.from_adj_lists_cached(adj, 500, "cpu", path)
-    g2 = DeviceGraph.from_adj_lists_cached(None, 500, "cpu", path)          # served from the cache: the dict is not touched
+    src = str(tmp_path / "adj_list.pickle")
+    open(src, "wb").write(b"x" * 100)                                        # stands for the pickle the dict came from
+    g1 = DeviceGraph.from_adj_lists_cached(adj, 500, "cpu", path, source_path=src)
+    g2 = DeviceGraph.from_adj_lists_cached(None, 500, "cpu", path, source_path=src)   # served from the cache: the dict is not touched
     assert np.array_equal(g1.rowptr_host, rowptr) and np.array_equal(g1.col_host, col)
     assert np.array_equal(g2.rowptr_host, rowptr) and np.array_equal(g2.col_host, col)
     g3 = DeviceGraph.from_adj_lists_cached(adj, 400 + 100, "cpu", str(tmp_path / "missing" / "x.npz"))   # unwritable: still works
     assert g3.nnz == g1.nnz
+    # a regenerated adjacency with the same node count must not be served from the stale cache (fingerprint of the source)
+    rowptr2, col2 = synth.make_graph(500, 3000, 4, kind="powerlaw", max_degree=40)
+    adj2 = synth.csr_to_adj_lists(rowptr2, col2)
+    open(src, "wb").write(b"y" * 137)
+    g4 = DeviceGraph.from_adj_lists_cached(adj2, 500, "cpu", path, source_path=src)
+    assert np.array_equal(g4.rowptr_host, rowptr2) and np.array_equal(g4.col_host, col2)
+    g5 = DeviceGraph.from_adj_lists_cached(adj, 500, "cpu", path)             # no source file: keyed by the dict's counts
+    assert np.array_equal(g5.col_host, col)
+    # a truncated cache file (a rank killed mid-write under the old fixed temporary name) is ignored, not fatal
+    open(path, "wb").write(open(path, "rb").read()[:200])
+    g6 = DeviceGraph.from_adj_lists_cached(adj, 500, "cpu", path)
+    assert np.array_equal(g6.col_host, col)
 
 
 def test_load_mat_split_equals_reference(tmp_path, capsys):

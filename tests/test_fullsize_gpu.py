@@ -100,11 +100,11 @@ def test_power_of_two_scaling_is_exact_over_the_whole_chunk(full):
     assert ch2.n_ents == ch.n_ents and ch2.last_hop2 == "ldsw"
     a1, b1 = ch.x1[:ch.n_rows * F], ch2.x1[:ch.n_rows * F]
     assert torch.equal((a1 * 2.0).view(torch.int32), b1.view(torch.int32))
-    n_own = int(ch.own_pos[ch.n_ents].item())
-    assert n_own == int(ch2.own_pos[ch2.n_ents].item()) and n_own > 500000      # ~4 K distinct columns per batch
+    n_own = int(ch.owner_entries().numel())
+    assert n_own == int(ch2.owner_entries().numel()) and n_own > 500000         # ~4 K distinct columns per batch
     # owner election is a race between duplicate entries of a batch: compare per (batch, column)
     def keyed(c):
-        own = c.own_list[:n_own].long()
+        own = c.owner_entries()
         bnd = torch.as_tensor(c.ent_ptr_host[c.batch_ptr_host][1:], device=DEV)
         k = torch.bucketize(own, bnd, right=True) * N + c.ent_col[own].long()
         o = torch.argsort(k)

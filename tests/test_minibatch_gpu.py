@@ -22,7 +22,7 @@ from oracle import ggad_oracle as O
 DEV = "cuda:0"
 
 
-def _setup(g, train=True, max_batches=8, hop2="tiled"):
+def _setup(g, train=True, max_batches=8, hop2="ldsw"):
     graph = DeviceGraph(g["rowptr"], g["col"], DEV)
     feat = torch.from_numpy(np.ascontiguousarray(g["feat"])).to(DEV)
     d = int(g["d"])
@@ -79,7 +79,7 @@ def _check_plan_against_oracle(g, ch, batches, feat_np, atol=2e-6):
                                        err_msg=f"x2 batch {b}")
 
 
-@pytest.mark.parametrize("hop2", ["ldsw", "tiled", "ktile", "global"])
+@pytest.mark.parametrize("hop2", ["ldsw", "global"])
 @pytest.mark.parametrize("name", ["minibatch_small.npz", "minibatch_dense.npz"])
 def test_plan_matches_golden_and_oracle(name, hop2):
     g = load_golden(name)
@@ -102,8 +102,7 @@ def test_plan_matches_golden_and_oracle(name, hop2):
     owner_of = {int(ent_col[e]): int(ent_own[e]) for e in range(e0, e1)}
     got = np.stack([x2[owner_of[int(u)]] for u in g["agg_unique"]])
     np.testing.assert_allclose(got, g["agg_to_feats_neigh"], atol=2e-6, rtol=0)
-    # slots are clean again after reset
-    ch.reset()
+    # the plan leaves its counter slots clean
     torch.cuda.synchronize()
     assert ch.last_hop2 == hop2
     assert int(ch.cnt1.abs().sum()) == 0 and (ch.cnt2 is None or int(ch.cnt2.abs().sum()) == 0)
@@ -169,7 +168,6 @@ def test_to_prob_vs_golden(name):
     out = torch.empty(len(nodes), dtype=torch.float32, device=DEV)
     eng.score_chunk(ch, out)
     np.testing.assert_allclose(out.cpu().numpy(), g["test_probs"], atol=2e-6, rtol=0)
-    ch.reset()
     torch.cuda.synchronize()
     assert int(ch.cnt1.abs().sum()) == 0
 
@@ -193,7 +191,7 @@ def _random_case(n, n_entries, f, d, seed, nb, bsz, n_ano):
     return dict(rowptr=rowptr, col=col, feat=feat, f=f, d=d), batches, labels
 
 
-@pytest.mark.parametrize("hop2", ["ldsw", "tiled", "ktile", "global"])
+@pytest.mark.parametrize("hop2", ["ldsw", "global"])
 @pytest.mark.parametrize("f,d", [(17, 64), (9, 32), (40, 64), (70, 48)])
 def test_random_graph_vs_oracle(f, d, hop2):
     g, batches, labels = _random_case(n=20000, n_entries=160000, f=f, d=d, seed=21 + f, nb=3, bsz=200, n_ano=50)
@@ -230,16 +228,16 @@ def test_random_graph_vs_oracle(f, d, hop2):
 
 
 @pytest.mark.parametrize("d,bsz,n_ano", [(64, 200, 50), (32, 333, 77), (48, 23, 5)])
-def test_rowwise_chain_equals_six_launch_chain(d, bsz, n_ano):
-    """Chain 0 (projection fused into the forward-rows kernel), the 6-launch chain 2 and the 3-launch row-wise chain 1
-    compute the same losses, gradients and Adam trajectory up to summation order; oracle check."""
+def test_fused_forward_chain_equals_six_launch_chain(d, bsz, n_ano):
+    """Chain 0 (projection fused into the forward-rows kernel) and the generic 6-launch chain 2 compute the same losses,
+    gradients and Adam trajectory up to summation order; oracle check."""
     g, batches, labels = _random_case(n=12000, n_entries=150000, f=17, d=d, seed=31 + d, nb=3, bsz=bsz, n_ano=n_ano)
     torch.manual_seed(d)
     w = torch.nn.init.xavier_uniform_(torch.empty(1, d))
     W = torch.nn.init.xavier_uniform_(torch.empty(d, 17))
     fc = torch.nn.init.xavier_uniform_(torch.empty(d, d))
     res = {}
-    for chain in (0, 1, 2):
+    for chain in (0, 2):
         graph, feat, ch = _setup(g, max_batches=3, hop2="ldsw")
         eng = MiniBatchEngine(17, d, DEV, chain=chain)
         eng.load_params(w, W, fc)
@@ -258,16 +256,15 @@ def test_rowwise_chain_equals_six_launch_chain(d, bsz, n_ano):
     np.testing.assert_allclose(res[0][0], res[2][0], atol=1e-6, rtol=1e-5)
     np.testing.assert_allclose(res[0][1], res[2][1], atol=1e-6, rtol=0)
     np.testing.assert_allclose(res[0][2], res[2][2], atol=1e-6, rtol=0)
-    np.testing.assert_allclose(res[0][0], res[1][0], atol=2e-6, rtol=2e-5)
-    np.testing.assert_allclose(res[0][1], res[1][1], atol=2e-6, rtol=0)
-    np.testing.assert_allclose(res[0][2], res[1][2], atol=2e-6, rtol=0)
     p = O.MiniParams(w.clone().requires_grad_(), W.clone().requires_grad_(), fc.clone().requires_grad_())
     agg = O.aggregate_batch(g["rowptr"], g["col"], g["feat"], batches[0], True)
     tot, cls, mar, rec = O.batch_loss(p, agg, labels[0])
     tot.backward()
     ref = np.concatenate([t.grad.numpy().reshape(-1) for t in p.tensors()])
-    np.testing.assert_allclose(res[1][0][0], ref, atol=3e-6, rtol=2e-5)
-    np.testing.assert_allclose(res[1][1][0], [tot.item(), cls.item(), mar.item(), rec.item()], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(res[2][0][0], ref, atol=3e-6, rtol=2e-5)
+    np.testing.assert_allclose(res[2][1][0], [tot.item(), cls.item(), mar.item(), rec.item()], atol=1e-5, rtol=0)
+    with pytest.raises(ValueError):
+        MiniBatchEngine(17, d, DEV, chain=1)
 
 
 def test_rebuild_reuses_clean_slots():
@@ -303,34 +300,8 @@ def test_fused_adam_chunk_equals_stepwise():
         np.testing.assert_array_equal(outs[0][1], o[1])
 
 
-@pytest.mark.parametrize("f,reset_mode", [(17, "memset"), (17, "walk"), (9, "auto"), (40, "auto")])
-def test_packed_feature_rows_layout(f, reset_mode):
-    """2-hop counters inside 128-byte feature rows (ggad_mb_packed_stride): same results as the oracle, rows restored."""
-    from ggad_amd.minibatch import pack_features
-    g, batches, labels = _random_case(n=20000, n_entries=160000, f=f, d=32, seed=60 + f, nb=3, bsz=200, n_ano=50)
-    graph = DeviceGraph(g["rowptr"], g["col"], DEV)
-    plain = torch.from_numpy(np.ascontiguousarray(g["feat"])).to(DEV)
-    table = pack_features(plain)
-    stride = table.shape[1]
-    assert stride % 32 == 0 and stride > f
-    ch = BatchChunk(graph, table, 32, max_batches=min(4, stride - f), rows_cap=64, ent_cap=64, train=True,
-                    reset_mode=reset_mode, feat_dim=f)
-    assert ch.packed and ch.cnt2 is None
-    for rep in range(2):
-        ch.build(batches, labels)
-        torch.cuda.synchronize()
-        _check_plan_against_oracle(g, ch, batches, g["feat"], atol=3e-6)
-    ch.reset()
-    torch.cuda.synchronize()
-    assert torch.equal(table[:, :f], plain)                                   # features untouched
-    assert int(table[:, f:].view(torch.int32).abs().sum()) == 0               # every counter word back to zero
-    assert int(ch.cnt1.abs().sum()) == 0
-    with pytest.raises(ValueError):
-        BatchChunk(graph, table, 32, max_batches=stride - f + 1, rows_cap=64, ent_cap=64, train=True, feat_dim=f)
-
-
-def test_tiled_hop2_many_tiles_and_isolated_owner():
-    """> 1 tile of 65,536 ids (n = 150k -> 3 tiles), hub rows spanning all tiles, and a node whose only neighbour is a
+def test_hop2_many_tiles_and_isolated_owner():
+    """> 1 tile of 32,768 ids (n = 150k -> 5 tiles), hub rows spanning all tiles, and a node whose only neighbour is a
     self loop removed: deg-0 owners must come out NaN like the dense 0/0 row of the reference (quirk 3)."""
     n = 150000
     rowptr, col = synth.make_graph(n, 1500000, 5, kind="powerlaw", max_degree=1500)
@@ -344,7 +315,7 @@ def test_tiled_hop2_many_tiles_and_isolated_owner():
         nodes[0] = hub
         lab = np.zeros(200, dtype=np.int64); lab[150:] = 1
         batches.append(nodes); labels.append(lab)
-    for hop2 in ("ldsw", "tiled", "ktile", "global"):
+    for hop2 in ("ldsw", "global"):
         graph, ft, ch = _setup(g, max_batches=3, hop2=hop2)
         ch.build(batches, labels)
         torch.cuda.synchronize()
@@ -353,7 +324,7 @@ def test_tiled_hop2_many_tiles_and_isolated_owner():
 
 
 def test_ldsw_hop2_owner_slabs_and_padded_rows():
-    """"ldsw" with a batch of > 6,144 owners (the LDS tables are walked in slabs), several 32,768-id tiles, and the
+    """"ldsw" with a batch of > 6,144 entries (the LDS tables are walked in slabs), several 32,768-id tiles, and the
     128-byte padded feature rows the trainer hands it: x2 must equal the global-counter path bit for bit per owner
     up to summation order, and the oracle within 2e-5 (hub rows)."""
     n = 120000
@@ -374,19 +345,18 @@ def test_ldsw_hop2_owner_slabs_and_padded_rows():
     ch = BatchChunk(graph, table, 64, max_batches=2, rows_cap=64, ent_cap=64, train=True, feat_dim=17, hop2="ldsw")
     ch.build(batches, labels)
     torch.cuda.synchronize()
-    assert ch.last_hop2 == "ldsw" and not ch.packed
-    n_own = int(ch.own_pos[ch.n_ents].item())
-    per_batch = [int(ch.own_pos[ch.batch_ents(b)[1]].item()) - int(ch.own_pos[ch.batch_ents(b)[0]].item()) for b in range(2)]
-    assert max(per_batch) > _lib.load().ggad_mb_ldsw_max_owners() and sum(per_batch) == n_own
+    assert ch.last_hop2 == "ldsw"
+    own = ch.owner_entries()
+    per_batch = [int(((own >= ch.batch_ents(b)[0]) & (own < ch.batch_ents(b)[1])).sum()) for b in range(2)]
+    assert max(per_batch) > _lib.load().ggad_mb_ldsw_max_owners() and sum(per_batch) == own.numel()
     _check_plan_against_oracle(g, ch, batches, feat, atol=2e-5)       # 3,000-neighbour hub rows: values up to ~2.5
     ref = BatchChunk(graph, torch.from_numpy(feat).to(DEV), 64, max_batches=2, rows_cap=64, ent_cap=64, train=True, hop2="global")
     ref.build(batches, labels)
     torch.cuda.synchronize()
-    own = ch.own_list[:n_own].long()
     a = ch.x2.view(-1, 17)[own]
     b_ = ref.x2.view(-1, 17)[ref.ent_own[own].long()]      # owner election is a race: same column, maybe another entry
     assert torch.allclose(a, b_, rtol=1e-5, atol=1e-6, equal_nan=True)    # same sums, weights rounded once more or less
-    ch.reset(); ch.build(batches[:1], labels[:1])           # rebuild after reset: counters clean, same rows again
+    ch.build(batches[:1], labels[:1])                       # rebuild: counters clean, same rows again
     torch.cuda.synchronize()
     _check_plan_against_oracle(g, ch, batches[:1], feat, atol=2e-5)
 
@@ -396,25 +366,26 @@ def test_ldsw_falls_back_to_global_counters():
     the device-atomic 2-hop kernels; same results, counters reset, and the next chunk goes back to "ldsw"."""
     g, batches, labels = _random_case(n=9000, n_entries=70000, f=17, d=64, seed=77, nb=3, bsz=120, n_ano=30)
     graph, feat, ch = _setup(g, max_batches=3, hop2="ldsw")
-    real = graph.pair_bound_host
-    graph.__dict__["_pair_bound"] = np.full_like(real, 1 << 27)
+    bound = graph.pair_bound_host                 # the table the native plan builder reads: overwritten in place
+    real = bound.copy()
+    bound[:] = 1 << 27
     ch.build(batches, labels)
     torch.cuda.synchronize()
     assert ch.last_hop2 == "global"
     _check_plan_against_oracle(g, ch, batches, g["feat"], atol=3e-6)
-    graph.__dict__["_pair_bound"] = real
-    ch.build(batches, labels)                     # build() resets the global counters of the previous plan first
+    assert int(ch.cnt1.abs().sum()) == 0 and int(ch.cnt2.abs().sum()) == 0       # the fallback cleans both counter families
+    bound[:] = real
+    ch.build(batches, labels)
     torch.cuda.synchronize()
     assert ch.last_hop2 == "ldsw"
     _check_plan_against_oracle(g, ch, batches, g["feat"], atol=3e-6)
-    ch.reset()
     assert int(ch.cnt1.abs().sum()) == 0 and int(ch.cnt2.abs().sum()) == 0
 
 
 def test_ldsw_node_major_gather_bit_identical():
-    """A hub that is an owner in 11 of 12 batches (two groups: 8 + 3 occurrences), nodes shared by 2 / 4 batches and
-    single occurrences: the node-major gather must equal the per-owner kernel bit for bit, leave node_head clean, and
-    match the oracle."""
+    """A hub (900 neighbours = 4 slices) that is an owner in 11 of 12 batches (two groups: 8 + 3 occurrences), nodes shared
+    by 2 / 4 batches and single occurrences: the node-major gather (work items = group x slice, partial sums combined in
+    slice order) must equal the per-owner kernel bit for bit, leave node_head clean, and match the oracle."""
     n = 60000
     rowptr, col = synth.make_graph(n, 600000, 13, kind="powerlaw", max_degree=900)
     feat = O.normalize_rows(synth.make_features(n, 17, 13)).astype(np.float32)
@@ -441,8 +412,7 @@ def test_ldsw_node_major_gather_bit_identical():
         ch.build(batches, labels)
         torch.cuda.synchronize()
         assert ch.last_hop2 == "ldsw"
-        n_own = int(ch.own_pos[ch.n_ents].item())
-        own = ch.own_list[:n_own].long()
+        own = ch.owner_entries()
         outs.append((ch.ent_col[own].clone(), torch.div(own, 1, rounding_mode="floor"), ch.x2.view(-1, 17)[own].clone()))
         if nm:
             assert int(ch.node_head.abs().sum()) == 0
@@ -488,56 +458,6 @@ def test_overlapped_chunks_equal_serial_execution():
     for o in outs[1:]:        # side-stream planning (CU-masked or plain streams) and the sampler thread change nothing
         np.testing.assert_array_equal(outs[0][0], o[0])
         np.testing.assert_array_equal(outs[0][1], o[1])
-
-
-@pytest.mark.parametrize("d,bsz,n_ano,wgs", [(64, 200, 50, 64), (32, 150, 40, 7), (48, 23, 5, 64), (64, 256, 64, 16)])
-def test_persistent_chunk_kernel_equals_launch_chain_and_oracle(d, bsz, n_ano, wgs):
-    """chain 3: all optimiser steps of a chunk in ONE persistent launch (grid barriers between the six phases of a step,
-    write-through hand-offs) against the 5/6-launch chain (same results up to the summation order of the row sums) and
-    against the oracle's autograd + torch Adam; hub rows (hundreds of 16-entry chunks), ragged last batch, few / many
-    workgroups, bit-deterministic."""
-    g, batches, labels = _random_case(n=30000, n_entries=300000, f=17, d=d, seed=5 + d, nb=7, bsz=bsz, n_ano=n_ano)
-    order = np.argsort(-np.diff(g["rowptr"]))
-    batches[2][:3] = order[:3]                                  # hub rows in one batch
-    batches[6], labels[6] = batches[6][:bsz - 9], labels[6][:bsz - 9]   # ragged
-    graph, feat, ch = _setup(g, max_batches=8, hop2="ldsw")
-    ch.build(batches, labels)
-    torch.cuda.synchronize()
-    torch.manual_seed(d)
-    w = torch.nn.init.xavier_uniform_(torch.empty(1, d))
-    W = torch.nn.init.xavier_uniform_(torch.empty(d, 17))
-    fc = torch.nn.init.xavier_uniform_(torch.empty(d, d))
-    runs = {}
-    for name, chain in (("launch", 0), ("pers", 3), ("pers2", 3)):
-        eng = MiniBatchEngine(17, d, DEV, lr=1e-3, weight_decay=0.007, chain=chain)
-        eng.persistent_wgs = wgs
-        eng.load_params(w, W, fc)
-        eng.train_chunk(ch)
-        torch.cuda.synchronize()
-        runs[name] = (eng.loss_log[:8 * 7].view(7, 8).cpu().numpy().copy(), eng.params.cpu().numpy().copy(),
-                      eng.exp_avg.cpu().numpy().copy(), eng.exp_avg_sq.cpu().numpy().copy(), int(eng.step_counter.item()),
-                      eng.grads.cpu().numpy().copy())
-    assert runs["pers"][4] == runs["launch"][4] == 7
-    for k in (0, 1, 2, 3, 5):
-        assert np.array_equal(runs["pers"][k], runs["pers2"][k]), k                      # deterministic
-    np.testing.assert_allclose(runs["pers"][0], runs["launch"][0], atol=2e-5, rtol=1e-5)  # all 8 logged scalars per step
-    np.testing.assert_allclose(runs["pers"][1], runs["launch"][1], atol=1e-5, rtol=0)
-    np.testing.assert_allclose(runs["pers"][2], runs["launch"][2], atol=1e-6, rtol=1e-4)
-    np.testing.assert_allclose(runs["pers"][5], runs["launch"][5], atol=3e-6, rtol=1e-4)
-    # the oracle's trajectory
-    p = O.MiniParams(w.clone().requires_grad_(), W.clone().requires_grad_(), fc.clone().requires_grad_())
-    opt = O.make_adam(p.tensors(), 1e-3, 0.007)
-    ref_losses = []
-    for b in range(7):
-        agg = O.aggregate_batch(g["rowptr"], g["col"], g["feat"], batches[b], True)
-        opt.zero_grad()
-        tot, cls, mar, rec = O.batch_loss(p, agg, labels[b])
-        tot.backward()
-        ref_losses.append([tot.item(), cls.item(), mar.item(), rec.item()])
-        opt.step()
-    np.testing.assert_allclose(runs["pers"][0][:, :4], np.array(ref_losses), atol=2e-5, rtol=0)
-    ref_p = np.concatenate([t.detach().numpy().reshape(-1) for t in p.tensors()])
-    np.testing.assert_allclose(runs["pers"][1][:len(ref_p)], ref_p, atol=2e-5, rtol=0)
 
 
 def test_chunk_parallel_forward_on_hub_batches_equals_six_launch_chain():
