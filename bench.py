@@ -256,7 +256,7 @@ def main():
                 # with overlap the launches run on the plan stream's CU partition while the dense chain of the previous
                 # chunk runs on the other CUs (the first chunk of a run has nothing to overlap with)
                 "concurrent_with_dense_chain": overlapped,
-                "cus": (256 - a.dense_cus) if (trainer.overlap and a.dense_cus > 0) else 256}
+                "cus": (256 - a.dense_cus) if (overlapped and a.dense_cus > 0) else 256}
 
     # ---------------- extra legs (single GPU): steady state, end to end with the sampler, the full-graph programs
     extras = {}

@@ -267,6 +267,8 @@ def _reorder_layer(x: torch.Tensor, weight: torch.Tensor) -> bool:
 
 def cached_aggregate(adj: "FullGraphAdj", x: torch.Tensor) -> torch.Tensor:
     """A_hat X for a constant X (N x F), computed once per (X storage, version) with the SpMM kernel on zero-padded columns."""
+    # the cache entry keeps a reference to the tensor: its storage stays alive, so the caching allocator cannot hand the same
+    # address (with version 0) to another tensor of the same shape while the entry exists
     key = (x.data_ptr(), x._version, tuple(x.shape))
     hit = adj._ax.get("key") == key
     if not hit:
@@ -275,7 +277,7 @@ def cached_aggregate(adj: "FullGraphAdj", x: torch.Tensor) -> torch.Tensor:
         xp = x if fp == f else torch.cat((x, torch.zeros(x.shape[0], fp - f, device=x.device)), 1)
         with torch.no_grad():
             ax = spmm(adj.A, xp.contiguous())
-        adj._ax = {"key": key, "ax": ax[:, :f].contiguous()}
+        adj._ax = {"key": key, "x": x, "ax": ax[:, :f].contiguous()}
     return adj._ax["ax"]
 
 

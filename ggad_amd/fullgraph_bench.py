@@ -1,0 +1,166 @@
+"""Synthetic full-graph configs at the published sizes, and their measurement (shared by run.py, bench.py and the full-size tests).
+
+No dataset ships with this repo (reference `README.md:45-48`): `make_dataset` builds, from the seed, a symmetric power-law graph with
+EXACTLY the published number of directed entries (`synth.make_graph(exact=True)`), U[0,1) features, Bernoulli anomaly labels at the
+published rate, and then follows `run.py:84-110` of the reference: `split_nodes` (python `random`), `preprocess_features` for the
+datasets the reference normalises (`run.py:87`: not Photo, and -- a typo there -- not T-Finance), the noise parameters of `run.py:61-66`.
+
+`bench_fullgraph` times the training epoch of `run.py:142-214` (forward, loss block, backward, Adam) per config and the two kernels that
+bound it, with their roofline fractions (CSR SpMM bytes = 8 nnz + 4 (N + 1) + 8 N H, flops = 2 nnz H; f32 MFMA
+157.3 TF; HBM 8 TB/s).
+"""
+from __future__ import annotations
+
+import random
+import time
+import types
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import synth
+from .utils import normalize_adj, preprocess_features, split_nodes
+
+# published sizes (reference README.md:53-58): nodes, directed entries, features, anomaly rate
+SIZES = {"reddit": (10984, 168016, 64, 0.033), "Amazon": (11944, 4398392, 25, 0.069), "photo": (7535, 119043, 745, 0.092),
+         "t_finance": (39357, 21222543, 10, 0.046), "elliptic": (46564, 73248, 93, 0.098)}
+EPOCHS = {"photo": 100, "elliptic": 150, "reddit": 300, "t_finance": 500, "Amazon": 800}
+NORMALISED = ("Amazon", "tf_finace", "reddit", "elliptic")            # run.py:87 (typo kept: never T-Finance)
+HBM_PEAK = 8.0e12
+F32_PEAK = 157.3e12
+
+
+def make_dataset(name: str, seed: int = 0, verbose: bool = False) -> Dict[str, object]:
+    """The inputs of `run.py` for config `name`: scipy adjacency, dense feature matrix (normalised as the reference would),
+    labels, index lists, noise parameters.  Consumes python's `random` stream like `load_mat` does (seed it first)."""
+    import scipy.sparse as sp
+    n, ne, f, rate = SIZES[name]
+    rowptr, col = synth.make_graph(n, ne, seed, kind="powerlaw", max_degree=max(64, n // 8), exact=True)
+    adj = synth.csr_to_scipy(rowptr, col, n)
+    feat = synth.make_features(n, f, seed)
+    ano = synth.make_labels(n, rate, seed)
+    all_idx, idx_train, idx_val, idx_test, normal_idx, abn_idx = split_nodes(ano, name, verbose=verbose)
+    features = preprocess_features(sp.lil_matrix(feat)) if name in NORMALISED else np.asarray(feat)
+    mean, var = (0.02, 0.01) if name in ("reddit", "photo") else (0.0, 0.0)                     # run.py:61-66
+    return dict(name=name, n=n, f=f, adj=adj, rowptr=rowptr, col=col, features=np.asarray(features, dtype=np.float32), ano=ano,
+                idx_test=idx_test, normal_idx=normal_idx, abn_idx=abn_idx, mean=mean, var=var)
+
+
+def build_model(ds, dev, h: int = 300, seed: int = 0):
+    """FullGraphAdj + Model + FlatAdam as `run.py` builds them (`:98-118`)."""
+    import scipy.sparse as sp
+    import torch
+    from .fullgraph import FlatAdam, FullGraphAdj
+    from .model import Model
+    n = ds["n"]
+    full = FullGraphAdj(normalize_adj(ds["adj"]) + sp.eye(n), ds["adj"] + sp.eye(n), dev)
+    torch.manual_seed(seed)
+    model = Model(ds["f"], h, "prelu", 1, "avg").to(dev)
+    opt = FlatAdam(model.parameters(), lr=1e-3, weight_decay=0.0)
+    feats = torch.from_numpy(ds["features"])[None].to(dev)
+    return full, model, opt, feats
+
+
+def _time_call(fn, reps: int = 20) -> float:
+    import torch
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e-3
+
+
+def bench_one(name: str, dev, epochs: int = 30, seed: int = 0, h: int = 300) -> Dict[str, object]:
+    """Median epoch time of the training epoch (eager launches, then -- as `run.py` does -- one captured hipGraph when the eager
+    epoch is launch-bound) and the times of the N x N x H product and the N x H x H projection of that config."""
+    import torch
+    from . import fullgraph as FG
+    random.seed(seed)
+    np.random.seed(seed)
+    ds = make_dataset(name, seed)
+    full, model, opt, feats = build_model(ds, dev, h, seed)
+    args = types.SimpleNamespace(mean=ds["mean"], var=ds["var"])
+    abn, nrm = ds["abn_idx"], ds["normal_idx"]
+    ls = full.loss_structs(nrm, abn)
+
+    def train_epoch():
+        opt.zero_grad()
+        emb, emb_combine, logits, emb_con, emb_abnormal = model(feats, full, abn, nrm, True, args)
+        out = FG.GgadLossFn.apply(emb[0], logits[0, :, 0], emb_con, emb_abnormal[0], full, ls, 0.7)
+        out[0].backward()
+        opt.step()
+        return out
+
+    model.train()
+    eager = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        out = train_epoch()
+        torch.cuda.synchronize()
+        eager.append(time.perf_counter() - t)
+    times, mode = [], "eager"
+    graph = None
+    if eager[-1] < 20e-3:
+        noise_buf = torch.zeros(1, len(abn), h, device=dev)
+        model.noise_override = noise_buf
+        out = None
+        opt.zero_grad()
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static = train_epoch()
+        model.noise_override = None
+        mode = "hipGraph"
+    for _ in range(epochs):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        if graph is not None:
+            noise_buf.copy_(torch.randn(1, len(abn), h) * ds["var"] + ds["mean"])
+            graph.replay()
+        else:
+            out = train_epoch()
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t)
+    med = float(np.median(times))
+    loss = float((static if graph is not None else out)[0].item())
+    # the two kernels that bound the epoch, alone: A_hat (N x H)  and  (N x H)(H x H)^T
+    n, nnz = ds["n"], int(full.A.nnz)
+    x = torch.randn(n, h, device=dev)
+    w = torch.randn(h, h, device=dev)
+    t_spmm = _time_call(lambda: FG.spmm(full.A, x))
+    t_gemm = _time_call(lambda: FG.gemm(x, w, False, True))
+    spmm_bytes = 8.0 * nnz + 4.0 * (n + 1) + 8.0 * n * h
+    spmm_flops = 2.0 * nnz * h
+    gemm_flops = 2.0 * n * h * h
+    bound = "fp32-fma" if spmm_flops / F32_PEAK > spmm_bytes / HBM_PEAK else "hbm"
+    return {"nodes": n, "stored_entries_incl_identity": nnz, "directed_entries": int(ds["adj"].nnz), "feat": ds["f"], "hidden": h,
+            "epoch_ms": med * 1e3, "nodes_per_s": n / med, "mode": mode, "epochs_timed": epochs, "eager_epoch_ms": eager[-1] * 1e3,
+            "loss_after": loss,
+            "spmm_NxNxH": {"us": t_spmm * 1e6, "tflops": spmm_flops / t_spmm / 1e12, "alg_gbs": spmm_bytes / t_spmm / 1e9,
+                           "bound": bound, "frac_of_f32_fma_peak": spmm_flops / t_spmm / F32_PEAK,
+                           "frac_of_hbm_peak": spmm_bytes / t_spmm / HBM_PEAK,
+                           "floor_us": max(spmm_flops / F32_PEAK, spmm_bytes / HBM_PEAK) * 1e6,
+                           "frac_of_bounding_roofline": max(spmm_flops / F32_PEAK, spmm_bytes / HBM_PEAK) / t_spmm},
+            "gemm_NxHxH": {"us": t_gemm * 1e6, "tflops": gemm_flops / t_gemm / 1e12, "frac_of_f32_mfma_peak": gemm_flops / t_gemm / F32_PEAK}}
+
+
+def bench_fullgraph(dev, epochs: int = 30, names: Optional[list] = None) -> Dict[str, object]:
+    """`run.py --synthetic` epochs of the four BASELINE full-graph configs (Reddit is the reference's CPU-runnable case)."""
+    import torch
+    out = {}
+    state = random.getstate()
+    try:
+        for name in (names or ["reddit", "Amazon", "photo", "t_finance"]):
+            with torch.cuda.device(dev):
+                out[name] = bench_one(name, dev, epochs)
+            torch.cuda.empty_cache()
+    finally:
+        random.setstate(state)
+    return out

@@ -119,14 +119,17 @@ class Model(nn.Module):
         self.disc = Discriminator(n_h, negsamp_round)
 
     def _index(self, idx, dev):
-        """Device copy of an index list, made once per list object (the lists of run.py never change between epochs;
-        a host -> device copy per forward would also break hipGraph capture of the epoch)."""
+        """Device copy of an index list, cached by CONTENTS (the lists of run.py never change between epochs and a host ->
+        device copy per forward would break hipGraph capture of the epoch; a caller that shuffles its list in place -- same
+        object, same length -- must still get the new order, as in the reference, which re-reads the list every forward)."""
         cache = self.__dict__.setdefault("_idx_cache", {})
-        key = (id(idx), len(idx), str(dev))
+        key = (tuple(int(i) for i in idx), str(dev))
         hit = cache.get(key)
-        if hit is None or hit[0] is not idx:
-            hit = cache[key] = (idx, torch.as_tensor(list(idx), dtype=torch.long, device=dev))
-        return hit[1]
+        if hit is None:
+            if len(cache) >= 16:
+                cache.clear()
+            hit = cache[key] = torch.as_tensor(key[0], dtype=torch.long, device=dev)
+        return hit
 
     def _score(self, x):
         f = LinearFn.apply(x, self.fc1.weight, True)                       # fc1 + relu     model.py:176-177

@@ -88,8 +88,8 @@ class DGraphTrainer:
         device atomics (the fallback the LDS path takes by itself when a chunk exceeds its limits).
         `overlap` (default): two chunk buffers; the plan + gather of chunk c+1 runs on one stream while the dense steps
         of chunk c run on another, the two streams confined to DISJOINT compute units (`dense_cus` CUs for the dense
-        chain, the rest for the plan; `ggad_stream_create_cu_mask`).  `dense_cus` None = by graph density: 32 when the plan
-        is the longer stream (average degree >= 8), 64 when the step chain is (average degree 2.3).  With plain streams
+        chain, the rest for the plan; `ggad_stream_create_cu_mask`).  `dense_cus` None = 64 (round-2 sweep at DGraph size:
+        24 -> 56.0, 32 -> 51.5, 48 -> 49.7, 64 -> 46.3, 80 -> 50.3, 96 -> 51.2, 128 -> 59.7 us per step).  With plain streams
         (`dense_cus=0`) there is no gain: the tiny dependent launches of the dense chain queue behind the chip-filling
         gather launches.
         `ramp`: sizes (batches) of the FIRST chunks of a `run_steps` call.  The plan of the first chunk cannot overlap
@@ -120,7 +120,7 @@ class DGraphTrainer:
             self.chunks.append(BatchChunk(graph, table, embed_dim, self.chunk_batches, rows, ent_cap, train=True, feat_dim=f,
                                           hop2=hop2))
             if dense_cus is None:
-                dense_cus = 32 if graph.nnz >= 8 * graph.n else 64
+                dense_cus = 64
             self.dense_cus = int(dense_cus)
             self.side, self.hi = self._make_streams(feat.device, int(dense_cus))
         self.steps_done = 0
@@ -137,11 +137,13 @@ class DGraphTrainer:
             head = list(self.ramp) if self.ramp is not None else [int(x) for x in env.split(",") if x]
         elif not self.overlap:
             head = []
-        elif n_steps <= 3 * 8:
-            k = max(1, (n_steps + 2) // 3)           # short run: three chunks of about equal size
-            head = [k, k]
+        elif n_steps <= 32:
+            # measured (MI355X, DGraph size, 20 steps): one chunk on the whole chip 2.04 M nodes/s; 2 or 3 overlapped chunks
+            # 1.6-1.8 M -- below ~16 batches a plan costs more per batch than the dense steps it could hide (little reuse of
+            # neighbour rows across so few batches), and the CU split slows both
+            head = [n_steps]
         else:
-            head = [8, 16, 32, 64]
+            head = [16, 32, 64]
         sizes, left = [], int(n_steps)
         for k in head:
             if left <= 0 or k >= self.chunk_batches:

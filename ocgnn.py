@@ -64,6 +64,7 @@ def main():
         sys.exit("ocgnn.py needs an MI355X: there is no CPU fallback")
     torch.set_num_threads(min(8, os.cpu_count() or 1))
     dev = torch.device("cuda", args.device)
+    torch.cuda.set_device(dev)      # the C-ABI launches on the CURRENT device's stream: it must be the one the tensors live on
     adj, features, ano_label, idx_test, normal_label_idx, abnormal_label_idx = load(args)
     if args.dataset in ["Amazon", "tf_finace", "reddit", "elliptic"]:                 # ocgnn.py:124 (same typo as run.py)
         features = preprocess_features(features)

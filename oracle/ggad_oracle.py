@@ -464,12 +464,17 @@ def ocgnn_loss(emb: torch.Tensor, r: float = 0.0, beta: float = 0.5):
     return r ** 2 + 1 / beta * torch.mean(torch.relu(score)), score
 
 
-def full_loss(emb, logits, emb_con, emb_abnormal, raw, abn_idx, normal_idx, margin_c: float = 0.7):
+def full_loss(emb, logits, emb_con, emb_abnormal, raw, abn_idx, normal_idx, margin_c: float = 0.7, by_column: bool = False):
     """Loss block of `run.py:165-210`, affinity as a per-edge SDDMM over raw_adj + I.
 
     affinity_j = sum_i cos(emb_i, emb_j) R_ij / sum_i R_ij   (column sums, `run.py:182-188`).
-    loss_rec reduces over the OUTLIER axis (quirk 4, `run.py:207-208`)."""
+    loss_rec reduces over the OUTLIER axis (quirk 4, `run.py:207-208`).
+    ``by_column``: the same sums associated per column, affinity_j = <e_hat_j, (R^T e_hat)_j> / colsum_j -- one sparse product
+    instead of an (edges x H) intermediate (21 M x 300 floats at T-Finance size do not fit a host); pinned against the
+    per-edge form and the reference's vectors in tests/test_oracle_golden.py."""
     rp, ci, va = raw
+    if by_column:
+        return _full_loss_by_column(emb, logits, emb_con, emb_abnormal, raw, abn_idx, normal_idx, margin_c)
     n_norm, n_out = len(normal_idx), emb_con.shape[0]
     lbl = torch.cat((torch.zeros(n_norm), torch.ones(n_out)))
     l_bce = torch.mean(F.binary_cross_entropy_with_logits(logits, lbl, reduction="none",
@@ -491,4 +496,29 @@ def full_loss(emb, logits, emb_con, emb_abnormal, raw, abn_idx, normal_idx, marg
     l_margin = (margin_c - (torch.mean(aff[nrm]) - torch.mean(aff[abn]))).clamp_min(min=0)
     diff = torch.pow(emb_con - emb_abnormal.unsqueeze(0), 2)              # (1, A, H)
     l_rec = torch.mean(torch.sqrt(torch.sum(diff, 1)))                    # sums over A  -> (1, H)
+    return l_margin + l_bce + l_rec, l_margin, l_bce, l_rec, aff
+
+
+def _full_loss_by_column(emb, logits, emb_con, emb_abnormal, raw, abn_idx, normal_idx, margin_c):
+    import scipy.sparse as sp
+    rp, ci, va = raw
+    n = emb.shape[0]
+    n_norm, n_out = len(normal_idx), emb_con.shape[0]
+    lbl = torch.cat((torch.zeros(n_norm), torch.ones(n_out)))
+    l_bce = torch.mean(F.binary_cross_entropy_with_logits(logits, lbl, reduction="none", pos_weight=torch.tensor([1])))
+    inv = torch.pow(torch.norm(emb, dim=-1, keepdim=True), -1)
+    inv = torch.where(torch.isinf(inv), torch.zeros_like(inv), inv)
+    en = emb * inv
+    rt = sp.csr_matrix((np.asarray(va, dtype=np.float32), ci.astype(np.int64), rp.astype(np.int64)), shape=(n, n)).T.tocsr()
+    rt.sort_indices()
+    rten = _spmm(rt.indptr, rt.indices, rt.data, en)                      # (R^T e_hat)_j = sum_i R_ij e_hat_i
+    rsum = torch.from_numpy(np.asarray(rt.sum(1), dtype=np.float32).reshape(-1))
+    r_inv = torch.pow(rsum, -1)
+    r_inv = torch.where(torch.isinf(r_inv), torch.zeros_like(r_inv), r_inv)
+    aff = (en * rten).sum(1) * r_inv
+    abn = torch.as_tensor(np.asarray(abn_idx), dtype=torch.long)
+    nrm = torch.as_tensor(np.asarray(normal_idx), dtype=torch.long)
+    l_margin = (margin_c - (torch.mean(aff[nrm]) - torch.mean(aff[abn]))).clamp_min(min=0)
+    diff = torch.pow(emb_con - emb_abnormal.unsqueeze(0), 2)
+    l_rec = torch.mean(torch.sqrt(torch.sum(diff, 1)))
     return l_margin + l_bce + l_rec, l_margin, l_bce, l_rec, aff

@@ -65,7 +65,7 @@ def load(args):
         if not args.synthetic:
             print("./dataset/{}.mat not found: using a synthetic graph of the same size".format(args.dataset))
         n, ne, f, rate = SIZES[args.dataset]
-        rowptr, col = synth.make_graph(n, ne, args.seed, kind="powerlaw", max_degree=max(64, n // 8))
+        rowptr, col = synth.make_graph(n, ne, args.seed, kind="powerlaw", max_degree=max(64, n // 8), exact=True)
         adj = synth.csr_to_scipy(rowptr, col, n)
         feat = sp.lil_matrix(synth.make_features(n, f, args.seed))
         ano = synth.make_labels(n, rate, args.seed)
@@ -88,6 +88,7 @@ def main():
     # intra-op thread per core (128 on the MI355X box) turns it into a 1-90 ms lottery on a loaded host
     torch.set_num_threads(min(8, os.cpu_count() or 1))
     dev = torch.device("cuda", args.device)
+    torch.cuda.set_device(dev)      # the C-ABI launches on the CURRENT device's stream: it must be the one the tensors live on
     adj, features, ano_label, idx_test, normal_label_idx, abnormal_label_idx = load(args)
     if args.dataset in ["Amazon", "tf_finace", "reddit", "elliptic"]:                 # run.py:87 (typo kept: never T-Finance)
         features = preprocess_features(features)

@@ -20,9 +20,9 @@ rows = cur.execute(sel).fetchall()
 dense = {"k_project", "k_fwd_rows", "k_fwd_rows_v", "k_fwd_chunks", "k_loss_pos", "k_loss_pos_ck", "k_loss_rows", "k_bwd_flat",
          "k_grad_reduce", "k_train_chunk_persistent"}
 ev = [(short(n).split("<")[0], s, e, q) for n, s, e, q in rows]
-g = [i for i, x in enumerate(ev) if x[0] == "k_gather2_groups"]
+g = [i for i, x in enumerate(ev) if x[0] == "k_gather2_items"]
 print("streams/queues seen:", sorted({x[3] for x in ev}))
-for a, b in zip(g[2:-1], g[3:]):
+for a, b in zip(g[5:-1], g[6:]):
     win = ev[a:b]
     t0, t1 = ev[a][1], ev[b][1]
     plan = [x for x in win if x[0] not in dense]

@@ -179,6 +179,26 @@ def test_full_forward_loss_grads_trajectory(name):
     assert abs(average_precision_score(yt, le.numpy()[g["idx_test"]]) - float(g["eval_ap"])) < 1e-4
 
 
+@pytest.mark.parametrize("name", ["fullgraph_reddit_like.npz", "fullgraph_amazon_like.npz"])
+def test_full_loss_by_column_equals_per_edge_form_and_reference(name):
+    """The column-sum association of the affinity (what the full-size GPU tests use as their oracle: the per-edge form needs an
+    (edges x H) intermediate) against the reference's vectors: loss terms, affinity, every gradient of the first step."""
+    g = load_golden(name)
+    adjn, raw = _full_setup(g)
+    P = {k: torch.tensor(g["init." + k], requires_grad=True) for k in O.FULL_PARAM_ORDER}
+    feat = torch.from_numpy(g["features"])
+    abn, nrm = g["abn_idx"], g["normal_idx"]
+    torch.manual_seed(1000)
+    noise = torch.randn(1, len(abn), int(g["n_h"]))[0] * float(g["var"]) + float(g["mean"])
+    emb, comb, logits, con, eab = O.full_forward(P, feat, adjn, abn, nrm, noise, True)
+    total, lm, lb, lr, aff = O.full_loss(emb, logits, con, eab, raw, abn, nrm, by_column=True)
+    total.backward()
+    np.testing.assert_allclose([total.item(), lm.item(), lb.item(), lr.item()], g["losses"][0], atol=1e-5)
+    np.testing.assert_allclose(aff.detach().numpy(), g["affinity"], atol=TOL)
+    for k in O.FULL_PARAM_ORDER:
+        np.testing.assert_allclose(P[k].grad.numpy(), g["grad." + k], atol=3e-6, rtol=1e-4, err_msg=k)
+
+
 @pytest.mark.parametrize("tag,pw", [("dominant", None), ("anomalydae", 0.5)])
 def test_baseline_models_on_the_1hop_aggregate(tag, pw):
     """DOMINANT / AnomalyDAE mini-batch variants (src/graphsage_dominant.py, src/graphsage_anomalydae.py): aggregate, decoder
