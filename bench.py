@@ -71,8 +71,11 @@ def parse():
     ap.add_argument("--e2e-steps", type=int, default=1500, help="extra leg: steps timed with the reference-exact sampler inside the window (0 = skip)")
     ap.add_argument("--fullgraph-epochs", type=int, default=30, help="extra leg: epochs timed per full-graph config (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="only the timed region (no steady-state / e2e / full-graph / CPU legs)")
-    ap.add_argument("--dp-path", action="store_true", help="1 GPU only: run the data-parallel step chain (backward -> exchange -> "
-                    "Adam, Adam not fused) with a no-op exchange, to measure what the multi-GPU step costs without the collective")
+    ap.add_argument("--exchange", default="oneshot", choices=["oneshot", "rccl"],
+                    help="multi-GPU gradient exchange: oneshot = peer-mapped buffers written inside the Adam launch (falls back to "
+                         "rccl when its self-test fails), rccl = torch.distributed all-reduce between backward and Adam")
+    ap.add_argument("--dp-path", action="store_true", help="1 GPU only: run the data-parallel step chain (backward -> exchange + Adam "
+                    "launch with a world of one) to measure what the multi-GPU step costs without the xGMI hop")
     ap.add_argument("--seed", type=int, default=72)
     return ap.parse_args()
 
@@ -120,23 +123,31 @@ def main():
     rng = PyCompatRandom.from_python_state(pyrandom.getstate())          # continue the python stream (model_handler.py:30)
     sched = BatchSchedule(split["idx_train"], split["idx_anomaly"], split["labels"], 150, rng)
     allreduce = None
+    exchange = None
     if world > 1:
         def allreduce(t):
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        if a.exchange == "oneshot":
+            # every rank must take the same path: a rank that cannot even allocate its buffer still joins the hand-shake
+            from ggad_amd.exchange import OneShotExchange
+            try:
+                exchange = OneShotExchange(rank, world, a.emb + a.emb * a.feat + a.emb * a.emb, dev)
+            except Exception:
+                exchange = None
+            good = exchange.connect(dist) if exchange is not None else OneShotExchange.decline(dist, dev)
+            if not good:                                 # e.g. no peer access between two devices: the RCCL all-reduce instead
+                exchange = None
     trainer = DGraphTrainer(graph, feat, a.emb, sched, lr=1e-3, weight_decay=0.007, chunk_batches=a.chunk, rank=rank,
                             world_size=world, allreduce=allreduce, hop2=a.hop2, overlap=not a.no_overlap, chain=a.chain,
                             dense_cus=(None if a.dense_cus < 0 else a.dense_cus),
-                            ramp=([int(x) for x in a.ramp.split(",") if x] if a.ramp else None))
+                            ramp=([int(x) for x in a.ramp.split(",") if x] if a.ramp else None), exchange=exchange)
     a.dense_cus = getattr(trainer, "dense_cus", 0 if a.dense_cus < 0 else a.dense_cus)
     if a.dp_path and world == 1:
-        if os.environ.get("GGAD_BENCH_REAL_ALLREDUCE") == "1":
-            # one-rank RCCL group: exercises ProcessGroupNCCL on the CU-masked dense stream from the C step loop's callback
-            import torch.distributed as dist1
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29577")
-            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            dist1.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-            trainer.allreduce = lambda t: dist1.all_reduce(t, op=dist1.ReduceOp.SUM)
+        # the data-parallel step chain on one GPU: backward -> k_xchg_adam with a world of one (publish to itself, flag, wait,
+        # sum, Adam) -- what the multi-GPU step costs without the xGMI hop; --exchange rccl: backward -> no-op callback -> Adam
+        if a.exchange == "oneshot":
+            from ggad_amd.exchange import OneShotExchange
+            trainer.exchange = OneShotExchange(0, 1, a.emb + a.emb * a.feat + a.emb * a.emb, dev)
         else:
             trainer.allreduce = lambda t: None
     torch.manual_seed(a.seed)
@@ -339,7 +350,9 @@ def main():
                        "graph": f"{a.graph_kind}(alpha=2.1,max_degree={a.max_degree})", "chunk_batches": trainer.chunk_batches,
                        "chunks_of_timed_region": sizes[:16], "hop2": a.hop2, "overlap": overlapped,
                        "dense_cus": (a.dense_cus if overlapped else 0), "chain": a.chain,
-                       "parallelism": f"dp{world}", "optimizer": "adam(lr=1e-3,wd=0.007)"},
+                       "parallelism": f"dp{world}", "optimizer": "adam(lr=1e-3,wd=0.007)",
+                       "gradient_exchange": (None if world == 1 else ("oneshot peer writes + in-kernel sum" if trainer.exchange is not None
+                                                                      else "rccl all-reduce"))},
             "value_is": "GPU path (plans + dense steps inside the window; batch schedule prepared by the host sampler beforehand)",
             "roofline": roofline, "cpu_baseline": cpu,
             "gpu_over_cpu": (value / cpu["value"]) if cpu else None,

@@ -58,6 +58,14 @@ SIGNATURES = {
     "ggad_stream_create_cu_mask": (c_int32, [_P, _I, _P]),
     "ggad_stream_destroy": (c_int32, [_P]),
     "ggad_device_cu_count": (c_int32, [_I, _P]),
+    "ggad_xchg_create": (c_int32, [_I, _I, _L, _P]),
+    "ggad_xchg_handle_bytes": (c_int32, []),
+    "ggad_xchg_handle": (c_int32, [_P, _P]),
+    "ggad_xchg_connect": (c_int32, [_P, _P]),
+    "ggad_xchg_error": (c_int32, [_P, _P]),
+    "ggad_xchg_destroy": (c_int32, [_P]),
+    "ggad_xchg_adam": (c_int32, [_P, _P, _P, _P, _I, _I, _F, _F, _F, _P, _P, _P]),
+    "ggad_mb_train_chunk_xchg": (c_int32, [_P, _I, _P, _P, _P, _P, _I, c_float, _P, _P]),
     "ggad_mb_param_count": (c_int64, [_I, _I]),
     "ggad_mb_param_block_elems": (c_int64, [_I, _I]),
     "ggad_mb_params_sync": (c_int32, [_P, _I, _I, _P]),

@@ -59,3 +59,20 @@ struct ggad_plan_view {      // device views into the staging block of ONE build
 int ggad_int_hop1(const ggad_mb_plan *P, const ggad_plan_view &V, int ldsw, int reset_now, hipStream_t st);
 int ggad_int_global_hop2(const ggad_mb_plan *P, const ggad_plan_view &V, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
 int ggad_int_ldsw_hop2(const ggad_mb_plan *P, const ggad_plan_view &V, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
+
+// ---- one-shot gradient exchange (exchange.cpp owns the handle, step.hip the kernel)
+constexpr int GGAD_XCHG_MAX_WORLD = 16;
+struct ggad_xchg_view {                          // what the kernel needs, passed by value
+  float *peer[GGAD_XCHG_MAX_WORLD];             // peer[q] = rank q's buffer as mapped into THIS process (peer[rank] = own)
+  int32_t rank, world;
+  int64_t n;                                     // floats per slot
+  int32_t *err;                                  // device word: set when a wait timed out
+};
+struct ggad_xchg {
+  ggad_xchg_view view;
+  void *local;                                   // own buffer (fine-grained device memory)
+  size_t bytes;
+  uint32_t step;                                 // exchanges done so far (all ranks call in lockstep)
+  bool opened[GGAD_XCHG_MAX_WORLD];
+};
+static inline size_t ggad_xchg_granules(int world, int64_t n) { return (size_t)2 * world * (size_t)n; }   // 8 bytes each: {value, step}

@@ -469,7 +469,7 @@ int ggad_exclusive_scan_i32(const int32_t *in, int32_t *out, int64_t n, int32_t 
   GGAD_REQUIRE(tiles <= SCAN_TILE);
   hipStream_t st = as_stream(stream);
   if (n == 0) {
-    hipMemsetAsync(out, 0, sizeof(int32_t), st);
+    (void)hipMemsetAsync(out, 0, sizeof(int32_t), st);
     GGAD_CHECK_LAUNCH("scan memset");
     return GGAD_OK;
   }

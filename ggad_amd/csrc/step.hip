@@ -546,14 +546,49 @@ __device__ __forceinline__ void adam_scalars(float *sc, const int32_t *step_coun
 // has at most 8 independent loads in flight and one round of them (128 partials / 16 slices), so the launch is one
 // memory round trip + the LDS combine instead of four dependent rounds.
 constexpr int GR_SUB = 16;
-template <bool FUSE_ADAM>
+// ---- one-shot data-parallel exchange (host side: exchange.cpp).  Every parameter travels as ONE aligned
+// 8-byte granule {gradient bits, step number}: the thread that owns parameter i stores its granule into slot (parity, rank, i) of
+// EVERY rank's buffer (fine-grained memory; over xGMI for the peers; an aligned 8-byte store is indivisible) and then reads the
+// granules (parity, q, i) of its own buffer until each carries this step's number.  No flag, no fence, no dependency between
+// threads: the data is its own "ready" signal (the layout RCCL's low-latency protocol uses).  The W values are added in rank
+// order -- the same order on every rank, so all replicas stay bit-identical.  Two parities: a rank cannot finish step s + 1
+// before every peer has published s + 1, i.e. finished reading s, so it never overwrites a slot that is still being read.  A wait
+// is bounded: a lost peer sets *err instead of hanging the GPU.
+__device__ __forceinline__ float xchg_sum(const ggad_xchg_view &X, uint32_t xstep, int i, float g) {
+  const int W = X.world, par = (int)(xstep & 1u);
+  const int64_t n = X.n;
+  const uint64_t mine = ((uint64_t)xstep << 32) | (uint64_t)__float_as_uint(g);
+  for (int r = 0; r < W; ++r) {
+    uint64_t *dst = reinterpret_cast<uint64_t *>(X.peer[r]) + ((int64_t)par * W + X.rank) * n + i;
+    __hip_atomic_store(dst, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  const uint64_t *src = reinterpret_cast<const uint64_t *>(X.peer[X.rank]) + (int64_t)par * W * n + i;
+  float s = 0.0f;
+  for (int q = 0; q < W; ++q) {
+    uint64_t gr = __hip_atomic_load(src + (int64_t)q * n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    int spins = 0;
+    while ((uint32_t)(gr >> 32) != xstep) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1 << 24)) { *X.err = 1; break; }                   // ~ seconds: a peer is gone
+      gr = __hip_atomic_load(src + (int64_t)q * n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    const float gq = __uint_as_float((uint32_t)gr);
+    s = q == 0 ? gq : s + gq;
+  }
+  return s;
+}
+
+// MODE 0: gradients only; 1: + Adam (single GPU); 2: + the one-shot data-parallel exchange (xchg_sum) and Adam.
+template <int MODE>
 __global__ void __launch_bounds__(64 * GR_SUB) k_grad_reduce(ParamLayout L, const int32_t *__restrict__ pos_meta, int row0,
                                                      const float *__restrict__ losses8, const float *__restrict__ nbar,
                                                      const float *__restrict__ dw_part, int n_parts,
                                                      const float *__restrict__ dz, const float *__restrict__ gw_part,
                                                      int n_gw, float *__restrict__ grads, float *__restrict__ params,
                                                      float *__restrict__ m, float *__restrict__ v, float lr, float wd,
-                                                     const int32_t *__restrict__ step_counter) {
+                                                     const int32_t *__restrict__ step_counter, ggad_xchg_view X, uint32_t xstep,
+                                                     float grad_scale) {
+  constexpr bool FUSE_ADAM = MODE != 0;
   __shared__ float sc[2];
   __shared__ float red[GR_SUB][64];
   const int tid = threadIdx.y * 64 + threadIdx.x;
@@ -602,12 +637,17 @@ __global__ void __launch_bounds__(64 * GR_SUB) k_grad_reduce(ParamLayout L, cons
   }
   red[sub][threadIdx.x] = g;
   __syncthreads();
-  if (sub != 0 || pidx < 0) return;
+  if (sub != 0 || (MODE != 2 && pidx < 0)) return;
   g = 0.0f;
 #pragma unroll
   for (int k = 0; k < GR_SUB; ++k) g += red[k][threadIdx.x];          // fixed order
-  grads[pidx] = g;
-  if (FUSE_ADAM) adam_update(params, m, v, L, pidx, g, wd, sc[0], sc[1]);
+  if (pidx >= 0) grads[pidx] = g;
+  if (MODE == 1) adam_update(params, m, v, L, pidx, g, wd, sc[0], sc[1]);
+  if (MODE == 2) {
+    if (pidx < 0) return;
+    const float s = xchg_sum(X, xstep, pidx, g);
+    adam_update(params, m, v, L, pidx, s * grad_scale, wd, sc[0], sc[1]);
+  }
 }
 
 __global__ void __launch_bounds__(256) k_adam(float *__restrict__ params, float *__restrict__ m, float *__restrict__ v,
@@ -618,6 +658,19 @@ __global__ void __launch_bounds__(256) k_adam(float *__restrict__ params, float 
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= L.n_train()) return;
   adam_update(params, m, v, L, i, grads[i] * grad_scale, wd, sc[0], sc[1]);
+}
+
+// The exchange + Adam on an existing packed gradient block (self-test of a connection, tests): see xchg_sum.
+__global__ void __launch_bounds__(256) k_xchg_adam(float *__restrict__ params, float *__restrict__ m, float *__restrict__ v,
+                                                   const float *__restrict__ grads, ParamLayout L, float lr, float wd,
+                                                   float grad_scale, const int32_t *__restrict__ step_counter, ggad_xchg_view X,
+                                                   uint32_t step) {
+  __shared__ float sc[2];
+  adam_scalars(sc, step_counter, lr);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= L.n_train()) return;
+  const float s = xchg_sum(X, step, i, grads[i]);
+  adam_update(params, m, v, L, i, s * grad_scale, wd, sc[0], sc[1]);
 }
 
 __global__ void __launch_bounds__(256) k_params_sync(float *__restrict__ params, ParamLayout L) {
@@ -1023,9 +1076,9 @@ int ggad_mb_grad_reduce(int32_t D, int32_t F, const int32_t *pos_meta, int32_t r
   ParamLayout L{D, F};
   const int nwg = loss_nwg(n_rows);
   const float *gw_part = loss_ws + (int64_t)n_rows * 8 + (int64_t)nwg * 8;
-  k_grad_reduce<false><<<dim3((L.n_train() + 63) / 64), dim3(64, GR_SUB), 0, as_stream(stream)>>>(
+  k_grad_reduce<0><<<dim3((L.n_train() + 63) / 64), dim3(64, GR_SUB), 0, as_stream(stream)>>>(
       L, pos_meta, row0, losses8, nbar, dw_part, BWD_PARTS, dz, gw_part, nwg, grads, nullptr, nullptr, nullptr, 0.f, 0.f,
-      nullptr);
+      nullptr, ggad_xchg_view{}, 0u, 1.0f);
   GGAD_CHECK_LAUNCH("mb_grad_reduce");
   return GGAD_OK;
 }
@@ -1072,7 +1125,16 @@ int64_t ggad_mb_dw_part_elems(int32_t n_rows, int32_t D, int32_t F) {
   return (int64_t)(n_rows > BWD_PARTS ? n_rows : BWD_PARTS) * F * D;
 }
 
+static int train_step_impl(const ggad_mb_step *s, int32_t fuse_adam, const ggad_xchg_view *xv, uint32_t xstep, float grad_scale,
+                           ggad_stream_t stream);
+
 int ggad_mb_train_step(const ggad_mb_step *s, int32_t fuse_adam, ggad_stream_t stream) {
+  return train_step_impl(s, fuse_adam ? 1 : 0, nullptr, 0u, 1.0f, stream);
+}
+
+// fuse_adam 0: gradients only; 1: Adam in the last launch; 2: one-shot exchange + Adam in the last launch (xv, xstep)
+static int train_step_impl(const ggad_mb_step *s, int32_t fuse_adam, const ggad_xchg_view *xv, uint32_t xstep, float grad_scale,
+                           ggad_stream_t stream) {
   GGAD_REQUIRE(s && s->params && s->exp_avg && s->exp_avg_sq && s->grads && s->step_counter);
   GGAD_REQUIRE(s->chain == 0 || s->chain == 2);
   const int D = s->D, F = s->F;
@@ -1130,9 +1192,16 @@ int ggad_mb_train_step(const ggad_mb_step *s, int32_t fuse_adam, ggad_stream_t s
   ParamLayout L{D, F};
   const int nwg = loss_nwg(s->n_rows);
   const float *gw_part = s->loss_ws + (int64_t)s->n_rows * 8 + (int64_t)nwg * 8;
-  k_grad_reduce<true><<<dim3((L.n_train() + 63) / 64), dim3(64, GR_SUB), 0, as_stream(stream)>>>(
-      L, s->pos_meta, s->row0, s->losses8, s->nbar, s->dw_part, BWD_PARTS, s->dz, gw_part, nwg, s->grads, s->params,
-      s->exp_avg, s->exp_avg_sq, s->lr, s->weight_decay, s->step_counter);
+  if (fuse_adam == 2) {
+    GGAD_REQUIRE(xv != nullptr);
+    k_grad_reduce<2><<<dim3((L.n_train() + 63) / 64), dim3(64, GR_SUB), 0, as_stream(stream)>>>(
+        L, s->pos_meta, s->row0, s->losses8, s->nbar, s->dw_part, BWD_PARTS, s->dz, gw_part, nwg, s->grads, s->params,
+        s->exp_avg, s->exp_avg_sq, s->lr, s->weight_decay, s->step_counter, *xv, xstep, grad_scale);
+  } else {
+    k_grad_reduce<1><<<dim3((L.n_train() + 63) / 64), dim3(64, GR_SUB), 0, as_stream(stream)>>>(
+        L, s->pos_meta, s->row0, s->losses8, s->nbar, s->dw_part, BWD_PARTS, s->dz, gw_part, nwg, s->grads, s->params,
+        s->exp_avg, s->exp_avg_sq, s->lr, s->weight_decay, s->step_counter, ggad_xchg_view{}, 0u, 1.0f);
+  }
   GGAD_CHECK_LAUNCH("mb_train_step");
   return GGAD_OK;
 }
@@ -1182,6 +1251,48 @@ int ggad_mb_train_chunk_dp(const ggad_mb_step *tmpl, int32_t n_batches, const in
                       stream);
     if (rc) return rc;
   }
+  return GGAD_OK;
+}
+
+/* Data-parallel form without any host call between the launches: per batch  backward (packed gradients) -> k_xchg_adam
+ * (publish to all peers' buffers, wait for theirs, sum in rank order, Adam with grad_scale).  Every rank calls it with the same
+ * number of batches.  xchg: handle of ggad_xchg_create / ggad_xchg_connect.  The exchange runs INSIDE the gradient-reduce launch
+ * (k_grad_reduce<2>: its workgroup of 64 parameters is the publishing unit), so the data-parallel step has the launch count of the
+ * single-GPU step. */
+int ggad_mb_train_chunk_xchg(const ggad_mb_step *tmpl, int32_t n_batches, const int32_t *batch_ptr, const int64_t *batch_ent_ptr,
+                             const int32_t *batch_max_row, float *loss_log, int32_t log_base, float grad_scale, ggad_xchg *xchg,
+                             ggad_stream_t stream) {
+  GGAD_REQUIRE(tmpl && batch_ptr && batch_ent_ptr && loss_log && xchg && n_batches >= 0 && log_base >= 0);
+  ParamLayout L{tmpl->D, tmpl->F};
+  GGAD_REQUIRE(xchg->view.n >= L.n_train());
+  for (int q = 0; q < xchg->view.world; ++q) GGAD_REQUIRE(xchg->view.peer[q] != nullptr);
+  for (int b = 0; b < n_batches; ++b) {
+    ggad_mb_step s = *tmpl;
+    s.row0 = batch_ptr[b];
+    s.n_rows = batch_ptr[b + 1] - batch_ptr[b];
+    s.ent0 = (int32_t)batch_ent_ptr[b];
+    s.n_ents = (int32_t)(batch_ent_ptr[b + 1] - batch_ent_ptr[b]);
+    s.losses8 = loss_log + (int64_t)8 * (log_base + b);
+    s.max_row_entries = batch_max_row ? batch_max_row[b] : 0;
+    xchg->step += 1;
+    const int rc = train_step_impl(&s, 2, &xchg->view, xchg->step, grad_scale, stream);     // exchange inside the reduce launch
+    if (rc) return rc;
+  }
+  return GGAD_OK;
+}
+
+/* One exchange + Adam on the caller's packed gradient block (tests, self-test of a new connection). */
+int ggad_xchg_adam(float *params, float *exp_avg, float *exp_avg_sq, const float *grads, int32_t D, int32_t F, float lr,
+                   float weight_decay, float grad_scale, const int32_t *step_counter, ggad_xchg *xchg, ggad_stream_t stream) {
+  GGAD_REQUIRE(params && exp_avg && exp_avg_sq && grads && step_counter && xchg && dims_ok(D, F));
+  ParamLayout L{D, F};
+  GGAD_REQUIRE(xchg->view.n >= L.n_train());
+  for (int q = 0; q < xchg->view.world; ++q) GGAD_REQUIRE(xchg->view.peer[q] != nullptr);
+  xchg->step += 1;
+  k_xchg_adam<<<dim3((L.n_train() + 255) / 256), dim3(256), 0, as_stream(stream)>>>(params, exp_avg, exp_avg_sq, grads, L, lr,
+                                                                                    weight_decay, grad_scale, step_counter,
+                                                                                    xchg->view, xchg->step);
+  GGAD_CHECK_LAUNCH("xchg_adam");
   return GGAD_OK;
 }
 

@@ -390,10 +390,19 @@ class MiniBatchEngine:
         call("ggad_mb_adam", ptr(self.params), ptr(self.exp_avg), ptr(self.exp_avg_sq), ptr(self.grads), self.D, self.F,
              self.lr, self.wd, float(grad_scale), ptr(self.step_counter))
 
-    def train_chunk(self, ch: BatchChunk, allreduce=None, world_size: int = 1, log_base: int = 0) -> None:
-        """One optimiser step per batch of the chunk (src/model_handler.py:330-364)."""
+    def train_chunk(self, ch: BatchChunk, allreduce=None, world_size: int = 1, log_base: int = 0, exchange=None) -> None:
+        """One optimiser step per batch of the chunk (src/model_handler.py:330-364).  Data parallel: `exchange` (a connected
+        `OneShotExchange`: gradients written straight into the peers' buffers, summed in rank order inside the Adam launch,
+        no host call in the loop) or `allreduce` (a callable, e.g. RCCL through torch.distributed, served by a callback)."""
         self.ensure_capacity(ch, log_base + ch.n_batches)
         stream = _lib.current_stream()
+        if exchange is not None:
+            s = self.step_desc(ch, 0, log_base)
+            bp, ep, mr = ch._bp_host, ch._bep_host, ch._bmr_host
+            _lib.check(self.lib.ggad_mb_train_chunk_xchg(ctypes.byref(s), ch.n_batches, bp.ctypes.data, ep.ctypes.data,
+                                                         mr.ctypes.data, self.loss_log.data_ptr(), log_base, 1.0 / world_size,
+                                                         exchange.handle, stream), "ggad_mb_train_chunk_xchg")
+            return
         fuse = 1 if (allreduce is None and world_size == 1) else 0
         if fuse:
             # single GPU: the whole chunk in one host call (the C loop issues the launches; Python per step costs more

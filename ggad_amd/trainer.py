@@ -82,7 +82,7 @@ class DGraphTrainer:
                  world_size: int = 1, allreduce: Optional[Callable[[torch.Tensor], None]] = None,
                  engine: Optional[MiniBatchEngine] = None, hop2: str = "ldsw",
                  overlap: bool = True, prefetch: bool = True, chain: int = 0, dense_cus: Optional[int] = None,
-                 ramp: Optional[Sequence[int]] = None):
+                 ramp: Optional[Sequence[int]] = None, exchange=None):
         """`feat` is the plain (N, F) table.  hop2 = "ldsw" (default): 2-hop counts in LDS per (tile, batch), per-pair
         counts streamed to the gather, feature rows padded to one 128-byte line; "global": per-batch counter slots in HBM +
         device atomics (the fallback the LDS path takes by itself when a chunk exceeds its limits).
@@ -95,12 +95,15 @@ class DGraphTrainer:
         `ramp`: sizes (batches) of the FIRST chunks of a `run_steps` call.  The plan of the first chunk cannot overlap
         anything, so a run starts with small chunks (the dense chain starts after a fraction of a millisecond instead of
         after a 150-batch plan) and grows to `chunk_batches`; None = `default_ramp`.
+        `exchange`: a connected `OneShotExchange` (ggad_amd/exchange.py) -- the data-parallel gradient exchange then happens
+        inside the Adam launch over peer-mapped buffers, with no host call per step; else `allreduce` (RCCL) is used.
         `prefetch`: the host sampler (bit-exact CPython shuffle, ~0.1 ms per batch for the 55k pool) runs in a
         background thread one chunk ahead; the C call releases the GIL, so sampling overlaps the GPU work."""
         self.graph, self.feat = graph, feat
         self.schedule = schedule
         self.rank, self.world = int(rank), int(world_size)
         self.allreduce = allreduce if self.world > 1 else None
+        self.exchange = exchange if (self.world > 1 and exchange is not None and exchange.ok) else None
         self.engine = engine or MiniBatchEngine(feat.shape[1], embed_dim, feat.device, lr, weight_decay, chain=chain)
         self.chunk_batches = int(chunk_batches)
         self.ramp = None if ramp is None else [int(k) for k in ramp]
@@ -286,7 +289,7 @@ class DGraphTrainer:
             for k in sizes:
                 bn, bl = take(k)
                 build(self.chunk, bn, bl)
-                self.engine.train_chunk(self.chunk, self.allreduce, self.world, log_base=done)   # loss log slot = step index
+                self.engine.train_chunk(self.chunk, self.allreduce, self.world, log_base=done, exchange=self.exchange)   # loss log slot = step index
                 nodes_seen += sum(len(b) for b in bn)
                 done += k
         else:
@@ -314,7 +317,7 @@ class DGraphTrainer:
                 main.wait_event(built[cur])
                 self.chunk = self.chunks[cur]
                 with torch.cuda.stream(main):
-                    self.engine.train_chunk(self.chunks[cur], self.allreduce, self.world, log_base=done)
+                    self.engine.train_chunk(self.chunks[cur], self.allreduce, self.world, log_base=done, exchange=self.exchange)
                 freed[cur].record(main)
                 done += k
             outer.wait_stream(main)

@@ -306,6 +306,26 @@ int ggad_mb_train_chunk_dp(const ggad_mb_step *tmpl, int32_t n_batches, const in
                            const int32_t *batch_max_row, float *loss_log, int32_t log_base, float grad_scale,
                            int (*exchange)(void *), void *user, ggad_stream_t stream);
 
+/* One-shot gradient exchange of the data-parallel step (the reference is single-device): buffers in
+ * fine-grained device memory, one per rank, exported / imported as HIP IPC handles; the kernel of step s writes this rank's
+ * 5,248 gradients into every rank's buffer (over xGMI), raises flags, waits for the peers', sums the W blocks in rank order and
+ * applies Adam -- one launch, no collective library call, no host callback (exchange.cpp, k_xchg_adam in step.hip).
+ * HOST handle; create -> exchange the ggad_xchg_handle_bytes()-byte handles (e.g. all_gather) -> connect.  A wait that times
+ * out (a lost peer) sets the error word read by ggad_xchg_error instead of hanging. */
+typedef struct ggad_xchg ggad_xchg;
+int ggad_xchg_create(int32_t rank, int32_t world, int64_t n_floats, ggad_xchg **out);
+int32_t ggad_xchg_handle_bytes(void);
+int ggad_xchg_handle(ggad_xchg *xchg, void *handle_host_out);
+int ggad_xchg_connect(ggad_xchg *xchg, const void *handles_host);     /* world x handle bytes, rank order */
+int ggad_xchg_error(ggad_xchg *xchg, int32_t *err_host);
+int ggad_xchg_destroy(ggad_xchg *xchg);
+int ggad_xchg_adam(float *params, float *exp_avg, float *exp_avg_sq, const float *grads, int32_t D, int32_t F, float lr,
+                   float weight_decay, float grad_scale, const int32_t *step_counter, ggad_xchg *xchg, ggad_stream_t stream);
+/* ggad_mb_train_chunk with the exchange: per batch  backward -> (publish, wait, sum in rank order, Adam x grad_scale). */
+int ggad_mb_train_chunk_xchg(const ggad_mb_step *tmpl, int32_t n_batches, const int32_t *batch_ptr, const int64_t *batch_ent_ptr,
+                             const int32_t *batch_max_row, float *loss_log, int32_t log_base, float grad_scale, ggad_xchg *xchg,
+                             ggad_stream_t stream);
+
 /* Inference embeddings: h[i] = relu(W x1[i])  (GCNEncoder.forward, train_flag False).   graphsage.py:412 */
 int ggad_mb_encode(const float *params, int32_t D, int32_t F, const float *x1, int32_t n_rows, float *h,
                    ggad_stream_t stream);

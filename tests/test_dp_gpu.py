@@ -40,7 +40,7 @@ def _inputs():
     return rowptr, col, feat, labels, train, pool, (w, W, fc)
 
 
-def _worker(rank, world, port, steps, out_dir):
+def _worker(rank, world, port, steps, out_dir, oneshot=False):
     import torch.distributed as dist
     from ggad_amd.graph import DeviceGraph
     from ggad_amd.sampler import PyCompatRandom
@@ -53,15 +53,39 @@ def _worker(rank, world, port, steps, out_dir):
     graph = DeviceGraph(rowptr, col, "cuda:0")
     ft = torch.from_numpy(feat).to("cuda:0")
     sched = BatchSchedule(train.copy(), pool.copy(), labels, 90, PyCompatRandom(72), n_pseudo=30, batches_per_epoch=7)
+    exchange = None
+    if oneshot:
+        from ggad_amd.exchange import OneShotExchange
+        exchange = OneShotExchange(rank, world, 64 + 64 * 17 + 64 * 64, "cuda:0")
+        assert exchange.connect(dist), "one-shot exchange: IPC hand-shake or self-test failed"
     tr = DGraphTrainer(graph, ft, 64, sched, chunk_batches=3, rank=rank, world_size=world,
-                       allreduce=lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM))
-    assert tr.overlap
+                       allreduce=lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM), exchange=exchange)
+    assert tr.overlap and (tr.exchange is not None) == oneshot
     tr.engine.load_params(w, W, fc)
     tr.run_steps(steps)
     torch.cuda.synchronize()
     np.save(os.path.join(out_dir, f"params_{rank}.npy"), tr.engine.params.cpu().numpy())
+    if exchange is not None:
+        assert exchange.error() == 0
     dist.barrier()
+    if exchange is not None:
+        exchange.close()
     dist.destroy_process_group()
+
+
+def test_one_shot_exchange_two_processes_one_gpu_bit_equal_to_allreduce(tmp_path):
+    """The one-shot exchange (each rank's gradient-Adam launch writes its block into the peer's IPC-mapped fine-grained
+    buffer, polls the peer's flags, sums in rank order) between two PROCESSES sharing one device: after 8 steps both ranks
+    hold bit-identical weights, and they are bit-identical to the all-reduce(SUM) + Adam(1 / W) path (g0 + g1 has one order)."""
+    import torch.multiprocessing as mp
+    steps, world = 8, 2
+    a, b = tmp_path / "oneshot", tmp_path / "allreduce"
+    a.mkdir(); b.mkdir()
+    mp.spawn(_worker, args=(world, _free_port(), steps, str(a), True), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), steps, str(b), False), nprocs=world, join=True)
+    p0, p1 = np.load(a / "params_0.npy"), np.load(a / "params_1.npy")
+    np.testing.assert_array_equal(p0, p1)
+    np.testing.assert_array_equal(p0, np.load(b / "params_0.npy"))
 
 
 def test_two_ranks_one_gpu_equal_gradient_averaging(tmp_path):

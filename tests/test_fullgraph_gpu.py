@@ -297,7 +297,8 @@ def test_spmm_at_t_finance_size_against_scipy_and_exact_scaling():
     (XCD-sliced) product against scipy in float64, exact under a factor 2, deterministic, with bias + PReLU epilogue."""
     import scipy.sparse as sp
     n, ne, w = 39357, 21222543, 300
-    rowptr, col = synth.make_graph(n, ne, 0, kind="powerlaw", max_degree=n // 8)
+    rowptr, col = synth.make_graph(n, ne, 0, kind="powerlaw", max_degree=n // 8, exact=True)
+    assert abs(int(rowptr[-1]) - ne) <= 1
     a = synth.csr_to_scipy(rowptr, col, n)
     csr = FG.Csr(U.normalize_adj(a) + sp.eye(n), DEV)
     rng = np.random.default_rng(1)
@@ -352,3 +353,4 @@ def test_gcn_layer_cached_aggregate_equals_reference_order(monkeypatch):
         monkeypatch.setenv("GGAD_GCN_REORDER", "0")
         o3 = layer(x[None], fa)[0]
     assert not torch.allclose(o1, o2) and torch.allclose(o2, o3, rtol=1e-5, atol=1e-5)
+
