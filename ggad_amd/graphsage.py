@@ -31,6 +31,7 @@ from torch.nn import init
 from . import _lib
 from ._lib import call, ptr
 from .graph import DeviceGraph
+from .fullgraph import LinearFn
 from .minibatch import BatchChunk, MiniBatchEngine
 
 _GRAPH_CACHE = {}
@@ -345,14 +346,18 @@ class Encoder(nn.Module):
     def forward(self, nodes):
         nodes_np = _node_array(nodes)
         adj = self.adj_lists
-        neigh_sets = [set(adj[int(v)]) for v in nodes_np] if not isinstance(adj, DeviceGraph) else \
-            [set(adj.col_host[adj.rowptr_host[v]:adj.rowptr_host[v + 1]].tolist()) for v in nodes_np]
+        # the reference hands the adjacency's own set objects to the aggregator (`:137`): `random.sample` walks a set in ITS
+        # iteration order, which a copy does not preserve -- so no copy; a CSR graph yields sets filled in ascending order, the
+        # construction of `synth.csr_to_adj_lists`
+        neigh_sets = [adj[int(v)] for v in nodes_np] if not isinstance(adj, DeviceGraph) else \
+            [set(int(c) for c in adj.col_host[adj.rowptr_host[v]:adj.rowptr_host[v + 1]]) for v in nodes_np]
         neigh_feats = self.aggregator.forward(nodes_np, neigh_sets, self.num_sample)
         if not self.gcn:
             combined = torch.cat((self.features(nodes_np), neigh_feats), dim=1)
         else:
             combined = neigh_feats
-        return torch.relu(self.weight.mm(combined.t()))
+        # relu(W . combined^T) (`:152`) on the exact-f32 MFMA GEMM with the ReLU epilogue; autograd = two more GEMMs (LinearFn)
+        return LinearFn.apply(combined.contiguous(), self.weight, True).t()
 
 
 class GraphSage(nn.Module):
@@ -365,7 +370,8 @@ class GraphSage(nn.Module):
         self.weight = nn.Parameter(w.to(enc.weight.device))
 
     def forward(self, nodes):
-        return self.weight.mm(self.enc(nodes)).t()
+        embeds = self.enc(nodes)                                            # (D, B)
+        return LinearFn.apply(embeds.t().contiguous(), self.weight, False)  # scores.t() = (weight . embeds)^T   (`:32-35`)
 
     def to_prob(self, nodes):
         return torch.sigmoid(self.forward(nodes))

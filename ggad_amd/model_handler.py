@@ -6,7 +6,10 @@ Same config keys (`src/dgraph.yml`), same split, same batch schedule for equal s
 same checkpoint format (state_dict keys of `GCN`).  What differs is where the work runs: the batch
 sub-graphs, the aggregation, the model step and Adam are HIP kernels on the MI355X; the python
 `random` stream is continued by the native sampler; validation scores thousands of reference batches
-per launch.  Only ``model: 'GCN'`` is runnable -- as in the reference.
+per launch.  ``model: 'GCN'`` is the GGAD model.  ``model: 'SAGE'`` (the vanilla GraphSAGE baseline of
+`src/graphsage.py:19-154`) cannot run through the reference's own loop -- `GraphSage.loss` returns one value where the loop
+unpacks four (`:358-362`), and `test_sage` calls `to_prob(nodes, None)` where `GraphSage.to_prob` takes one argument
+ -- here it is REPAIRED with exactly those two changes (`_train_sage`).
 
 Extra, optional config keys:  ``device`` (cuda index), ``num_batches`` (default 150, the reference's
 hard override `:317`), ``data`` = (adj_lists | DeviceGraph | (rowptr, col), feat_data, labels) to bypass
@@ -27,7 +30,7 @@ import torch.nn as nn
 
 from .dgraph import load_dgraphfin, normalize_features, split_dgraphfin
 from .graph import DeviceGraph
-from .graphsage import GCN, FeatureTable, GCNAggregator, GCNEncoder
+from .graphsage import GCN, Encoder, FeatureTable, GCNAggregator, GCNEncoder, GraphSage, MeanAggregator
 from .sage_utils import test_sage
 from .sampler import PyCompatRandom
 from .trainer import BatchSchedule, DGraphTrainer
@@ -62,8 +65,11 @@ class ModelHandler(object):
 
     def train(self):
         args = self.args
+        if args.model == "SAGE":
+            return self._train_sage()
         if args.model != "GCN":
-            raise NotImplementedError("only model 'GCN' is trainable, as in the reference (SURVEY.md §3.2 quirk 7)")
+            raise NotImplementedError("models 'GCN' (GGAD) and 'SAGE' are trainable; 'PCGNN' needs three relation graphs and an "
+                                      "undefined `test_pcgnn` in the reference (SURVEY.md §3.2 quirk 7)")
         if not torch.cuda.is_available():
             raise RuntimeError("ModelHandler.train needs an MI355X: the GGAD hot path has no CPU fallback")
         dist = torch.distributed if (torch.distributed.is_available() and torch.distributed.is_initialized()) else None
@@ -167,3 +173,98 @@ class ModelHandler(object):
                 dist.broadcast(engine.params, src=0)          # every rank tests the restored weights
             engine.sync_params()
         return test_sage(idx_test, y_test, gnn_model, args.batch_size, args.thres, dist=dist, verbose=rank == 0)
+
+
+    # ---------------------------------------------------------------------------------------------------------------- SAGE
+    def _train_sage(self):
+        """`model: 'SAGE'`: MeanAggregator -> Encoder(gcn=False) -> GraphSage(2, enc) as `src/model_handler.py:278-293` builds
+        them, trained by the loop of `:310-370` with the two repairs named in the module docstring.  Host side as in the reference
+        (python `random` shuffles and neighbour sampling, python sets); the arithmetic -- segment mean of sampled neighbour
+        rows, the two projections and their gradients, Adam -- runs in libggad_hip.so."""
+        from .fullgraph import FlatAdam
+        args = self.args
+        if not torch.cuda.is_available():
+            raise RuntimeError("ModelHandler.train needs an MI355X: there is no CPU fallback")
+        dev = torch.device("cuda", int(getattr(args, "device", torch.cuda.current_device())))
+        torch.cuda.set_device(dev)
+        feat_data, adj_lists = self.dataset["feat_data"], self.dataset["adj_lists"]
+        idx_train = list(self.dataset["idx_train"])
+        idx_valid, y_valid, idx_test, y_test = (self.dataset["idx_test"], self.dataset["y_test"],
+                                                self.dataset["idx_test"], self.dataset["y_test"])   # :260-261
+        n, f = feat_data.shape
+        nn.Embedding(n, f)                                            # RNG consumption of :263
+        if isinstance(adj_lists, tuple):
+            adj_lists = DeviceGraph(adj_lists[0], adj_lists[1], dev)
+        features = FeatureTable(torch.FloatTensor(np.asarray(feat_data, dtype=np.float32)))
+        agg_sage = MeanAggregator(features, cuda=True)
+        enc_sage = Encoder(features, f, args.emb_size, adj_lists, agg_sage, gcn=False, cuda=True)
+        enc_sage.num_samples = 5                                       # :291 (a new attribute: the encoder keeps num_sample = 10)
+        gnn_model = GraphSage(2, enc_sage).to(dev)
+        features.to(dev)
+        optimizer = FlatAdam([p for p in gnn_model.parameters() if p.requires_grad], lr=args.lr, weight_decay=args.weight_decay)
+        self.model = gnn_model
+        num_batches = int(getattr(args, "num_batches", 150))           # :317
+        n_pseudo = int(getattr(args, "n_pseudo", 50))
+        idx_anomaly = list(self.dataset["idx_anomaly"])
+        labels = self.dataset["labels"]
+        timestamp = datetime.datetime.fromtimestamp(int(time.time())).strftime("%Y-%m-%d %H-%M-%S")
+        dir_saver = args.save_dir + timestamp
+        path_saver = os.path.join(dir_saver, "{}_{}.pkl".format(args.data_name, args.model))
+        f1_mac_best, auc_best, ep_best = 0, 0, -1
+        total_time = 0.0
+        self.sage_losses = []
+        for epoch in range(args.num_epochs):
+            t_epoch = time.time()
+            random.shuffle(idx_train)                                  # :314
+            loss_sum, epoch_time = 0.0, 0.0
+            for batch in range(num_batches):
+                t0 = time.time()
+                i0, i1 = batch * args.batch_size, min((batch + 1) * args.batch_size, len(idx_train))
+                batch_nodes = idx_train[i0:i1]
+                random.shuffle(idx_anomaly)                            # :341
+                batch_nodes = batch_nodes + idx_anomaly[:n_pseudo]     # :342,347
+                batch_label = labels[np.array(batch_nodes)]
+                optimizer.zero_grad()
+                loss = gnn_model.loss(batch_nodes, torch.as_tensor(batch_label, device=dev).long())    # repair 1
+                loss.backward()
+                optimizer.step()
+                epoch_time += time.time() - t0
+                self.sage_losses.append(float(loss.item()))
+                loss_sum += self.sage_losses[-1]
+            print(f"Epoch: {epoch}, loss: {loss_sum / num_batches}, time: {epoch_time}s")
+            total_time += time.time() - t_epoch
+            if epoch % args.valid_epochs == 0:
+                print("Valid at epoch {}".format(epoch))
+                f1_mac_val, f1_1_val, f1_0_val, auc_val, gmean_val = self._test_graphsage(idx_valid, y_valid, gnn_model, args.batch_size,
+                                                                                          args.thres)
+                if auc_val > auc_best:
+                    f1_mac_best, auc_best, ep_best = f1_mac_val, auc_val, epoch
+                    if not os.path.exists(dir_saver):
+                        os.makedirs(dir_saver)
+                    print("  Saving model ...")
+                    torch.save(gnn_model.state_dict(), path_saver)
+        if ep_best >= 0:
+            print("Restore model from epoch {}".format(ep_best))
+            print("Model path: {}".format(path_saver))
+            gnn_model.load_state_dict(torch.load(path_saver))
+        return self._test_graphsage(idx_test, y_test, gnn_model, args.batch_size, args.thres)
+
+    @staticmethod
+    def _test_graphsage(test_cases, labels, model, batch_size, thres=0.5):
+        """`test_sage` (`src/utils.py:207-247`) for the two-class GraphSage head: `to_prob(nodes)` (repair 2: one argument), the
+        score of a node = its class-1 probability."""
+        from .metrics import binary_report
+        test_cases = list(test_cases)
+        probs = []
+        with torch.no_grad():
+            for it in range(int(len(test_cases) / batch_size) + 1):
+                chunk = test_cases[it * batch_size:min((it + 1) * batch_size, len(test_cases))]
+                if not chunk:
+                    continue
+                probs.append(model.to_prob(chunk)[:, 1])
+        probs = torch.cat(probs)
+        r = binary_report(probs, torch.as_tensor(np.asarray(labels), device=probs.device), thres)
+        print(f"   GNN F1-binary-1: {r['f1_1']:.4f}\tF1-binary-0: {r['f1_0']:.4f}" +
+              f"\tF1-macro: {r['f1_macro']:.4f}\tG-Mean: {r['gmean']:.4f}\tAUC: {r['auc']:.4f}")
+        print("Testing AP:", r["ap"])
+        return r["f1_macro"], r["f1_1"], r["f1_0"], r["auc"], r["gmean"]

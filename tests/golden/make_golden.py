@@ -548,6 +548,67 @@ def baseline_case():
     print("wrote", path)
 
 
+def sage_train_case():
+    """The vanilla GraphSAGE model of the reference (src/graphsage.py:19-154: MeanAggregator with python `random.sample`
+    neighbour sampling, Encoder relu(W [self || mean]), GraphSage + CrossEntropyLoss) trained the way `ModelHandler` builds it
+    for `model: 'SAGE'` (src/model_handler.py:278-293: gcn=False, `enc_sage.num_samples = 5` -- a typo that creates a new
+    attribute, the encoder keeps num_sample = 10) with the batch loop of :310-365 (epoch shuffle of the train list, per-batch
+    shuffle of the pseudo-anomaly pool, batch + first 50 pool nodes).  The reference's own loop cannot run this model: it
+    unpacks four values from `GraphSage.loss` (which returns one) and calls `to_prob(nodes, None)` (which takes one argument);
+    the harness makes exactly those two repairs.  Captured: the batches, per-step losses, weights, `to_prob` of test nodes."""
+    import torch.nn as nn
+    import graphsage as gs                       # /root/reference/src/graphsage.py
+    n, f, d, seed = 900, 17, 64, 11
+    rowptr, col, feat_raw, feat, adj_lists = _mini_setup(n, 9000, f, seed, "powerlaw", 0.0)
+    rng = np.random.default_rng(seed)
+    labels = (rng.random(n) < 0.1).astype(np.int64)
+    idx_train = list(range(100, 700))
+    idx_anomaly = [int(i) for i in np.nonzero(labels)[0][:60]]
+    random.seed(72)
+    np.random.seed(72)
+    torch.manual_seed(72)
+    features = nn.Embedding(n, f)
+    features.weight = nn.Parameter(torch.FloatTensor(feat), requires_grad=False)
+    agg = gs.MeanAggregator(features, cuda=False)
+    enc = gs.Encoder(features, f, d, adj_lists, agg, gcn=False, cuda=False)
+    enc.num_samples = 5                          # model_handler.py:291 (the typo is part of the reference)
+    model = gs.GraphSage(2, enc)
+    opt = torch.optim.Adam(filter(lambda p: p.requires_grad, model.parameters()), lr=0.001, weight_decay=0.007)
+    out = dict(rowptr=rowptr, col=col, feat=feat.astype(np.float32), labels=labels, idx_train=np.array(idx_train),
+               idx_anomaly=np.array(idx_anomaly), f=f, d=d)
+    out["init.enc.weight"] = _np(enc.weight).copy()
+    out["init.weight"] = _np(model.weight).copy()
+    bs, nb, n_pseudo = 40, 4, 10
+    losses, batches = [], []
+    for epoch in range(2):
+        random.shuffle(idx_train)                                    # :314
+        for b in range(nb):
+            batch_nodes = idx_train[b * bs:(b + 1) * bs]
+            random.shuffle(idx_anomaly)                              # :341
+            batch_nodes = batch_nodes + idx_anomaly[:n_pseudo]       # :342,347
+            batch_label = labels[np.array(batch_nodes)]
+            opt.zero_grad()
+            loss = model.loss(batch_nodes, torch.LongTensor(batch_label))    # repair 1: one return value
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.item()))
+            batches.append(np.array(batch_nodes, dtype=np.int64))
+    out["losses"] = np.array(losses, dtype=np.float64)
+    out["batches"] = np.stack(batches)
+    out["final.enc.weight"] = _np(enc.weight).copy()
+    out["final.weight"] = _np(model.weight).copy()
+    test_nodes = list(range(700, 790))
+    with torch.no_grad():
+        probs = np.concatenate([_np(model.to_prob(test_nodes[s:s + 30])) for s in range(0, 90, 30)])   # repair 2: one argument
+    out["test_nodes"] = np.array(test_nodes)
+    out["test_probs"] = probs.astype(np.float32)
+    st = random.getstate()
+    out["py_random_after"] = np.array(st[1], dtype=np.uint64)
+    path = os.path.join(HERE, "minibatch_sage.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "losses", losses)
+
+
 def part_mini(with_handler: bool):
     _stub_third_party()
     sys.path.insert(0, os.path.join(REF, "src"))
@@ -556,13 +617,14 @@ def part_mini(with_handler: bool):
     mini_module_case("dense", n=150, n_entries=3000, f=9, d=32, seed=8, n_norm=24, n_ano=6,
                      kind="er", k_steps=3, self_loop_frac=1.0)
     sampler_case()
+    sage_train_case()
     if with_handler:
         handler_case()
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--part", choices=["all", "full", "mini", "baselines", "ocgnn", "ingest"], default="all")
+    ap.add_argument("--part", choices=["all", "full", "mini", "baselines", "ocgnn", "ingest", "sage"], default="all")
     ap.add_argument("--no-handler", action="store_true", help="skip the slow end-to-end ModelHandler case")
     a = ap.parse_args()
     if not os.path.isdir(REF):
@@ -583,6 +645,10 @@ if __name__ == "__main__":
         _stub_third_party()
         sys.path.insert(0, REF)
         ocgnn_case()
+    elif a.part == "sage":
+        _stub_third_party()
+        sys.path.insert(0, os.path.join(REF, "src"))
+        sage_train_case()
     elif a.part == "baselines":
         _stub_third_party()
         sys.path.insert(0, os.path.join(REF, "src"))
