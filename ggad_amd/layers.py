@@ -76,3 +76,88 @@ class IntraAgg(nn.Module):
         to_feats_neigh = LinearFn.apply(agg2, wt, True)
         self.last_unique = np.asarray(unique_nodes_list, dtype=np.int64)
         return to_feats, to_feats_neigh, mask
+
+
+class InterAgg(nn.Module):
+    """Inter-relation aggregator of the reference's PC-GNN skeleton (`src/layers.py:11-153`): three `IntraAgg`s (one per relation
+    graph), their batch embeddings concatenated and projected, the same for the neighbourhood means of their 2-hop embeddings,
+    and the cosine affinity between the two (`:125-153`).  Same constructor, parameter names and return values
+    (`combined.t()` (D, B), `affinity` (B,)).  The reference also evaluates a label-aware score head (`label_clf`, `:80-101`) whose
+    results only feed the neighbour filtering it has commented out (`:193-198`): the head is kept as a parameter (state_dict and RNG
+    parity), its evaluation is skipped.  Aggregations: HIP ragged gathers inside `IntraAgg`; every product (the per-relation
+    projections, mask @ to_feats_neigh, the two (3D -> D) projections) runs on the MFMA GEMM with autograd (`LinearFn`)."""
+
+    def __init__(self, features, feature_dim, embed_dim, train_pos, adj_lists, intraggs, inter="GNN", cuda=True):
+        super().__init__()
+        self.features = _features(features)
+        self.dropout = 0.6
+        self.adj_lists = adj_lists
+        self.intra_agg1, self.intra_agg2, self.intra_agg3 = intraggs[0], intraggs[1], intraggs[2]
+        self.embed_dim = embed_dim
+        self.feat_dim = feature_dim
+        self.inter = inter
+        self.cuda = cuda
+        for a in intraggs:
+            a.cuda = cuda
+        self.train_pos = train_pos
+        self.thresholds = [0.5, 0.5, 0.5]
+        dev = self.features.weight.device
+        w = torch.empty(self.embed_dim * len(intraggs), self.embed_dim)
+        self.weight_gen = nn.Parameter(torch.zeros(self.embed_dim, self.embed_dim, device=dev))     # unused in the reference too (:49)
+        init.xavier_uniform_(w)                                                                    # :51
+        self.weight = nn.Parameter(w.to(dev))
+        self.label_clf = nn.Linear(self.feat_dim, 2).to(dev)                                       # :54
+        self.weights_log, self.thresholds_log, self.relation_score_log = [], [self.thresholds], []
+
+    def forward(self, nodes, labels, train_flag=True):
+        nodes = [int(v) for v in _node_array(nodes)]
+        r_feats, nb_feats = [], []
+        for agg, adj in zip((self.intra_agg1, self.intra_agg2, self.intra_agg3), self.adj_lists):
+            to_feats, to_feats_neigh, mask = agg.forward(nodes, labels, None, None, None, None, None, train_flag, adj)   # :104-112
+            r_feats.append(to_feats)
+            nb_feats.append(LinearFn.apply(mask.contiguous(), to_feats_neigh.t().contiguous(), False))   # mask.mm(to_feats_neigh) :131-133
+        wt = self.weight.t().contiguous()
+        combined = LinearFn.apply(torch.cat(r_feats, dim=1), wt, True)                                  # :127-129
+        neigh = LinearFn.apply(torch.cat(nb_feats, dim=1), wt, True)                                    # :135-136
+        cn = combined / torch.norm(combined, dim=-1, keepdim=True)                                      # :139-145
+        cn = torch.where(torch.isnan(cn), torch.full_like(cn, 0), cn)
+        nn_ = neigh / torch.norm(neigh, dim=-1, keepdim=True)
+        nn_ = torch.where(torch.isnan(nn_), torch.full_like(nn_, 0), nn_)
+        affinity = (nn_ * cn).sum(1)                                                                    # diag(mm(.,.T))  :146
+        return combined.t(), affinity
+
+
+class PCALayer(nn.Module):
+    """`PCALayer` of the reference's `src/model.py:8-48`: class scores from the inter-relation embedding, cross entropy +
+    5 x the affinity margin (margin 1); `loss` returns (total, margin term), `to_prob` the two sigmoid score sets."""
+
+    def __init__(self, num_classes, inter1, lambda_1):
+        super().__init__()
+        self.inter1 = inter1
+        self.xent = nn.CrossEntropyLoss()
+        w = torch.empty(num_classes, inter1.embed_dim)
+        init.xavier_uniform_(w)
+        self.weight = nn.Parameter(w.to(inter1.weight.device))
+        self.lambda_1 = lambda_1
+        self.epsilon = 0.1
+
+    def forward(self, nodes, labels, train_flag=True):
+        embeds1, affinity = self.inter1(nodes, labels, train_flag)
+        scores_t = LinearFn.apply(embeds1.t().contiguous(), self.weight, False)        # (weight.mm(embeds1)).t()   :25-26
+        return scores_t, affinity
+
+    def to_prob(self, nodes, labels, train_flag=True):
+        gnn_logits, label_logits = self.forward(nodes, labels, train_flag)
+        return torch.sigmoid(gnn_logits), torch.sigmoid(label_logits)
+
+    def affinity(self, affinity, labels):
+        a0 = torch.mean(affinity[torch.argwhere(labels == 0)], 0)
+        a1 = torch.mean(affinity[torch.argwhere(labels == 1)], 0)
+        return (1 - (a0 - a1)).clamp_min(min=0)                                        # :36-41
+
+    def loss(self, nodes, labels, train_flag=True):
+        labels = torch.as_tensor(labels, device=self.weight.device).long()
+        label_scores, affinity = self.forward(nodes, labels, train_flag)
+        loss_cls = self.xent(label_scores, labels.squeeze())
+        loss_constraint = self.affinity(affinity, labels)
+        return loss_cls + 5 * loss_constraint, loss_constraint

@@ -609,6 +609,52 @@ def sage_train_case():
     print("wrote", path, "losses", losses)
 
 
+def pcgnn_case():
+    """PC-GNN skeleton of the reference (src/layers.py:11-153 `InterAgg`, src/model.py:8-48 `PCALayer`) on three synthetic relation
+    graphs: the reference's `ModelHandler` cannot reach it on dgraphfin (one relation there, `test_pcgnn` undefined), so the vectors
+    are module level -- embeddings, affinity, the two loss values, the gradient of every parameter that receives one, `to_prob`."""
+    import torch.nn as nn
+    import layers as rl                          # /root/reference/src/layers.py
+    import model as rm                           # /root/reference/src/model.py
+    import utils as sutils
+    n, f, d, seed = 500, 17, 32, 21
+    rels = [synth.make_graph(n, 3000 + 1500 * k, seed + k, kind="powerlaw", max_degree=40) for k in range(3)]
+    feat = np.asarray(sutils.normalize(synth.make_features(n, f, seed))).astype(np.float32)
+    adjs = [synth.csr_to_adj_lists(rp, ci) for rp, ci in rels]
+    rng = np.random.default_rng(seed)
+    nodes = [int(x) for x in rng.choice(n, size=48, replace=False)]
+    labels = np.zeros(48, dtype=np.int64)
+    labels[36:] = 1
+    labels[[3, 17]] = 1
+    torch.manual_seed(seed)
+    features = nn.Embedding(n, f)
+    features.weight = nn.Parameter(torch.FloatTensor(feat), requires_grad=False)
+    intras = [rl.IntraAgg(features, f, d, [], 0.5, cuda=False) for _ in range(3)]
+    inter = rl.InterAgg(features, f, d, [], adjs, intras, inter="GNN", cuda=False)
+    model = rm.PCALayer(2, inter, 2)
+    out = dict(f=f, d=d, feat=feat, nodes=np.array(nodes), labels=labels)
+    for k, (rp, ci) in enumerate(rels):
+        out[f"rowptr{k}"], out[f"col{k}"] = rp, ci
+    names = {"inter1.weight": inter.weight, "inter1.intra_agg1.weight": intras[0].weight, "inter1.intra_agg2.weight": intras[1].weight,
+             "inter1.intra_agg3.weight": intras[2].weight, "weight": model.weight}
+    for k, p in names.items():
+        out["init." + k] = _np(p).copy()
+    lab_t = torch.LongTensor(labels)
+    emb, aff = inter.forward(nodes, lab_t, True)
+    out["combined"], out["affinity"] = _np(emb), _np(aff)
+    loss, lcon = model.loss(nodes, lab_t, True)
+    loss.backward()
+    out["loss"] = np.array([loss.item(), lcon.item()], dtype=np.float64)
+    for k, p in names.items():
+        out["grad." + k] = _np(p.grad).copy()
+    with torch.no_grad():
+        gs_, ls_ = model.to_prob(nodes, lab_t, False)
+    out["prob_gnn"], out["prob_label"] = _np(gs_), _np(ls_)
+    path = os.path.join(HERE, "minibatch_pcgnn.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "loss", out["loss"])
+
+
 def part_mini(with_handler: bool):
     _stub_third_party()
     sys.path.insert(0, os.path.join(REF, "src"))
@@ -618,13 +664,14 @@ def part_mini(with_handler: bool):
                      kind="er", k_steps=3, self_loop_frac=1.0)
     sampler_case()
     sage_train_case()
+    pcgnn_case()
     if with_handler:
         handler_case()
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--part", choices=["all", "full", "mini", "baselines", "ocgnn", "ingest", "sage"], default="all")
+    ap.add_argument("--part", choices=["all", "full", "mini", "baselines", "ocgnn", "ingest", "sage", "pcgnn"], default="all")
     ap.add_argument("--no-handler", action="store_true", help="skip the slow end-to-end ModelHandler case")
     a = ap.parse_args()
     if not os.path.isdir(REF):
@@ -645,6 +692,10 @@ if __name__ == "__main__":
         _stub_third_party()
         sys.path.insert(0, REF)
         ocgnn_case()
+    elif a.part == "pcgnn":
+        _stub_third_party()
+        sys.path.insert(0, os.path.join(REF, "src"))
+        pcgnn_case()
     elif a.part == "sage":
         _stub_third_party()
         sys.path.insert(0, os.path.join(REF, "src"))
