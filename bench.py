@@ -208,6 +208,7 @@ def main():
     nodes_local = trainer.run_steps(a.steps, prepared=timed, gather_hook=timed_build)
     barrier()
     elapsed = time.perf_counter() - t1
+    trainer.check_exchange()
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

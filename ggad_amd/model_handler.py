@@ -117,9 +117,22 @@ class ModelHandler(object):
         if world > 1:
             def allreduce(t):
                 dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        exchange = None
+        if world > 1 and os.environ.get("GGAD_EXCHANGE", "oneshot") == "oneshot":
+            # one-shot peer-write exchange inside the gradient / Adam launch; every rank agrees on whether
+            # it is usable, else all of them keep the all-reduce
+            from .exchange import OneShotExchange
+            n_par = int(engine.n_train)
+            try:
+                exchange = OneShotExchange(rank, world, n_par, features.weight.device)
+            except Exception:
+                exchange = None
+            good = exchange.connect(dist) if exchange is not None else OneShotExchange.decline(dist, features.weight.device)
+            if not good:
+                exchange = None
         steps_per_epoch = max(1, num_batches // world)
         trainer = DGraphTrainer(graph, features.weight.data, args.emb_size, sched, chunk_batches=steps_per_epoch, rank=rank,
-                                world_size=world, allreduce=allreduce, engine=engine)
+                                world_size=world, allreduce=allreduce, engine=engine, exchange=exchange)
         self.trainer, self.model = trainer, gnn_model
         trainer.start_stream(steps_per_epoch * args.num_epochs)        # sampler thread alive across the validation pauses
         total_time = 0.0
@@ -134,6 +147,7 @@ class ModelHandler(object):
             t0 = time.time()
             trainer.run_steps(steps_per_epoch * n_ep)
             torch.cuda.synchronize()
+            trainer.check_exchange()
             block_time = time.time() - t0
             lall = engine.losses(steps_per_epoch * n_ep).astype(np.float64)
             for j in range(n_ep):

@@ -131,6 +131,13 @@ class DGraphTrainer:
         self._stream = None
         self._pending = ([], [])        # batches taken from the sampler stream but not consumed yet
 
+    def check_exchange(self) -> None:
+        """Raise if a one-shot exchange step timed out waiting for a peer (the kernel's bounded spin sets an error word instead of
+        hanging).  Reads device memory: call after a synchronisation point (end of a run / before a validation sweep)."""
+        if self.exchange is not None and self.exchange.error() != 0:
+            raise RuntimeError("ggad_amd: one-shot gradient exchange timed out waiting for a peer rank (weights are no longer "
+                               "in step across the ranks)")
+
     def default_ramp(self, n_steps: int) -> List[int]:
         """Chunk sizes of a run of n optimiser steps.  With overlap the first plan is exposed and the last chunk's dense steps
         are: start small, grow geometrically to `chunk_batches`, and keep the tail chunk short when the run itself is short."""
