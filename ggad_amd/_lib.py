@@ -110,6 +110,8 @@ SIGNATURES = {
     "ggad_mt_set_state": (c_int32, [c_void_p, POINTER(c_uint32), c_int32]),
     "ggad_mt_get_state": (c_int32, [c_void_p, POINTER(c_uint32), POINTER(c_int32)]),
     "ggad_mt_shuffle_i64": (c_int32, [c_void_p, POINTER(c_int64), c_int64]),
+    "ggad_mt_shuffle_targets": (c_int32, [c_void_p, c_int64, c_void_p]),
+    "ggad_apply_swaps_i64": (c_int32, [c_void_p, c_int64, c_void_p]),
     "ggad_mt_getrandbits32": (c_uint32, [c_void_p]),
     "ggad_sched_batches": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_int32,
                                      c_void_p, c_void_p]),

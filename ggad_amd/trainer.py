@@ -55,7 +55,7 @@ class BatchSchedule:
 
     def next_batches(self, count: int, rank: int = 0, world: int = 1) -> Tuple[List[np.ndarray], List[np.ndarray]]:
         """`count` optimiser steps worth of batches for this rank (every rank advances the same stream).  One native call:
-        the generator walk of the next shuffle overlaps the swaps of the current one (`ggad_sched_batches`)."""
+        a pipeline of threads -- generator, acceptance walk, permutation builders, composition -- confined to one L3 (`ggad_sched_batches`, csrc/sampler.cpp)."""
         import ctypes
         total = int(count) * int(world)
         if total == 0:
@@ -71,7 +71,12 @@ class BatchSchedule:
                                           lens.ctypes.data), "ggad_sched_batches")
         self._in_epoch = int(ie.value)
         self.global_batch += total
-        nodes = [out[s * world + rank, :lens[s * world + rank]].copy() for s in range(count)]
+        mine = out[rank::world][:count]                      # this rank's batches (rows of the fresh array: views, no copies)
+        mlen = lens[rank::world][:count]
+        if int(mlen.min()) == stride:
+            lab2d = self.labels[mine].astype(np.int64)      # one vectorised lookup for the whole call
+            return list(mine), list(lab2d)
+        nodes = [mine[s, :mlen[s]] for s in range(count)]
         labs = [self.labels[n].astype(np.int64) for n in nodes]
         return nodes, labs
 
@@ -215,11 +220,8 @@ class DGraphTrainer:
         if getattr(self, "_stream", None) is not None:
             raise RuntimeError("a batch stream is already running")
         q = queue.Queue(maxsize=3)
-        sizes = []
-        left = int(total_steps)
-        while left > 0:
-            sizes.append(min(self.chunk_batches, left))
-            left -= sizes[-1]
+        # the first deliveries are small (the chunk ramp of `default_ramp`): the GPU starts after 16 batches of sampling instead of 150
+        sizes = self.default_ramp(int(total_steps))
 
         def produce():
             try:

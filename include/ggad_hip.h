@@ -431,6 +431,10 @@ int ggad_mt_get_state(const ggad_mt19937 *, uint32_t *mt624_host, int32_t *index
 /* random.shuffle(list) in place on an int64 array. */
 int ggad_mt_shuffle_i64(ggad_mt19937 *, int64_t *data_host, int64_t n);
 uint32_t ggad_mt_getrandbits32(ggad_mt19937 *);
+/* The two halves of random.shuffle for callers that pipeline them: (1) consume the generator -> targets_out[c] = swap partner
+ * of position n - 1 - c (int32[n + 16], data-independent); (2) apply recorded swaps to a list. */
+int ggad_mt_shuffle_targets(ggad_mt19937 *, int64_t n, int32_t *targets_host_out);
+int ggad_apply_swaps_i64(int64_t *data_host, int64_t n, const int32_t *targets_host);
 /* `count` consecutive batches of the reference's stream (src/model_handler.py:310-345: random.shuffle(train) at every
  * epoch start, random.shuffle(pool) before every batch, batch = train[i0:i1] ++ pool[:n_pseudo]) in one call, the
  * generator walk running one shuffle ahead of the swaps in a helper thread.  HOST pointers; train / pool are shuffled in

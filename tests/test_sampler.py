@@ -73,6 +73,13 @@ def test_native_batch_stream_equals_per_batch_path():
         assert np.array_equal(rn, gn) and np.array_equal(rl, gl)
     assert np.array_equal(a.train, b.train) and np.array_equal(a.pool, b.pool)
     assert a.rng.to_python_state() == b.rng.to_python_state() and a._in_epoch == b._in_epoch
+    # a long call: more pool shuffles in flight than the pipeline's ring holds (128), dozens of epoch shuffles (train double buffer)
+    ref_long = [a.next_batch() for _ in range(300)]
+    nn, ll = b.next_batches(300)
+    for (rn, rl), gn, gl in zip(ref_long, nn, ll):
+        assert np.array_equal(rn, gn) and np.array_equal(rl, gl)
+    assert np.array_equal(a.train, b.train) and np.array_equal(a.pool, b.pool)
+    assert a.rng.to_python_state() == b.rng.to_python_state() and a._in_epoch == b._in_epoch
     # three ranks: rank r of step s gets global batch 3 s + r
     c = make()
     ref3 = [c.next_batch() for _ in range(12)]
