@@ -21,9 +21,7 @@
 namespace {
 
 constexpr int BM = 128, BN = 64, BK = 32;      // BM: the large row tile; BM / 2 is used when the grid would not fill the chip
-constexpr int LDA_S = BM + 1, LDB_S = BN + 1;       // +1 pad: the transposing LDS store is conflict-free
-constexpr int A_PER_T = BM * BK / 256;              // 16 elements of the A tile per thread
-constexpr int B_PER_T = BN * BK / 256;              // 8 elements of the B tile per thread
+constexpr int LDB_S = BN + 1;                       // +1 pad: the transposing LDS store is conflict-free
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
@@ -189,11 +187,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
     __syncthreads();
   }
   const int i = lane & 31, kk = lane >> 5;
+  // (a second LDS buffer with one barrier per K-tile was measured: no gain -- 66 vs 63-72 TF on 39357 x 300 x 300, 106 vs 116 TF on
+  // 4096^3; rocprofv3: the MFMA pipe is busy 45 % / 68 % of the kernel's cycles on those shapes, profiles/r02_gemm_mfma_pmc.csv)
   for (int k0 = k_begin; k0 < k_end; k0 += BK) {
     const bool more = (k0 + BK) < k_end;
     if (more) fetch(k0 + BK);
-#pragma unroll 4
-    for (int ks = 0; ks < BK; ks += 2) {
+    auto mma = [&](int ks) {
       const float b = Bs[ks + kk][wc * 32 + i];
       const float a0 = As[ks + kk][wr * 32 * NACC + i];
       acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
@@ -201,6 +200,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
         const float a1 = As[ks + kk][wr * 64 + 32 + i];
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
       }
+    };
+    if (more) {
+#pragma unroll 4
+      for (int ks = 0; ks < BK; ks += 2) mma(ks);
+    } else {
+      // the last K-tile of K = 300 holds 12 valid k: its zero-padded tail is not multiplied (6 % of the MFMAs of such a product)
+      const int ks_end = min(BK, (k_end - k0 + 1) & ~1);
+      for (int ks = 0; ks < ks_end; ks += 2) mma(ks);
     }
     __syncthreads();
     if (more) {

@@ -231,6 +231,104 @@ def ocgnn_case():
     print("wrote", path, "losses", losses, "auc", out["eval_auc"])
 
 
+def tam_case():
+    """Full-graph TAM comparison model: the imported `model_tam.Model` / `utils_tam` functions and the two functions `tam.py`
+    defines (`max_message`, `inference`; pulled out of the script by name with `ast`, because importing `tam.py` runs it),
+    driven by the loop of `tam.py:153-214` on a small graph: distances, two successive truncations, normalisation, forward,
+    loss, gradients, a k-step Adam trajectory, scores."""
+    import ast
+    import contextlib
+    import io
+    import tempfile
+    import scipy.io as sio
+    import scipy.sparse as sp
+    import utils_tam as U                        # /root/reference/utils_tam.py
+    from model_tam import Model                  # /root/reference/model_tam.py
+    ns = {"torch": torch}
+    tree = ast.parse(open(os.path.join(REF, "tam.py")).read())
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name in ("max_message", "inference"):
+            exec(compile(ast.Module(body=[node], type_ignores=[]), "tam.py", "exec"), ns)
+    max_message, inference = ns["max_message"], ns["inference"]
+    n, n_entries, f, n_h, seed, k_steps, lr = 300, 2400, 20, 32, 9, 5, 1e-3
+    rowptr, col = synth.make_graph(n, n_entries, seed, kind="powerlaw", max_degree=n // 4)
+    feat = synth.make_features(n, f, seed)
+    ano = synth.make_labels(n, 0.08, seed)
+    adj_sp = synth.csr_to_scipy(rowptr, col)
+    out = dict(n=n, f=f, n_h=n_h, seed=seed, lr=lr, rowptr=rowptr, col=col, feat_raw=feat, ano=ano,
+               inputs_crc=synth.crc_of(rowptr, col, feat, ano))
+    tmp = tempfile.mkdtemp(prefix="ggad_tam_")
+    os.makedirs(os.path.join(tmp, "data"))
+    cwd = os.getcwd()
+    os.chdir(tmp)
+    try:
+        sio.savemat(os.path.join("data", "tiny.mat"), {"Network": sp.csr_matrix(adj_sp), "Attributes": sp.csr_matrix(feat),
+                                                        "Label": ano.reshape(-1, 1)})
+        random.seed(seed)
+        adj, features, ano_label, _, _, normal_label_idx, idx_test = U.load_mat("tiny")
+        out["split.tail"] = np.array([random.getrandbits(32) for _ in range(3)], dtype=np.int64)
+    finally:
+        os.chdir(cwd)
+    out.update(normal_idx=np.array(normal_label_idx, dtype=np.int64), idx_test=np.array(idx_test, dtype=np.int64))
+    features, _ = U.preprocess_features(features)                       # tam.py:55-57 (the 'Amazon' branch)
+    raw_features = features
+    raw_adj = (adj + sp.eye(n)).todense()
+    raw_features_t = torch.FloatTensor(raw_features[np.newaxis])
+    features_t = torch.FloatTensor(features[np.newaxis])
+    raw_adj_t = torch.FloatTensor(raw_adj[np.newaxis])
+    out["features"] = _np(features_t[0])
+    with contextlib.redirect_stdout(io.StringIO()):
+        dis_array = U.calc_distance(raw_adj_t[0], raw_features_t[0])   # tam.py:168
+    out["dis_array_nz"] = _np(dis_array)[np.asarray(raw_adj) > 0]      # row-major over the stored entries of A + I
+    np.random.seed(seed)
+    all_cut = raw_adj_t.clone()
+    torch.manual_seed(seed)
+    models = [Model(f, n_h, "prelu", 2, "avg") for _ in range(2)]
+    for k, v in models[0].state_dict().items():
+        out["init0." + k] = _np(v).copy()
+    for k, v in models[1].state_dict().items():
+        out["init1." + k] = _np(v).copy()
+    msgs = []
+    for cut in range(2):
+        cut_adj = U.graph_nsgt(dis_array, all_cut[0]).unsqueeze(0)      # tam.py:180 (in place on all_cut[0] too)
+        out[f"cut{cut}.adj_nz"] = np.argwhere(_np(cut_adj[0]) > 0).astype(np.int32)
+        adj_norm = U.normalize_adj_tensor(cut_adj)
+        out[f"cut{cut}.adj_norm_vals"] = _np(adj_norm[0])[_np(cut_adj[0]) > 0]
+        model = models[cut]
+        opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=0.0)
+        opt.zero_grad()                                                 # ONCE per cut, as tam.py:182 (gradients accumulate)
+        model.train()
+        losses = []
+        for epoch in range(k_steps):
+            node_emb, feat1, feat2 = model.forward(features_t, adj_norm)
+            loss, message_sum1 = max_message(node_emb[0], raw_adj_t[0], normal_label_idx)
+            message_sum = inference(node_emb[0], raw_adj_t[0])
+            loss.backward()
+            if epoch == 0:
+                out.update({f"cut{cut}.emb": _np(node_emb[0]), f"cut{cut}.feat1": _np(feat1[0]), f"cut{cut}.feat2": _np(feat2[0]),
+                            f"cut{cut}.message_norm": _np(message_sum1), f"cut{cut}.message": _np(message_sum)})
+                for kk, pp in model.named_parameters():
+                    if pp.grad is not None:
+                        out[f"cut{cut}.grad." + kk] = _np(pp.grad).copy()
+            opt.step()
+            losses.append(float(loss.detach()))
+        out[f"cut{cut}.losses"] = np.array(losses, dtype=np.float64)
+        out[f"cut{cut}.message_last"] = _np(message_sum)
+        for k, v in model.state_dict().items():
+            out[f"cut{cut}.final." + k] = _np(v).copy()
+        msgs.append(message_sum.detach().unsqueeze(0))
+        all_cut[0] = cut_adj[0]
+    from sklearn.metrics import roc_auc_score, average_precision_score
+    mean_msg = torch.mean(torch.cat(msgs), 0).numpy()
+    score = 1 - U.normalize_score(mean_msg)
+    out.update(score=score, auc=roc_auc_score(ano_label, score),
+               ap=average_precision_score(ano_label, score, average="macro", pos_label=1),
+               nprandom_tail=np.random.random_sample(3))
+    path = os.path.join(HERE, "fullgraph_tam.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, {k: out[k] for k in ("auc", "ap")}, "losses", out["cut0.losses"], out["cut1.losses"])
+
+
 def ingest_case():
     """`load_mat` of the reference (utils.py:66-141) on a small .mat written from seeded synthetic data: the index lists the
     split produces (python `random` driven), for the two outlier-seed fractions ('Amazon' 5 %, every other name 15 %)."""
@@ -671,7 +769,7 @@ def part_mini(with_handler: bool):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--part", choices=["all", "full", "mini", "baselines", "ocgnn", "ingest", "sage", "pcgnn"], default="all")
+    ap.add_argument("--part", choices=["all", "full", "mini", "baselines", "ocgnn", "ingest", "sage", "pcgnn", "tam"], default="all")
     ap.add_argument("--no-handler", action="store_true", help="skip the slow end-to-end ModelHandler case")
     a = ap.parse_args()
     if not os.path.isdir(REF):
@@ -692,6 +790,11 @@ if __name__ == "__main__":
         _stub_third_party()
         sys.path.insert(0, REF)
         ocgnn_case()
+    elif a.part == "tam":
+        _stub_third_party()
+        sys.modules["torch_geometric.nn"].GINConv = object
+        sys.path.insert(0, REF)
+        tam_case()
     elif a.part == "pcgnn":
         _stub_third_party()
         sys.path.insert(0, os.path.join(REF, "src"))
