@@ -100,6 +100,7 @@ SIGNATURES = {
     "ggad_rownorm_f32": (c_int32, [_P, _I, _I, _P, _P, _P]),
     "ggad_rownorm_bwd_f32": (c_int32, [_P, _P, _P, _I, _I, _P, _P]),
     "ggad_rowdot_f32": (c_int32, [_P, _P, _P, _I, _I, _P, _P, _P]),
+    "ggad_edge_dist_f32": (c_int32, [_P, _P, _P, _I, _I, _P, _P]),
     "ggad_rows_scale_f32": (c_int32, [_P, _P, _P, _I, _I, _I, _P, _P]),
     "ggad_full_loss_workspace_elems": (c_int64, [_I, _I]),
     "ggad_full_loss_f32": (c_int32, [_P, _P, _I, _I, _P, _P, _I, _F, _P, _P, _P, _P, _P, _P]),

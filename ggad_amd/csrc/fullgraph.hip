@@ -371,6 +371,24 @@ __global__ void __launch_bounds__(256) k_rowdot(const float *__restrict__ A, con
   if (lane == 0) out[p] = (scale ? scale[p] : 1.0f) * dot;
 }
 
+// out[e] = || X[row(e)] - X[col[e]] ||_2 for every stored entry e of a CSR matrix (TAM's calc_distance, utils_tam.py:190-199:
+// the attribute distance of every edge, computed once per dataset).  One wave per entry; lanes stride over the W attributes.
+__global__ void __launch_bounds__(256) k_edge_dist(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                   const float *__restrict__ X, int n_rows, int W, float *__restrict__ out) {
+  const int row = blockIdx.x;
+  if (row >= n_rows) return;
+  const int lane = lane_id(), wid = threadIdx.x >> 6;
+  const int s = rowptr[row], e = rowptr[row + 1];
+  const float *xi = X + (int64_t)row * W;
+  for (int p = s + wid; p < e; p += 4) {
+    const float *xj = X + (int64_t)col[p] * W;
+    float acc = 0.f;
+    for (int c = lane; c < W; c += 64) { const float d = xi[c] - xj[c]; acc = fmaf(d, d, acc); }
+    acc = wave_sum(acc);
+    if (lane == 0) out[p] = sqrtf(acc);
+  }
+}
+
 // out[p][:] = coef[p] * X[sel[p]][:]   (gather + scale);  with add_to: out[sel[p]][:] += coef[p] * X[p][:]  (sel unique)
 __global__ void __launch_bounds__(256) k_rows_scale(const float *__restrict__ X, const int32_t *__restrict__ sel,
                                                     const float *__restrict__ coef, int n, int W, int scatter_add,
@@ -600,6 +618,15 @@ int ggad_rownorm_bwd_f32(const float *Xn, const float *inv, const float *dXn, in
   if (M == 0) return GGAD_OK;
   k_rownorm_bwd<<<dim3((M + 3) / 4), dim3(256), 0, as_stream(stream)>>>(Xn, inv, dXn, M, W, dX);
   GGAD_CHECK_LAUNCH("rownorm_bwd_f32");
+  return GGAD_OK;
+}
+
+int ggad_edge_dist_f32(const int32_t *rowptr, const int32_t *col, const float *X, int32_t n_rows, int32_t W, float *out,
+                       ggad_stream_t stream) {
+  GGAD_REQUIRE(rowptr && col && X && out && n_rows >= 0 && W >= 1);
+  if (n_rows == 0) return GGAD_OK;
+  k_edge_dist<<<dim3(n_rows), dim3(256), 0, as_stream(stream)>>>(rowptr, col, X, n_rows, W, out);
+  GGAD_CHECK_LAUNCH("edge_dist_f32");
   return GGAD_OK;
 }
 

@@ -145,6 +145,20 @@ class FullGraphAdj:
         self._abn: Dict[tuple, tuple] = {}
         self._loss: Dict[tuple, tuple] = {}
         self._ax: Dict[str, object] = {}                         # cached A_hat X of the constant input layer (`cached_aggregate`)
+        self._devc: Dict[str, torch.Tensor] = {}                 # small per-node device vectors (`r_inv_dev`, `arange_dev`)
+
+    def r_inv_dev(self) -> torch.Tensor:
+        """1 / colsum(raw) (inf -> 0) on the device, one value per node."""
+        t = self._devc.get("r_inv")
+        if t is None:
+            t = self._devc["r_inv"] = _dev_f32(self.r_inv_host, self.dev)
+        return t
+
+    def arange_dev(self) -> torch.Tensor:
+        t = self._devc.get("arange")
+        if t is None:
+            t = self._devc["arange"] = torch.arange(self.n, dtype=torch.int32, device=self.dev)
+        return t
 
     @classmethod
     def from_dense(cls, adj, raw_adj, device):

@@ -396,6 +396,9 @@ int ggad_relu_bwd_f32(const float *g, const float *y, int64_t n, float *dz, ggad
 int ggad_rownorm_f32(const float *X, int32_t M, int32_t W, float *inv, float *Xn, ggad_stream_t stream);
 int ggad_rownorm_bwd_f32(const float *Xn, const float *inv, const float *dXn, int32_t M, int32_t W, float *dX,
                          ggad_stream_t stream);
+/* out[e] = || X[row(e)] - X[col[e]] ||_2 per stored entry of a CSR matrix (TAM calc_distance, utils_tam.py:190-199) */
+int ggad_edge_dist_f32(const int32_t *rowptr, const int32_t *col, const float *X, int32_t n_rows, int32_t W, float *out,
+                       ggad_stream_t stream);
 /* out[p] = scale[p] * <A[sel[p]], B[p]>   (affinity_j = r_inv_j <e_hat_j, (R^T e_hat)_j>, run.py:188) */
 int ggad_rowdot_f32(const float *A, const int32_t *sel, const float *B, int32_t n, int32_t W, const float *scale, float *out,
                     ggad_stream_t stream);

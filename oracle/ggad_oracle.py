@@ -522,3 +522,89 @@ def _full_loss_by_column(emb, logits, emb_con, emb_abnormal, raw, abn_idx, norma
     diff = torch.pow(emb_con - emb_abnormal.unsqueeze(0), 2)
     l_rec = torch.mean(torch.sqrt(torch.sum(diff, 1)))
     return l_margin + l_bce + l_rec, l_margin, l_bce, l_rec, aff
+
+
+# ----------------------------------------------------------------------------------
+# TAM comparison model (`tam.py`, `model_tam.py`, `utils_tam.py`): truncated affinity maximisation
+# ----------------------------------------------------------------------------------
+def tam_split(ano_labels: np.ndarray, rng) -> Tuple[List[int], np.ndarray]:
+    """The index lists of `load_mat` (`utils_tam.py:163-179`): 30 % / 10 % / 60 % split of a python-`random` shuffle, 80 % of
+    the normal training nodes, plus 15 % "contamination" -- the reference indexes the SHUFFLED list with the positions of
+    the anomalies (`:172`), so the contaminating nodes are random nodes, not anomalies (kept).  `rng` = python's `random`.
+    Returns (normal_label_idx, idx_test)."""
+    n = len(ano_labels)
+    all_idx = list(range(n))
+    rng.shuffle(all_idx)
+    n_train, n_val = int(n * 0.3), int(n * 0.1)
+    idx_train, idx_test = all_idx[:n_train], all_idx[n_train + n_val:]
+    all_normal = [i for i in idx_train if ano_labels[i] == 0]
+    normal = all_normal[: int(len(all_normal) * 0.8)]
+    real_abnormal = np.array(all_idx)[np.argwhere(ano_labels == 1).squeeze()].tolist()
+    add_rate = 0.15 * len(real_abnormal)
+    rng.shuffle(real_abnormal)
+    add = real_abnormal[:int(add_rate)]
+    return normal + add, np.setdiff1d(idx_test, add, False)
+
+
+def tam_calc_distance(rowptr, col, feat: np.ndarray) -> np.ndarray:
+    """`calc_distance` (`utils_tam.py:190-199`) on the stored entries of A + I: Euclidean distance of the two attribute rows,
+    aligned with `col` (the reference fills a dense N x N array entry by entry)."""
+    x = torch.from_numpy(np.asarray(feat, dtype=np.float32))
+    rows = np.repeat(np.arange(len(rowptr) - 1), np.diff(rowptr))
+    d = x[torch.from_numpy(rows.astype(np.int64))] - x[torch.from_numpy(np.asarray(col, dtype=np.int64))]
+    return torch.sqrt(torch.sum(d * d, 1)).numpy()
+
+
+def tam_graph_nsgt(dis: torch.Tensor, adj: torch.Tensor, nprandom) -> torch.Tensor:
+    """`graph_nsgt` (`utils_tam.py:222-240`), dense like the reference (small graphs only): per row, if the largest distance to
+    a neighbour exceeds the mean non-zero distance over the current edges, draw ONE number from numpy's global stream and
+    cut the row's edges longer than min + u (max - min); an edge survives if either direction survives (adj + adj.T)."""
+    adj = adj.clone()
+    du = dis * adj
+    mean_dis = du[du != 0].mean()
+    for i in range(dis.shape[0]):
+        node_index = torch.argwhere(adj[i, :] > 0)
+        if node_index.shape[0] != 0:
+            max_dis = dis[i, node_index].max()
+            if max_dis > mean_dis:
+                random_value = (max_dis - mean_dis) * nprandom.random_sample() + mean_dis
+                cutting = torch.argwhere(dis[i, node_index[:, 0]] > random_value)
+                if cutting.shape[0] != 0:
+                    adj[i, node_index[cutting[:, 0]]] = 0
+    adj = adj + adj.T
+    adj[adj > 1] = 1
+    return adj
+
+
+def tam_normalize_adj(adj: torch.Tensor) -> torch.Tensor:
+    """`normalize_adj_tensor` (`utils_tam.py:45-53`): D^-1/2 A D^-1/2 with D = column sums, inf -> 0."""
+    r_inv = torch.pow(torch.sum(adj, 0), -0.5).flatten()
+    r_inv[torch.isinf(r_inv)] = 0.0
+    return torch.mm(torch.diag_embed(r_inv), torch.mm(adj, torch.diag_embed(r_inv)))
+
+
+def tam_forward(P: Dict[str, torch.Tensor], feat: torch.Tensor, adj_norm: torch.Tensor):
+    """`model_tam.Model.forward` (`model_tam.py:150-157`): two GCN layers (`:36-45`), then the two unused projections."""
+    def gcn(x, pre):
+        return F.prelu(adj_norm.mm(x.mm(P[pre + ".fc.weight"].t())) + P[pre + ".bias"], P[pre + ".act.weight"])
+    emb = gcn(gcn(feat, "gcn1"), "gcn2")
+    return emb, emb.mm(P["fc1.weight"].t()), emb.mm(P["fc2.weight"].t())
+
+
+def tam_message(emb: torch.Tensor, raw_adj: torch.Tensor, zero_nan: bool) -> torch.Tensor:
+    """The local affinity of `tam.py:113-127,136-146`: row sums of (e_hat e_hat^T) * raw_adj, divided by the column sums of
+    raw_adj (inf -> 0); `max_message` also zeroes inf / NaN products, `inference` does not."""
+    f = emb / torch.norm(emb, dim=-1, keepdim=True)
+    sim = torch.mm(f, f.T) * raw_adj
+    if zero_nan:
+        sim = torch.where(torch.isinf(sim) | torch.isnan(sim), torch.zeros_like(sim), sim)
+    r_inv = torch.pow(torch.sum(raw_adj, 0), -1).flatten()
+    r_inv = torch.where(torch.isinf(r_inv), torch.zeros_like(r_inv), r_inv)
+    return torch.sum(sim, 1) * r_inv
+
+
+def tam_max_message(emb: torch.Tensor, raw_adj: torch.Tensor, normal_idx) -> Tuple[torch.Tensor, torch.Tensor]:
+    """`max_message` (`tam.py:113-133`): min-max normalised affinity, loss = - sum over the labelled normal nodes."""
+    m = tam_message(emb, raw_adj, True)
+    m = (m - torch.min(m)) / (torch.max(m) - torch.min(m))
+    return -torch.sum(m[torch.as_tensor(np.asarray(normal_idx), dtype=torch.long)]), m
