@@ -7,7 +7,7 @@ sklearn.  Definitions follow scikit-learn's (the reference's metric library), in
   average_precision_score  sum_n (R_n - R_{n-1}) P_n over the distinct thresholds, descending
   f1_score / confusion     from the thresholded predictions (score >= thres)
 
-sklearn itself stays the checker in the tests (tests/test_metrics_gpu.py)."""
+sklearn itself stays the checker in the tests (tests/test_metrics.py)."""
 from __future__ import annotations
 
 from typing import Dict

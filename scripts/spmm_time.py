@@ -1,0 +1,23 @@
+"""N x N x 300 product of the full-graph path alone:  python scripts/spmm_time.py [t_finance|Amazon ...]"""
+import random
+import sys
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+sys.path.insert(0, __file__.rsplit('/', 2)[0])
+from ggad_amd import fullgraph as FG  # noqa: E402
+from ggad_amd.fullgraph_bench import make_dataset, _time_call  # noqa: E402
+from ggad_amd.utils import normalize_adj  # noqa: E402
+
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+for name in (sys.argv[1:] or ["t_finance", "Amazon"]):
+    random.seed(0); np.random.seed(0)
+    ds = make_dataset(name, 0)
+    n = ds["n"]
+    full = FG.FullGraphAdj(normalize_adj(ds["adj"]) + sp.eye(n), ds["adj"] + sp.eye(n), dev)
+    x = torch.randn(n, 300, device=dev)
+    t = _time_call(lambda: FG.spmm(full.A, x), 30)
+    print(name, "spmm N x N x 300: %.1f us" % (t * 1e6))
