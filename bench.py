@@ -68,7 +68,7 @@ def parse():
     ap.add_argument("--ramp", default="", help="comma-separated sizes of the first chunks of a run (default: DGraphTrainer.default_ramp)")
     ap.add_argument("--steady-steps", type=int, default=3000, help="extra leg after the timed region: steps of one long run (0 = skip; "
                     "skipped when --steps is already >= this)")
-    ap.add_argument("--e2e-steps", type=int, default=1500, help="extra leg: steps timed with the reference-exact sampler inside the window (0 = skip)")
+    ap.add_argument("--e2e-steps", type=int, default=3000, help="extra leg: steps timed with the reference-exact sampler inside the window (0 = skip)")
     ap.add_argument("--fullgraph-epochs", type=int, default=30, help="extra leg: epochs timed per full-graph config (0 = skip)")
     ap.add_argument("--no-extras", action="store_true", help="only the timed region (no steady-state / e2e / full-graph / CPU legs)")
     ap.add_argument("--exchange", default="oneshot", choices=["oneshot", "rccl"],
