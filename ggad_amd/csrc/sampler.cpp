@@ -244,7 +244,8 @@ int ggad_apply_swaps_i64(int64_t *data, int64_t n, const int32_t *targets) {
 //   stage B (1 thread)   the acceptance walk over that stream -> swap targets of every shuffle, in stream order;
 //   stage C (W threads)  for a pool shuffle: the permutation P it amounts to (the swaps applied to 0..n-1) -- independent of
 //                        the list's contents, so consecutive shuffles are built CONCURRENTLY; for the epoch shuffle of the
-//                        ~1.05 M train list: the swaps applied in place (once per epoch, while B and the other workers run on);
+//                        ~1.05 M train list: a copy of the list with the swaps applied (once per epoch, into the other half of a
+//                        double buffer, while the caller still copies batches out of the old order);
 //   stage D (caller)     pool <- pool[P] (a gather: no dependent swaps) and the copy of the batch.
 // Same outputs consumed in the same order, same permutations, same final lists and generator state as the per-shuffle calls.
 namespace {
@@ -259,7 +260,7 @@ inline void wait_until(F cond) {
 }
 
 constexpr int RING_BLOCKS = 256;            // generator blocks between stage A and stage B (256 x 624 words = 640 KB)
-constexpr int POOL_RING = 128;              // pool shuffles in flight between B and D (bridges the in-place epoch shuffle)
+constexpr int POOL_RING = 128;              // pool shuffles in flight between B and D
 
 struct SchedBuffers {                       // reused across calls (per calling thread): no page faults in steady state
   std::vector<uint32_t> temp, raw;
@@ -433,7 +434,7 @@ int ggad_sched_batches(ggad_mt19937 *g, int64_t *train, int64_t n_train, int64_t
     w_end = w;
   });
 
-  // ---- stage C: permutations of the pool shuffles (concurrently), the epoch shuffle in place
+  // ---- stage C: permutations of the pool shuffles (concurrently), the epoch shuffle into the other train buffer
   unsigned hw = std::thread::hardware_concurrency();
   int n_workers = hw >= 8 ? 3 : (hw >= 6 ? 2 : 1);
   if ((int64_t)n_workers > n_items) n_workers = (int)n_items;
