@@ -111,6 +111,12 @@ class ModelHandler(object):
 
         num_batches = int(getattr(args, "num_batches", 150))                            # :317
         rng = PyCompatRandom.from_python_state(random.getstate())
+        # data parallel: `dp_sampler: shared` (default) deals the reference's ONE stream to the ranks (rank r takes batches
+        # r, r + W, ...: every rank generates all of them); `dp_sampler: independent` gives every rank a stream of its own
+        # (seed * 1000003 + rank + 1), which is what lets an end-to-end run scale past the serial sampler (trainer.py)
+        own_stream = world > 1 and str(getattr(args, "dp_sampler", "shared")) == "independent"
+        if own_stream:
+            rng = PyCompatRandom(int(getattr(args, "seed", 0)) * 1000003 + rank + 1)
         sched = BatchSchedule(idx_train, self.dataset["idx_anomaly"], self.dataset["labels"], args.batch_size, rng,
                               n_pseudo=50, batches_per_epoch=num_batches)
         allreduce = None
@@ -132,7 +138,7 @@ class ModelHandler(object):
                 exchange = None
         steps_per_epoch = max(1, num_batches // world)
         trainer = DGraphTrainer(graph, features.weight.data, args.emb_size, sched, chunk_batches=steps_per_epoch, rank=rank,
-                                world_size=world, allreduce=allreduce, engine=engine, exchange=exchange)
+                                world_size=world, allreduce=allreduce, engine=engine, exchange=exchange, own_stream=own_stream)
         self.trainer, self.model = trainer, gnn_model
         trainer.start_stream(steps_per_epoch * args.num_epochs)        # sampler thread alive across the validation pauses
         total_time = 0.0

@@ -87,7 +87,7 @@ class DGraphTrainer:
                  world_size: int = 1, allreduce: Optional[Callable[[torch.Tensor], None]] = None,
                  engine: Optional[MiniBatchEngine] = None, hop2: str = "ldsw",
                  overlap: bool = True, prefetch: bool = True, chain: int = 0, dense_cus: Optional[int] = None,
-                 ramp: Optional[Sequence[int]] = None, exchange=None):
+                 ramp: Optional[Sequence[int]] = None, exchange=None, own_stream: bool = False):
         """`feat` is the plain (N, F) table.  hop2 = "ldsw" (default): 2-hop counts in LDS per (tile, batch), per-pair
         counts streamed to the gather, feature rows padded to one 128-byte line; "global": per-batch counter slots in HBM +
         device atomics (the fallback the LDS path takes by itself when a chunk exceeds its limits).
@@ -100,6 +100,10 @@ class DGraphTrainer:
         `ramp`: sizes (batches) of the FIRST chunks of a `run_steps` call.  The plan of the first chunk cannot overlap
         anything, so a run starts with small chunks (the dense chain starts after a fraction of a millisecond instead of
         after a 150-batch plan) and grows to `chunk_batches`; None = `default_ramp`.
+        `own_stream`: data parallel with one batch stream PER RANK instead of one stream dealt to the ranks.  The bit-exact sampler
+        is serial (one Mersenne-Twister stream: ~37 us per batch on the host); dealing one stream to W ranks makes every rank
+        generate W batches per step, which bounds an end-to-end run at about two GPUs' worth of steps.  With W > 1 the
+        trajectory is not the reference's anyway (global batch W x 150), so ranks may draw from streams of their own.
         `exchange`: a connected `OneShotExchange` (ggad_amd/exchange.py) -- the data-parallel gradient exchange then happens
         inside the Adam launch over peer-mapped buffers, with no host call per step; else `allreduce` (RCCL) is used.
         `prefetch`: the host sampler (bit-exact CPython shuffle, ~0.1 ms per batch for the 55k pool) runs in a
@@ -107,6 +111,9 @@ class DGraphTrainer:
         self.graph, self.feat = graph, feat
         self.schedule = schedule
         self.rank, self.world = int(rank), int(world_size)
+        # which batches of `schedule` are this rank's: every W-th one of the stream all ranks generate (default: the reference's
+        # stream dealt to the ranks), or all of them (`own_stream`: the schedule is this rank's alone, e.g. seeded per rank)
+        self.sched_rank, self.sched_world = (0, 1) if own_stream else (self.rank, self.world)
         self.allreduce = allreduce if self.world > 1 else None
         self.exchange = exchange if (self.world > 1 and exchange is not None and exchange.ok) else None
         self.engine = engine or MiniBatchEngine(feat.shape[1], embed_dim, feat.device, lr, weight_decay, chain=chain)
@@ -226,7 +233,7 @@ class DGraphTrainer:
         def produce():
             try:
                 for k in sizes:
-                    q.put((k, self.schedule.next_batches(k, self.rank, self.world)))
+                    q.put((k, self.schedule.next_batches(k, self.sched_rank, self.sched_world)))
             except BaseException as exc:      # surface sampler errors in the consumer
                 q.put((0, exc))
         th = threading.Thread(target=produce, daemon=True)
@@ -270,7 +277,7 @@ class DGraphTrainer:
             def produce():
                 try:
                     for k in sizes:
-                        q.put(self.schedule.next_batches(k, self.rank, self.world))
+                        q.put(self.schedule.next_batches(k, self.sched_rank, self.sched_world))
                 except BaseException as exc:      # surface sampler errors in the consumer
                     q.put(exc)
             producer = threading.Thread(target=produce, daemon=True)
@@ -288,7 +295,7 @@ class DGraphTrainer:
                 if isinstance(item, BaseException):
                     raise item
                 return item
-            return self.schedule.next_batches(k, self.rank, self.world)
+            return self.schedule.next_batches(k, self.sched_rank, self.sched_world)
 
         def build(ch, bn, bl):
             ch.build(bn, bl) if gather_hook is None else gather_hook(ch, bn, bl)

@@ -40,7 +40,7 @@ def _inputs():
     return rowptr, col, feat, labels, train, pool, (w, W, fc)
 
 
-def _worker(rank, world, port, steps, out_dir, oneshot=False):
+def _worker(rank, world, port, steps, out_dir, oneshot=False, own_stream=False):
     import torch.distributed as dist
     from ggad_amd.graph import DeviceGraph
     from ggad_amd.sampler import PyCompatRandom
@@ -52,19 +52,21 @@ def _worker(rank, world, port, steps, out_dir, oneshot=False):
     rowptr, col, feat, labels, train, pool, (w, W, fc) = _inputs()
     graph = DeviceGraph(rowptr, col, "cuda:0")
     ft = torch.from_numpy(feat).to("cuda:0")
-    sched = BatchSchedule(train.copy(), pool.copy(), labels, 90, PyCompatRandom(72), n_pseudo=30, batches_per_epoch=7)
+    sched = BatchSchedule(train.copy(), pool.copy(), labels, 90, PyCompatRandom(72 + (rank if own_stream else 0)), n_pseudo=30,
+                          batches_per_epoch=7)
     exchange = None
     if oneshot:
         from ggad_amd.exchange import OneShotExchange
         exchange = OneShotExchange(rank, world, 64 + 64 * 17 + 64 * 64, "cuda:0")
         assert exchange.connect(dist), "one-shot exchange: IPC hand-shake or self-test failed"
     tr = DGraphTrainer(graph, ft, 64, sched, chunk_batches=3, rank=rank, world_size=world,
-                       allreduce=lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM), exchange=exchange)
+                       allreduce=lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM), exchange=exchange, own_stream=own_stream)
     assert tr.overlap and (tr.exchange is not None) == oneshot
     tr.engine.load_params(w, W, fc)
     tr.run_steps(steps)
     torch.cuda.synchronize()
     np.save(os.path.join(out_dir, f"params_{rank}.npy"), tr.engine.params.cpu().numpy())
+    np.save(os.path.join(out_dir, f"seen_{rank}.npy"), np.array([sched.global_batch]))
     if exchange is not None:
         assert exchange.error() == 0
     dist.barrier()
@@ -86,6 +88,18 @@ def test_one_shot_exchange_two_processes_one_gpu_bit_equal_to_allreduce(tmp_path
     p0, p1 = np.load(a / "params_0.npy"), np.load(a / "params_1.npy")
     np.testing.assert_array_equal(p0, p1)
     np.testing.assert_array_equal(p0, np.load(b / "params_0.npy"))
+
+
+def test_rank_owned_streams_keep_the_ranks_in_step(tmp_path):
+    """`own_stream`: every rank draws its batches from a schedule of its own (here seeded per rank) and generates only the
+    batches it trains on; the averaged update is still identical on every rank."""
+    import torch.multiprocessing as mp
+    steps, world = 6, 2
+    mp.spawn(_worker, args=(world, _free_port(), steps, str(tmp_path), False, True), nprocs=world, join=True)
+    p0, p1 = np.load(tmp_path / "params_0.npy"), np.load(tmp_path / "params_1.npy")
+    np.testing.assert_array_equal(p0, p1)
+    assert np.isfinite(p0).all()
+    assert int(np.load(tmp_path / "seen_0.npy")[0]) == steps and int(np.load(tmp_path / "seen_1.npy")[0]) == steps
 
 
 def test_two_ranks_one_gpu_equal_gradient_averaging(tmp_path):
