@@ -75,12 +75,29 @@ int ggad_mb_plan_build(const ggad_mb_plan *P, const int64_t *nodes_host, const i
   const bool want_ldsw = train && P->hop2 == 1;
   if (want_ldsw) GGAD_REQUIRE(P->pair_bound_host && P->tile_off && P->own_deg && P->own_rp && P->pw_base && P->node_head &&
                               P->own_next && P->grp && P->counters);
+  // the two static per-node tables are read at random (one cache miss per batch node each): request them ahead of the walk and
+  // keep the closed degree of every row for the second pass (this loop is on the critical path of a run of ONE chunk)
+  static thread_local std::vector<int32_t> row_deg;
+  if ((int64_t)row_deg.size() < rows) row_deg.resize((size_t)rows);
+  constexpr int PF = 24;
+  for (int64_t i = 0; i < rows && i < PF; ++i) {
+    const int64_t v = nodes_host[i];
+    GGAD_REQUIRE(v >= 0 && v < P->n_nodes);
+    __builtin_prefetch(&P->closed_deg_host[v]);
+    if (want_ldsw) __builtin_prefetch(&P->pair_bound_host[v]);
+  }
   for (int b = 0; b < nb; ++b) {
     int64_t be = 0;
     for (int64_t i = batch_ptr_host[b]; i < batch_ptr_host[b + 1]; ++i) {
+      if (i + PF < rows) {
+        const int64_t vn = nodes_host[i + PF];
+        GGAD_REQUIRE(vn >= 0 && vn < P->n_nodes);
+        __builtin_prefetch(&P->closed_deg_host[vn]);
+        if (want_ldsw) __builtin_prefetch(&P->pair_bound_host[vn]);
+      }
       const int64_t v = nodes_host[i];
-      GGAD_REQUIRE(v >= 0 && v < P->n_nodes);
       const int64_t r = P->closed_deg_host[v];
+      row_deg[(size_t)i] = (int32_t)r;
       be += r;
       n_chunks += (r + CL - 1) / CL;
       if (want_ldsw) bound += P->pair_bound_host[v];
@@ -139,7 +156,7 @@ int ggad_mb_plan_build(const ggad_mb_plan *P, const int64_t *nodes_host, const i
     int max_r = 0;
     for (int i = r0; i < r1; ++i) {
       const int32_t v = (int32_t)nodes_host[i];
-      const int r = P->closed_deg_host[v];
+      const int r = row_deg[(size_t)i];
       nd[i] = v;
       slot[i] = b;
       eptr[i] = (int32_t)e;

@@ -201,18 +201,14 @@ class BatchChunk:
         sizes = np.fromiter((len(b) for b in batches), dtype=np.int64, count=nb)
         if (sizes == 0).any():
             raise ValueError("empty batch")
-        nodes = np.ascontiguousarray(np.concatenate([np.asarray(b, dtype=np.int64) for b in batches]))
-        if nodes.min() < 0 or nodes.max() >= self.g.n:
-            raise ValueError("batch node id out of range")
+        nodes = np.concatenate(batches).astype(np.int64, copy=False)          # (ids and labels are range-checked by the native call)
         lab = None
         if self.train:
             if labels is None:
                 raise ValueError("training chunk needs labels")
-            lab = np.ascontiguousarray(np.concatenate([np.asarray(l, dtype=np.int64) for l in labels]))
+            lab = np.concatenate(labels).astype(np.int64, copy=False)
             if len(lab) != len(nodes):
                 raise ValueError("labels / batches length mismatch")
-            if ((lab != 0) & (lab != 1)).any():
-                raise ValueError("labels must be 0/1")
         bp = self._bp_host
         bp[0] = 0
         np.cumsum(sizes, out=bp[1:nb + 1])
@@ -243,6 +239,8 @@ class BatchChunk:
             if I.need_cnt2 and self.cnt2 is None:       # the LDS path cannot take this chunk: device-atomic counters
                 self.cnt2 = torch.zeros(self.max_batches * self.g.n, dtype=torch.int32, device=self.dev)
             self._alloc(I.need_rows, I.need_ents, I.need_chunks, I.need_stage, I.need_pairs, I.need_items, I.need_part2, I.need_seg)
+        if rc == -1:
+            raise ValueError("ggad_mb_plan_build: a batch node id is out of range, a label is not 0/1, or the plan descriptor is incomplete")
         _lib.check(rc, "ggad_mb_plan_build")
         self.n_batches, self.n_rows, self.n_ents, self.n_chunks = nb, int(I.n_rows), int(I.n_ents), int(I.n_chunks)
         self.last_hop2 = ("none", "ldsw", "global")[int(I.mode)]

@@ -64,3 +64,27 @@ for k in (20, 150):
                 res_b.append(time.perf_counter() - t0)
         print(f"{k:4d} batches | {name:28s} | dense chain {1e6 * np.mean(res_t[1:]) / k:6.1f} us/step | plan {1e3 * np.mean(res_b[1:]):.3f} ms",
               flush=True)
+
+# fresh batches every time, as the bench does: plan + dense chain back to back without a sync in between
+for k in (20,):
+    tot, sep_b, sep_t = [], [], []
+    for rep in range(6):
+        bn, bl = sched.next_batches(k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tr.chunk.build(bn, bl)
+        tr.engine.train_chunk(tr.chunk)
+        torch.cuda.synchronize()
+        tot.append(time.perf_counter() - t0)
+        bn, bl = sched.next_batches(k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tr.chunk.build(bn, bl)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        tr.engine.train_chunk(tr.chunk)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        sep_b.append(t1 - t0); sep_t.append(t2 - t1)
+    print(f"{k} fresh batches: plan + dense back to back {1e3 * np.mean(tot[1:]):.3f} ms | with a sync in between: plan {1e3 * np.mean(sep_b[1:]):.3f} ms + "
+          f"dense {1e3 * np.mean(sep_t[1:]):.3f} ms ({1e6 * np.mean(sep_t[1:]) / k:.1f} us/step)")
