@@ -88,3 +88,29 @@ def test_native_batch_stream_equals_per_batch_path():
         nn, _ = d.next_batches(4, rank=r, world=3)
         for s_ in range(4):
             assert np.array_equal(nn[s_], ref3[3 * s_ + r][0])
+
+
+def test_native_batch_stream_rejects_ids_beyond_int32_and_handles_tiny_lists():
+    """The pipelined scheduler keeps the pool as int32 while it runs: ids that do not fit are refused (no silent truncation);
+    one-element lists (no swap to draw) pass through unchanged and consume nothing of the generator."""
+    import ctypes
+    import numpy as np
+    from ggad_amd import _lib
+    from ggad_amd.sampler import PyCompatRandom
+    lib = _lib.load()
+    r = PyCompatRandom(5)
+    train = np.arange(10, dtype=np.int64)
+    pool = np.array([1, 2, 1 << 31], dtype=np.int64)
+    ie = ctypes.c_int32(3)
+    out = np.zeros((4, 5), dtype=np.int64)
+    lens = np.zeros(4, dtype=np.int32)
+    rc = lib.ggad_sched_batches(r._h, train.ctypes.data, 10, pool.ctypes.data, 3, 3, 2, 3, ctypes.byref(ie), 2, out.ctypes.data,
+                                lens.ctypes.data)
+    assert rc == -1
+    before = r.to_python_state()
+    one_t, one_p = np.array([7], dtype=np.int64), np.array([9], dtype=np.int64)
+    ie = ctypes.c_int32(1)
+    rc = lib.ggad_sched_batches(r._h, one_t.ctypes.data, 1, one_p.ctypes.data, 1, 1, 1, 1, ctypes.byref(ie), 3, out.ctypes.data,
+                                lens.ctypes.data)
+    assert rc == 0 and r.to_python_state() == before
+    assert lens.tolist()[:3] == [2, 2, 2] and out.reshape(-1)[:6].tolist() == [7, 9, 7, 9, 7, 9] and one_t[0] == 7 and one_p[0] == 9
