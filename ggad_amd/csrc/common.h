@@ -51,6 +51,14 @@ __device__ __forceinline__ int lower_bound_i32(const int32_t *__restrict__ a, in
 }
 
 // ---- internal (C++ linkage) pieces of ggad_mb_plan_build, shared between plan_build.cpp, plan.hip and hop2_ldsw.hip
+// counters[] of a plan: every counter on a 64-byte line of its own.  A device-scope atomic on ONE address (or line) completes every
+// ~7 ns whoever issues it (measured: 43 K wave-level atomics = 313 us of k_build_groups), so the plan kernels reserve storage
+// once per WORKGROUP (wg_reserve below), not once per wave, and the work-item cursor of the 2-hop gather is bumped by big grabs.
+constexpr int GGAD_CTR_STRIDE = 16;
+constexpr int GGAD_CTR_GROUPS = 0 * GGAD_CTR_STRIDE, GGAD_CTR_ITEMS = 1 * GGAD_CTR_STRIDE, GGAD_CTR_PART = 2 * GGAD_CTR_STRIDE,
+              GGAD_CTR_CURSOR = 3 * GGAD_CTR_STRIDE, GGAD_CTR_PC = 4 * GGAD_CTR_STRIDE;
+constexpr int GGAD_PLAN_COUNTERS = 8 * GGAD_CTR_STRIDE;      // ints of ggad_mb_plan::counters
+
 struct ggad_plan_view {      // device views into the staging block of ONE build + its exact sizes (known on the host)
   const int32_t *batch_ptr, *batch_ent_ptr, *nodes, *row_slot, *ent_ptr, *row_ck_ptr, *ck_rc, *ck_e0;
   int32_t n_batches, n_rows, n_ents, n_chunks;

@@ -127,7 +127,7 @@ __device__ __forceinline__ float reduce_groups(float acc, int F, int rpi) {
 }
 
 // ------------------------------------------------------------------ plan kernels
-// counters[] of a plan (int32[8], zeroed by k_expand): 0 groups, 1 work items, 2 partial slots of the 2-hop gather,
+// counters[] of a plan (GGAD_PLAN_COUNTERS ints, one counter per 64-byte line, zeroed by k_expand): groups, work items, partial slots of the 2-hop gather,
 // 3 its work cursor, 4 pair-count storage cursor (pc[] allocation of k_gather1c)
 __global__ void __launch_bounds__(256) k_expand(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                 const int32_t *__restrict__ nodes, const int32_t *__restrict__ row_slot,
@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(256) k_expand(const int32_t *__restrict__ rowp
                                                 int32_t *__restrict__ ent_col, int32_t *__restrict__ ent_slot,
                                                 int32_t *__restrict__ ent_row, int32_t *__restrict__ cnt1,
                                                 int32_t *__restrict__ own1, int32_t *__restrict__ counters) {
-  if (blockIdx.x == 0 && threadIdx.x < 8 && counters != nullptr) counters[threadIdx.x] = 0;
+  if (blockIdx.x == 0 && threadIdx.x < GGAD_PLAN_COUNTERS && counters != nullptr) counters[threadIdx.x] = 0;
   const int ck = (int)((blockIdx.x * 256u + threadIdx.x) >> 4);
   const int i = threadIdx.x & 15;
   if (ck >= n_chunks) return;
@@ -228,9 +228,18 @@ __global__ void __launch_bounds__(256) k_gather1c(const float *__restrict__ feat
       if (lane >= off) inc += t;
     }
     const int total = __shfl(inc, GGAD_WAVE - 1, GGAD_WAVE);
-    int base = 0;
-    if (lane == GGAD_WAVE - 1 && total > 0) base = atomicAdd(&counters[4], total);
-    base = __shfl(base, GGAD_WAVE - 1, GGAD_WAVE);
+    // one atomic per WORKGROUP on the cursor (the four waves' totals meet in LDS): same-address atomics are serialised chip-wide
+    __shared__ int wg_tot[5];
+    const int wid = threadIdx.x >> 6;
+    if (lane == 0) wg_tot[wid] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int sum = 0;
+      for (int w = 0; w < 4; ++w) { const int t = wg_tot[w]; wg_tot[w] = sum; sum += t; }
+      wg_tot[4] = sum > 0 ? atomicAdd(&counters[GGAD_CTR_PC], sum) : 0;
+    }
+    __syncthreads();
+    const int base = wg_tot[4] + wg_tot[wid];
     if (valid) pw_base[e] = base + inc - deg;
   }
   const int rpi = F <= 64 ? 64 / F : 1;

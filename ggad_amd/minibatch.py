@@ -73,7 +73,7 @@ class BatchChunk:
         self.cnt2 = None
         if self.train and self.hop2 == "global":
             self.cnt2 = torch.zeros(self.max_batches * graph.n, dtype=torch.int32, device=d)
-        self.counters = torch.zeros(8, dtype=torch.int32, device=d)
+        self.counters = torch.zeros(int(self.lib.ggad_mb_plan_counter_elems()), dtype=torch.int32, device=d)
         self.cl = int(self.lib.ggad_mb_chunk_len())
         self.part_stride = max(64, self.F)
         self.generation = 0

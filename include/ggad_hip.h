@@ -134,6 +134,7 @@ typedef struct ggad_mb_plan_info {
 int32_t ggad_mb_chunk_len(void);          /* 16 */
 int32_t ggad_mb_slice_len(void);          /* neighbours per work item of the 2-hop gather */
 int32_t ggad_mb_group_words(void);        /* ints per record of grp[] */
+int32_t ggad_mb_plan_counter_elems(void); /* ints of ggad_mb_plan::counters (one counter per 64-byte line) */
 /* nodes_host: the batches back to back; batch_ptr_host[nb+1]; labels_host (0/1, NULL for inference plans).  Host outputs
  * (each may be NULL): ent_ptr_host_out[R+1], batch_ent_ptr_host_out[nb+1], batch_max_row_host_out[nb]. */
 int ggad_mb_plan_build(const ggad_mb_plan *plan, const int64_t *nodes_host, const int32_t *batch_ptr_host, int32_t n_batches,
