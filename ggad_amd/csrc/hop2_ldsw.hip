@@ -587,7 +587,7 @@ int ggad_int_ldsw_hop2(const ggad_mb_plan *P, const ggad_plan_view &V, hipStream
     else
       k_gather2_items<0><<<dim3(wgs), dim3(256), 0, st>>>(P->col, P->feat, F, P->feat_stride, P->own_rp, P->own_deg, P->pw_base,
                                                           P->pc, P->grp, P->items, P->counters, P->x2, P->part2);
-    const unsigned cg = (unsigned)std::min<int64_t>(((int64_t)V.n_ents + 3) / 4, 1024);
+    const unsigned cg = (unsigned)std::min<int64_t>(((int64_t)V.n_ents + 3) / 4, 16384);        // ~2 groups per wave: every group costs a dependent load of its record
     k_gather2_combine<<<dim3(cg), dim3(256), 0, st>>>(P->grp, P->counters, P->part2, F, P->x2);
   } else {
     k_gather2_w<<<dim3((unsigned)((V.n_ents + 3) / 4)), dim3(256), 0, st>>>(P->col, P->feat, F, P->feat_stride, P->ent_own, V.n_ents,
