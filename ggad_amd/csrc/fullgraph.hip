@@ -299,8 +299,19 @@ __global__ void __launch_bounds__(256) k_prelu_bwd_final(const float *__restrict
   __shared__ float red[256];
   float acc_a = 0.f;
   for (int c = threadIdx.x; c < W; c += 256) {
-    float sb = 0.f, sa = 0.f;
-    for (int s = 0; s < S; ++s) { sb += part_db[(int64_t)s * W + c]; sa += part_da[(int64_t)s * W + c]; }
+    // eight partials of each array in flight (one dependent load per partial made this single-block kernel 21 us at S = 43);
+    // fixed order: four interleaved running sums, combined pairwise
+    float b4[4] = {0.f, 0.f, 0.f, 0.f}, a4[4] = {0.f, 0.f, 0.f, 0.f};
+    int s0 = 0;
+    for (; s0 + 8 <= S; s0 += 8) {
+      float vb[8], va[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { vb[k] = part_db[(int64_t)(s0 + k) * W + c]; va[k] = part_da[(int64_t)(s0 + k) * W + c]; }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { b4[k & 3] += vb[k]; a4[k & 3] += va[k]; }
+    }
+    for (; s0 < S; ++s0) { b4[s0 & 3] += part_db[(int64_t)s0 * W + c]; a4[s0 & 3] += part_da[(int64_t)s0 * W + c]; }
+    const float sb = (b4[0] + b4[1]) + (b4[2] + b4[3]), sa = (a4[0] + a4[1]) + (a4[2] + a4[3]);
     if (db) db[c] = sb;
     acc_a += sa;
   }
@@ -518,6 +529,42 @@ __global__ void __launch_bounds__(256) k_adam_flat(float *__restrict__ p, float 
 
 __global__ void k_bump(int32_t *c) { *c += 1; }
 
+// The same update for up to ADAM_MAX_T tensors in ONE launch (the pointers travel as kernel arguments): a model step was one
+// k_adam_flat + one k_bump per parameter -- 20 launches of a few microseconds in an epoch of ~125.
+constexpr int ADAM_MAX_T = 16;
+struct AdamMulti {
+  float *p[ADAM_MAX_T], *m[ADAM_MAX_T], *v[ADAM_MAX_T];
+  const float *g[ADAM_MAX_T];
+  int32_t *ctr[ADAM_MAX_T];
+  int64_t n[ADAM_MAX_T];
+  int blk0[ADAM_MAX_T + 1];          // first workgroup of every tensor
+  int n_t;
+};
+__global__ void __launch_bounds__(256) k_adam_multi(AdamMulti A, float lr, float wd) {
+  __shared__ float sc[2];
+  int t = 0;
+  while (t + 1 < A.n_t && (int)blockIdx.x >= A.blk0[t + 1]) ++t;          // workgroup-uniform
+  if (threadIdx.x == 0) {
+    const double ts = (double)(*A.ctr[t] + 1);
+    sc[0] = (float)((double)lr / (1.0 - pow(0.9, ts)));
+    sc[1] = (float)sqrt(1.0 - pow(0.999, ts));
+  }
+  __syncthreads();
+  const int64_t i = (int64_t)((int)blockIdx.x - A.blk0[t]) * 256 + threadIdx.x;
+  if (i < A.n[t]) {
+    float *p = A.p[t], *m = A.m[t], *v = A.v[t];
+    float pi = p[i];
+    float gi = fmaf(wd, pi, A.g[t][i]);
+    float mi = m[i], vi = v[i];
+    mi = fmaf(gi - mi, 0.1f, mi);
+    vi = fmaf(0.001f * gi, gi, vi * 0.999f);
+    const float denom = sqrtf(vi) / sc[1] + 1e-8f;
+    pi = pi - sc[0] * (mi / denom);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+  }
+}
+__global__ void k_bump_multi(AdamMulti A) { if ((int)threadIdx.x < A.n_t) *A.ctr[threadIdx.x] += 1; }
+
 }  // namespace
 
 extern "C" {
@@ -674,6 +721,37 @@ int ggad_adam_f32(float *params, float *exp_avg, float *exp_avg_sq, const float 
                                                                      step_counter, 1);
   if (bump_after) k_bump<<<dim3(1), dim3(1), 0, st>>>(step_counter);
   GGAD_CHECK_LAUNCH("adam_f32");
+  return GGAD_OK;
+}
+
+
+int32_t ggad_adam_multi_max(void) { return ADAM_MAX_T; }
+
+/* ggad_adam_f32 (bump_after = 1) for n_tensors <= ggad_adam_multi_max() tensors in two launches; the arrays are HOST arrays of
+ * device pointers / element counts; every tensor has its own step counter (torch keeps `step` per parameter). */
+int ggad_adam_multi_f32(int32_t n_tensors, float *const *params, float *const *exp_avg, float *const *exp_avg_sq,
+                        const float *const *grads, const int64_t *n_elems, int32_t *const *step_counters, float lr,
+                        float weight_decay, ggad_stream_t stream) {
+  GGAD_REQUIRE(n_tensors >= 0 && n_tensors <= ADAM_MAX_T && params && exp_avg && exp_avg_sq && grads && n_elems && step_counters);
+  if (n_tensors == 0) return GGAD_OK;
+  AdamMulti A;
+  int blocks = 0, k = 0;
+  for (int t = 0; t < n_tensors; ++t) {
+    GGAD_REQUIRE(params[t] && exp_avg[t] && exp_avg_sq[t] && grads[t] && step_counters[t] && n_elems[t] >= 0);
+    if (n_elems[t] == 0) continue;
+    A.p[k] = params[t]; A.m[k] = exp_avg[t]; A.v[k] = exp_avg_sq[t]; A.g[k] = grads[t]; A.ctr[k] = step_counters[t];
+    A.n[k] = n_elems[t];
+    A.blk0[k] = blocks;
+    blocks += (int)((n_elems[t] + 255) / 256);
+    ++k;
+  }
+  if (k == 0) return GGAD_OK;
+  A.blk0[k] = blocks;
+  A.n_t = k;
+  hipStream_t st = as_stream(stream);
+  k_adam_multi<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(A, lr, weight_decay);
+  k_bump_multi<<<dim3(1), dim3(64), 0, st>>>(A);
+  GGAD_CHECK_LAUNCH("adam_multi_f32");
   return GGAD_OK;
 }
 

@@ -438,6 +438,9 @@ class FlatAdam:
             p.grad = None
 
     def step(self):
+        """One multi-tensor launch (+ one for the step counters) per <= 16 parameters with a gradient."""
+        import ctypes
+        todo = []
         for p in self.params:
             if p.grad is None:
                 continue
@@ -445,5 +448,12 @@ class FlatAdam:
             if st is None:
                 st = self.state[p] = (torch.zeros_like(p.data), torch.zeros_like(p.data),
                                       torch.zeros(1, dtype=torch.int32, device=p.device))
-            g = p.grad.contiguous()
-            call("ggad_adam_f32", ptr(p.data), ptr(st[0]), ptr(st[1]), ptr(g), p.numel(), self.lr, self.wd, ptr(st[2]), 1)
+            todo.append((p, st, p.grad.contiguous()))
+        cap = int(_lib.load().ggad_adam_multi_max())
+        for i0 in range(0, len(todo), cap):
+            part = todo[i0:i0 + cap]
+            n = len(part)
+            arr = ctypes.c_void_p * n
+            call("ggad_adam_multi_f32", n, arr(*[ptr(p.data) for p, _, _ in part]), arr(*[ptr(st[0]) for _, st, _ in part]),
+                 arr(*[ptr(st[1]) for _, st, _ in part]), arr(*[ptr(g) for _, _, g in part]),
+                 (ctypes.c_int64 * n)(*[p.numel() for p, _, _ in part]), arr(*[ptr(st[2]) for _, st, _ in part]), self.lr, self.wd)
