@@ -379,6 +379,7 @@ class GgadLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, emb, logits, emb_con, emb_abn, adj: FullGraphAdj, ls, margin: float):
+        ctx.set_materialize_grads(False)       # only `total` is differentiated: no zero tensors for the three other outputs
         emb = emb.contiguous()
         n, h = emb.shape
         dev = emb.device
@@ -411,6 +412,8 @@ class GgadLossFn(torch.autograd.Function):
         adj, ls = ctx.adj, ctx.ls
         n, h = en.shape
         J, L, nn_ = ls["J"], int(ls["J"].numel()), ls["n_normal"]
+        if g_total is None:
+            return None, None, None, None, None, None, None
         c = g_aff * ls["r_inv_J"] * g_total                                               # d total / d (e_hat_j . S_j)
         xc = torch.empty(L, h, dtype=torch.float32, device=en.device)
         call("ggad_rows_scale_f32", ptr(en), ptr(J), ptr(c), L, h, 0, ptr(xc))            # c_j e_hat_j
