@@ -266,11 +266,13 @@ static void launch_gemm(int mode, bool a_kfast, bool b_nfast, dim3 grid, hipStre
   else launch_gemm2<TM, false, false>(a_kfast, b_nfast, grid, st, args...);
 }
 
-// Row tile: 128 when that still gives >= 3 workgroups per CU (they hide each other's global-load latency: the kernel has one
-// K-tile of look-ahead), else 64.
+// Row tile: 64 x 64 workgroup tiles everywhere.  The 128-row tile (two accumulators per wave) was the default for grids of
+// >= 3 workgroups per CU; measured again in round 2 it loses on every shape of the path (39357 x 300 x 300: 105-107 vs 98 us,
+// 4096^3: 1269 vs 1239 us, Photo's K = 745: 79 vs 60 us).  GGAD_GEMM_TM=128 still selects it for experiments.
 static int pick_tm(int M, int N) {
-  const int64_t tiles128 = (int64_t)((M + 127) / 128) * ((N + BN - 1) / BN);
-  return tiles128 >= 3 * 256 ? 128 : 64;
+  static const int forced = [] { const char *e = getenv("GGAD_GEMM_TM"); return e ? atoi(e) : 0; }();
+  (void)M; (void)N;
+  return forced == 128 ? 128 : 64;
 }
 }  // namespace
 
