@@ -8,6 +8,6 @@ def run(args):
         return round(d["value"]), round(d["ms_per_step"] * 1e3, 2), d["roofline"]["avg_launch_ms"]
     except Exception as e:
         return out[-300:]
-for cus in "40 48 56 64 72 80 96".split():
+for cus in "56 64 72 80 96 112".split():
     print("dense_cus", cus, run(["--steps", "4500", "--warmup", "150", "--no-extras", "--dense-cus", cus]), flush=True)
 PY
