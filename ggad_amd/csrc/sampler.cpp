@@ -246,7 +246,9 @@ int ggad_apply_swaps_i64(int64_t *data, int64_t n, const int32_t *targets) {
 //                        the list's contents, so consecutive shuffles are built CONCURRENTLY; for the epoch shuffle of the
 //                        ~1.05 M train list: a copy of the list with the swaps applied (once per epoch, into the other half of a
 //                        double buffer, while the caller still copies batches out of the old order);
-//   stage D (caller)     pool <- pool[P] (a gather: no dependent swaps) and the copy of the batch.
+//   stage M (2 threads)  the pool's state after every 8th shuffle: X_{s+1}[p] = X_s[P_f[ ... P_l[p]]], each thread its share of p;
+//   stage D (caller)     the n_pseudo positions a batch reads, followed through the permutations since the last composed state,
+//                        and the copy of the batch.
 // Same outputs consumed in the same order, same permutations, same final lists and generator state as the per-shuffle calls.
 namespace {
 inline void spin_wait_step(int &spins) {
@@ -261,6 +263,8 @@ inline void wait_until(F cond) {
 
 constexpr int RING_BLOCKS = 256;            // generator blocks between stage A and stage B (256 x 624 words = 640 KB)
 constexpr int POOL_RING = 128;              // pool shuffles in flight between B and D
+constexpr int SEG = 8;                      // pool shuffles per composed segment (stage M); POOL_RING holds 16 of them
+static_assert(POOL_RING % SEG == 0 && POOL_RING >= 4 * SEG, "a slot is reused only after its whole segment");
 
 struct SchedBuffers {                       // reused across calls (per calling thread): no page faults in steady state
   std::vector<uint32_t> temp, raw;
@@ -334,20 +338,21 @@ int ggad_sched_batches(ggad_mt19937 *g, int64_t *train, int64_t n_train, int64_t
     if (pool[p] < 0 || pool[p] > 0x7fffffffLL) return GGAD_E_INVALID;
   // work items in stream order: kind 0 = epoch shuffle of train, kind 1 = batch shuffle of pool
   // free_after: item whose consumption frees this item's target slot; free_prev (epoch shuffles): the previous epoch shuffle
-  struct Item { int kind; int slot; int64_t free_after; int64_t free_prev; };
+  struct Item { int kind; int slot; int64_t free_after; int64_t free_prev; int64_t ord; };     // ord: ordinal among the pool shuffles
   std::vector<Item> items;
+  std::vector<int64_t> pool_idx;                                // item index of every pool shuffle
   {
-    std::vector<int64_t> pool_idx, train_idx;
+    std::vector<int64_t> train_idx;
     int ie = *in_epoch_io;
     for (int b = 0; b < count; ++b) {
       if (ie >= batches_per_epoch) {
         const size_t r = train_idx.size();
-        items.push_back({0, (int)(r % 2), r >= 2 ? train_idx[r - 2] : -1, r >= 1 ? train_idx[r - 1] : -1});
+        items.push_back({0, (int)(r % 2), r >= 2 ? train_idx[r - 2] : -1, r >= 1 ? train_idx[r - 1] : -1, -1});
         train_idx.push_back((int64_t)items.size() - 1);
         ie = 0;
       }
       const size_t q = pool_idx.size();
-      items.push_back({1, (int)(q % POOL_RING), q >= (size_t)POOL_RING ? pool_idx[q - POOL_RING] : -1, -1});
+      items.push_back({1, (int)(q % POOL_RING), q >= (size_t)POOL_RING ? pool_idx[q - POOL_RING] : -1, -1, (int64_t)q});
       pool_idx.push_back((int64_t)items.size() - 1);
       ++ie;
     }
@@ -378,9 +383,11 @@ int ggad_sched_batches(ggad_mt19937 *g, int64_t *train, int64_t n_train, int64_t
   alignas(64) std::atomic<int64_t> done_items{0};
   alignas(64) std::atomic<int64_t> next_claim{0};
   alignas(64) std::atomic<bool> stop{false};
+  alignas(64) std::atomic<int64_t> mat_done{0};              // segments whose END state has been composed (stage M)
   std::unique_ptr<std::atomic<int>[]> status(new std::atomic<int>[(size_t)n_items]);
   for (int64_t i = 0; i < n_items; ++i) status[i].store(0, std::memory_order_relaxed);
 
+  const unsigned hw = std::thread::hardware_concurrency();
   cpu_set_t llc, caller_mask;
   const bool pin = llc_cpus_of_current(&llc) && pthread_getaffinity_np(pthread_self(), sizeof(caller_mask), &caller_mask) == 0 &&
                    pthread_setaffinity_np(pthread_self(), sizeof(llc), &llc) == 0;      // threads created below inherit the mask
@@ -413,7 +420,18 @@ int ggad_sched_batches(ggad_mt19937 *g, int64_t *train, int64_t n_train, int64_t
     int64_t w = g->index;
     for (int64_t i = 0; i < n_items; ++i) {
       const Item &it = items[(size_t)i];
-      if (it.free_after >= 0) wait_until([&] { return done_items.load(std::memory_order_acquire) > it.free_after; });
+      if (it.free_after >= 0) {
+        if (it.kind == 1) {
+          // the permutation in this slot serves EVERY later batch of its segment (their chains run through it) and the composition
+          // of the segment's end state: free once the caller's thread is past the segment and stage M has composed it
+          const int64_t s_old = (it.ord - POOL_RING) / SEG;
+          const int64_t seg_last_item = pool_idx[(size_t)(s_old * SEG + SEG - 1)];
+          wait_until([&] { return done_items.load(std::memory_order_acquire) > seg_last_item; });
+          wait_until([&] { return mat_done.load(std::memory_order_acquire) > s_old; });
+        } else {
+          wait_until([&] { return done_items.load(std::memory_order_acquire) > it.free_after; });
+        }
+      }
       const int64_t n = it.kind == 0 ? n_train : n_pool;
       int32_t *T = it.kind == 0 ? train_t + (size_t)it.slot * tstride : pool_t + (size_t)it.slot * pstride;
       const int64_t need = n - 1;
@@ -435,8 +453,8 @@ int ggad_sched_batches(ggad_mt19937 *g, int64_t *train, int64_t n_train, int64_t
   });
 
   // ---- stage C: permutations of the pool shuffles (concurrently), the epoch shuffle into the other train buffer
-  unsigned hw = std::thread::hardware_concurrency();
-  int n_workers = hw >= 8 ? 3 : (hw >= 6 ? 2 : 1);
+  static const int env_c = [] { const char *e = getenv("GGAD_SCHED_C"); return e ? atoi(e) : 0; }();
+  int n_workers = env_c > 0 ? env_c : (hw >= 8 ? 3 : (hw >= 6 ? 2 : 1));
   if ((int64_t)n_workers > n_items) n_workers = (int)n_items;
   std::vector<std::thread> workers;
   for (int wk = 0; wk < n_workers; ++wk) {
@@ -460,12 +478,59 @@ int ggad_sched_batches(ggad_mt19937 *g, int64_t *train, int64_t n_train, int64_t
     });
   }
 
-  // ---- stage D (this thread): compose, copy the batches out
+  // ---- stage M (NM threads): the pool's state after every SEG-th shuffle.  x_q = x_{q-1}[P_q[.]], so the state after the shuffles
+  // f .. l of a segment is X_s[P_f[P_{f+1}[... P_l[p]]]]: every element is a chain of SEG look-ups, independent of the others --
+  // each thread composes its share of the positions (the caller's thread used to gather all 55 K elements after EVERY shuffle: 32 us
+  // per batch, the bottleneck of the pipeline; it now follows only the chains of the n_pseudo positions a batch reads).
+  const int64_t n_pool_items = (int64_t)pool_idx.size();
+  const int64_t n_full_seg = n_pool_items / SEG;             // segments that end inside this call
+  int32_t *Xb[2] = {pool_a, pool_b};                          // X_s (state before segment s) lives in Xb[s % 2]
+  for (int64_t p = 0; p < n_pool; ++p) Xb[0][p] = (int32_t)pool[p];
+  std::unique_ptr<std::atomic<int>[]> seg_arrived(new std::atomic<int>[(size_t)n_full_seg + 1]);
+  for (int64_t sgi = 0; sgi <= n_full_seg; ++sgi) seg_arrived[sgi].store(0, std::memory_order_relaxed);
+  auto perm_of = [&](int64_t q) -> const int32_t * { return pool_p + (size_t)items[(size_t)pool_idx[(size_t)q]].slot * pstride; };
+  // positions [p0, p1) of X_s[P_first[ ... P_last[p]]].  Level by level over blocks of positions (each level a plain gather: independent
+  // loads; following one position through all levels at a time is a chain of dependent cache misses and was measured 3 x slower)
+  auto compose = [&](const int32_t *X, int32_t *out, int64_t first, int64_t last, int64_t p0, int64_t p1) {
+    const int n_chain = (int)(last - first + 1);
+    const int32_t *chain[SEG];
+    for (int k = 0; k < n_chain; ++k) chain[k] = perm_of(last - k);          // applied last-to-first
+    constexpr int BLK = 2048;
+    int32_t idx[BLK];
+    for (int64_t b0 = p0; b0 < p1; b0 += BLK) {
+      const int nb = (int)std::min<int64_t>(BLK, p1 - b0);
+      for (int j = 0; j < nb; ++j) idx[j] = chain[0][b0 + j];
+      for (int k = 1; k < n_chain; ++k) {
+        const int32_t *c = chain[k];
+        for (int j = 0; j < nb; ++j) idx[j] = c[idx[j]];
+      }
+      for (int j = 0; j < nb; ++j) out[b0 + j] = X[idx[j]];
+    }
+  };
+  static const int env_m = [] { const char *e = getenv("GGAD_SCHED_M"); return e ? atoi(e) : 0; }();
+  const int NM = env_m > 0 ? env_m : (hw >= 8 ? 2 : 1);
+  std::vector<std::thread> composers;
+  if (n_pool >= 2) {
+    for (int m = 0; m < NM; ++m) {
+      composers.emplace_back([&, m] {
+        for (int64_t sg = 0; sg < n_full_seg; ++sg) {
+          const int64_t first = sg * SEG, last = first + SEG - 1;
+          for (int64_t q = first; q <= last; ++q)
+            wait_until([&] { return status[pool_idx[(size_t)q]].load(std::memory_order_acquire) == 2; });
+          wait_until([&] { return mat_done.load(std::memory_order_acquire) >= sg; });                    // X_sg is there
+          if (sg >= 1)                                           // the buffer to write still serves the batches of segment sg - 1
+            wait_until([&] { return done_items.load(std::memory_order_acquire) > pool_idx[(size_t)(first - 1)]; });
+          const int64_t p0 = n_pool * m / NM, p1 = n_pool * (m + 1) / NM;
+          compose(Xb[sg & 1], Xb[(sg + 1) & 1], first, last, p0, p1);
+          if (seg_arrived[sg].fetch_add(1, std::memory_order_acq_rel) + 1 == NM) mat_done.store(sg + 1, std::memory_order_release);
+        }
+      });
+    }
+  }
+
+  // ---- stage D (this thread): follow the chains of the positions a batch reads, copy the batches out
   int ie = *in_epoch_io;
   const int stride = batch_size + n_pseudo;
-  // the pool's state as int32 while the call runs (node ids < 2^31 is checked below): half the footprint of the random reads
-  int32_t *cur = pool_a, *alt = pool_b;
-  for (int64_t p = 0; p < n_pool; ++p) cur[p] = (int32_t)pool[p];
   int b = 0;
   const int64_t *cur_train = train;
   for (int64_t i = 0; i < n_items; ++i) {
@@ -475,23 +540,37 @@ int ggad_sched_batches(ggad_mt19937 *g, int64_t *train, int64_t n_train, int64_t
       ie = 0;
       cur_train = tb[1 - it.slot];
     } else {
-      if (n_pool >= 2) {
-        const int32_t *P = pool_p + (size_t)it.slot * pstride;
-        for (int64_t p = 0; p < n_pool; ++p) alt[p] = cur[P[p]];
-        int32_t *t = cur; cur = alt; alt = t;
-      }
       const int64_t i0 = (int64_t)ie * batch_size;
       int64_t i1 = i0 + batch_size;
       if (i1 > n_train) i1 = n_train;
       const int64_t nt = i1 > i0 ? i1 - i0 : 0;
       int64_t *dst = out_nodes + (int64_t)b * stride;
       if (nt > 0) std::memcpy(dst, cur_train + i0, (size_t)nt * sizeof(int64_t));
-      for (int p = 0; p < n_pseudo; ++p) dst[nt + p] = (int64_t)cur[p];
+      const int64_t sg = it.ord / SEG;
+      if (n_pool >= 2) {
+        wait_until([&] { return mat_done.load(std::memory_order_acquire) >= sg; });
+        int32_t head[256];
+        for (int64_t c0 = 0; c0 < n_pseudo; c0 += 256) {
+          const int64_t c1 = std::min<int64_t>(n_pseudo, c0 + 256);
+          compose(Xb[sg & 1], head - c0, sg * SEG, it.ord, c0, c1);
+          for (int64_t p = c0; p < c1; ++p) dst[nt + p] = (int64_t)head[p - c0];
+        }
+      } else {
+        for (int p = 0; p < n_pseudo; ++p) dst[nt + p] = (int64_t)Xb[0][p];
+      }
       out_len[b] = (int32_t)(nt + n_pseudo);
       ++b;
       ++ie;
     }
     done_items.store(i + 1, std::memory_order_release);
+  }
+  for (auto &t : composers) t.join();
+  // the pool's final state: the end of the last full segment, or the shuffles of a last partial segment applied to it
+  int32_t *cur = Xb[n_full_seg & 1];
+  if (n_pool >= 2 && n_pool_items > n_full_seg * SEG) {
+    int32_t *fin = Xb[(n_full_seg + 1) & 1];
+    compose(cur, fin, n_full_seg * SEG, n_pool_items - 1, 0, n_pool);
+    cur = fin;
   }
   for (auto &t : workers) t.join();
   stage_b.join();

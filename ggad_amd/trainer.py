@@ -227,8 +227,24 @@ class DGraphTrainer:
         if getattr(self, "_stream", None) is not None:
             raise RuntimeError("a batch stream is already running")
         q = queue.Queue(maxsize=3)
-        # the first deliveries are small (the chunk ramp of `default_ramp`): the GPU starts after 16 batches of sampling instead of 150
-        sizes = self.default_ramp(int(total_steps))
+        # the first deliveries are small (the chunk ramp of `default_ramp`): the GPU starts after 16 batches of sampling instead of 150.
+        # Later calls of the native sampler cover FOUR chunks: a call that starts on an epoch boundary begins with the epoch shuffle
+        # of the ~1 M-element train list (targets, copy, swaps: ~3.4 ms during which its pipeline has nothing else to do), which
+        # costs 23 us per batch on a call of 150 batches and 6 us on a call of 600
+        # (the calls grow 1, 2, 4 chunks: a long call delivers late, and the GPU must not run dry while it is under way)
+        ramp = self.default_ramp(int(total_steps))
+        sizes, acc, want = [], 0, 1
+        for k in ramp:
+            if k < self.chunk_batches:
+                sizes.append(k)
+            else:
+                acc += k
+                if acc >= want * self.chunk_batches:
+                    sizes.append(acc)
+                    acc = 0
+                    want = min(4, want * 2)
+        if acc:
+            sizes.append(acc)
 
         def produce():
             try:
