@@ -124,13 +124,14 @@ constexpr int SPMM_SL = 8;                          // float4 lanes per (row, sl
 __host__ __device__ inline int spmm_n_slices(int W) { return ((W >> 2) + SPMM_SL - 1) / SPMM_SL; }
 
 __global__ void __launch_bounds__(256) k_slice_major(const float *__restrict__ X, int64_t ldx, int n_rows, int W, int n_slices,
-                                                     float4 *__restrict__ XS) {
+                                                     const float *__restrict__ row_scale, float4 *__restrict__ XS) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int per_row = n_slices * SPMM_SL;
   if (t >= (int64_t)n_rows * per_row) return;
   const int r = (int)(t / per_row), q = (int)(t - (int64_t)r * per_row);       // q = slice * 8 + j = float4 index in the row
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   if (q < (W >> 2)) v = reinterpret_cast<const float4 *>(X + (int64_t)r * ldx)[q];
+  if (row_scale) { const float c = row_scale[r]; v.x *= c; v.y *= c; v.z *= c; v.w *= c; }
   XS[((int64_t)(q >> 3) * n_rows + r) * SPMM_SL + (q & 7)] = v;
 }
 
@@ -236,6 +237,98 @@ __global__ void __launch_bounds__(256) k_spmm_sliced(const int32_t *__restrict__
     spmm_epilogue_store(acc, vi, bias, prelu_a, a, out + (int64_t)orow * ldo, out_pre ? out_pre + (int64_t)orow * ldo : nullptr);
   else
     reinterpret_cast<float4 *>(part + (int64_t)(-orow - 1) * W)[vi] = acc;
+}
+
+// ---- LDS-panel variant for dense neighbourhoods whose values factor as  val[i][j] = rs[i] * cs[j]  (+ a diagonal) -------
+// (normalize_adj: D^-1/2 A D^-1/2 (+ I), utils.py:47-54 -- every full N x N x H product of an epoch.)  The sliced kernel above
+// fetches one 128-byte line per (entry, slice) through the vector L1 and runs at that path's rate.  Here a workgroup of 16
+// waves owns (slice, row block) and walks the operand in PANELS of 1,024 consecutive source rows x 32 floats staged in LDS
+// (128 KB + one zero row): every entry then costs one ds_read_b128 of 8 lanes instead of a global line.  The operand is
+// pre-scaled by cs[] while it is re-laid slice-major, the sum is scaled by rs[] in the epilogue, so the entry stream
+// carries no values: it is a host-built list of LDS byte offsets, packed per (wave, panel, round of 8 rows) in steps of 8 entries --
+// lane group g = lane / 8 accumulates row g of the round, a shorter row is padded with the offset of the zero row -- and
+// read 4 steps at a time (one 16-byte load per lane, the 8 lanes of a group share it).  A wave keeps its <= 8 rounds
+// (64 rows x 32 floats) in registers across all panels; rows are dealt to rounds in order of degree (the 8 rows of a round
+// have similar lengths: 70 % of the step slots carry an entry on the power-law graphs) and rounds are dealt round-robin to
+// the workgroups (equal work).  Summation order: ascending column inside a row -> deterministic.
+constexpr int PAN_R = 1024;                         // source rows per LDS panel
+constexpr int PAN_WAVES = 16;                       // waves per workgroup
+constexpr int PAN_KR = 8;                           // rounds (of 8 rows) per wave at most
+constexpr int PAN_LDS = (PAN_R + 1) * SPMM_SL * 16; // bytes: panel + zero row
+
+__global__ void __launch_bounds__(1024) k_spmm_panel(const int32_t *__restrict__ wg_tab, const uint32_t *__restrict__ dir,
+                                                     const uint4 *__restrict__ stream, const int32_t *__restrict__ row_tab,
+                                                     int n_chunks, const float4 *__restrict__ XS, int n_src, int W,
+                                                     const float *__restrict__ row_scale, const float *__restrict__ diag,
+                                                     const float *__restrict__ X, int64_t ldx, const float *__restrict__ bias,
+                                                     const float *__restrict__ prelu_a, float *__restrict__ out, int64_t ldo,
+                                                     float *__restrict__ out_pre) {
+  extern __shared__ __attribute__((aligned(16))) float4 panel[];
+  const int slice = wg_tab[2 * blockIdx.x], block = wg_tab[2 * blockIdx.x + 1];
+  if (slice < 0) return;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 3, j = lane & 7;
+  if (tid < SPMM_SL) panel[PAN_R * SPMM_SL + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 acc[PAN_KR];
+#pragma unroll
+  for (int k = 0; k < PAN_KR; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 *__restrict__ xs = XS + (int64_t)slice * n_src * SPMM_SL;
+  const uint32_t *__restrict__ d = dir + (int64_t)(block * PAN_WAVES + wave) * n_chunks * 8;
+  const char *pl = reinterpret_cast<const char *>(panel) + j * 16;
+  for (int c = 0; c < n_chunks; ++c) {
+    const int left = n_src - c * PAN_R;
+    const int nf4 = (left < PAN_R ? left : PAN_R) * SPMM_SL;
+    const float4 *__restrict__ src = xs + (int64_t)c * PAN_R * SPMM_SL;
+    __syncthreads();                                 // the previous panel has been consumed
+    if (nf4 == PAN_R * SPMM_SL) {
+      float4 t0 = src[tid], t1 = src[1024 + tid], t2 = src[2048 + tid], t3 = src[3072 + tid];
+      float4 t4 = src[4096 + tid], t5 = src[5120 + tid], t6 = src[6144 + tid], t7 = src[7168 + tid];
+      panel[tid] = t0; panel[1024 + tid] = t1; panel[2048 + tid] = t2; panel[3072 + tid] = t3;
+      panel[4096 + tid] = t4; panel[5120 + tid] = t5; panel[6144 + tid] = t6; panel[7168 + tid] = t7;
+    } else {
+      for (int i = tid; i < nf4; i += 1024) panel[i] = src[i];
+    }
+    __syncthreads();
+    const uint32_t off = d[c * 8];
+    const uint4 *__restrict__ sp = stream + (int64_t)off * 8 + g;
+    uint4 o = *sp;                                   // (the stream ends with one spare quad)
+#pragma unroll
+    for (int k = 0; k < PAN_KR; ++k) {
+      const int nq = (int)((d[c * 8 + 1 + (k >> 1)] >> ((k & 1) * 16)) & 0xffffu);
+      for (int q = 0; q < nq; ++q) {
+        sp += 8;
+        const uint4 on = *sp;
+        const float4 x0 = *reinterpret_cast<const float4 *>(pl + o.x);
+        const float4 x1 = *reinterpret_cast<const float4 *>(pl + o.y);
+        const float4 x2 = *reinterpret_cast<const float4 *>(pl + o.z);
+        const float4 x3 = *reinterpret_cast<const float4 *>(pl + o.w);
+        acc[k].x += x0.x; acc[k].y += x0.y; acc[k].z += x0.z; acc[k].w += x0.w;
+        acc[k].x += x1.x; acc[k].y += x1.y; acc[k].z += x1.z; acc[k].w += x1.w;
+        acc[k].x += x2.x; acc[k].y += x2.y; acc[k].z += x2.z; acc[k].w += x2.w;
+        acc[k].x += x3.x; acc[k].y += x3.y; acc[k].z += x3.z; acc[k].w += x3.w;
+        o = on;
+      }
+    }
+  }
+  const int vi = slice * SPMM_SL + j;
+  if (vi >= (W >> 2)) return;
+  const float a = prelu_a ? *prelu_a : 1.0f;
+  const int32_t *__restrict__ rt = row_tab + (int64_t)(block * PAN_WAVES + wave) * PAN_KR * 8 + g;
+#pragma unroll
+  for (int k = 0; k < PAN_KR; ++k) {
+    const int row = rt[k * 8];
+    if (row < 0) continue;
+    float4 z = acc[k];
+    if (row_scale) { const float r = row_scale[row]; z.x *= r; z.y *= r; z.z *= r; z.w *= r; }
+    if (diag) {
+      const float dv = diag[row];
+      const float4 x = reinterpret_cast<const float4 *>(X + (int64_t)row * ldx)[vi];
+      z.x = fmaf(dv, x.x, z.x); z.y = fmaf(dv, x.y, z.y); z.z = fmaf(dv, x.z, z.z); z.w = fmaf(dv, x.w, z.w);
+    }
+    spmm_epilogue_store(z, vi, bias, prelu_a, a, out + (int64_t)row * ldo, out_pre ? out_pre + (int64_t)row * ldo : nullptr);
+  }
 }
 
 // rows split into several segments: out[row] = epilogue(sum of part[first .. first + count))   (fixed order)
@@ -609,7 +702,7 @@ int ggad_spmm_sliced_f32(const int32_t *col, const float *val, const int32_t *se
   GGAD_REQUIRE(nb < (1ll << 31));
   hipStream_t st = as_stream(stream);
   const int64_t nt = n_src_rows * S * SPMM_SL;
-  k_slice_major<<<dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st>>>(X, ldx, (int)n_src_rows, W, S,
+  k_slice_major<<<dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st>>>(X, ldx, (int)n_src_rows, W, S, nullptr,
                                                                         reinterpret_cast<float4 *>(xs_workspace));
   k_spmm_sliced<<<dim3((unsigned)nb), dim3(256), 0, st>>>(col, val, seg_beg, seg_end, seg_out, n_seg,
                                                          reinterpret_cast<const float4 *>(xs_workspace), (int)n_src_rows, S, W, bias,
@@ -618,6 +711,33 @@ int ggad_spmm_sliced_f32(const int32_t *col, const float *val, const int32_t *se
     k_spmm_combine<<<dim3((n_multi + 3) / 4), dim3(256), 0, st>>>(multi_row, multi_first, multi_count, n_multi, part, W, bias,
                                                                  prelu_a, out, ldo, out_pre);
   GGAD_CHECK_LAUNCH("spmm_sliced_f32");
+  return GGAD_OK;
+}
+
+int32_t ggad_spmm_panel_rows(void) { return PAN_R; }
+int32_t ggad_spmm_panel_waves(void) { return PAN_WAVES; }
+int32_t ggad_spmm_panel_rounds(void) { return PAN_KR; }
+
+int ggad_spmm_panel_f32(const int32_t *wg_tab, int32_t n_wg, const uint32_t *dir, const uint32_t *stream, const int32_t *row_tab,
+                        int32_t n_chunks, const float *col_scale, const float *row_scale, const float *diag, const float *X,
+                        int64_t ldx, int32_t W, int64_t n_src_rows, float *xs_workspace, const float *bias, const float *prelu_a,
+                        float *out, int64_t ldo, float *out_pre, ggad_stream_t stream_) {
+  GGAD_REQUIRE(wg_tab && dir && stream && row_tab && X && out && xs_workspace && W >= 4 && (W & 3) == 0 && n_wg >= 0);
+  GGAD_REQUIRE((ldx & 3) == 0 && (ldo & 3) == 0 && ldx >= W && ldo >= W && n_src_rows >= 1);
+  const int S = spmm_n_slices(W);
+  GGAD_REQUIRE(n_src_rows * S * SPMM_SL < (1ll << 31));
+  GGAD_REQUIRE(n_chunks == (int32_t)((n_src_rows + PAN_R - 1) / PAN_R));
+  if (n_wg == 0) return GGAD_OK;
+  hipStream_t st = as_stream(stream_);
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void *)k_spmm_panel, hipFuncAttributeMaxDynamicSharedMemorySize, PAN_LDS); attr = true; }
+  const int64_t nt = n_src_rows * S * SPMM_SL;
+  k_slice_major<<<dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st>>>(X, ldx, (int)n_src_rows, W, S, col_scale,
+                                                                        reinterpret_cast<float4 *>(xs_workspace));
+  k_spmm_panel<<<dim3((unsigned)n_wg), dim3(1024), PAN_LDS, st>>>(wg_tab, dir, reinterpret_cast<const uint4 *>(stream), row_tab, n_chunks,
+                                                                 reinterpret_cast<const float4 *>(xs_workspace), (int)n_src_rows, W,
+                                                                 row_scale, diag, X, ldx, bias, prelu_a, out, ldo, out_pre);
+  GGAD_CHECK_LAUNCH("spmm_panel_f32");
   return GGAD_OK;
 }
 

@@ -117,6 +117,133 @@ class Csr:
             self._plans[key] = p
         return p
 
+    def value_factors(self):
+        """(rs, cs, diag) such that value[i][j] = rs[i] * cs[j] off the diagonal (to fp32 round-off) and value[i][i] = diag[i] --
+        the shape `normalize_adj` (`utils.py:47-54`: D^-1/2 A D^-1/2 of a 0/1 matrix, with or without self loops, `+ I`
+        afterwards or not) gives every adjacency of this code base.  (None, None, None): all stored values are 1.
+        False: the values do not factor (the LDS-panel product is then not used).  Host arrays, cached."""
+        f = self._plans.get("factors")
+        if f is not None:
+            return f
+        m = self.host
+        val = m.data.astype(np.float32)
+        f = False
+        if np.all(val == np.float32(1.0)):
+            f = (None, None, None)
+        elif m.shape[0] == m.shape[1]:
+            n = m.shape[0]
+            cnt = np.diff(m.indptr).astype(np.int64)
+            row = np.repeat(np.arange(n, dtype=np.int64), cnt)
+            colv = m.indices.astype(np.int64)
+            offd = row != colv
+            diag = np.zeros(n, dtype=np.float32)
+            diag[row[~offd]] = val[~offd]
+            n_off = np.bincount(row[offd], minlength=n)
+            for degree in (n_off, cnt):                                   # normalize_adj(A) [+ I]  /  normalize_adj(A + I)
+                with np.errstate(divide="ignore"):
+                    r = np.power(degree.astype(np.float64), -0.5)
+                r[np.isinf(r)] = 0.0
+                want = (r[row[offd]] * r[colv[offd]]).astype(np.float32)
+                if np.allclose(val[offd], want, rtol=4e-7, atol=0.0):
+                    r32 = r.astype(np.float32)
+                    f = (r32, r32, diag if np.any(diag != 0) else None)
+                    break
+        self._plans["factors"] = f
+        return f
+
+    def panel_plan(self, n_slices: int):
+        """Entry stream, directory, row table and workgroup table of `ggad_spmm_panel_f32` (whole matrix; layout described at
+        k_spmm_panel in fullgraph.hip), or None when the values do not factor / the step slots would be less than 45 % full.
+        Built once on the host (a few seconds at 21 M entries), cached per slice count."""
+        key = ("panel", int(n_slices))
+        if key in self._plans:
+            return self._plans[key]
+        lib = _lib.load()
+        R, NW, KR = int(lib.ggad_spmm_panel_rows()), int(lib.ggad_spmm_panel_waves()), int(lib.ggad_spmm_panel_rounds())
+        fac = self.value_factors()
+        plan = None
+        if fac is not False:
+            plan = self._build_panel(int(n_slices), R, NW, KR, fac)
+        self._plans[key] = plan
+        return plan
+
+    def _build_panel(self, n_slices, R, NW, KR, fac):
+        m = self.host
+        n_rows, n_src = m.shape
+        cnt = np.diff(m.indptr).astype(np.int64)
+        row = np.repeat(np.arange(n_rows, dtype=np.int64), cnt)
+        colv = m.indices.astype(np.int64)
+        rs, cs, diag = fac
+        if diag is not None:                                              # the diagonal is applied in the epilogue
+            keep = row != colv
+            row, colv = row[keep], colv[keep]
+        nnz = len(row)
+        if nnz == 0:
+            return None
+        deg = np.bincount(row, minlength=n_rows)
+        rrank = np.empty(n_rows, dtype=np.int64)
+        rrank[np.argsort(-deg, kind="stable")] = np.arange(n_rows, dtype=np.int64)       # rows of similar length share a round
+        n_rounds = (n_rows + 7) // 8
+        nb = kr = None
+        for mult in range(1, 65):                                         # workgroups ~ a multiple of the 256 CUs
+            nb = max(1, (256 * mult) // n_slices)
+            kr = -(-n_rounds // (nb * NW))
+            if kr <= KR:
+                break
+        if kr is None or kr > KR:
+            return None
+        NC = (n_src + R - 1) // R
+        q = rrank // 8
+        slot = q // nb                                                    # rounds dealt round-robin to the workgroups
+        wave_of = (q % nb) * NW + slot % NW                               # (block, wave) of every row
+        k_of = slot // NW
+        g_of = rrank % 8
+        tile = (wave_of[row] * NC + colv // R) * KR + k_of[row]
+        keyv = tile * 8 + g_of[row]
+        n_tiles = nb * NW * NC * KR
+        per = np.bincount(keyv, minlength=n_tiles * 8)
+        tq = (per.reshape(n_tiles, 8).max(1) + 3) // 4                    # quads (4 steps) per tile
+        total_q = int(tq.sum())
+        fill = nnz / float(max(1, total_q) * 32)
+        if fill < 0.45 or total_q + 1 >= 2 ** 28 or int(tq.max()) > 0xffff:
+            return None
+        offq = np.zeros(n_tiles + 1, dtype=np.int64)
+        np.cumsum(tq, out=offq[1:])
+        start = np.zeros(n_tiles * 8 + 1, dtype=np.int64)
+        np.cumsum(per, out=start[1:])
+        order = np.argsort(keyv, kind="stable")                           # CSR order inside a (tile, row): ascending column
+        ks = keyv[order]
+        t = np.arange(nnz, dtype=np.int64) - start[ks]
+        pos = (offq[ks >> 3] + (t >> 2)) * 32 + (ks & 7) * 4 + (t & 3)
+        stream = np.full((total_q + 1) * 32, R * 128, dtype=np.uint32)    # padding: the zero row; one spare quad at the end
+        stream[pos] = ((colv[order] % R) * 128).astype(np.uint32)
+        tq2 = tq.reshape(nb * NW * NC, KR).astype(np.uint32)
+        dirv = np.zeros((nb * NW * NC, 8), dtype=np.uint32)
+        dirv[:, 0] = offq[:-1].reshape(nb * NW * NC, KR)[:, 0].astype(np.uint32)
+        for k in range(KR):
+            dirv[:, 1 + (k >> 1)] |= tq2[:, k] << np.uint32(16 * (k & 1))
+        row_tab = np.full((nb * NW * KR, 8), -1, dtype=np.int32)
+        row_tab[wave_of * KR + k_of, g_of] = np.arange(n_rows, dtype=np.int32)
+        # workgroup table: the workgroups of a slice share an XCD (workgroup b runs on XCD b % 8) and its L2; the slices of an
+        # incomplete round of 8 are dealt over all XCDs
+        lists = [[] for _ in range(8)]
+        full = (n_slices // 8) * 8
+        for sl in range(full):
+            lists[sl % 8].extend((sl, b) for b in range(nb))
+        rest = [(sl, b) for b in range(nb) for sl in range(full, n_slices)]
+        for i, it in enumerate(rest):
+            lists[i % 8].append(it)
+        L = max(len(x) for x in lists)
+        wg = np.full((L * 8, 2), -1, dtype=np.int32)
+        for x in range(8):
+            if lists[x]:
+                wg[x + 8 * np.arange(len(lists[x]))] = np.asarray(lists[x], dtype=np.int32)
+        dev = self.dev
+        as_i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(dev)
+        return dict(wg=_dev_i32(wg, dev), n_wg=int(L * 8), dir=as_i32(dirv), stream=as_i32(stream), row_tab=_dev_i32(row_tab, dev),
+                    n_chunks=int(NC), rs=None if rs is None else _dev_f32(rs, dev), cs=None if cs is None else _dev_f32(cs, dev),
+                    diag=None if diag is None else _dev_f32(diag, dev), fill=fill, blocks=int(nb), rounds=int(kr))
+
 
 class FullGraphAdj:
     """Everything the full-graph step needs from the two adjacency matrices, built once on the host.
@@ -225,6 +352,26 @@ def _use_sliced(csr: Csr, p, X: torch.Tensor) -> bool:
     return w >= 64 and X.shape[0] * w * 4 >= (6 << 20) and p["n_seg"] > 0 and p.get("nnz", csr.nnz) >= 24 * p["n_seg"]
 
 
+def _use_panel(csr: Csr, p, X: torch.Tensor):
+    """Whole-matrix products with dense neighbourhoods and factoring values: the LDS-panel kernel (k_spmm_panel).  Returns its
+    plan or None.  GGAD_SPMM_PANEL=0 turns it off, =1 forces it wherever a plan can be built."""
+    force = os.environ.get("GGAD_SPMM_PANEL")
+    if force == "0" or p.get("rows") is not None or X.shape[0] != csr.shape[1]:
+        return None
+    w = X.shape[1]
+    if force != "1" and not (w >= 64 and csr.nnz >= 64 * csr.shape[0] and csr.nnz >= (1 << 20)):
+        return None
+    return csr.panel_plan((w // 4 + 7) // 8)
+
+
+def _xs_workspace(X: torch.Tensor, n_ws: int) -> torch.Tensor:
+    key = (str(X.device), torch.cuda.current_stream(X.device).cuda_stream)
+    xs = _XS_WORKSPACE.get(key)
+    if xs is None or xs.numel() < n_ws:          # one staging buffer per stream: consumed by the launch that follows its fill
+        xs = _XS_WORKSPACE[key] = torch.empty(n_ws, dtype=torch.float32, device=X.device)
+    return xs
+
+
 def _part_buffer(p, W: int, dev):
     """Partial sums of the rows that are split into several segments (cached on the plan)."""
     if p["n_multi"] == 0:
@@ -244,7 +391,13 @@ def spmm(csr: Csr, X: torch.Tensor, plan=None, bias=None, prelu_a=None, want_pre
     pre = torch.empty_like(out) if want_pre else None
     opt = (ptr(bias) if bias is not None else 0, ptr(prelu_a) if prelu_a is not None else 0, ptr(out), W,
            ptr(pre) if pre is not None else 0)
-    if _use_sliced(csr, p, X):
+    pp = _use_panel(csr, p, X)
+    if pp is not None:
+        xs = _xs_workspace(X, int(_lib.load().ggad_spmm_sliced_workspace_elems(X.shape[0], W)))
+        opt_p = lambda t: ptr(t) if t is not None else 0
+        call("ggad_spmm_panel_f32", ptr(pp["wg"]), pp["n_wg"], ptr(pp["dir"]), ptr(pp["stream"]), ptr(pp["row_tab"]), pp["n_chunks"],
+             opt_p(pp["cs"]), opt_p(pp["rs"]), opt_p(pp["diag"]), ptr(X), W, W, X.shape[0], ptr(xs), *opt)
+    elif _use_sliced(csr, p, X):
         if p["long"] is None:      # the sliced kernel walks long segments (8 index loads, one reduction and store per wave)
             # (GGAD_SPMM_COL_RANGES > 1 cuts them at column-range boundaries and launches range by range so that one phase's
             # operand rows fit an L2 -- measured slower, 1.35 -> 1.67 ms with 2 ranges on T-Finance: the sliced kernel is bound
@@ -253,11 +406,7 @@ def spmm(csr: Csr, X: torch.Tensor, plan=None, bias=None, prelu_a=None, want_pre
             p["long"] = csr.plan(p["rows"], key=None, seg=int(_lib.load().ggad_spmm_sliced_seg_len()), col_ranges=ranges)
         p = p["long"]
         part = _part_buffer(p, W, X.device)
-        n_ws = int(_lib.load().ggad_spmm_sliced_workspace_elems(X.shape[0], W))
-        key = (str(X.device), torch.cuda.current_stream(X.device).cuda_stream)
-        xs = _XS_WORKSPACE.get(key)
-        if xs is None or xs.numel() < n_ws:          # one staging buffer per stream: consumed by the launch that follows its fill
-            xs = _XS_WORKSPACE[key] = torch.empty(n_ws, dtype=torch.float32, device=X.device)
+        xs = _xs_workspace(X, int(_lib.load().ggad_spmm_sliced_workspace_elems(X.shape[0], W)))
         call("ggad_spmm_sliced_f32", ptr(csr.col), ptr(csr.val), ptr(p["seg_beg"]), ptr(p["seg_end"]), ptr(p["seg_out"]),
              p["n_seg"], ptr(p["multi_row"]), ptr(p["multi_first"]), ptr(p["multi_count"]), p["n_multi"], ptr(X), W, W, X.shape[0],
              ptr(xs), *opt, ptr(part) if part is not None else 0)

@@ -383,6 +383,23 @@ int ggad_spmm_sliced_f32(const int32_t *col, const float *val, const int32_t *se
                          float *xs_workspace, const float *bias, const float *prelu_a, float *out, int64_t ldo, float *out_pre,
                          float *part, ggad_stream_t stream);
 
+/* Same product for WHOLE matrices with dense neighbourhoods whose values factor as value[i][j] = row_scale[i] * col_scale[j]
+ * off the diagonal (normalize_adj, utils.py:47-54; scales may be NULL = 1) plus an optional diagonal diag[i] (NULL = none,
+ * its entries are then part of the stream): out[i] = act(row_scale[i] * sum_j col_scale[j] X[j] + diag[i] X[i] + bias).
+ * A workgroup of ggad_spmm_panel_waves() waves owns (32-float column slice, row block) and walks the operand in panels of
+ * ggad_spmm_panel_rows() source rows staged in LDS; the entries are a host-built stream of LDS byte offsets (layout at
+ * k_spmm_panel in fullgraph.hip; built by ggad_amd/fullgraph.py::Csr.panel_plan): wg_tab[n_wg][2] = (slice, block) or (-1, -1),
+ * dir[(block * waves + wave) * n_chunks + chunk][8] = {first quad, 8 x 16-bit quad counts}, stream = 32 offsets per quad,
+ * row_tab[(block * waves + wave) * rounds + round][8] = output row or -1.  xs_workspace as for ggad_spmm_sliced_f32.
+ * Deterministic; agrees with the other two kernels to fp32 round-off (the scales are applied outside the sum). */
+int32_t ggad_spmm_panel_rows(void);
+int32_t ggad_spmm_panel_waves(void);
+int32_t ggad_spmm_panel_rounds(void);
+int ggad_spmm_panel_f32(const int32_t *wg_tab, int32_t n_wg, const uint32_t *dir, const uint32_t *stream, const int32_t *row_tab,
+                        int32_t n_chunks, const float *col_scale, const float *row_scale, const float *diag, const float *X,
+                        int64_t ldx, int32_t W, int64_t n_src_rows, float *xs_workspace, const float *bias, const float *prelu_a,
+                        float *out, int64_t ldo, float *out_pre, ggad_stream_t stream_);
+
 /* PReLU backward: dz = g * (z > 0 ? 1 : a); db[W] = column sums of dz; *da = sum g * z * [z <= 0].
  * workspace: float[2 * ggad_prelu_bwd_splits(M) * W].  db / da may be NULL. */
 int32_t ggad_prelu_bwd_splits(int32_t M);

@@ -1,4 +1,5 @@
-"""N x N x 300 product of the full-graph path alone:  python scripts/spmm_time.py [t_finance|Amazon ...]"""
+"""N x N x 300 product of the full-graph path alone, every kernel variant:  python scripts/spmm_time.py [t_finance|Amazon ...]"""
+import os
 import random
 import sys
 
@@ -19,5 +20,18 @@ for name in (sys.argv[1:] or ["t_finance", "Amazon"]):
     n = ds["n"]
     full = FG.FullGraphAdj(normalize_adj(ds["adj"]) + sp.eye(n), ds["adj"] + sp.eye(n), dev)
     x = torch.randn(n, 300, device=dev)
+    b = torch.randn(300, device=dev)
+    a = torch.tensor([0.25], device=dev)
+    os.environ["GGAD_SPMM_PANEL"] = "0"
+    ref = FG.spmm(full.A, x, bias=b, prelu_a=a)
     t = _time_call(lambda: FG.spmm(full.A, x), 30)
-    print(name, "spmm N x N x 300: %.1f us" % (t * 1e6))
+    print(name, "sliced  N x N x 300: %.1f us" % (t * 1e6), flush=True)
+    os.environ["GGAD_SPMM_PANEL"] = "1"
+    pp = full.A.panel_plan(10)
+    if pp is None:
+        print(name, "no panel plan"); continue
+    got = FG.spmm(full.A, x, bias=b, prelu_a=a)
+    err = ((got - ref).abs().max() / ref.abs().max()).item()
+    t = _time_call(lambda: FG.spmm(full.A, x), 30)
+    print(name, "panel   N x N x 300: %.1f us   (fill %.2f, %d blocks x %d rounds, %d workgroups; max rel diff to sliced %.2e)"
+          % (t * 1e6, pp["fill"], pp["blocks"], pp["rounds"], pp["n_wg"], err), flush=True)

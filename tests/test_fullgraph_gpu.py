@@ -1,5 +1,6 @@
 """GPU parity tests of the full-graph GGAD path (CSR SpMM / MFMA GEMM / affinity kernels through the C-ABI and the
 drop-in `Model` / `GCN` classes) against golden vectors captured from the imported reference (dense N x N path)."""
+import os
 import types
 
 import numpy as np
@@ -292,9 +293,46 @@ def test_spmm_xcd_sliced_equals_row_major(w, monkeypatch):
     assert FG._use_sliced(csr, csr.plan(), x) == (w >= 64 and n * w * 4 >= (6 << 20))
 
 
+@pytest.mark.parametrize("w", [300, 64, 4])
+def test_spmm_lds_panel_equals_row_major(w, monkeypatch):
+    """The LDS-panel product (k_spmm_panel: operand staged in 1,024-row panels, values factored into row / column scales, the
+    diagonal applied in the epilogue) against the wave-per-segment kernel and scipy: normalised adjacency with `+ I`
+    (3 panels, the last one partial) with bias + PReLU + pre-activation, and a 0/1 pattern matrix (diagonal inside the
+    stream); deterministic; a row subset and a matrix whose values do not factor keep the other kernels."""
+    import scipy.sparse as sp
+    n = 3000
+    rowptr, col = synth.make_graph(n, 240000, 9, kind="powerlaw", max_degree=n // 3)
+    a = synth.csr_to_scipy(rowptr, col, n)
+    rng = np.random.default_rng(w)
+    x = torch.from_numpy(rng.standard_normal((n, w)).astype(np.float32)).to(DEV)
+    bias = torch.from_numpy(rng.standard_normal(w).astype(np.float32)).to(DEV)
+    slope = torch.tensor([0.25], device=DEV)
+    for mat in (U.normalize_adj(a) + sp.eye(n), U.normalize_adj(a + sp.eye(n)), (a + sp.eye(n)).tocsr()):
+        csr = FG.Csr(mat, DEV)
+        monkeypatch.setenv("GGAD_SPMM_PANEL", "0")
+        monkeypatch.setenv("GGAD_SPMM_SLICED", "0")
+        o0, pre0 = FG.spmm(csr, x, bias=bias, prelu_a=slope, want_pre=True)
+        monkeypatch.setenv("GGAD_SPMM_PANEL", "1")
+        assert FG._use_panel(csr, csr.plan(), x) is not None
+        o1, pre1 = FG.spmm(csr, x, bias=bias, prelu_a=slope, want_pre=True)
+        o2 = FG.spmm(csr, x, bias=bias, prelu_a=slope)
+        ref = csr.host.astype(np.float64) @ x.cpu().numpy().astype(np.float64) + bias.cpu().numpy().astype(np.float64)
+        scale = np.abs(ref).max() + 1.0
+        assert np.abs(pre1.cpu().numpy() - ref).max() / scale < 2e-6
+        assert (pre1 - pre0).abs().max().item() / scale < 2e-6 and (o1 - o0).abs().max().item() / scale < 2e-6
+        assert torch.equal(o1.view(torch.int32), o2.view(torch.int32))
+        rows = rng.permutation(n)[:100]
+        assert FG._use_panel(csr, csr.plan(rows, key=("p", w)), x) is None
+    weighted = (U.normalize_adj(a) + sp.eye(n)).tocsr()
+    weighted.data = weighted.data * rng.uniform(0.5, 1.5, size=weighted.nnz)
+    csr = FG.Csr(weighted, DEV)
+    assert FG._use_panel(csr, csr.plan(), x) is None
+
+
 def test_spmm_at_t_finance_size_against_scipy_and_exact_scaling():
     """BASELINE's largest full-graph config (39,357 nodes, 21.2 M directed entries, H = 300): the automatically chosen
-    (XCD-sliced) product against scipy in float64, exact under a factor 2, deterministic, with bias + PReLU epilogue."""
+    (LDS-panel) product against scipy in float64, exact under a factor 2, deterministic, with bias + PReLU epilogue; the
+    XCD-sliced kernel on the same matrix."""
     import scipy.sparse as sp
     n, ne, w = 39357, 21222543, 300
     rowptr, col = synth.make_graph(n, ne, 0, kind="powerlaw", max_degree=n // 8, exact=True)
@@ -304,7 +342,7 @@ def test_spmm_at_t_finance_size_against_scipy_and_exact_scaling():
     rng = np.random.default_rng(1)
     xh = rng.standard_normal((n, w)).astype(np.float32)
     x = torch.from_numpy(xh).to(DEV)
-    assert FG._use_sliced(csr, csr.plan(), x)
+    assert FG._use_sliced(csr, csr.plan(), x) and FG._use_panel(csr, csr.plan(), x) is not None
     bias = torch.from_numpy(rng.standard_normal(w).astype(np.float32)).to(DEV)
     slope = torch.tensor([0.1], device=DEV)
     out, pre = FG.spmm(csr, x, bias=bias, prelu_a=slope, want_pre=True)
@@ -316,6 +354,12 @@ def test_spmm_at_t_finance_size_against_scipy_and_exact_scaling():
     again = FG.spmm(csr, x)
     assert torch.equal(plain.view(torch.int32), again.view(torch.int32))                      # fixed summation order
     assert torch.equal((plain * 2.0).view(torch.int32), FG.spmm(csr, x * 2.0).view(torch.int32))
+    os.environ["GGAD_SPMM_PANEL"] = "0"
+    try:
+        sliced = FG.spmm(csr, x)
+    finally:
+        del os.environ["GGAD_SPMM_PANEL"]
+    assert (sliced - plain).abs().max().item() / scale < 2e-6
 
 
 def test_gcn_layer_cached_aggregate_equals_reference_order(monkeypatch):
