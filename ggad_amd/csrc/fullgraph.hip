@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(256) k_spmm_sliced(const int32_t *__restrict__
 constexpr int PAN_R = 1024;                         // source rows per LDS panel
 constexpr int PAN_WAVES = 16;                       // waves per workgroup
 constexpr int PAN_KR = 8;                           // rounds (of 8 rows) per wave at most
-constexpr int PAN_LDS = (PAN_R + 1) * SPMM_SL * 16; // bytes: panel + zero row
+constexpr int PAN_LDS = (PAN_R + 2) * SPMM_SL * 16; // bytes: panel + two zero rows (one per bank half)
 
 __global__ void __launch_bounds__(1024) k_spmm_panel(const int32_t *__restrict__ wg_tab, const uint32_t *__restrict__ dir,
                                                      const uint4 *__restrict__ stream, const int32_t *__restrict__ row_tab,
@@ -270,13 +270,20 @@ __global__ void __launch_bounds__(1024) k_spmm_panel(const int32_t *__restrict__
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 3, j = lane & 7;
-  if (tid < SPMM_SL) panel[PAN_R * SPMM_SL + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (tid < 2 * SPMM_SL) panel[PAN_R * SPMM_SL + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 acc[PAN_KR];
 #pragma unroll
   for (int k = 0; k < PAN_KR; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
   const float4 *__restrict__ xs = XS + (int64_t)slice * n_src * SPMM_SL;
   const uint32_t *__restrict__ d = dir + (int64_t)(block * PAN_WAVES + wave) * n_chunks * 8;
   const char *pl = reinterpret_cast<const char *>(panel) + j * 16;
+  // entry stream of this wave: 16-bit panel row indices, one 16-byte load per lane and OCT (8 steps), contiguous over rounds
+  // and panels; hipcc unrolls the oct loop by two and keeps two loads in flight (vmcnt(1)).  Measured and dropped: 32-bit
+  // offsets in quads of 4 steps (fill 0.70 instead of 0.64, but the loop runs at the latency of its stream loads: +7 %), four
+  // quads in flight through a rotating register set (the moves wait for the youngest load), LDS reads one oct ahead of the
+  // additions (same reason: 735 -> 1,185 us).
+  const uint4 *__restrict__ sp = stream + (int64_t)d[0] * 8 + g;
+  uint4 o = *sp;
   for (int c = 0; c < n_chunks; ++c) {
     const int left = n_src - c * PAN_R;
     const int nf4 = (left < PAN_R ? left : PAN_R) * SPMM_SL;
@@ -291,26 +298,23 @@ __global__ void __launch_bounds__(1024) k_spmm_panel(const int32_t *__restrict__
       for (int i = tid; i < nf4; i += 1024) panel[i] = src[i];
     }
     __syncthreads();
-    const uint32_t off = d[c * 8];
-    const uint4 *__restrict__ sp = stream + (int64_t)off * 8 + g;
-    uint4 o = *sp;                                   // (the stream ends with one spare quad)
+#define PAN_STEP(IDX_)                                                                        \
+  {                                                                                           \
+    const float4 x = *reinterpret_cast<const float4 *>(pl + ((IDX_) << 7));                    \
+    acc[k].x += x.x; acc[k].y += x.y; acc[k].z += x.z; acc[k].w += x.w;                       \
+  }
 #pragma unroll
     for (int k = 0; k < PAN_KR; ++k) {
       const int nq = (int)((d[c * 8 + 1 + (k >> 1)] >> ((k & 1) * 16)) & 0xffffu);
       for (int q = 0; q < nq; ++q) {
         sp += 8;
-        const uint4 on = *sp;
-        const float4 x0 = *reinterpret_cast<const float4 *>(pl + o.x);
-        const float4 x1 = *reinterpret_cast<const float4 *>(pl + o.y);
-        const float4 x2 = *reinterpret_cast<const float4 *>(pl + o.z);
-        const float4 x3 = *reinterpret_cast<const float4 *>(pl + o.w);
-        acc[k].x += x0.x; acc[k].y += x0.y; acc[k].z += x0.z; acc[k].w += x0.w;
-        acc[k].x += x1.x; acc[k].y += x1.y; acc[k].z += x1.z; acc[k].w += x1.w;
-        acc[k].x += x2.x; acc[k].y += x2.y; acc[k].z += x2.z; acc[k].w += x2.w;
-        acc[k].x += x3.x; acc[k].y += x3.y; acc[k].z += x3.z; acc[k].w += x3.w;
+        const uint4 on = *sp;                        // the next oct
+        PAN_STEP(o.x & 0xffffu) PAN_STEP(o.x >> 16) PAN_STEP(o.y & 0xffffu) PAN_STEP(o.y >> 16)
+        PAN_STEP(o.z & 0xffffu) PAN_STEP(o.z >> 16) PAN_STEP(o.w & 0xffffu) PAN_STEP(o.w >> 16)
         o = on;
       }
     }
+#undef PAN_STEP
   }
   const int vi = slice * SPMM_SL + j;
   if (vi >= (W >> 2)) return;

@@ -29,7 +29,7 @@ def _normalized(n, density, seed, self_loops_inside):
 def _replay(plan, x, n_rows, R, NW, KR):
     """out = rs * (sum over the stream of cs-scaled rows) + diag * x, in the kernel's order."""
     dirv = plan["dir"].numpy().view(np.uint32).reshape(-1, 8)
-    stream = plan["stream"].numpy().view(np.uint32)
+    stream = plan["stream"].numpy().view(np.uint16)
     row_tab = plan["row_tab"].numpy().reshape(-1, 8)
     nc = plan["n_chunks"]
     xs = x if plan["cs"] is None else x * plan["cs"].numpy()[:, None]
@@ -42,14 +42,14 @@ def _replay(plan, x, n_rows, R, NW, KR):
             for k in range(KR):
                 nq = int((d[1 + (k >> 1)] >> (16 * (k & 1))) & 0xffff)
                 for q in range(nq):
-                    quad = stream[(off + q) * 32:(off + q + 1) * 32].reshape(8, 4)
+                    octv = stream[(off + q) * 64:(off + q + 1) * 64].reshape(8, 8)
                     for g in range(8):
                         r = row_tab[wv * KR + k, g]
-                        for o in quad[g]:
-                            assert o % 128 == 0 and o // 128 <= R
-                            if o // 128 < R:
+                        for o in octv[g]:
+                            assert o <= R + 1
+                            if o < R:
                                 assert r >= 0
-                                out[r] += xs[c * R + o // 128]
+                                out[r] += xs[c * R + o]
                                 seen += 1
                 off += nq
     if plan["rs"] is not None:
@@ -76,6 +76,9 @@ def test_panel_plan_replays_to_the_sparse_product(inside):
     np.testing.assert_allclose(out, m @ x, rtol=2e-6, atol=1e-6)
     rows = plan["row_tab"].numpy().reshape(-1)
     assert sorted(rows[rows >= 0].tolist()) == list(range(n))            # every output row is written once
+    st = plan["stream"].numpy().view(np.uint16).reshape(-1, 8, 8)      # rows of a bank-sharing pair alternate parities
+    same = (st & 1) == (st[:, [3, 2, 1, 0, 7, 6, 5, 4], :] & 1)
+    assert same.mean() < 0.25
     wg = plan["wg"].numpy().reshape(-1, 2)
     real = wg[wg[:, 0] >= 0]
     assert len(real) == 3 * plan["blocks"] and len({tuple(t) for t in real.tolist()}) == len(real)
