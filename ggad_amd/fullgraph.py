@@ -126,25 +126,27 @@ class Csr:
         if f is not None:
             return f
         m = self.host
-        val = m.data.astype(np.float32)
+        val = np.ascontiguousarray(m.data, dtype=np.float32)
         f = False
         if np.all(val == np.float32(1.0)):
             f = (None, None, None)
         elif m.shape[0] == m.shape[1]:
             n = m.shape[0]
-            cnt = np.diff(m.indptr).astype(np.int64)
-            row = np.repeat(np.arange(n, dtype=np.int64), cnt)
-            colv = m.indices.astype(np.int64)
-            offd = row != colv
-            diag = np.zeros(n, dtype=np.float32)
-            diag[row[~offd]] = val[~offd]
-            n_off = np.bincount(row[offd], minlength=n)
+            lib = _lib.load()
+            rowptr = np.ascontiguousarray(m.indptr, dtype=np.int64)
+            colv = np.ascontiguousarray(m.indices, dtype=np.int32)
+            cnt = np.diff(rowptr)
+            diag = m.diagonal().astype(np.float32)
+            n_off = cnt - (diag != 0)
             for degree in (n_off, cnt):                                   # normalize_adj(A) [+ I]  /  normalize_adj(A + I)
                 with np.errstate(divide="ignore"):
                     r = np.power(degree.astype(np.float64), -0.5)
                 r[np.isinf(r)] = 0.0
-                want = (r[row[offd]] * r[colv[offd]]).astype(np.float32)
-                if np.allclose(val[offd], want, rtol=4e-7, atol=0.0):
+                ok = int(lib.ggad_spmm_panel_values_factor(rowptr.ctypes.data, colv.ctypes.data, val.ctypes.data, r.ctypes.data, n,
+                                                           4e-7, 0))
+                if ok < 0:
+                    raise _lib.GgadKernelError("ggad_spmm_panel_values_factor: invalid arguments")
+                if ok == 1:
                     r32 = r.astype(np.float32)
                     f = (r32, r32, diag if np.any(diag != 0) else None)
                     break
@@ -168,21 +170,23 @@ class Csr:
         return plan
 
     def _build_panel(self, n_slices, R, NW, KR, fac):
+        import heapq
+        lib = _lib.load()
         m = self.host
         n_rows, n_src = m.shape
-        cnt = np.diff(m.indptr).astype(np.int64)
-        row = np.repeat(np.arange(n_rows, dtype=np.int64), cnt)
-        colv = m.indices.astype(np.int64)
         rs, cs, diag = fac
-        if diag is not None:                                              # the diagonal is applied in the epilogue
-            keep = row != colv
-            row, colv = row[keep], colv[keep]
-        nnz = len(row)
+        skip_diag = 1 if diag is not None else 0                          # the diagonal is applied in the epilogue
+        rowptr = np.ascontiguousarray(m.indptr, dtype=np.int64)
+        colv = np.ascontiguousarray(m.indices, dtype=np.int32)
+        cnt = np.diff(rowptr)
+        if skip_diag:
+            cnt = cnt - (m.diagonal() != 0)
+        nnz = int(cnt.sum())
         if nnz == 0:
             return None
-        deg = np.bincount(row, minlength=n_rows)
+        order = np.argsort(-cnt, kind="stable")                           # rows of similar length share a round
         rrank = np.empty(n_rows, dtype=np.int64)
-        rrank[np.argsort(-deg, kind="stable")] = np.arange(n_rows, dtype=np.int64)       # rows of similar length share a round
+        rrank[order] = np.arange(n_rows, dtype=np.int64)
         n_rounds = (n_rows + 7) // 8
         nb = kr = None
         for mult in range(1, 65):                                         # workgroups ~ a multiple of the 256 CUs
@@ -193,48 +197,58 @@ class Csr:
         if kr is None or kr > KR:
             return None
         NC = (n_src + R - 1) // R
-        q = rrank // 8
-        slot = q // nb                                                    # rounds dealt round-robin to the workgroups
-        wave_of = (q % nb) * NW + slot % NW                               # (block, wave) of every row
-        k_of = slot // NW
-        g_of = rrank % 8
-        tile = (wave_of[row] * NC + colv // R) * KR + k_of[row]
-        keyv = tile * 8 + g_of[row]
+        round_rows = np.full(n_rounds * 8, -1, dtype=np.int32)
+        round_rows[:n_rows] = order.astype(np.int32)                      # round q = rows order[8 q .. 8 q + 7], lane group = position
+        steps_rc = np.empty(n_rounds * NC, dtype=np.int32)
+        hp = lambda a: a.ctypes.data
+        _lib.check(lib.ggad_spmm_panel_count(hp(rowptr), hp(colv), n_rounds, hp(round_rows), skip_diag, R, NC, hp(steps_rc), 0),
+                   "ggad_spmm_panel_count")
+        # work of a round = its octs over all panels (the longest of its 8 rows counts).  A workgroup waits at two barriers per
+        # panel for its slowest wave, and the rounds of the hub rows are many times longer than the others: rounds are dealt to the
+        # workgroups in a snake over the work order and inside a workgroup to the least loaded wave that has a free slot
+        # (longest first) -- dealt in rank order, the slowest wave of a panel had 2.2 x the mean work on the T-Finance-size graph
+        # (1.5 x now: the longest round alone is 1.4 mean wave loads; splitting hub rows over waves is the step not taken).
+        octs_rc = (steps_rc.astype(np.int64) + 7) // 8
+        work = octs_rc.reshape(n_rounds, NC).sum(1)
+        by_work = np.argsort(-work, kind="stable")
+        pos_w = np.arange(n_rounds, dtype=np.int64)
+        lap, idx = pos_w // nb, pos_w % nb
+        blk_of_round = np.empty(n_rounds, dtype=np.int64)
+        blk_of_round[by_work] = np.where(lap % 2 == 0, idx, nb - 1 - idx)
+        wave_of_round = np.empty(n_rounds, dtype=np.int64)
+        k_of_round = np.empty(n_rounds, dtype=np.int64)
+        members = [[] for _ in range(nb)]
+        for r_ in by_work.tolist():                                       # every workgroup's rounds, longest first
+            members[blk_of_round[r_]].append(r_)
+        work_l = work.tolist()
+        for b in range(nb):
+            heap = [(0, w) for w in range(NW)]
+            used = [0] * NW
+            for r_ in members[b]:
+                load, w = heapq.heappop(heap)
+                wave_of_round[r_], k_of_round[r_] = w, used[w]
+                used[w] += 1
+                if used[w] < KR:
+                    heapq.heappush(heap, (load + work_l[r_], w))
+        gwave_of_round = blk_of_round * NW + wave_of_round                # (block, wave)
         n_tiles = nb * NW * NC * KR
-        per = np.bincount(keyv, minlength=n_tiles * 8)
-        tq = (per.reshape(n_tiles, 8).max(1) + 7) // 8                    # octs (8 steps = one 16-byte load per lane) per tile
+        tq = np.zeros(n_tiles, dtype=np.int64)                            # octs (8 steps = one 16-byte load per lane) per tile
+        tile_of_rc = ((gwave_of_round[:, None] * NC + np.arange(NC, dtype=np.int64)[None, :]) * KR + k_of_round[:, None]).reshape(-1)
+        tq[tile_of_rc] = octs_rc
         total_q = int(tq.sum())
         fill = nnz / float(max(1, total_q) * 64)
         if fill < 0.4 or total_q + 8 >= 2 ** 28 or int(tq.max()) > 0xffff:
             return None
         offq = np.zeros(n_tiles + 1, dtype=np.int64)
         np.cumsum(tq, out=offq[1:])
-        # Order inside a (tile, row): a ds_read_b128 is served in groups of 16 lanes that hold the low (or high) halves of the
-        # 128-byte rows of two lane groups -- (0,3) (1,2) (4,7) (5,6) -- and those collide when both rows lie in the same
-        # half of the 64 banks, i.e. when their panel rows have the same parity (MI355X_MICROARCH, LDS).  So the first row of a
-        # pair takes its entries even, odd, even, ... and the second odd, even, odd, ... (ascending column inside a parity;
-        # what is left of the longer parity follows), and padding reads the zero row of the parity its partner does not use.
-        parity = (colv % R) & 1
-        key2 = keyv * 2 + parity
-        per2 = np.bincount(key2, minlength=n_tiles * 16)
-        start2 = np.zeros(n_tiles * 16 + 1, dtype=np.int64)
-        np.cumsum(per2, out=start2[1:])
-        order = np.argsort(key2, kind="stable")                           # CSR order inside (tile, row, parity): ascending column
-        k2 = key2[order]
-        ks = k2 >> 1
-        par = k2 & 1
-        i = np.arange(nnz, dtype=np.int64) - start2[k2]                   # ordinal inside the parity
-        first = np.array([0, 0, 1, 1, 0, 0, 1, 1], dtype=np.int64)[ks & 7]   # parity this row starts with
-        mn = np.minimum(per2[ks * 2], per2[ks * 2 + 1])
-        t = np.where(par == first, i + np.minimum(i, mn), i + np.minimum(i + 1, mn))
-        pos = (offq[ks >> 3] + (t >> 3)) * 64 + (ks & 7) * 8 + (t & 7)
-        PAD = np.uint16(0xffff)
-        stream = np.full((total_q + 8, 8, 8), PAD, dtype=np.uint16)       # [oct][lane group][step]: panel row index; 8 spare octs (read-ahead)
-        stream.reshape(-1)[pos] = (colv[order] % R).astype(np.uint16)
-        partner = stream[:, [3, 2, 1, 0, 7, 6, 5, 4], :]
-        other = np.where(partner == PAD, np.array([1, 1, 0, 0, 1, 1, 0, 0], dtype=np.uint16)[None, :, None], partner & np.uint16(1))
-        np.copyto(stream, (np.uint16(R) + (np.uint16(1) - other)).astype(np.uint16), where=(stream == PAD))
-        stream = stream.reshape(-1).view(np.uint32)
+        tile_oct = np.ascontiguousarray(offq[tile_of_rc])
+        stream = np.empty((total_q + 8) * 64, dtype=np.uint16)            # [oct][lane group][step]: panel row index; 8 spare octs (read-ahead)
+        _lib.check(lib.ggad_spmm_panel_fill(hp(rowptr), hp(colv), n_rounds, hp(round_rows), skip_diag, R, NC, hp(steps_rc), hp(tile_oct),
+                                            hp(stream), total_q, 8, 0), "ggad_spmm_panel_fill")
+        stream = stream.view(np.uint32)
+        q_row, g_of = rrank // 8, rrank % 8
+        wave_of = gwave_of_round[q_row]                                   # (block, wave), round slot and lane group of every row
+        k_of = k_of_round[q_row]
         tq2 = tq.reshape(nb * NW * NC, KR).astype(np.uint32)
         dirv = np.zeros((nb * NW * NC, 8), dtype=np.uint32)
         dirv[:, 0] = offq[:-1].reshape(nb * NW * NC, KR)[:, 0].astype(np.uint32)

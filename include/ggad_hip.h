@@ -392,6 +392,20 @@ int ggad_spmm_sliced_f32(const int32_t *col, const float *val, const int32_t *se
  * dir[(block * waves + wave) * n_chunks + chunk][8] = {first quad, 8 x 16-bit quad counts}, stream = 32 offsets per quad,
  * row_tab[(block * waves + wave) * rounds + round][8] = output row or -1.  xs_workspace as for ggad_spmm_sliced_f32.
  * Deterministic; agrees with the other two kernels to fp32 round-off (the scales are applied outside the sum). */
+/* Host half of its plan (csrc/spmm_panel_build.cpp, host pointers, threads; n_threads <= 0: one per core, 32 at most):
+ * round_rows[n_rounds][8] = the 8 rows of a round (-1: none); ggad_spmm_panel_count -> steps_rc[round][panel] = entries of the
+ * round's longest row in that panel of panel_rows columns; ggad_spmm_panel_fill writes the entry stream: tile (round, panel)
+ * starts at oct tile_oct[round][panel], [oct][lane group][step] 16-bit panel row indices (ceil(steps_rc / 8) octs), empty
+ * slots = a zero row (panel_rows / panel_rows + 1), spare_octs zero octs after the last tile.  skip_diag: entries col == row
+ * are left out (diag[] of ggad_spmm_panel_f32 carries them). */
+int ggad_spmm_panel_count(const int64_t *rowptr, const int32_t *col, int32_t n_rounds, const int32_t *round_rows,
+                          int32_t skip_diag, int32_t panel_rows, int32_t n_panels, int32_t *steps_rc, int32_t n_threads);
+int ggad_spmm_panel_fill(const int64_t *rowptr, const int32_t *col, int32_t n_rounds, const int32_t *round_rows, int32_t skip_diag,
+                         int32_t panel_rows, int32_t n_panels, const int32_t *steps_rc, const int64_t *tile_oct, uint16_t *stream,
+                         int64_t total_octs, int32_t spare_octs, int32_t n_threads);
+/* 1: every off-diagonal value[i][j] equals (float)(r[i] * r[j]) to a relative rtol; 0: not; < 0: invalid arguments. */
+int ggad_spmm_panel_values_factor(const int64_t *rowptr, const int32_t *col, const float *val, const double *r, int32_t n_rows,
+                                  double rtol, int32_t n_threads);
 int32_t ggad_spmm_panel_rows(void);
 int32_t ggad_spmm_panel_waves(void);
 int32_t ggad_spmm_panel_rounds(void);

@@ -27,7 +27,9 @@ for name in (sys.argv[1:] or ["t_finance", "Amazon"]):
     t = _time_call(lambda: FG.spmm(full.A, x), 30)
     print(name, "sliced  N x N x 300: %.1f us" % (t * 1e6), flush=True)
     os.environ["GGAD_SPMM_PANEL"] = "1"
-    pp = full.A.panel_plan(10)
+    import time
+    t0 = time.time(); full.A.value_factors(); t1 = time.time(); pp = full.A.panel_plan(10); t2 = time.time()
+    print(name, "host: value factors %.2f s, panel plan %.2f s" % (t1 - t0, t2 - t1), flush=True)
     if pp is None:
         print(name, "no panel plan"); continue
     got = FG.spmm(full.A, x, bias=b, prelu_a=a)
