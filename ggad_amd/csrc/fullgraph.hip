@@ -251,6 +251,7 @@ __global__ void __launch_bounds__(256) k_spmm_sliced(const int32_t *__restrict__
 // (64 rows x 32 floats) in registers across all panels; rows are dealt to rounds in order of degree (the 8 rows of a round
 // have similar lengths: 70 % of the step slots carry an entry on the power-law graphs) and rounds are dealt round-robin to
 // the workgroups (equal work).  Summation order: ascending column inside a row -> deterministic.
+typedef float pan_f4 __attribute__((ext_vector_type(4)));
 constexpr int PAN_R = 1024;                         // source rows per LDS panel
 constexpr int PAN_WAVES = 16;                       // waves per workgroup
 constexpr int PAN_KR = 8;                           // rounds (of 8 rows) per wave at most
@@ -276,44 +277,60 @@ __global__ void __launch_bounds__(1024) k_spmm_panel(const int32_t *__restrict__
   for (int k = 0; k < PAN_KR; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
   const float4 *__restrict__ xs = XS + (int64_t)slice * n_src * SPMM_SL;
   const uint32_t *__restrict__ d = dir + (int64_t)(block * PAN_WAVES + wave) * n_chunks * 8;
-  const char *pl = reinterpret_cast<const char *>(panel) + j * 16;
+  const uint32_t lane_off = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)panel + j * 16, row_bytes = SPMM_SL * 16;
   // entry stream of this wave: 16-bit panel row indices, one 16-byte load per lane and OCT (8 steps), contiguous over rounds
   // and panels; hipcc unrolls the oct loop by two and keeps two loads in flight (vmcnt(1)).  Measured and dropped: 32-bit
   // offsets in quads of 4 steps (fill 0.70 instead of 0.64, but the loop runs at the latency of its stream loads: +7 %), four
   // quads in flight through a rotating register set (the moves wait for the youngest load), LDS reads one oct ahead of the
   // additions (same reason: 735 -> 1,185 us).
   const uint4 *__restrict__ sp = stream + (int64_t)d[0] * 8 + g;
-  uint4 o = *sp;
+  uint4 o = sp[0], o2 = sp[8];                       // the two octs to come
   for (int c = 0; c < n_chunks; ++c) {
     const int left = n_src - c * PAN_R;
     const int nf4 = (left < PAN_R ? left : PAN_R) * SPMM_SL;
     const float4 *__restrict__ src = xs + (int64_t)c * PAN_R * SPMM_SL;
-    __syncthreads();                                 // the previous panel has been consumed
-    if (nf4 == PAN_R * SPMM_SL) {
-      float4 t0 = src[tid], t1 = src[1024 + tid], t2 = src[2048 + tid], t3 = src[3072 + tid];
-      float4 t4 = src[4096 + tid], t5 = src[5120 + tid], t6 = src[6144 + tid], t7 = src[7168 + tid];
+    if (nf4 == PAN_R * SPMM_SL) {                    // the loads of the next panel fly while the slower waves finish this one
+      const float4 t0 = src[tid], t1 = src[1024 + tid], t2 = src[2048 + tid], t3 = src[3072 + tid];
+      const float4 t4 = src[4096 + tid], t5 = src[5120 + tid], t6 = src[6144 + tid], t7 = src[7168 + tid];
+      __syncthreads();                               // the previous panel has been consumed
       panel[tid] = t0; panel[1024 + tid] = t1; panel[2048 + tid] = t2; panel[3072 + tid] = t3;
       panel[4096 + tid] = t4; panel[5120 + tid] = t5; panel[6144 + tid] = t6; panel[7168 + tid] = t7;
     } else {
+      __syncthreads();
       for (int i = tid; i < nf4; i += 1024) panel[i] = src[i];
     }
     __syncthreads();
-#define PAN_STEP(IDX_)                                                                        \
+    // address of a row = index * 128 + lane part, from either half of a stream word in ONE instruction (v_mad_u32_u16; hipcc
+    // takes and / shift / add -- 2.7 instead of 1 VALU per step, and the loop is bound by issue slots as much as by LDS)
+#define PAN_STEP(WORD_, HI_)                                                                  \
   {                                                                                           \
-    const float4 x = *reinterpret_cast<const float4 *>(pl + ((IDX_) << 7));                    \
+    uint32_t ad_;                                                                             \
+    if (HI_) asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(ad_) : "v"(WORD_), "v"(row_bytes), "v"(lane_off)); \
+    else asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(ad_) : "v"(WORD_), "v"(row_bytes), "v"(lane_off)); \
+    const pan_f4 x = *(const __attribute__((address_space(3))) pan_f4 *)(ad_);               \
     acc[k].x += x.x; acc[k].y += x.y; acc[k].z += x.z; acc[k].w += x.w;                       \
   }
+#define PAN_OCT(O_)                                                                           \
+  PAN_STEP(O_.x, 0) PAN_STEP(O_.x, 1) PAN_STEP(O_.y, 0) PAN_STEP(O_.y, 1)                      \
+  PAN_STEP(O_.z, 0) PAN_STEP(O_.z, 1) PAN_STEP(O_.w, 0) PAN_STEP(O_.w, 1)
 #pragma unroll
     for (int k = 0; k < PAN_KR; ++k) {
       const int nq = (int)((d[c * 8 + 1 + (k >> 1)] >> ((k & 1) * 16)) & 0xffffu);
-      for (int q = 0; q < nq; ++q) {
+      int q = 0;
+      for (; q + 2 <= nq; q += 2) {                  // two octs per trip: their successors are loaded a whole trip ahead
+        const uint4 n1 = sp[16], n2 = sp[24];
+        sp += 16;
+        PAN_OCT(o) PAN_OCT(o2)
+        o = n1; o2 = n2;
+      }
+      if (q < nq) {
+        const uint4 n1 = sp[16];
         sp += 8;
-        const uint4 on = *sp;                        // the next oct
-        PAN_STEP(o.x & 0xffffu) PAN_STEP(o.x >> 16) PAN_STEP(o.y & 0xffffu) PAN_STEP(o.y >> 16)
-        PAN_STEP(o.z & 0xffffu) PAN_STEP(o.z >> 16) PAN_STEP(o.w & 0xffffu) PAN_STEP(o.w >> 16)
-        o = on;
+        PAN_OCT(o)
+        o = o2; o2 = n1;
       }
     }
+#undef PAN_OCT
 #undef PAN_STEP
   }
   const int vi = slice * SPMM_SL + j;
