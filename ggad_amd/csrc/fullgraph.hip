@@ -408,6 +408,58 @@ __global__ void __launch_bounds__(256) k_prelu_bwd(const float *__restrict__ g, 
 }
 
 // db[c] = sum_s part_db[s][c];  da = sum_c sum_s part_da[s][c]   (single block, fixed order)
+// The same pass for W % 4 == 0 (every layer width here): float4 accesses, 256 / (W / 4) rows per workgroup pass, four row
+// steps (8 loads) in flight per thread, one workgroup per split.  The scalar version above moved 1.7 TB/s (84 us on
+// 39,357 x 300: one 256-byte row piece per wave and trip, 5 waves per CU).
+__global__ void __launch_bounds__(256) k_prelu_bwd_v4(const float4 *__restrict__ g, const float4 *__restrict__ z,
+                                                      const float *__restrict__ prelu_a, int M, int nvec, float4 *__restrict__ dz,
+                                                      float4 *__restrict__ part_db, float4 *__restrict__ part_da) {
+  __shared__ float4 sb[256], sa[256];
+  const int t = threadIdx.x;
+  const int RP = 256 / nvec;                        // rows per pass of the workgroup (nvec <= 256)
+  const int ro = t / nvec, cv = t - ro * nvec;
+  const float a = *prelu_a;
+  float4 adb = make_float4(0.f, 0.f, 0.f, 0.f), ada = make_float4(0.f, 0.f, 0.f, 0.f);
+#define PRELU_ONE(G_, Z_, O_)                                                                                     \
+  {                                                                                                               \
+    float4 d;                                                                                                     \
+    d.x = Z_.x > 0.f ? G_.x : a * G_.x; d.y = Z_.y > 0.f ? G_.y : a * G_.y;                                       \
+    d.z = Z_.z > 0.f ? G_.z : a * G_.z; d.w = Z_.w > 0.f ? G_.w : a * G_.w;                                       \
+    dz[O_] = d;                                                                                                   \
+    adb.x += d.x; adb.y += d.y; adb.z += d.z; adb.w += d.w;                                                       \
+    ada.x += Z_.x > 0.f ? 0.f : G_.x * Z_.x; ada.y += Z_.y > 0.f ? 0.f : G_.y * Z_.y;                             \
+    ada.z += Z_.z > 0.f ? 0.f : G_.z * Z_.z; ada.w += Z_.w > 0.f ? 0.f : G_.w * Z_.w;                             \
+  }
+  if (ro < RP) {
+    const int64_t stride = (int64_t)gridDim.x * RP;
+    int64_t r = (int64_t)blockIdx.x * RP + ro;
+    for (; r + 3 * stride < M; r += 4 * stride) {
+      const int64_t o0 = r * nvec + cv, o1 = o0 + stride * nvec, o2 = o1 + stride * nvec, o3 = o2 + stride * nvec;
+      const float4 g0 = g[o0], g1 = g[o1], g2 = g[o2], g3 = g[o3];
+      const float4 z0 = z[o0], z1 = z[o1], z2 = z[o2], z3 = z[o3];
+      PRELU_ONE(g0, z0, o0) PRELU_ONE(g1, z1, o1) PRELU_ONE(g2, z2, o2) PRELU_ONE(g3, z3, o3)
+    }
+    for (; r < M; r += stride) {
+      const int64_t o0 = r * nvec + cv;
+      const float4 g0 = g[o0], z0 = z[o0];
+      PRELU_ONE(g0, z0, o0)
+    }
+  }
+#undef PRELU_ONE
+  sb[t] = adb; sa[t] = ada;
+  __syncthreads();
+  if (t < nvec) {
+    float4 b = sb[t], q = sa[t];
+    for (int k = 1; k < RP; ++k) {
+      const float4 b2 = sb[k * nvec + t], q2 = sa[k * nvec + t];
+      b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
+      q.x += q2.x; q.y += q2.y; q.z += q2.z; q.w += q2.w;
+    }
+    part_db[(int64_t)blockIdx.x * nvec + t] = b;
+    part_da[(int64_t)blockIdx.x * nvec + t] = q;
+  }
+}
+
 __global__ void __launch_bounds__(256) k_prelu_bwd_final(const float *__restrict__ part_db, const float *__restrict__ part_da,
                                                          int S, int W, float *__restrict__ db, float *__restrict__ da) {
   __shared__ float red[256];
@@ -762,7 +814,7 @@ int ggad_spmm_panel_f32(const int32_t *wg_tab, int32_t n_wg, const uint32_t *dir
   return GGAD_OK;
 }
 
-int32_t ggad_prelu_bwd_splits(int32_t M) { int s = (M + 255) / 256; return s < 1 ? 1 : (s > 64 ? 64 : s); }
+int32_t ggad_prelu_bwd_splits(int32_t M) { int s = (M + 63) / 64; return s < 1 ? 1 : (s > 256 ? 256 : s); }
 
 int ggad_prelu_bwd_f32(const float *g, const float *z, const float *prelu_a, int32_t M, int32_t W, float *dz, float *db,
                        float *da, float *workspace, ggad_stream_t stream) {
@@ -770,7 +822,11 @@ int ggad_prelu_bwd_f32(const float *g, const float *z, const float *prelu_a, int
   const int S = ggad_prelu_bwd_splits(M);
   float *pdb = workspace, *pda = workspace + (int64_t)S * W;
   hipStream_t st = as_stream(stream);
-  k_prelu_bwd<<<dim3((W + 63) / 64, S), dim3(256), 0, st>>>(g, z, prelu_a, M, W, dz, pdb, pda);
+  if ((W & 3) == 0 && W <= 1024 && (((uintptr_t)g | (uintptr_t)z | (uintptr_t)dz | (uintptr_t)workspace) & 15) == 0 && (((int64_t)S * W) & 3) == 0)
+    k_prelu_bwd_v4<<<dim3(S), dim3(256), 0, st>>>(reinterpret_cast<const float4 *>(g), reinterpret_cast<const float4 *>(z), prelu_a, M, W >> 2,
+                                                  reinterpret_cast<float4 *>(dz), reinterpret_cast<float4 *>(pdb), reinterpret_cast<float4 *>(pda));
+  else
+    k_prelu_bwd<<<dim3((W + 63) / 64, S), dim3(256), 0, st>>>(g, z, prelu_a, M, W, dz, pdb, pda);
   k_prelu_bwd_final<<<dim3(1), dim3(256), 0, st>>>(pdb, pda, S, W, db, da);
   GGAD_CHECK_LAUNCH("prelu_bwd_f32");
   return GGAD_OK;

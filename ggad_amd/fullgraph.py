@@ -153,23 +153,25 @@ class Csr:
         self._plans["factors"] = f
         return f
 
-    def panel_plan(self, n_slices: int):
-        """Entry stream, directory, row table and workgroup table of `ggad_spmm_panel_f32` (whole matrix; layout described at
-        k_spmm_panel in fullgraph.hip), or None when the values do not factor / the step slots would be less than 45 % full.
-        Built once on the host (a few seconds at 21 M entries), cached per slice count."""
+    def panel_plan(self, n_slices: int, rows_sel: Optional[np.ndarray] = None, cache: Optional[dict] = None):
+        """Entry stream, directory, row table and workgroup table of `ggad_spmm_panel_f32` (layout described at k_spmm_panel in
+        fullgraph.hip) for the whole matrix or the row subset `rows_sel` (output row i = matrix row rows_sel[i]), or None when
+        the values do not factor / the step slots would be less than 40 % full / a row subset has a separate diagonal.
+        Built in the library (0.1 s at 21 M entries), cached per slice count (in `cache`, default: on the matrix)."""
         key = ("panel", int(n_slices))
-        if key in self._plans:
-            return self._plans[key]
+        store = self._plans if cache is None else cache
+        if key in store:
+            return store[key]
         lib = _lib.load()
         R, NW, KR = int(lib.ggad_spmm_panel_rows()), int(lib.ggad_spmm_panel_waves()), int(lib.ggad_spmm_panel_rounds())
         fac = self.value_factors()
         plan = None
-        if fac is not False:
-            plan = self._build_panel(int(n_slices), R, NW, KR, fac)
-        self._plans[key] = plan
+        if fac is not False and (rows_sel is None or fac[2] is None):
+            plan = self._build_panel(int(n_slices), R, NW, KR, fac, rows_sel)
+        store[key] = plan
         return plan
 
-    def _build_panel(self, n_slices, R, NW, KR, fac):
+    def _build_panel(self, n_slices, R, NW, KR, fac, rows_sel=None):
         import heapq
         lib = _lib.load()
         m = self.host
@@ -181,6 +183,10 @@ class Csr:
         cnt = np.diff(rowptr)
         if skip_diag:
             cnt = cnt - (m.diagonal() != 0)
+        rows = None if rows_sel is None else np.asarray(rows_sel, dtype=np.int64)
+        if rows is not None:                                              # output row i = matrix row rows[i]
+            cnt = cnt[rows]
+            n_rows = len(rows)
         nnz = int(cnt.sum())
         if nnz == 0:
             return None
@@ -198,7 +204,7 @@ class Csr:
             return None
         NC = (n_src + R - 1) // R
         round_rows = np.full(n_rounds * 8, -1, dtype=np.int32)
-        round_rows[:n_rows] = order.astype(np.int32)                      # round q = rows order[8 q .. 8 q + 7], lane group = position
+        round_rows[:n_rows] = (order if rows is None else rows[order]).astype(np.int32)   # round q = rows order[8 q .. 8 q + 7], lane group = position
         steps_rc = np.empty(n_rounds * NC, dtype=np.int32)
         hp = lambda a: a.ctypes.data
         _lib.check(lib.ggad_spmm_panel_count(hp(rowptr), hp(colv), n_rounds, hp(round_rows), skip_diag, R, NC, hp(steps_rc), 0),
@@ -272,6 +278,8 @@ class Csr:
                 wg[x + 8 * np.arange(len(lists[x]))] = np.asarray(lists[x], dtype=np.int32)
         dev = self.dev
         as_i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(dev)
+        if rs is not None and rows is not None:
+            rs = rs[rows]
         return dict(wg=_dev_i32(wg, dev), n_wg=int(L * 8), dir=as_i32(dirv), stream=as_i32(stream), row_tab=_dev_i32(row_tab, dev),
                     n_chunks=int(NC), rs=None if rs is None else _dev_f32(rs, dev), cs=None if cs is None else _dev_f32(cs, dev),
                     diag=None if diag is None else _dev_f32(diag, dev), fill=fill, blocks=int(nb), rounds=int(kr))
@@ -385,14 +393,17 @@ def _use_sliced(csr: Csr, p, X: torch.Tensor) -> bool:
 
 
 def _use_panel(csr: Csr, p, X: torch.Tensor):
-    """Whole-matrix products with dense neighbourhoods and factoring values: the LDS-panel kernel (k_spmm_panel).  Returns its
-    plan or None.  GGAD_SPMM_PANEL=0 turns it off, =1 forces it wherever a plan can be built."""
+    """Products with dense neighbourhoods and factoring values (whole matrix, or a row subset of a matrix without separate
+    diagonal): the LDS-panel kernel (k_spmm_panel).  Returns its plan or None.  GGAD_SPMM_PANEL=0 turns it off, =1 forces it wherever a plan can be built."""
     force = os.environ.get("GGAD_SPMM_PANEL")
-    if force == "0" or p.get("rows") is not None or X.shape[0] != csr.shape[1]:
+    if force == "0" or X.shape[0] != csr.shape[1]:
         return None
     w = X.shape[1]
-    if force != "1" and not (w >= 64 and csr.nnz >= 64 * csr.shape[0] and csr.nnz >= (1 << 20)):
+    nnz = p.get("nnz", csr.nnz)
+    if force != "1" and not (w >= 64 and nnz >= 64 * p["n_out"] and nnz >= (1 << 20)):
         return None
+    if p.get("rows") is not None:                                         # row subset: the plan lives on the segment plan
+        return csr.panel_plan((w // 4 + 7) // 8, p["rows"], p.setdefault("panel_cache", {}))
     return csr.panel_plan((w // 4 + 7) // 8)
 
 

@@ -293,12 +293,42 @@ def test_spmm_xcd_sliced_equals_row_major(w, monkeypatch):
     assert FG._use_sliced(csr, csr.plan(), x) == (w >= 64 and n * w * 4 >= (6 << 20))
 
 
+@pytest.mark.parametrize("shape", [(39357, 300), (1000, 300), (5, 12), (777, 28), (513, 30), (300, 1024)])
+def test_prelu_backward_kernel_against_autograd(shape):
+    """ggad_prelu_bwd_f32 (float4 path for widths that are multiples of 4, scalar path otherwise): dZ, the bias gradient (column
+    sums of dZ) and the slope gradient against torch autograd of PReLU(z) with the same upstream gradient; deterministic."""
+    from ggad_amd import _lib
+    from ggad_amd._lib import call, ptr
+    M, W = shape
+    gen = torch.Generator(device="cpu").manual_seed(M + W)
+    z = torch.randn(M, W, generator=gen).to(DEV)
+    g = torch.randn(M, W, generator=gen).to(DEV)
+    a = torch.tensor([0.25], device=DEV)
+    S = int(_lib.load().ggad_prelu_bwd_splits(M))
+    outs = []
+    for _ in range(2):
+        ws = torch.empty(2 * S * W, dtype=torch.float32, device=DEV)
+        dz, db, da = torch.empty_like(z), torch.empty(W, device=DEV), torch.empty(1, device=DEV)
+        call("ggad_prelu_bwd_f32", ptr(g), ptr(z), ptr(a), M, W, ptr(dz), ptr(db), ptr(da), ptr(ws))
+        outs.append((dz, db, da))
+    zr = z.double().requires_grad_(True)
+    ar = a.double().requires_grad_(True)
+    (torch.nn.functional.prelu(zr, ar) * g.double()).sum().backward()
+    dz, db, da = outs[0]
+    assert torch.equal(dz.double(), zr.grad.float().double())
+    assert (db.double() - zr.grad.sum(0)).abs().max().item() <= 2e-5 * (1.0 + zr.grad.abs().sum(0).max().item())
+    assert abs(da.item() - ar.grad.item()) <= 2e-5 * (1.0 + (g.double() * z.double()).abs().sum().item())
+    for x, y in zip(outs[0], outs[1]):
+        assert torch.equal(x.view(torch.int32), y.view(torch.int32))
+
+
 @pytest.mark.parametrize("w", [300, 64, 4])
 def test_spmm_lds_panel_equals_row_major(w, monkeypatch):
     """The LDS-panel product (k_spmm_panel: operand staged in 1,024-row panels, values factored into row / column scales, the
     diagonal applied in the epilogue) against the wave-per-segment kernel and scipy: normalised adjacency with `+ I`
     (3 panels, the last one partial) with bias + PReLU + pre-activation, and a 0/1 pattern matrix (diagonal inside the
-    stream); deterministic; a row subset and a matrix whose values do not factor keep the other kernels."""
+    stream); deterministic; row subsets (panels for the pattern matrix, segments where the diagonal is separate); a matrix whose values do
+    not factor keeps the other kernels."""
     import scipy.sparse as sp
     n = 3000
     rowptr, col = synth.make_graph(n, 240000, 9, kind="powerlaw", max_degree=n // 3)
@@ -321,8 +351,11 @@ def test_spmm_lds_panel_equals_row_major(w, monkeypatch):
         assert np.abs(pre1.cpu().numpy() - ref).max() / scale < 2e-6
         assert (pre1 - pre0).abs().max().item() / scale < 2e-6 and (o1 - o0).abs().max().item() / scale < 2e-6
         assert torch.equal(o1.view(torch.int32), o2.view(torch.int32))
-        rows = rng.permutation(n)[:100]
-        assert FG._use_panel(csr, csr.plan(rows, key=("p", w)), x) is None
+        rows = np.concatenate((rng.permutation(n)[:100], [5, 5]))               # a row subset (one row twice): panels when the
+        sp_plan = csr.plan(rows, key=("p", w))                                 # matrix has no separate diagonal, else segments
+        assert (FG._use_panel(csr, sp_plan, x) is None) == (csr.value_factors()[2] is not None)
+        sub = FG.spmm(csr, x, plan=sp_plan, bias=bias).cpu().numpy()
+        assert np.abs(sub - ref[rows]).max() / scale < 2e-6
     weighted = (U.normalize_adj(a) + sp.eye(n)).tocsr()
     weighted.data = weighted.data * rng.uniform(0.5, 1.5, size=weighted.nnz)
     csr = FG.Csr(weighted, DEV)

@@ -97,6 +97,13 @@ def test_pattern_matrix_keeps_its_diagonal_in_the_stream_and_unfactorable_values
     out, seen = _replay(plan, x, n, int(lib.ggad_spmm_panel_rows()), int(lib.ggad_spmm_panel_waves()), int(lib.ggad_spmm_panel_rounds()))
     assert seen == pat.nnz
     np.testing.assert_allclose(out, pat @ x, rtol=1e-9, atol=1e-9)
+    rows = np.array([7, 1499, 3, 3, 640, 0] + list(range(100, 160)))         # row subset: output row i = matrix row rows[i]
+    sub = csr.panel_plan(2, rows, {})
+    assert sub is not None
+    out, seen = _replay(sub, x, len(rows), int(lib.ggad_spmm_panel_rows()), int(lib.ggad_spmm_panel_waves()), int(lib.ggad_spmm_panel_rounds()))
+    assert seen == pat[rows].nnz
+    np.testing.assert_allclose(out, pat[rows] @ x, rtol=1e-9, atol=1e-9)
+    assert Csr(m, "cpu").panel_plan(2, rows, {}) is None                     # separate diagonal: no subset plan
     w = m.copy()
     w.data = w.data * np.random.default_rng(2).uniform(0.5, 1.5, size=w.nnz)
     bad = Csr(w, "cpu")
