@@ -460,34 +460,42 @@ __global__ void __launch_bounds__(256) k_prelu_bwd_v4(const float4 *__restrict__
   }
 }
 
-__global__ void __launch_bounds__(256) k_prelu_bwd_final(const float *__restrict__ part_db, const float *__restrict__ part_da,
-                                                         int S, int W, float *__restrict__ db, float *__restrict__ da) {
-  __shared__ float red[256];
+__global__ void __launch_bounds__(1024) k_prelu_bwd_final(const float *__restrict__ part_db, const float *__restrict__ part_da,
+                                                          int S, int W, float *__restrict__ db, float *__restrict__ da) {
+  // one workgroup of 4 x 256 threads: quarter q of the threads sums quarter q of the S partials of its columns, eight
+  // partials of each array in flight (one dependent load per partial made a single-block version 21 us at S = 43); fixed
+  // order: four interleaved running sums per quarter, combined pairwise, quarters added in order
+  __shared__ float qb[4][1024], qa[4][256];
+  const int tc = threadIdx.x & 255, q = threadIdx.x >> 8;
+  const int s_lo = (int)((int64_t)S * q / 4), s_hi = (int)((int64_t)S * (q + 1) / 4);
   float acc_a = 0.f;
-  for (int c = threadIdx.x; c < W; c += 256) {
-    // eight partials of each array in flight (one dependent load per partial made this single-block kernel 21 us at S = 43);
-    // fixed order: four interleaved running sums, combined pairwise
+  for (int c = tc; c < W; c += 256) {
     float b4[4] = {0.f, 0.f, 0.f, 0.f}, a4[4] = {0.f, 0.f, 0.f, 0.f};
-    int s0 = 0;
-    for (; s0 + 8 <= S; s0 += 8) {
+    int s0 = s_lo;
+    for (; s0 + 8 <= s_hi; s0 += 8) {
       float vb[8], va[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) { vb[k] = part_db[(int64_t)(s0 + k) * W + c]; va[k] = part_da[(int64_t)(s0 + k) * W + c]; }
 #pragma unroll
       for (int k = 0; k < 8; ++k) { b4[k & 3] += vb[k]; a4[k & 3] += va[k]; }
     }
-    for (; s0 < S; ++s0) { b4[s0 & 3] += part_db[(int64_t)s0 * W + c]; a4[s0 & 3] += part_da[(int64_t)s0 * W + c]; }
-    const float sb = (b4[0] + b4[1]) + (b4[2] + b4[3]), sa = (a4[0] + a4[1]) + (a4[2] + a4[3]);
-    if (db) db[c] = sb;
-    acc_a += sa;
+    for (; s0 < s_hi; ++s0) { b4[(s0 - s_lo) & 3] += part_db[(int64_t)s0 * W + c]; a4[(s0 - s_lo) & 3] += part_da[(int64_t)s0 * W + c]; }
+    qb[q][c] = (b4[0] + b4[1]) + (b4[2] + b4[3]);
+    acc_a += (a4[0] + a4[1]) + (a4[2] + a4[3]);
   }
-  red[threadIdx.x] = acc_a;
+  qa[q][tc] = acc_a;
+  __syncthreads();
+  if (q == 0) {
+    if (db)
+      for (int c = tc; c < W; c += 256) db[c] = (qb[0][c] + qb[1][c]) + (qb[2][c] + qb[3][c]);
+    qa[0][tc] = (qa[0][tc] + qa[1][tc]) + (qa[2][tc] + qa[3][tc]);
+  }
   __syncthreads();
   for (int off = 128; off >= 1; off >>= 1) {
-    if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    if (threadIdx.x < off) qa[0][threadIdx.x] += qa[0][threadIdx.x + off];
     __syncthreads();
   }
-  if (threadIdx.x == 0 && da) *da = red[0];
+  if (threadIdx.x == 0 && da) *da = qa[0][0];
 }
 
 __global__ void __launch_bounds__(256) k_relu_bwd(const float *__restrict__ g, const float *__restrict__ y, int64_t n,
@@ -818,7 +826,7 @@ int32_t ggad_prelu_bwd_splits(int32_t M) { int s = (M + 63) / 64; return s < 1 ?
 
 int ggad_prelu_bwd_f32(const float *g, const float *z, const float *prelu_a, int32_t M, int32_t W, float *dz, float *db,
                        float *da, float *workspace, ggad_stream_t stream) {
-  GGAD_REQUIRE(g && z && prelu_a && dz && workspace && M >= 1 && W >= 1);
+  GGAD_REQUIRE(g && z && prelu_a && dz && workspace && M >= 1 && W >= 1 && W <= 1024);
   const int S = ggad_prelu_bwd_splits(M);
   float *pdb = workspace, *pda = workspace + (int64_t)S * W;
   hipStream_t st = as_stream(stream);
@@ -827,7 +835,7 @@ int ggad_prelu_bwd_f32(const float *g, const float *z, const float *prelu_a, int
                                                   reinterpret_cast<float4 *>(dz), reinterpret_cast<float4 *>(pdb), reinterpret_cast<float4 *>(pda));
   else
     k_prelu_bwd<<<dim3((W + 63) / 64, S), dim3(256), 0, st>>>(g, z, prelu_a, M, W, dz, pdb, pda);
-  k_prelu_bwd_final<<<dim3(1), dim3(256), 0, st>>>(pdb, pda, S, W, db, da);
+  k_prelu_bwd_final<<<dim3(1), dim3(1024), 0, st>>>(pdb, pda, S, W, db, da);
   GGAD_CHECK_LAUNCH("prelu_bwd_f32");
   return GGAD_OK;
 }
