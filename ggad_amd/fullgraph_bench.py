@@ -149,6 +149,9 @@ def bench_one(name: str, dev, epochs: int = 30, seed: int = 0, h: int = 300) -> 
     x = torch.randn(n, h, device=dev)
     w = torch.randn(h, h, device=dev)
     t_spmm = _time_call(lambda: FG.spmm(full.A, x))
+    plan0 = full.A.plan()
+    kernel = ("k_spmm_panel" if FG._use_panel(full.A, plan0, x) is not None
+              else "k_spmm_sliced" if FG._use_sliced(full.A, plan0, x) else "k_spmm_seg")
     t_gemm = _time_call(lambda: FG.gemm(x, w, False, True))
     spmm_bytes = 8.0 * nnz + 4.0 * (n + 1) + 8.0 * n * h
     spmm_flops = 2.0 * nnz * h
@@ -157,7 +160,7 @@ def bench_one(name: str, dev, epochs: int = 30, seed: int = 0, h: int = 300) -> 
     return {"nodes": n, "stored_entries_incl_identity": nnz, "directed_entries": int(ds["adj"].nnz), "feat": ds["f"], "hidden": h,
             "epoch_ms": med * 1e3, "nodes_per_s": n / med, "mode": mode, "epochs_timed": epochs, "eager_epoch_ms": eager_med * 1e3,
             "loss_after": loss,
-            "spmm_NxNxH": {"us": t_spmm * 1e6, "tflops": spmm_flops / t_spmm / 1e12, "alg_gbs": spmm_bytes / t_spmm / 1e9,
+            "spmm_NxNxH": {"kernel": kernel, "us": t_spmm * 1e6, "tflops": spmm_flops / t_spmm / 1e12, "alg_gbs": spmm_bytes / t_spmm / 1e9,
                            "bound": bound, "frac_of_f32_fma_peak": spmm_flops / t_spmm / F32_PEAK,
                            "frac_of_hbm_peak": spmm_bytes / t_spmm / HBM_PEAK,
                            "floor_us": max(spmm_flops / F32_PEAK, spmm_bytes / HBM_PEAK) * 1e6,
