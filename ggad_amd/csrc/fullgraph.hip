@@ -242,8 +242,8 @@ __global__ void __launch_bounds__(256) k_spmm_sliced(const int32_t *__restrict__
 // ---- LDS-panel variant for dense neighbourhoods whose values factor as  val[i][j] = rs[i] * cs[j]  (+ a diagonal) -------
 // (normalize_adj: D^-1/2 A D^-1/2 (+ I), utils.py:47-54 -- every full N x N x H product of an epoch.)  The sliced kernel above
 // fetches one 128-byte line per (entry, slice) through the vector L1 and runs at that path's rate.  Here a workgroup of 16
-// waves owns (slice, row block) and walks the operand in PANELS of 1,024 consecutive source rows x 32 floats staged in LDS
-// (128 KB + one zero row): every entry then costs one ds_read_b128 of 8 lanes instead of a global line.  The operand is
+// waves owns (slice, row block) and walks the operand in PANELS of 1,270 consecutive source rows x 32 floats staged in LDS
+// (159 KB + two zero rows: all of a CU's LDS): every entry then costs one ds_read_b128 of 8 lanes instead of a global line.  The operand is
 // pre-scaled by cs[] while it is re-laid slice-major, the sum is scaled by rs[] in the epilogue, so the entry stream
 // carries no values: it is a host-built list of LDS byte offsets, packed per (wave, panel, round of 8 rows) in steps of 8 entries --
 // lane group g = lane / 8 accumulates row g of the round, a shorter row is padded with the offset of the zero row -- and
@@ -252,7 +252,7 @@ __global__ void __launch_bounds__(256) k_spmm_sliced(const int32_t *__restrict__
 // have similar lengths: 70 % of the step slots carry an entry on the power-law graphs) and rounds are dealt round-robin to
 // the workgroups (equal work).  Summation order: ascending column inside a row -> deterministic.
 typedef float pan_f4 __attribute__((ext_vector_type(4)));
-constexpr int PAN_R = 1024;                         // source rows per LDS panel
+constexpr int PAN_R = 1270;                         // source rows per LDS panel (with two zero rows: 162,816 of the 163,840 bytes)
 constexpr int PAN_WAVES = 16;                       // waves per workgroup
 constexpr int PAN_KR = 8;                           // rounds (of 8 rows) per wave at most
 constexpr int PAN_LDS = (PAN_R + 2) * SPMM_SL * 16; // bytes: panel + two zero rows (one per bank half)
@@ -290,11 +290,15 @@ __global__ void __launch_bounds__(1024) k_spmm_panel(const int32_t *__restrict__
     const int nf4 = (left < PAN_R ? left : PAN_R) * SPMM_SL;
     const float4 *__restrict__ src = xs + (int64_t)c * PAN_R * SPMM_SL;
     if (nf4 == PAN_R * SPMM_SL) {                    // the loads of the next panel fly while the slower waves finish this one
-      const float4 t0 = src[tid], t1 = src[1024 + tid], t2 = src[2048 + tid], t3 = src[3072 + tid];
-      const float4 t4 = src[4096 + tid], t5 = src[5120 + tid], t6 = src[6144 + tid], t7 = src[7168 + tid];
+      constexpr int LAST = PAN_R * SPMM_SL - 9 * 1024;                          // float4 of the tenth pass
+      static_assert(LAST > 0 && LAST <= 1024, "staging is written for 9 full passes of 1,024 float4 and a partial one");
+      const float4 t0 = src[tid], t1 = src[1024 + tid], t2 = src[2048 + tid], t3 = src[3072 + tid], t4 = src[4096 + tid];
+      const float4 t5 = src[5120 + tid], t6 = src[6144 + tid], t7 = src[7168 + tid], t8 = src[8192 + tid];
+      const float4 t9 = src[tid < LAST ? 9216 + tid : 0];
       __syncthreads();                               // the previous panel has been consumed
-      panel[tid] = t0; panel[1024 + tid] = t1; panel[2048 + tid] = t2; panel[3072 + tid] = t3;
-      panel[4096 + tid] = t4; panel[5120 + tid] = t5; panel[6144 + tid] = t6; panel[7168 + tid] = t7;
+      panel[tid] = t0; panel[1024 + tid] = t1; panel[2048 + tid] = t2; panel[3072 + tid] = t3; panel[4096 + tid] = t4;
+      panel[5120 + tid] = t5; panel[6144 + tid] = t6; panel[7168 + tid] = t7; panel[8192 + tid] = t8;
+      if (tid < LAST) panel[9216 + tid] = t9;
     } else {
       __syncthreads();
       for (int i = tid; i < nf4; i += 1024) panel[i] = src[i];

@@ -1,7 +1,7 @@
 // Host half of the LDS-panel product (k_spmm_panel in fullgraph.hip): the two O(nnz) passes of its plan, on threads.
 //
 // ggad_amd/fullgraph.py::Csr.panel_plan sorts the rows into rounds of 8, calls ggad_spmm_panel_count (entries of every row
-// per 1,024-column panel -> the longest row of every (round, panel)), deals the rounds to workgroups / waves and lays the
+// per panel of ggad_spmm_panel_rows() columns -> the longest row of every (round, panel)), deals the rounds to workgroups / waves and lays the
 // tiles out (numpy on n_rounds x n_panels values), then calls ggad_spmm_panel_fill, which writes the entry stream the
 // kernel walks: per tile [oct][lane group][step] 16-bit panel row indices.  Both passes walk the CSR once, a thread per
 // block of rounds (a round's 8 rows and its tiles belong to one thread: no shared writes).  numpy did the same in 1.3 s

@@ -324,7 +324,7 @@ def test_prelu_backward_kernel_against_autograd(shape):
 
 @pytest.mark.parametrize("w", [300, 64, 4])
 def test_spmm_lds_panel_equals_row_major(w, monkeypatch):
-    """The LDS-panel product (k_spmm_panel: operand staged in 1,024-row panels, values factored into row / column scales, the
+    """The LDS-panel product (k_spmm_panel: operand staged in 1,270-row panels, values factored into row / column scales, the
     diagonal applied in the epilogue) against the wave-per-segment kernel and scipy: normalised adjacency with `+ I`
     (3 panels, the last one partial) with bias + PReLU + pre-activation, and a 0/1 pattern matrix (diagonal inside the
     stream); deterministic; row subsets (panels for the pattern matrix, segments where the diagonal is separate); a matrix whose values do

@@ -63,7 +63,7 @@ def _replay(plan, x, n_rows, R, NW, KR):
 def test_panel_plan_replays_to_the_sparse_product(inside):
     lib = _lib.load()
     R, NW, KR = int(lib.ggad_spmm_panel_rows()), int(lib.ggad_spmm_panel_waves()), int(lib.ggad_spmm_panel_rounds())
-    n = 2500                                                              # 3 panels, the last one partial
+    n = 2 * R + 452                                                       # 3 panels, the last one partial
     m = _normalized(n, 0.05, 3, inside)
     csr = Csr(m, "cpu")
     rs, cs, diag = csr.value_factors()
