@@ -143,7 +143,9 @@ class Model(nn.Module):
         h_1 = GcnLayerFn.apply(x, self.gcn1.fc.weight, self.gcn1.bias, self.gcn1.act.weight, fa)
         emb = GcnLayerFn.apply(h_1, self.gcn2.fc.weight, self.gcn2.bias, self.gcn2.act.weight, fa)      # (N, H)
         abn = self._index(sample_abnormal_idx, dev)
-        emb_abnormal = emb[abn].unsqueeze(0)
+        # (index_select: same rows as emb[abn]; its backward is one index_add_ on distinct rows -- exact -- where advanced indexing
+        # sorts the indices on the device every epoch: ~5 launches of 4-5 us each, twice per epoch)
+        emb_abnormal = emb.index_select(0, abn).unsqueeze(0)
         override = self.__dict__.get("noise_override")
         if override is not None:
             # captured epoch (run.py): the caller drew the very same CPU noise and copied it into this static device buffer
@@ -158,7 +160,7 @@ class Model(nn.Module):
             emb_con = SpmmRowsFn.apply(emb, fa, rows_sel, sub_t)                                        # :151-155
             emb_con = LinearFn.apply(emb_con, self.fc4.weight, True)                                    # relu(fc4(.))  :156
             nrm = self._index(normal_idx, dev)
-            emb_combine = torch.cat((emb[nrm], emb_con), 0)                                             # :159
+            emb_combine = torch.cat((emb.index_select(0, nrm), emb_con), 0)                              # :159
             f_3 = self._score(emb_combine)
             emb = emb.index_copy(0, abn, emb_con)                                                       # :182 (in-place there)
             return emb.unsqueeze(0), emb_combine.unsqueeze(0), f_3.unsqueeze(0), emb_con, emb_abnormal

@@ -167,7 +167,7 @@ def max_message(emb: torch.Tensor, adj: FullGraphAdj, normal_label_idx) -> Tuple
     m = (m - torch.min(m)) / (torch.max(m) - torch.min(m))
     idx = normal_label_idx if isinstance(normal_label_idx, torch.Tensor) else torch.as_tensor(
         np.asarray(normal_label_idx, dtype=np.int64), device=m.device)
-    return -torch.sum(m[idx]), m
+    return -torch.sum(m.index_select(0, idx.reshape(-1).long())), m
 
 
 def normalize_score(ano_score: np.ndarray) -> np.ndarray:
