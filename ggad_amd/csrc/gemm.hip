@@ -281,11 +281,14 @@ extern "C" {
 int64_t ggad_gemm_workspace_elems(int32_t M, int32_t N, int32_t K) {
   const int tm = pick_tm(M, N);
   const int64_t tiles = (int64_t)((M + tm - 1) / tm) * ((N + BN - 1) / BN);
-  if (K < 2048 || tiles >= 256) return 0;
+  // (the bar was K >= 2048 with >= 256 of K per split: the weight gradients of the scorer MLP on Reddit / Photo / Amazon -- K = the
+  // 1,200-1,900 rows the loss reads, 1-15 tiles -- then ran as a handful of workgroups walking 58 K-tiles each: 92-99 us per
+  // call, three calls per epoch, a quarter of a 1 ms epoch)
+  if (K < 512 || tiles >= 256) return 0;
   int splits = (int)((512 + tiles - 1) / tiles);
-  const int max_splits = (K + 255) / 256;
+  const int max_splits = K >= 2048 ? (K + 255) / 256 : (K + 127) / 128;
   if (splits > max_splits) splits = max_splits;
-  if (splits > 64) splits = 64;
+  if (splits > 128) splits = 128;
   return splits <= 1 ? 0 : (int64_t)splits * M * N;
 }
 
