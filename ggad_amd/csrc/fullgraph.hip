@@ -373,7 +373,16 @@ __global__ void __launch_bounds__(256) k_spmm_combine(const int32_t *__restrict_
     const int vi = ch * 64 + lane;
     if (vi < nvec) {
       float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int k = 0; k < count; ++k) {
+      int k = 0;
+      for (; k + 4 <= count; k += 4) {               // four partials in flight, added in slot order
+        const float4 *src = reinterpret_cast<const float4 *>(part + (int64_t)(first + k) * W) + vi;
+        const float4 p0 = src[0], p1 = src[(W >> 2)], p2 = src[2 * (W >> 2)], p3 = src[3 * (W >> 2)];
+        z.x += p0.x; z.y += p0.y; z.z += p0.z; z.w += p0.w;
+        z.x += p1.x; z.y += p1.y; z.z += p1.z; z.w += p1.w;
+        z.x += p2.x; z.y += p2.y; z.z += p2.z; z.w += p2.w;
+        z.x += p3.x; z.y += p3.y; z.z += p3.z; z.w += p3.w;
+      }
+      for (; k < count; ++k) {
         const float4 p = reinterpret_cast<const float4 *>(part + (int64_t)(first + k) * W)[vi];
         z.x += p.x; z.y += p.y; z.z += p.z; z.w += p.w;
       }
