@@ -475,14 +475,15 @@ __global__ void __launch_bounds__(256) k_prelu_bwd_v4(const float4 *__restrict__
 
 __global__ void __launch_bounds__(1024) k_prelu_bwd_final(const float *__restrict__ part_db, const float *__restrict__ part_da,
                                                           int S, int W, float *__restrict__ db, float *__restrict__ da) {
-  // one workgroup of 4 x 256 threads: quarter q of the threads sums quarter q of the S partials of its columns, eight
-  // partials of each array in flight (one dependent load per partial made a single-block version 21 us at S = 43); fixed
-  // order: four interleaved running sums per quarter, combined pairwise, quarters added in order
-  __shared__ float qb[4][1024], qa[4][256];
-  const int tc = threadIdx.x & 255, q = threadIdx.x >> 8;
-  const int s_lo = (int)((int64_t)S * q / 4), s_hi = (int)((int64_t)S * (q + 1) / 4);
-  float acc_a = 0.f;
-  for (int c = tc; c < W; c += 256) {
+  // one workgroup of 1,024 threads = G groups of (W rounded up to 64) threads, W <= 1024: group g sums its share of the S
+  // partials of every column, eight partials of each array in flight (one dependent load per partial made a single-block
+  // version 21 us at S = 43); fixed order: four interleaved running sums per group, combined pairwise, groups added in order
+  __shared__ float qb[1024], qa[1024];
+  const int Wp = (W + 63) & ~63, G = 1024 / Wp;
+  const int g = threadIdx.x / Wp, c = threadIdx.x - g * Wp;
+  float sum_b = 0.f, sum_a = 0.f;
+  if (g < G && c < W) {
+    const int s_lo = (int)((int64_t)S * g / G), s_hi = (int)((int64_t)S * (g + 1) / G);
     float b4[4] = {0.f, 0.f, 0.f, 0.f}, a4[4] = {0.f, 0.f, 0.f, 0.f};
     int s0 = s_lo;
     for (; s0 + 8 <= s_hi; s0 += 8) {
@@ -493,22 +494,26 @@ __global__ void __launch_bounds__(1024) k_prelu_bwd_final(const float *__restric
       for (int k = 0; k < 8; ++k) { b4[k & 3] += vb[k]; a4[k & 3] += va[k]; }
     }
     for (; s0 < s_hi; ++s0) { b4[(s0 - s_lo) & 3] += part_db[(int64_t)s0 * W + c]; a4[(s0 - s_lo) & 3] += part_da[(int64_t)s0 * W + c]; }
-    qb[q][c] = (b4[0] + b4[1]) + (b4[2] + b4[3]);
-    acc_a += (a4[0] + a4[1]) + (a4[2] + a4[3]);
+    sum_b = (b4[0] + b4[1]) + (b4[2] + b4[3]);
+    sum_a = (a4[0] + a4[1]) + (a4[2] + a4[3]);
   }
-  qa[q][tc] = acc_a;
+  qb[threadIdx.x] = sum_b; qa[threadIdx.x] = sum_a;
   __syncthreads();
-  if (q == 0) {
-    if (db)
-      for (int c = tc; c < W; c += 256) db[c] = (qb[0][c] + qb[1][c]) + (qb[2][c] + qb[3][c]);
-    qa[0][tc] = (qa[0][tc] + qa[1][tc]) + (qa[2][tc] + qa[3][tc]);
+  float col_a = 0.f;
+  if (g == 0 && c < W) {
+    float b = qb[c];
+    col_a = qa[c];
+    for (int k = 1; k < G; ++k) { b += qb[k * Wp + c]; col_a += qa[k * Wp + c]; }
+    if (db) db[c] = b;
   }
   __syncthreads();
-  for (int off = 128; off >= 1; off >>= 1) {
-    if (threadIdx.x < off) qa[0][threadIdx.x] += qa[0][threadIdx.x + off];
+  qa[threadIdx.x] = col_a;
+  __syncthreads();
+  for (int off = 512; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) qa[threadIdx.x] += qa[threadIdx.x + off];
     __syncthreads();
   }
-  if (threadIdx.x == 0 && da) *da = qa[0][0];
+  if (threadIdx.x == 0 && da) *da = qa[0];
 }
 
 __global__ void __launch_bounds__(256) k_relu_bwd(const float *__restrict__ g, const float *__restrict__ y, int64_t n,

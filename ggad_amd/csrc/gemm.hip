@@ -244,7 +244,16 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(const float *__restrict__
   if (idx >= (int64_t)M * N) return;
   const int m = (int)(idx / N), n = (int)(idx - (int64_t)m * N);
   float s = 0.0f;
-  for (int k = 0; k < splits; ++k) s += ws[(int64_t)k * split_stride + (int64_t)m * N + n];   // fixed order
+  const float *__restrict__ p = ws + (int64_t)m * N + n;
+  int k = 0;
+  for (; k + 8 <= splits; k += 8) {                  // eight partials in flight, added in split order (one dependent load per
+    float v[8];                                      // split made this 26 us at 128 splits of a 300 x 10 gradient)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(k + u) * split_stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; k < splits; ++k) s += p[(int64_t)k * split_stride];
   if (bias != nullptr) s += bias[n];
   if (relu) s = fmaxf(s, 0.0f);
   C[(int64_t)m * ldc + n] = s;
