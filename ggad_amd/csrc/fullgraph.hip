@@ -656,12 +656,13 @@ __global__ void __launch_bounds__(1024) k_full_loss(const float *__restrict__ lo
 //   k_rec_part : partial column sums of squares per row block                       -> ws[block][H]
 //   k_rec_apply: column norms from the partials (block order, identical in every workgroup), dD for the block's rows;
 //                workgroup 0 also reduces rec and adds it to the loss record
-constexpr int REC_ROWS = 32;
+constexpr int REC_ROWS = 8;     // (32 rows walked one dependent-looking load at a time made the two launches 17 + 13 us on 238 x 300)
 __global__ void __launch_bounds__(256) k_rec_part(const float *__restrict__ emb_con, const float *__restrict__ emb_abn, int A, int H,
                                                   float *__restrict__ ws) {
   const int a0 = blockIdx.x * REC_ROWS, a1 = min(A, a0 + REC_ROWS);
   for (int h = threadIdx.x; h < H; h += 256) {
     float ss = 0.f;
+#pragma unroll 8
     for (int a = a0; a < a1; ++a) { const float d = emb_con[(int64_t)a * H + h] - emb_abn[(int64_t)a * H + h]; ss = fmaf(d, d, ss); }
     ws[(int64_t)blockIdx.x * H + h] = ss;
   }
@@ -675,10 +676,12 @@ __global__ void __launch_bounds__(256) k_rec_apply(const float *__restrict__ emb
   float s_rec = 0.f;
   for (int h = threadIdx.x; h < H; h += 256) {
     float ss = 0.f;
+#pragma unroll 8
     for (int b = 0; b < n_blocks; ++b) ss += ws[(int64_t)b * H + h];          // fixed order
     const float nrm = sqrtf(ss);
     s_rec += nrm;
     const float k = 1.0f / ((float)H * nrm);
+#pragma unroll 8
     for (int a = a0; a < a1; ++a) {
       const float d = emb_con[(int64_t)a * H + h] - emb_abn[(int64_t)a * H + h];
       dD[(int64_t)a * H + h] = d * k;
