@@ -501,6 +501,7 @@ __global__ void __launch_bounds__(256) k_gather2_combine(const int32_t *__restri
       const int ej = __shfl(rv, j & 7, GGAD_WAVE);
       if (g < rpi && j < 8 && ej >= 0) {
         float acc = 0.0f;
+#pragma unroll 4
         for (int sl = 0; sl < ns; ++sl) acc += part2[((int64_t)pbase + (int64_t)j * ns + sl) * F + f];
         x2[(int64_t)ej * F + f] = acc;
       }

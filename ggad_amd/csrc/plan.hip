@@ -320,8 +320,18 @@ __global__ void __launch_bounds__(256) k_combine1_reset(int row_blocks, int n_ro
     const int fw = F <= 64 ? F : min(64, F - fbase);
     const int g = lane / fw, f = lane - g * fw;
     float acc = 0.0f;
-    if (g < rpi)
-      for (int c = g; c < nck; c += rpi) acc += part1[(int64_t)(c0 + c) * pstride + fbase + f];
+    if (g < rpi) {
+      const float *__restrict__ src = part1 + (int64_t)c0 * pstride + fbase + f;
+      int c = g;
+      for (; c + 7 * rpi < nck; c += 8 * rpi) {      // eight pieces in flight (a 2,000-entry hub row is 125 pieces: 42 loads one
+        float v[8];                                  // after the other per lane group made this launch a fixed ~15 us); same order
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(c + u * rpi) * pstride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+      }
+      for (; c < nck; c += rpi) acc += src[(int64_t)c * pstride];
+    }
     const float tot = (F <= 64) ? reduce_groups(acc, fw, rpi) : acc;
     if (lane < fw) x1[(int64_t)row * F + fbase + lane] = tot;
   }
