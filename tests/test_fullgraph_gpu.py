@@ -362,6 +362,23 @@ def test_spmm_lds_panel_equals_row_major(w, monkeypatch):
     assert FG._use_panel(csr, csr.plan(), x) is None
 
 
+def test_spmm_lds_panel_single_partial_panel_and_rectangular(monkeypatch):
+    """Operands shorter than one panel (one partial panel, the zero rows behind it) and a rectangular pattern matrix (the N x |J|
+    column subset of the affinity backward, `run.py:182-188`): forced LDS-panel product against scipy."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(5)
+    monkeypatch.setenv("GGAD_SPMM_PANEL", "1")
+    for n_rows, n_src, dens in ((900, 900, 0.2), (2000, 700, 0.15), (300, 2900, 0.1)):
+        a = sp.random(n_rows, n_src, density=dens, random_state=7, format="csr", dtype=np.float32)
+        a.data[:] = 1.0
+        csr = FG.Csr(a, DEV)
+        x = torch.from_numpy(rng.standard_normal((n_src, 300)).astype(np.float32)).to(DEV)
+        assert FG._use_panel(csr, csr.plan(), x) is not None
+        got = FG.spmm(csr, x).cpu().numpy()
+        ref = a.astype(np.float64) @ x.cpu().numpy().astype(np.float64)
+        assert np.abs(got - ref).max() / (np.abs(ref).max() + 1.0) < 2e-6, (n_rows, n_src)
+
+
 def test_spmm_at_t_finance_size_against_scipy_and_exact_scaling():
     """BASELINE's largest full-graph config (39,357 nodes, 21.2 M directed entries, H = 300): the automatically chosen
     (LDS-panel) product against scipy in float64, exact under a factor 2, deterministic, with bias + PReLU epilogue; the
