@@ -319,7 +319,10 @@ __global__ void __launch_bounds__(1024) k_spmm_panel(const int32_t *__restrict__
   PAN_STEP(O_.z, 0) PAN_STEP(O_.z, 1) PAN_STEP(O_.w, 0) PAN_STEP(O_.w, 1)
 #pragma unroll
     for (int k = 0; k < PAN_KR; ++k) {
-      const int nq = (int)((d[c * 8 + 1 + (k >> 1)] >> ((k & 1) * 16)) & 0xffffu);
+      // the directory counts QUADS (4 steps): whole octs, then -- when the longest row of the tile ends in the first half of its last
+      // oct -- only that half (a tenth of the steps were padding of the second half)
+      const int nh = (int)((d[c * 8 + 1 + (k >> 1)] >> ((k & 1) * 16)) & 0xffffu);
+      const int nq = nh >> 1;
       int q = 0;
       for (; q + 2 <= nq; q += 2) {                  // two octs per trip: their successors are loaded a whole trip ahead
         const uint4 n1 = sp[16], n2 = sp[24];
@@ -331,6 +334,12 @@ __global__ void __launch_bounds__(1024) k_spmm_panel(const int32_t *__restrict__
         const uint4 n1 = sp[16];
         sp += 8;
         PAN_OCT(o)
+        o = o2; o2 = n1;
+      }
+      if (nh & 1) {
+        const uint4 n1 = sp[16];
+        sp += 8;
+        PAN_STEP(o.x, 0) PAN_STEP(o.x, 1) PAN_STEP(o.y, 0) PAN_STEP(o.y, 1)
         o = o2; o2 = n1;
       }
     }

@@ -215,7 +215,8 @@ class Csr:
         # (longest first) -- dealt in rank order, the slowest wave of a panel had 2.2 x the mean work on the T-Finance-size graph
         # (1.5 x now: the longest round alone is 1.4 mean wave loads; splitting hub rows over waves is the step not taken).
         octs_rc = (steps_rc.astype(np.int64) + 7) // 8
-        work = octs_rc.reshape(n_rounds, NC).sum(1)
+        quads_rc = (steps_rc.astype(np.int64) + 3) // 4                   # what the kernel walks: whole octs, then half of the last one
+        work = quads_rc.reshape(n_rounds, NC).sum(1)
         by_work = np.argsort(-work, kind="stable")
         pos_w = np.arange(n_rounds, dtype=np.int64)
         lap, idx = pos_w // nb, pos_w % nb
@@ -241,9 +242,11 @@ class Csr:
         tq = np.zeros(n_tiles, dtype=np.int64)                            # octs (8 steps = one 16-byte load per lane) per tile
         tile_of_rc = ((gwave_of_round[:, None] * NC + np.arange(NC, dtype=np.int64)[None, :]) * KR + k_of_round[:, None]).reshape(-1)
         tq[tile_of_rc] = octs_rc
+        th = np.zeros(n_tiles, dtype=np.int64)                            # quads (4 steps) walked per tile: 2 * octs or 2 * octs - 1
+        th[tile_of_rc] = quads_rc
         total_q = int(tq.sum())
-        fill = nnz / float(max(1, total_q) * 64)
-        if fill < 0.4 or total_q + 8 >= 2 ** 28 or int(tq.max()) > 0xffff:
+        fill = nnz / float(max(1, int(th.sum())) * 32)
+        if fill < 0.4 or total_q + 8 >= 2 ** 28 or int(th.max()) > 0xffff:
             return None
         offq = np.zeros(n_tiles + 1, dtype=np.int64)
         np.cumsum(tq, out=offq[1:])
@@ -255,7 +258,7 @@ class Csr:
         q_row, g_of = rrank // 8, rrank % 8
         wave_of = gwave_of_round[q_row]                                   # (block, wave), round slot and lane group of every row
         k_of = k_of_round[q_row]
-        tq2 = tq.reshape(nb * NW * NC, KR).astype(np.uint32)
+        tq2 = th.reshape(nb * NW * NC, KR).astype(np.uint32)             # the directory counts quads
         dirv = np.zeros((nb * NW * NC, 8), dtype=np.uint32)
         dirv[:, 0] = offq[:-1].reshape(nb * NW * NC, KR)[:, 0].astype(np.uint32)
         for k in range(KR):

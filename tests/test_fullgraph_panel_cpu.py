@@ -40,12 +40,15 @@ def _replay(plan, x, n_rows, R, NW, KR):
             d = dirv[wv * nc + c]
             off = int(d[0])
             for k in range(KR):
-                nq = int((d[1 + (k >> 1)] >> (16 * (k & 1))) & 0xffff)
+                nh = int((d[1 + (k >> 1)] >> (16 * (k & 1))) & 0xffff)       # quads: whole octs, then half of the last one
+                nq = (nh + 1) // 2
                 for q in range(nq):
                     octv = stream[(off + q) * 64:(off + q + 1) * 64].reshape(8, 8)
+                    steps = 4 if (q == nq - 1 and nh % 2 == 1) else 8
+                    assert (octv[:, steps:] >= R).all()                      # nothing but padding in a half that is not walked
                     for g in range(8):
                         r = row_tab[wv * KR + k, g]
-                        for o in octv[g]:
+                        for o in octv[g, :steps]:
                             assert o <= R + 1
                             if o < R:
                                 assert r >= 0
