@@ -311,7 +311,7 @@ __global__ void __launch_bounds__(1024) k_spmm_panel(const int32_t *__restrict__
     uint32_t ad_;                                                                             \
     if (HI_) asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(ad_) : "v"(WORD_), "v"(row_bytes), "v"(lane_off)); \
     else asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(ad_) : "v"(WORD_), "v"(row_bytes), "v"(lane_off)); \
-    const pan_f4 x = *(const __attribute__((address_space(3))) pan_f4 *)(ad_);               \
+    const pan_f4 x = *(const __attribute__((address_space(3))) pan_f4 *)(uintptr_t)(ad_);              \
     acc[k].x += x.x; acc[k].y += x.y; acc[k].z += x.z; acc[k].w += x.w;                       \
   }
 #define PAN_OCT(O_)                                                                           \
