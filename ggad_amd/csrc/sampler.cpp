@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 #include <immintrin.h>
@@ -266,11 +267,27 @@ constexpr int POOL_RING = 128;              // pool shuffles in flight between B
 constexpr int SEG = 8;                      // pool shuffles per composed segment (stage M); POOL_RING holds 16 of them
 static_assert(POOL_RING % SEG == 0 && POOL_RING >= 4 * SEG, "a slot is reused only after its whole segment");
 
-struct SchedBuffers {                       // reused across calls (per calling thread): no page faults in steady state
+struct SchedBuffers {                       // ~75 MB at DGraph-Fin size; reused across calls: no page faults in steady state
   std::vector<uint32_t> temp, raw;
   std::vector<int32_t> pool_t, pool_p, train_t;
   std::vector<int32_t> pool_a, pool_b;
   std::vector<int64_t> train_alt;
+};
+// One set per CONCURRENT call, kept process-wide: they used to be thread_local, and the trainer's producer thread -- a new thread
+// per start_stream() -- paid the first touch of all of it again (~30 ms: a quarter of a 3,000-step run).
+struct SchedBufferLease {
+  static std::mutex &mu() { static std::mutex m; return m; }
+  static std::vector<std::unique_ptr<SchedBuffers>> &idle() { static std::vector<std::unique_ptr<SchedBuffers>> v; return v; }
+  std::unique_ptr<SchedBuffers> b;
+  SchedBufferLease() {
+    std::lock_guard<std::mutex> lk(mu());
+    if (!idle().empty()) { b = std::move(idle().back()); idle().pop_back(); }
+    else b.reset(new SchedBuffers());
+  }
+  ~SchedBufferLease() {
+    std::lock_guard<std::mutex> lk(mu());
+    idle().push_back(std::move(b));
+  }
 };
 
 // The stages hand each other ~0.9 MB per batch (outputs -> targets -> permutation -> list).  On a multi-die host (EPYC: 8 cores per
@@ -358,7 +375,8 @@ int ggad_sched_batches(ggad_mt19937 *g, int64_t *train, int64_t n_train, int64_t
     }
   }
   const int64_t n_items = (int64_t)items.size();
-  static thread_local SchedBuffers B;
+  SchedBufferLease lease;
+  SchedBuffers &B = *lease.b;
   const size_t ring_words = (size_t)RING_BLOCKS * MT_N;
   if (B.temp.size() < ring_words + 64) { B.temp.assign(ring_words + 64, 0u); B.raw.assign(ring_words, 0u); }
   const size_t pstride = (size_t)n_pool + 16;
@@ -369,7 +387,6 @@ int ggad_sched_batches(ggad_mt19937 *g, int64_t *train, int64_t n_train, int64_t
   for (const Item &it : items) any_train |= it.kind == 0;
   if (any_train && B.train_t.size() < 2 * tstride) B.train_t.assign(2 * tstride, 0);
   if (any_train && B.train_alt.size() < (size_t)n_train) B.train_alt.assign((size_t)n_train, 0);
-  // (plain pointers: a thread_local object named inside another thread's lambda would be THAT thread's instance)
   uint32_t *temp = B.temp.data(), *raw = B.raw.data();
   int32_t *pool_t = B.pool_t.data(), *pool_p = B.pool_p.data(), *train_t = any_train ? B.train_t.data() : nullptr;
   int32_t *pool_a = B.pool_a.data(), *pool_b = B.pool_b.data();
