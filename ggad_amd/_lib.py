@@ -97,8 +97,8 @@ SIGNATURES = {
     "ggad_spmm_panel_waves": (c_int32, []),
     "ggad_spmm_panel_rounds": (c_int32, []),
     "ggad_spmm_panel_values_factor": (c_int32, [_P, _P, _P, _P, _I, ctypes.c_double, _I]),
-    "ggad_spmm_panel_count": (c_int32, [_P, _P, _I, _P, _I, _I, _I, _P, _I]),
-    "ggad_spmm_panel_fill": (c_int32, [_P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _L, _I, _I]),
+    "ggad_spmm_panel_count": (c_int32, [_P, _P, _I, _P, _P, _I, _I, _I, _P, _I]),
+    "ggad_spmm_panel_fill": (c_int32, [_P, _P, _I, _P, _P, _I, _I, _I, _P, _P, _P, _L, _I, _I]),
     "ggad_spmm_panel_f32": (c_int32, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _L, _P, _P, _P, _P, _L, _P, _P]),
     "ggad_spmm_sliced_f32": (c_int32, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _L, _I, _L, _P, _P, _P, _P, _L, _P, _P, _P]),
     "ggad_prelu_bwd_splits": (c_int32, [_I]),

@@ -352,9 +352,18 @@ __global__ void __launch_bounds__(1024) k_spmm_panel(const int32_t *__restrict__
   const int32_t *__restrict__ rt = row_tab + (int64_t)(block * PAN_WAVES + wave) * PAN_KR * 8 + g;
 #pragma unroll
   for (int k = 0; k < PAN_KR; ++k) {
-    const int row = rt[k * 8];
-    if (row < 0) continue;
+    const int rowv = rt[k * 8];
+    if (rowv < 0) continue;                          // (the 8 slots of a round are all set or -- past the last row -- a tail of -1)
     float4 z = acc[k];
+    const int row = rowv & ~GGAD_SPMM_PANEL_WIDE;
+    if (rowv & GGAD_SPMM_PANEL_WIDE) {               // wide round: ONE row over the 8 lane groups (same flag in all 8 slots)
+#pragma unroll
+      for (int off = 8; off < GGAD_WAVE; off <<= 1) {                           // fixed butterfly over lane bits 3..5
+        z.x += __shfl_xor(z.x, off, GGAD_WAVE); z.y += __shfl_xor(z.y, off, GGAD_WAVE);
+        z.z += __shfl_xor(z.z, off, GGAD_WAVE); z.w += __shfl_xor(z.w, off, GGAD_WAVE);
+      }
+      if (g != 0) continue;
+    }
     if (row_scale) { const float r = row_scale[row]; z.x *= r; z.y *= r; z.z *= r; z.w *= r; }
     if (diag) {
       const float dv = diag[row];

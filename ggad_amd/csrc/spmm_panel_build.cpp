@@ -3,7 +3,10 @@
 // ggad_amd/fullgraph.py::Csr.panel_plan sorts the rows into rounds of 8, calls ggad_spmm_panel_count (entries of every row
 // per panel of ggad_spmm_panel_rows() columns -> the longest row of every (round, panel)), deals the rounds to workgroups / waves and lays the
 // tiles out (numpy on n_rounds x n_panels values), then calls ggad_spmm_panel_fill, which writes the entry stream the
-// kernel walks: per tile [oct][lane group][step] 16-bit panel row indices.  Both passes walk the CSR once, a thread per
+// kernel walks: per tile [oct][lane group][step] 16-bit panel row indices.  A round is 8 rows (lane group g walks row g) or, for
+// the hub rows, ONE row WIDE: its entries of a panel are dealt over all 8 lane groups (even panel rows to groups 0 1 4 5, odd to
+// 3 2 7 6: the bank-sharing pairs read opposite halves by construction) and the kernel adds the 8 accumulators in the epilogue --
+// a 7,000-entry row is then 900 steps of work for one wave instead of 7,000, and the longest round no longer exceeds a wave's share.  Both passes walk the CSR once, a thread per
 // block of rounds (a round's 8 rows and its tiles belong to one thread: no shared writes).  numpy did the same in 1.3 s
 // at 21 M entries -- more than the 500 epochs of a T-Finance run save; this takes a few tens of milliseconds.
 #include <algorithm>
@@ -17,6 +20,7 @@ constexpr int GROUPS = 8;
 // lane groups whose 128-byte rows share a 16-lane service group of ds_read_b128: (0,3) (1,2) (4,7) (5,6)
 constexpr int PARTNER[GROUPS] = {3, 2, 1, 0, 7, 6, 5, 4};
 constexpr bool FIRST_ODD[GROUPS] = {false, false, true, true, false, false, true, true};
+constexpr int EVEN_GROUPS[4] = {0, 1, 4, 5}, ODD_GROUPS[4] = {3, 2, 7, 6};   // wide rounds: where even / odd panel rows go
 
 template <class F>
 void parallel_rounds(int32_t n_rounds, int32_t n_threads, F &&body) {
@@ -41,13 +45,29 @@ extern "C" {
 // steps_rc[round * n_panels + panel] = entries of the longest of the round's rows in that panel.
 // round_rows[round * 8 + g] = row of lane group g, or -1.  skip_diag: entries with col == row are not part of the stream.
 int ggad_spmm_panel_count(const int64_t *rowptr, const int32_t *col, int32_t n_rounds, const int32_t *round_rows,
-                          int32_t skip_diag, int32_t panel_rows, int32_t n_panels, int32_t *steps_rc, int32_t n_threads) {
+                          const int32_t *round_wide, int32_t skip_diag, int32_t panel_rows, int32_t n_panels, int32_t *steps_rc,
+                          int32_t n_threads) {
   if (!rowptr || !col || !round_rows || !steps_rc || n_rounds < 0 || panel_rows < 1 || n_panels < 1) return -1;
   parallel_rounds(n_rounds, n_threads, [&](int32_t r0, int32_t r1) {
-    std::vector<int32_t> cnt(n_panels);
+    std::vector<int32_t> cnt(n_panels), odd(n_panels);
     for (int32_t r = r0; r < r1; ++r) {
       int32_t *dst = steps_rc + (int64_t)r * n_panels;
       std::fill(dst, dst + n_panels, 0);
+      if (round_wide && round_wide[r]) {             // one row over 8 lane groups: 4 take its even panel rows, 4 its odd ones
+        const int32_t row = round_rows[(int64_t)r * GROUPS];
+        if (row < 0) continue;
+        std::fill(cnt.begin(), cnt.end(), 0);
+        std::fill(odd.begin(), odd.end(), 0);
+        for (int64_t e = rowptr[row]; e < rowptr[row + 1]; ++e) {
+          const int32_t c = col[e];
+          if (skip_diag && c == row) continue;
+          const int32_t p = c / panel_rows;
+          ++cnt[p];
+          odd[p] += (c - p * panel_rows) & 1;
+        }
+        for (int32_t p = 0; p < n_panels; ++p) dst[p] = std::max((cnt[p] - odd[p] + 3) / 4, (odd[p] + 3) / 4);
+        continue;
+      }
       for (int g = 0; g < GROUPS; ++g) {
         const int32_t row = round_rows[(int64_t)r * GROUPS + g];
         if (row < 0) continue;
@@ -69,9 +89,9 @@ int ggad_spmm_panel_count(const int64_t *rowptr, const int32_t *col, int32_t n_r
 // pair takes its entries even, odd, even, ... (panel row parity), the second odd, even, ...; ascending column inside a parity,
 // what is left of the longer parity follows; a slot without entry reads the zero row (panel_rows or panel_rows + 1) of the
 // parity its partner does not use.
-int ggad_spmm_panel_fill(const int64_t *rowptr, const int32_t *col, int32_t n_rounds, const int32_t *round_rows, int32_t skip_diag,
-                         int32_t panel_rows, int32_t n_panels, const int32_t *steps_rc, const int64_t *tile_oct, uint16_t *stream,
-                         int64_t total_octs, int32_t spare_octs, int32_t n_threads) {
+int ggad_spmm_panel_fill(const int64_t *rowptr, const int32_t *col, int32_t n_rounds, const int32_t *round_rows,
+                         const int32_t *round_wide, int32_t skip_diag, int32_t panel_rows, int32_t n_panels, const int32_t *steps_rc,
+                         const int64_t *tile_oct, uint16_t *stream, int64_t total_octs, int32_t spare_octs, int32_t n_threads) {
   if (!rowptr || !col || !round_rows || !steps_rc || !tile_oct || !stream || panel_rows < 2 || panel_rows > 65000) return -1;
   const uint16_t zero_even = (uint16_t)(panel_rows + (panel_rows & 1)), zero_odd = (uint16_t)(panel_rows + 1 - (panel_rows & 1));
   parallel_rounds(n_rounds, n_threads, [&](int32_t r0, int32_t r1) {
@@ -86,6 +106,24 @@ int ggad_spmm_panel_fill(const int64_t *rowptr, const int32_t *col, int32_t n_ro
         uint16_t *tile = stream + tile_oct[(int64_t)r * n_panels + p] * 64;
         const int32_t slots = (steps + 7) / 8 * 8;
         const int32_t lo = p * panel_rows, hi = lo + panel_rows;
+        if (round_wide && round_wide[r]) {
+          const int32_t row = rows[0];
+          const int64_t end = rowptr[row + 1];
+          int32_t n_even = 0, n_odd = 0;
+          int64_t e = pos[0];
+          for (; e < end && col[e] < hi; ++e) {
+            if (skip_diag && col[e] == row) continue;
+            const int32_t local = col[e] - lo;
+            if (local & 1) { tile[(int64_t)((n_odd >> 2) >> 3) * 64 + ODD_GROUPS[n_odd & 3] * 8 + ((n_odd >> 2) & 7)] = (uint16_t)local; ++n_odd; }
+            else { tile[(int64_t)((n_even >> 2) >> 3) * 64 + EVEN_GROUPS[n_even & 3] * 8 + ((n_even >> 2) & 7)] = (uint16_t)local; ++n_even; }
+          }
+          pos[0] = e;
+          for (int u = 0; u < 4; ++u) {              // padding: the zero row of the group's own parity class
+            for (int32_t t = (n_even - u + 3) / 4; t < slots; ++t) tile[(int64_t)(t >> 3) * 64 + EVEN_GROUPS[u] * 8 + (t & 7)] = zero_even;
+            for (int32_t t = (n_odd - u + 3) / 4; t < slots; ++t) tile[(int64_t)(t >> 3) * 64 + ODD_GROUPS[u] * 8 + (t & 7)] = zero_odd;
+          }
+          continue;
+        }
         for (int g = 0; g < GROUPS; ++g) {
           len[g] = 0;
           const int32_t row = rows[g];

@@ -191,9 +191,22 @@ class Csr:
         if nnz == 0:
             return None
         order = np.argsort(-cnt, kind="stable")                           # rows of similar length share a round
-        rrank = np.empty(n_rows, dtype=np.int64)
-        rrank[order] = np.arange(n_rows, dtype=np.int64)
-        n_rounds = (n_rows + 7) // 8
+        NC = (n_src + R - 1) // R
+        # Hub rows get a round of their own, WIDE: the row's entries are dealt over all 8 lane groups and the kernel adds the 8
+        # accumulators in its epilogue.  A round of 8 hub rows of 7,000 entries is 7,000 steps for ONE wave -- 1.4 times the share
+        # of a wave on the T-Finance-size graph, so the slowest wave of a panel had 1.5 x the mean work however the rounds were
+        # dealt; as 8 wide rounds of 900 steps the same work spreads over 8 waves.  Wide: rows longer than half a wave's share.
+        nb0 = max(1, 256 // n_slices)
+        while -(-((n_rows + 7) // 8) // (nb0 * NW)) > KR:
+            nb0 += max(1, 256 // n_slices)
+        share = nnz / 8.0 / (nb0 * NW)                                    # steps of a wave if all slots were full
+        n_wide = int(np.searchsorted(-cnt[order], -max(256.0, share / 2.0), side="left"))
+        # (bounded: a wide row takes a round slot of its own, and the workgroup count -- every workgroup stages the whole operand --
+        # must not grow for it: with 76 instead of 51 row blocks the T-Finance product took 654 instead of 573 us)
+        room = nb0 * NW * KR - (n_rows + 7) // 8
+        n_wide = max(0, min(n_wide, int(room * 8 // 7 * 0.9)))
+        n_norm_rounds = (n_rows - n_wide + 7) // 8
+        n_rounds = n_wide + n_norm_rounds
         nb = kr = None
         for mult in range(1, 65):                                         # workgroups ~ a multiple of the 256 CUs
             nb = max(1, (256 * mult) // n_slices)
@@ -202,18 +215,27 @@ class Csr:
                 break
         if kr is None or kr > KR:
             return None
-        NC = (n_src + R - 1) // R
-        round_rows = np.full(n_rounds * 8, -1, dtype=np.int32)
-        round_rows[:n_rows] = (order if rows is None else rows[order]).astype(np.int32)   # round q = rows order[8 q .. 8 q + 7], lane group = position
+        src_rows = (order if rows is None else rows[order]).astype(np.int32)     # matrix row of every output row, longest first
+        round_rows = np.full((n_rounds, 8), -1, dtype=np.int32)           # matrix rows of a round (lane group = position)
+        round_out = np.full((n_rounds, 8), -1, dtype=np.int32)            # output rows of a round (row_tab)
+        WIDE = 0x40000000
+        round_rows[:n_wide, :] = src_rows[:n_wide, None]
+        round_out[:n_wide, :] = (order[:n_wide, None] | WIDE).astype(np.int32)
+        rest = n_rows - n_wide
+        round_rows[n_wide:].reshape(-1)[:rest] = src_rows[n_wide:]
+        round_out[n_wide:].reshape(-1)[:rest] = order[n_wide:].astype(np.int32)
+        round_wide = np.zeros(n_rounds, dtype=np.int32)
+        round_wide[:n_wide] = 1
+        round_rows = np.ascontiguousarray(round_rows.reshape(-1))
         steps_rc = np.empty(n_rounds * NC, dtype=np.int32)
         hp = lambda a: a.ctypes.data
-        _lib.check(lib.ggad_spmm_panel_count(hp(rowptr), hp(colv), n_rounds, hp(round_rows), skip_diag, R, NC, hp(steps_rc), 0),
-                   "ggad_spmm_panel_count")
+        _lib.check(lib.ggad_spmm_panel_count(hp(rowptr), hp(colv), n_rounds, hp(round_rows), hp(round_wide), skip_diag, R, NC,
+                                             hp(steps_rc), 0), "ggad_spmm_panel_count")
         # work of a round = its octs over all panels (the longest of its 8 rows counts).  A workgroup waits at two barriers per
         # panel for its slowest wave, and the rounds of the hub rows are many times longer than the others: rounds are dealt to the
         # workgroups in a snake over the work order and inside a workgroup to the least loaded wave that has a free slot
         # (longest first) -- dealt in rank order, the slowest wave of a panel had 2.2 x the mean work on the T-Finance-size graph
-        # (1.5 x now: the longest round alone is 1.4 mean wave loads; splitting hub rows over waves is the step not taken).
+        # (1.5 x with 8-row rounds only: the longest round alone was 1.4 mean wave loads -- hence the wide rounds above).
         octs_rc = (steps_rc.astype(np.int64) + 7) // 8
         quads_rc = (steps_rc.astype(np.int64) + 3) // 4                   # what the kernel walks: whole octs, then half of the last one
         work = quads_rc.reshape(n_rounds, NC).sum(1)
@@ -252,19 +274,16 @@ class Csr:
         np.cumsum(tq, out=offq[1:])
         tile_oct = np.ascontiguousarray(offq[tile_of_rc])
         stream = np.empty((total_q + 8) * 64, dtype=np.uint16)            # [oct][lane group][step]: panel row index; 8 spare octs (read-ahead)
-        _lib.check(lib.ggad_spmm_panel_fill(hp(rowptr), hp(colv), n_rounds, hp(round_rows), skip_diag, R, NC, hp(steps_rc), hp(tile_oct),
-                                            hp(stream), total_q, 8, 0), "ggad_spmm_panel_fill")
+        _lib.check(lib.ggad_spmm_panel_fill(hp(rowptr), hp(colv), n_rounds, hp(round_rows), hp(round_wide), skip_diag, R, NC,
+                                            hp(steps_rc), hp(tile_oct), hp(stream), total_q, 8, 0), "ggad_spmm_panel_fill")
         stream = stream.view(np.uint32)
-        q_row, g_of = rrank // 8, rrank % 8
-        wave_of = gwave_of_round[q_row]                                   # (block, wave), round slot and lane group of every row
-        k_of = k_of_round[q_row]
         tq2 = th.reshape(nb * NW * NC, KR).astype(np.uint32)             # the directory counts quads
         dirv = np.zeros((nb * NW * NC, 8), dtype=np.uint32)
         dirv[:, 0] = offq[:-1].reshape(nb * NW * NC, KR)[:, 0].astype(np.uint32)
         for k in range(KR):
             dirv[:, 1 + (k >> 1)] |= tq2[:, k] << np.uint32(16 * (k & 1))
         row_tab = np.full((nb * NW * KR, 8), -1, dtype=np.int32)
-        row_tab[wave_of * KR + k_of, g_of] = np.arange(n_rows, dtype=np.int32)
+        row_tab[gwave_of_round * KR + k_of_round] = round_out             # (a wide round: its row in all 8 slots, flagged)
         # workgroup table: the workgroups of a slice share an XCD (workgroup b runs on XCD b % 8) and its L2; the slices of an
         # incomplete round of 8 are dealt over all XCDs
         lists = [[] for _ in range(8)]

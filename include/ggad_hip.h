@@ -397,12 +397,16 @@ int ggad_spmm_sliced_f32(const int32_t *col, const float *val, const int32_t *se
  * round's longest row in that panel of panel_rows columns; ggad_spmm_panel_fill writes the entry stream: tile (round, panel)
  * starts at oct tile_oct[round][panel], [oct][lane group][step] 16-bit panel row indices (ceil(steps_rc / 8) octs), empty
  * slots = a zero row (panel_rows / panel_rows + 1), spare_octs zero octs after the last tile.  skip_diag: entries col == row
- * are left out (diag[] of ggad_spmm_panel_f32 carries them). */
+ * are left out (diag[] of ggad_spmm_panel_f32 carries them).  round_wide[round] != 0 (NULL: none): the round is ONE row (slot 0 of
+ * round_rows) dealt over all 8 lane groups -- even panel rows to groups 0 1 4 5, odd to 3 2 7 6 -- and its row_tab entries carry
+ * GGAD_SPMM_PANEL_WIDE: the kernel adds the 8 accumulators before its epilogue. */
+#define GGAD_SPMM_PANEL_WIDE 0x40000000
 int ggad_spmm_panel_count(const int64_t *rowptr, const int32_t *col, int32_t n_rounds, const int32_t *round_rows,
-                          int32_t skip_diag, int32_t panel_rows, int32_t n_panels, int32_t *steps_rc, int32_t n_threads);
-int ggad_spmm_panel_fill(const int64_t *rowptr, const int32_t *col, int32_t n_rounds, const int32_t *round_rows, int32_t skip_diag,
-                         int32_t panel_rows, int32_t n_panels, const int32_t *steps_rc, const int64_t *tile_oct, uint16_t *stream,
-                         int64_t total_octs, int32_t spare_octs, int32_t n_threads);
+                          const int32_t *round_wide, int32_t skip_diag, int32_t panel_rows, int32_t n_panels, int32_t *steps_rc,
+                          int32_t n_threads);
+int ggad_spmm_panel_fill(const int64_t *rowptr, const int32_t *col, int32_t n_rounds, const int32_t *round_rows,
+                         const int32_t *round_wide, int32_t skip_diag, int32_t panel_rows, int32_t n_panels, const int32_t *steps_rc,
+                         const int64_t *tile_oct, uint16_t *stream, int64_t total_octs, int32_t spare_octs, int32_t n_threads);
 /* 1: every off-diagonal value[i][j] equals (float)(r[i] * r[j]) to a relative rtol; 0: not; < 0: invalid arguments. */
 int ggad_spmm_panel_values_factor(const int64_t *rowptr, const int32_t *col, const float *val, const double *r, int32_t n_rows,
                                   double rtol, int32_t n_threads);

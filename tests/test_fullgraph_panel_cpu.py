@@ -12,7 +12,10 @@ def _normalized(n, density, seed, self_loops_inside):
     rng = np.random.default_rng(seed)
     a = sp.random(n, n, density=density, random_state=rng, format="csr")
     a.data[:] = 1.0
-    a = ((a + a.T) > 0).astype(np.float64).tolil()
+    a = a.tolil()
+    for hub in range(0, n, max(1, n // 12)):                              # a dozen hub rows: they become WIDE rounds of the plan
+        a[hub, rng.permutation(n)[: n // 2]] = 1.0
+    a = ((a.tocsr() + a.tocsr().T) > 0).astype(np.float64).tolil()
     a.setdiag(0)
     a = a.tocsr()
     a.eliminate_zeros()
@@ -24,6 +27,9 @@ def _normalized(n, density, seed, self_loops_inside):
     r[np.isinf(r)] = 0.0
     m = sp.diags(r) @ a @ sp.diags(r)
     return (m if self_loops_inside else m + sp.eye(n)).tocsr()
+
+
+WIDE = 0x40000000
 
 
 def _replay(plan, x, n_rows, R, NW, KR):
@@ -48,6 +54,7 @@ def _replay(plan, x, n_rows, R, NW, KR):
                     assert (octv[:, steps:] >= R).all()                      # nothing but padding in a half that is not walked
                     for g in range(8):
                         r = row_tab[wv * KR + k, g]
+                        r = r if r < 0 else r & ~WIDE                        # a wide round: the same row in all 8 lane groups
                         for o in octv[g, :steps]:
                             assert o <= R + 1
                             if o < R:
@@ -77,8 +84,11 @@ def test_panel_plan_replays_to_the_sparse_product(inside):
     out, seen = _replay(plan, x, n, R, NW, KR)
     assert seen == m.nnz - n                                              # every off-diagonal entry exactly once
     np.testing.assert_allclose(out, m @ x, rtol=2e-6, atol=1e-6)
-    rows = plan["row_tab"].numpy().reshape(-1)
-    assert sorted(rows[rows >= 0].tolist()) == list(range(n))            # every output row is written once
+    rt = plan["row_tab"].numpy().reshape(-1, 8)
+    wide = rt[(rt[:, 0] >= 0) & ((rt[:, 0] & WIDE) != 0)]
+    assert len(wide) >= 8 and (wide == wide[:, :1]).all()                # the hub rows: one row in all 8 slots of its round
+    normal = rt[(rt[:, 0] & WIDE) == 0].reshape(-1)
+    assert sorted(normal[normal >= 0].tolist() + (wide[:, 0] & ~WIDE).tolist()) == list(range(n))   # every output row once
     st = plan["stream"].numpy().view(np.uint16).reshape(-1, 8, 8)      # rows of a bank-sharing pair alternate parities
     same = (st & 1) == (st[:, [3, 2, 1, 0, 7, 6, 5, 4], :] & 1)
     assert same.mean() < 0.25
