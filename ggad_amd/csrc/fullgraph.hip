@@ -245,12 +245,13 @@ __global__ void __launch_bounds__(256) k_spmm_sliced(const int32_t *__restrict__
 // waves owns (slice, row block) and walks the operand in PANELS of 1,270 consecutive source rows x 32 floats staged in LDS
 // (159 KB + two zero rows: all of a CU's LDS): every entry then costs one ds_read_b128 of 8 lanes instead of a global line.  The operand is
 // pre-scaled by cs[] while it is re-laid slice-major, the sum is scaled by rs[] in the epilogue, so the entry stream
-// carries no values: it is a host-built list of LDS byte offsets, packed per (wave, panel, round of 8 rows) in steps of 8 entries --
-// lane group g = lane / 8 accumulates row g of the round, a shorter row is padded with the offset of the zero row -- and
-// read 4 steps at a time (one 16-byte load per lane, the 8 lanes of a group share it).  A wave keeps its <= 8 rounds
+// carries no values: it is a host-built list of 16-bit panel row indices, packed per (wave, panel, round of 8 rows) in steps of 8
+// entries -- lane group g = lane / 8 accumulates row g of the round, a shorter row is padded with the index of a zero row -- and
+// read 8 steps (an oct) at a time (one 16-byte load per lane, the 8 lanes of a group share it).  A wave keeps its <= 8 rounds
 // (64 rows x 32 floats) in registers across all panels; rows are dealt to rounds in order of degree (the 8 rows of a round
-// have similar lengths: 70 % of the step slots carry an entry on the power-law graphs) and rounds are dealt round-robin to
-// the workgroups (equal work).  Summation order: ascending column inside a row -> deterministic.
+// have similar lengths: 72-80 % of the step slots carry an entry on the power-law graphs), a hub row gets a WIDE round of its
+// own (its entries over all 8 lane groups, the 8 accumulators added in the epilogue), and rounds are dealt to workgroups and
+// waves by their work (csrc/spmm_panel_build.cpp, Csr.panel_plan).  Summation order: fixed by the plan -> deterministic.
 typedef float pan_f4 __attribute__((ext_vector_type(4)));
 constexpr int PAN_R = 1270;                         // source rows per LDS panel (with two zero rows: 162,816 of the 163,840 bytes)
 constexpr int PAN_WAVES = 16;                       // waves per workgroup

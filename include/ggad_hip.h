@@ -383,14 +383,15 @@ int ggad_spmm_sliced_f32(const int32_t *col, const float *val, const int32_t *se
                          float *xs_workspace, const float *bias, const float *prelu_a, float *out, int64_t ldo, float *out_pre,
                          float *part, ggad_stream_t stream);
 
-/* Same product for WHOLE matrices with dense neighbourhoods whose values factor as value[i][j] = row_scale[i] * col_scale[j]
+/* Same product (whole matrix, or a row subset of a matrix without separate diagonal) for dense neighbourhoods whose values factor as value[i][j] = row_scale[i] * col_scale[j]
  * off the diagonal (normalize_adj, utils.py:47-54; scales may be NULL = 1) plus an optional diagonal diag[i] (NULL = none,
  * its entries are then part of the stream): out[i] = act(row_scale[i] * sum_j col_scale[j] X[j] + diag[i] X[i] + bias).
  * A workgroup of ggad_spmm_panel_waves() waves owns (32-float column slice, row block) and walks the operand in panels of
- * ggad_spmm_panel_rows() source rows staged in LDS; the entries are a host-built stream of LDS byte offsets (layout at
+ * ggad_spmm_panel_rows() source rows staged in LDS; the entries are a host-built stream of 16-bit panel row indices (layout at
  * k_spmm_panel in fullgraph.hip; built by ggad_amd/fullgraph.py::Csr.panel_plan): wg_tab[n_wg][2] = (slice, block) or (-1, -1),
- * dir[(block * waves + wave) * n_chunks + chunk][8] = {first quad, 8 x 16-bit quad counts}, stream = 32 offsets per quad,
- * row_tab[(block * waves + wave) * rounds + round][8] = output row or -1.  xs_workspace as for ggad_spmm_sliced_f32.
+ * dir[(block * waves + wave) * n_chunks + chunk][8] = {first oct of the wave's tiles of that panel, 8 x 16-bit counts of the QUADS
+ * (4 steps) walked per round: whole octs, then half of the last one}, stream = [oct][8 lane groups][8 steps] uint16, two
+ * per uint32, + 8 spare octs, row_tab[(block * waves + wave) * rounds + round][8] = output row (| GGAD_SPMM_PANEL_WIDE) or -1.  xs_workspace as for ggad_spmm_sliced_f32.
  * Deterministic; agrees with the other two kernels to fp32 round-off (the scales are applied outside the sum). */
 /* Host half of its plan (csrc/spmm_panel_build.cpp, host pointers, threads; n_threads <= 0: one per core, 32 at most):
  * round_rows[n_rounds][8] = the 8 rows of a round (-1: none); ggad_spmm_panel_count -> steps_rc[round][panel] = entries of the
