@@ -1,0 +1,947 @@
+// One launch per CHUNK, resident on ONE XCD: the optimiser steps of all batches of a chunk (the per-batch loop of
+// src/model_handler.py:330-364 -- GCNEncoder.forward + GCN.loss (src/graphsage.py:395-454, 171-258), backward, Adam
+// (model_handler.py:363-364)) inside one persistent kernel whose workgroups all sit behind the same L2.
+//
+// Why one XCD.  The launch chain of step.hip is 5 dependent launches per 200-row step: 33-35 us for < 30 MFLOP and < 2 MB,
+// because every dependent level of loads misses the L2 (written a launch earlier on other XCDs) and every boundary costs
+// ~1.5-1.9 us.  A persistent kernel spread over the chip (round 1) paid the same at every phase: a chip-wide barrier needs the
+// agent-scope release / acquire (L2 write-back, write-through stores) because the eight L2s are not coherent with each other.
+// Inside ONE XCD none of that is needed: plain stores stay in the shared L2, sc1 loads bypass the reader's L1 and are served by
+// that L2 (119 ns), and a barrier is a tagged-slot all-gather -- every workgroup stores the round number into its own 4-byte slot
+// and one wave polls the 32 slots with one L2-served load: 0.43 us (scripts/xcd_barrier_bench.hip: 1.16 us for a round of
+// 2 KB hand-offs + barrier + 3 remote reads; zero stale words under skewed arrivals and HBM noise; a device-scope counter
+// barrier over the chip: 3-7 us).  The other seven XCDs stay free for the plan kernels of the next chunk.
+//
+// Placement.  HIP cannot place workgroups, so the launch does not assume it: every workgroup reads HW_REG_XCC_ID, registers
+// in a per-XCD counter and waits until the whole grid has registered; the XCD with the most registrations (lowest id on ties) is
+// picked by everyone from the same final counts, its workgroups take ranks in registration order, all others exit.  Work is
+// dealt to NVWG = 32 VIRTUAL workgroups of 8 waves; the G survivors loop over them (G = 32 on a 256-workgroup grid: one each), so
+// every floating-point sum has the same order for any G and the results do not depend on the placement.  A barrier wait is
+// bounded (wall clock); on a time-out the error word is set and the kernel leaves instead of hanging the GPU.
+//
+// Phases of one step (4 barriers), lane = embedding channel d, F = 17:
+//   A   pieces (<= 16 consecutive entries of ONE row, tables of the plan): partial sums of relu(W x2[own(e)]) -> chunk_part;
+//       rows: h1 = relu(W x1), 16 rows per wave.  Both on the matrix cores (one piece = the M of a 16 x 16 x 4 tile); the
+//       operands of a wave's pieces stay in registers for phase C.
+//   R   positions q of combined_all: nbar = (1/r) sum of the row's piece partials (piece order), gen = relu(fc nbar) of the
+//       source row of a generated column, score, BCE term, cosine affinity, norms, recon norm (graphsage.py:174,197,234,246)
+//   C   loss scalars (same reduction tree as k_loss_rows), per piece: the row's backward coefficients recomputed by the wave
+//       that owns the piece (no extra barrier), relu mask recomputed (same instructions as in A: same bits), dW += C^T X on the
+//       matrix cores, dW partial per virtual workgroup (fixed LDS combine)
+//   E   gradient reduction over the 32 partials / the label-1 rows / the rows (fixed order), [data-parallel exchange,] Adam,
+//       transposed weight copies; next step's weights are re-read through the L2 after the barrier
+// Latency.  What bounds a step on 32 compute units is neither flops nor bytes but the number of DEPENDENT memory round trips
+// (~0.7 us each under load, L2 hits included): the first version walked ~20 per step (piece -> first entry -> owner -> feature
+// row; row -> label / position -> that position's label; ...) and ran at the launch chain's 35 us.  Now (1) k_xcd_prep, one
+// whole-chip launch per chunk, flattens the plan's tables into one 32-byte record per piece and per position and completes x2
+// per entry, so a piece's rows are consecutive; (2) the records and matrix-core operands of step b + 1 are requested during
+// phase C of step b, BEHIND that phase's own loads (loads return in order), and wait in registers; (3) every phase issues all
+// its loads first: one round trip per phase.
+//
+// Same piece order per row and the same loss reduction tree as the launch chain; the projections run as f32 MFMA k-steps of 4
+// instead of 17 sequential fma, and the dW partial sums are grouped by piece instead of by flat entry stripes, so losses and
+// gradients agree with the chain to fp32 round-off (tests: 2e-6).  Everything is deterministic (no float atomics), for any
+// number of surviving workgroups.
+#include <algorithm>
+#include <cstdlib>
+
+#include "common.h"
+#include "step_common.h"
+
+namespace {
+
+constexpr int GGAD_MAX_DEVICES = 16;
+constexpr int XW = 8;                 // waves per workgroup
+constexpr int XT = XW * GGAD_WAVE;    // threads per workgroup
+constexpr int NVWG = 32;              // virtual workgroups (= CUs of an XCD)
+constexpr int NVW = NVWG * XW;        // virtual waves
+constexpr int XFT = 17;               // feature width (DGraph-Fin)
+
+constexpr int XPC = 2;                // pieces per virtual wave whose records / operands are fetched a step ahead and kept in registers
+constexpr int XRA = 512;              // label-1 rows of a batch listed in LDS for phase E
+constexpr int XBT = 256;              // batches whose offsets are staged in LDS at launch (later ones are read per step)
+constexpr int FCS = GGAD_MAX_D + 1;   // row stride of fc^T in LDS (conflict-free for both access patterns)
+
+struct XcdCtrl {
+  unsigned reg[8][16];                // [xcc][0]: workgroups registered on that XCD (one 64-byte line each)
+  unsigned slot[64];                  // barrier: last round number published by rank r
+  unsigned err, survivors, xcc, placed;  // placed: launch id, written by rank 0 once xcc is valid (read by the helper kernel)
+  unsigned long long prof[16];        // wall clocks (100 MHz) of rank 0 per phase (0..7) and sub-phase (8..15), accumulated over the launch
+  unsigned done, helpers, pad[2];     // done: the chunk kernel has left; helpers: registration counter of the helper kernel
+};
+static_assert(sizeof(XcdCtrl) <= 1024 && sizeof(XcdCtrl) % 16 == 0, "control block is 256 floats of the workspace");
+
+struct XcdArgs {
+  ggad_mb_step s;
+  const int32_t *batch_ptr;           // device, n_batches + 1 row offsets
+  int n_batches, log_base, ld_o;      // ld_o: positions per row of pos_o (multiple of 4)
+  float *loss_log;
+  XcdCtrl *ctrl;
+  float *pos_scal, *pos_o, *gw_row, *dw_part;
+  const int32_t *ck_rec, *pos_rec;    // records of k_xcd_prep (8 ints per piece / per position)
+  ggad_xchg_view X;
+  uint32_t xstep0;
+  float grad_scale;
+  unsigned long long timeout_ticks;
+  unsigned launch_id;
+};
+
+__device__ __forceinline__ float cld(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned cldu(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float rl(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+__device__ __forceinline__ int ri(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+
+// All workgroups of the launch sit on one XCD: plain stores are in the shared L2 once the wave's vmcnt has drained; the round
+// number in the own slot publishes them; one wave polls all slots with one L1-bypassing load.
+__device__ __forceinline__ bool xcd_barrier(XcdCtrl *C, int rank, int G, unsigned round, unsigned long long timeout) {
+  __shared__ int s_dead;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x < GGAD_WAVE) {
+    if (threadIdx.x == 0) { C->slot[rank] = round; s_dead = 0; }
+    const int l = (int)threadIdx.x < G ? (int)threadIdx.x : 0;
+    const unsigned long long t0 = wall_clock64();
+    int spins = 0;
+    while (true) {
+      const unsigned v = cldu(&C->slot[l]);
+      if (__all((int)(v - round) >= 0)) break;
+      __builtin_amdgcn_s_sleep(1);
+      if ((++spins & 1023) == 0 && (wall_clock64() - t0 > timeout || cldu(&C->err) != 0)) {
+        if (threadIdx.x == 0) { C->err = 1; C->done = 1; s_dead = 1; }
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  return s_dead == 0;
+}
+
+// ---- the per-piece products on the matrix cores.  v_mfma_f32_16x16x4_f32: D[16 x 16] += A[16 x 4] B[4 x 16]; lane l = (a, g) =
+// (l % 16, l / 16) holds A[a][g], B[g][a] and D[4 g + v][a] (v = 0..3).  A piece is <= 16 entries of one row = the M of one tile.
+//   forward / relu mask:  H[e][ch] = sum_f X[e][f] W[ch][f]     A = X (entry a, features 4 j + g), B = W^T tile t (channels 16 t + a),
+//                         5 k-steps (17 features padded to 20) x 4 channel tiles = 20 instructions for 16 x 64 outputs;
+//   weight gradient:      dW[ch][f] += sum_e C[e][ch] X[e][f]   A = the masked coefficients IN THE LAYOUT THE FORWARD PRODUCT
+//                         LEAVES THEM (lane (a, g), register v = entry 4 g + v, channel 16 t + a: k-step v covers the entries
+//                         {v, 4 + v, 8 + v, 12 + v}), B = X (entry 4 g + v, feature a < 16): 16 instructions; feature 16 is a
+//                         separate column accumulated on the VALU (4 fma per tile).
+// (The readlane-broadcast VALU form of the same arithmetic, lane = channel, costs 34 / 53 VALU instructions per entry.)
+typedef float f4 __attribute__((ext_vector_type(4)));
+constexpr int XKS = (XFT + 3) / 4;       // k-steps of the forward product (5)
+constexpr int XNT = GGAD_MAX_D / 16;     // channel tiles (4)
+constexpr int XLS = 68;                  // LDS row stride of a dW partial: position of (f, ch) = 68 f + 16 (ch % 4) + ch / 4 is
+                                         // conflict-free for the tile layout (bank 4 a + g) and for lane = channel
+__device__ __forceinline__ int dw_pos(int f, int ch) { return XLS * f + 16 * (ch & 3) + (ch >> 2); }
+
+struct PieceX {
+  float a[XKS];      // forward operand: X[entry a][4 j + g]
+  float b[4];        // gradient operand: X[entry 4 g + v][feature a]
+};
+// n consecutive rows of x (stride XFT floats) from row `base` on; rows beyond n read as zero.  Every load is unconditional
+// (clamped address, select afterwards): 9 loads in flight per piece.
+__device__ __forceinline__ void load_piece_x(const float *__restrict__ x, int base, int n, int lane, PieceX &P) {
+  const int a = lane & 15, g = lane >> 4;
+  const int64_t ra = base + min(a, n - 1);
+#pragma unroll
+  for (int j = 0; j < XKS; ++j) {
+    const int f = 4 * j + g;
+    const float xv = x[ra * XFT + (f < XFT ? f : 0)];
+    P.a[j] = (a < n && f < XFT) ? xv : 0.0f;
+  }
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int e = 4 * g + v;
+    const float xv = x[(int64_t)(base + min(e, n - 1)) * XFT + a];
+    P.b[v] = e < n ? xv : 0.0f;
+  }
+}
+__device__ __forceinline__ void piece_fwd(const PieceX &P, const float (&WB)[XKS][XNT], f4 (&h)[XNT]) {
+#pragma unroll
+  for (int t = 0; t < XNT; ++t) h[t] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int j = 0; j < XKS; ++j)
+#pragma unroll
+    for (int t = 0; t < XNT; ++t) h[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(P.a[j], WB[j][t], h[t], 0, 0, 0);
+}
+
+// ---- records (k_xcd_prep, once per chunk): everything a step needs to know about a piece / a position in ONE 32-byte line,
+// so that no phase walks a chain of dependent table look-ups (row -> label / position -> position's label, source row -> its pieces)
+//   piece c:        [0] (row << 6) | entries   [1] first entry   [2] label | first piece of its row << 1 | label of position q1 << 2
+//                   [3] entries of the row     [4] q1 = position whose column this row is     [5] pos_meta of position (row - row0)
+//   position q:     [0] pos_meta   [1] first piece of row q   [2] its pieces   [3] entries of row q
+//                   [4] first piece of the source row (generated columns)   [5] its pieces   [6] its entries
+constexpr int REC = 8;
+struct RowIn { float H1, NB, Gl, p1v, p2v, nbq, c2; };
+
+// Adam on one parameter whose state is already in registers (torch.optim.Adam's single-tensor update op by op, step_common.h)
+__device__ __forceinline__ void adam_apply(float *__restrict__ params, float *__restrict__ m, float *__restrict__ v, ParamLayout L,
+                                           int i, float p, float mi, float vi, float g, float wd, float step_size, float bc2s) {
+  g = fmaf(wd, p, g);                                       // grad.add(param, alpha=weight_decay)
+  mi = fmaf(g - mi, 0.1f, mi);                              // exp_avg.lerp_(grad, 1 - beta1)
+  vi = fmaf(0.001f * g, g, vi * 0.999f);                    // mul_(beta2).addcmul_(g, g, 1 - beta2)
+  const float denom = sqrtf(vi) / bc2s + 1e-8f;
+  p = p - step_size * (mi / denom);                         // addcdiv_(exp_avg, denom, -step_size)
+  params[i] = p; m[i] = mi; v[i] = vi;
+  const int D = L.D, F = L.F;
+  if (i >= L.o_W() && i < L.o_fc()) {
+    const int u = i - L.o_W(); const int d = u / F, f = u - d * F;
+    params[L.o_Wt() + f * D + d] = p;
+  } else if (i >= L.o_fc()) {
+    const int u = i - L.o_fc(); const int d = u / D, d2 = u - d * D;
+    params[L.o_fcT() + d2 * D + d] = p;
+  }
+}
+
+template <int MODE>      // 1: Adam; 2: one-shot data-parallel exchange + Adam
+__global__ void __launch_bounds__(XT) k_train_chunk_xcd(XcdArgs A) {
+  __shared__ int s_rank, s_G;
+  __shared__ float wt_lds[XFT * GGAD_MAX_D];            // W^T of this step
+  __shared__ float w_lds[GGAD_MAX_D];
+  __shared__ float fct[GGAD_MAX_D * FCS];               // fc^T of this step, rows padded
+  __shared__ float accw[XW][XFT * XLS];                 // dW combine (phase C), sub-reducer partials (phase E)
+  __shared__ int ra_lds[XRA];                           // label-1 rows of the batch (sources of the generated columns), phase E
+  __shared__ float t_lds[8];
+  __shared__ float sc[2];
+  __shared__ int bt_row0[XBT + 1], bt_ck0[XBT + 1];     // row / piece offsets of the first XBT batches (no dependent loads per step)
+  XcdCtrl *C = A.ctrl;
+  // ---------------------------------------------------------------- placement
+  if (threadIdx.x == 0) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 7u;
+    const unsigned r = __hip_atomic_fetch_add(&C->reg[xcc][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned tot = 0, pick = 0, best = 0;
+    const unsigned long long t0 = wall_clock64();
+    bool ok = true;
+    while (true) {
+      tot = 0; pick = 0; best = 0;
+#pragma unroll
+      for (unsigned k = 0; k < 8; ++k) {
+        const unsigned ck = cldu(&C->reg[k][0]);
+        tot += ck;
+        if (ck > best) { best = ck; pick = k; }             // most registrations, lowest id on ties
+      }
+      if (tot >= gridDim.x) break;
+      __builtin_amdgcn_s_sleep(2);
+      if (wall_clock64() - t0 > A.timeout_ticks) { ok = false; C->err = 2; C->done = 1; break; }
+    }
+    s_rank = (ok && xcc == pick) ? (int)r : -1;
+    s_G = (int)min(best, 64u);
+    if (ok && xcc == pick && r == 0) {
+      C->survivors = best; C->xcc = pick;
+      __hip_atomic_store(&C->placed, A.launch_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  __syncthreads();
+  const int rank = s_rank, G = s_G;
+  if (rank < 0 || rank >= 64) return;
+
+  const ggad_mb_step &S = A.s;
+  const ParamLayout L{S.D, XFT};
+  const int D = S.D;
+  const int lane = lane_id(), wid = threadIdx.x / GGAD_WAVE;
+  const int la = lane & 15, lg = lane >> 4;             // (a, g) of the matrix-core layouts
+  const int l8 = lane & 7;
+  const bool on = lane < D;
+  const int d = on ? lane : D - 1;
+  const int fl = lane < XFT ? lane : XFT - 1;
+  // one virtual workgroup per workgroup (the normal case): the records and operands of step b + 1 are fetched into registers
+  // during step b; otherwise every phase loads what it needs in place
+  const bool piped = (G == NVWG);
+  float *params = S.params;
+  const int step0 = *S.step_counter;
+  for (int i = threadIdx.x; i <= min(A.n_batches, XBT); i += XT) {
+    const int r0 = A.batch_ptr[i];
+    bt_row0[i] = r0;
+    bt_ck0[i] = S.row_ck_ptr[r0];
+  }
+  __syncthreads();
+  auto batch_info = [&](int bb, int &row0, int &B, int &ck0, int &nck) {
+    if (bb < XBT) {
+      row0 = bt_row0[bb]; B = bt_row0[bb + 1] - row0; ck0 = bt_ck0[bb]; nck = bt_ck0[bb + 1] - ck0;
+    } else {
+      row0 = A.batch_ptr[bb]; B = A.batch_ptr[bb + 1] - row0; ck0 = S.row_ck_ptr[row0]; nck = S.row_ck_ptr[row0 + B] - ck0;
+    }
+  };
+  // virtual wave of this wave in its first virtual workgroup: pieces / positions v0, v0 + NVW, ...  Consecutive pieces (and
+  // positions) go to consecutive WORKGROUPS, so a batch of 358 pieces puts 11-12 on every compute unit
+  const int v0 = rank + NVWG * wid;
+  auto piece_rec = [&](int c) { return A.ck_rec[(int64_t)c * REC + l8]; };
+  auto pos_rec = [&](int row) { return A.pos_rec[(int64_t)row * REC + l8]; };
+  auto issue_recs = [&](int bb, int (&rv)[XPC], int &pv) {          // records of this wave's pieces / position in step bb
+    int r0, Bn, c0, nc;
+    batch_info(bb, r0, Bn, c0, nc);
+#pragma unroll
+    for (int j = 0; j < XPC; ++j) rv[j] = piece_rec(c0 + min(v0 + j * NVW, max(nc - 1, 0)));
+    pv = pos_rec(r0 + min(v0, max(Bn - 1, 0)));
+  };
+  auto issue_ops = [&](int rv, PieceX &P) { load_piece_x(S.x2, ri(rv, 1), max(ri(rv, 0) & 63, 1), lane, P); };
+  int recv[XPC], posv = 0, recn[XPC], posn = 0;
+  PieceX xc[XPC], xn[XPC];
+#pragma unroll
+  for (int j = 0; j < XPC; ++j) { recv[j] = 0; recn[j] = 0; }
+  if (piped) {
+    issue_recs(0, recv, posv);
+#pragma unroll
+    for (int j = 0; j < XPC; ++j) issue_ops(recv[j], xc[j]);
+  }
+  unsigned round = 0;
+  unsigned long long t_prev = wall_clock64();
+#define XCD_TICK(slot)                                                         \
+  if (rank == 0 && threadIdx.x == 0) {                                         \
+    const unsigned long long t_now = wall_clock64();                           \
+    C->prof[slot] += t_now - t_prev;                                           \
+    t_prev = t_now;                                                            \
+  }
+#define XCD_BARRIER()                                                          \
+  if (!xcd_barrier(C, rank, G, ++round, A.timeout_ticks)) return;
+
+  for (int b = 0; b < A.n_batches; ++b) {
+    int row0, B, ck0, nck;
+    batch_info(b, row0, B, ck0, nck);
+    float *log8 = A.loss_log + (int64_t)8 * (A.log_base + b);
+    // ---------------------------------------------------------------- weights of this step: L2 -> LDS (written by phase E of the previous step)
+    for (int i = threadIdx.x; i < XFT * D; i += XT) wt_lds[i] = cld(params + L.o_Wt() + i);
+    if (threadIdx.x < GGAD_WAVE) w_lds[lane] = on ? cld(params + lane) : 0.0f;
+    for (int i = threadIdx.x; i < D * D; i += XT) {
+      const int r2 = i / D, c2 = i - r2 * D;
+      fct[r2 * FCS + c2] = cld(params + L.o_fcT() + i);
+    }
+    __syncthreads();
+    float WB[XKS][XNT];                                   // W^T in the B-operand layout: W[16 t + a][4 j + g]
+#pragma unroll
+    for (int j = 0; j < XKS; ++j)
+#pragma unroll
+      for (int t = 0; t < XNT; ++t) {
+        const int f = 4 * j + lg, ch = 16 * t + la;
+        WB[j][t] = (f < XFT && ch < D) ? wt_lds[f * D + ch] : 0.0f;
+      }
+    const float wd_r = w_lds[d];
+    XCD_TICK(8)
+
+    // ================================================================ A: piece partials of relu(W x2), rows' h1
+    auto fwd_piece = [&](int c, const PieceX &P) {
+      f4 h[XNT];
+      piece_fwd(P, WB, h);
+      float out = 0.0f;
+#pragma unroll
+      for (int t = 0; t < XNT; ++t) {                      // relu(W x2[u])   graphsage.py:419 ; entries beyond cnt are zero rows
+        float st = (fmaxf(h[t][0], 0.0f) + fmaxf(h[t][1], 0.0f)) + (fmaxf(h[t][2], 0.0f) + fmaxf(h[t][3], 0.0f));
+        st += __shfl_xor(st, 16, GGAD_WAVE);
+        st += __shfl_xor(st, 32, GGAD_WAVE);
+        out = lg == t ? st : out;                           // lane l = channel 16 (l / 16) + l % 16
+      }
+      S.chunk_part[(int64_t)c * 64 + lane] = out;
+    };
+    for (int vw = rank; vw < NVWG; vw += G) {
+      const int v = vw + NVWG * wid;
+#pragma unroll
+      for (int j = 0; j < XPC; ++j) {
+        const int w = v + j * NVW;
+        if (w < nck) {
+          if (!piped) { recv[j] = piece_rec(ck0 + w); issue_ops(recv[j], xc[j]); }
+          fwd_piece(ck0 + w, xc[j]);
+        }
+      }
+      for (int w = v + XPC * NVW; w < nck; w += NVW) {     // more than XPC pieces per wave (a batch of > 8,000 entries)
+        PieceX P;
+        issue_ops(piece_rec(ck0 + w), P);
+        fwd_piece(ck0 + w, P);
+      }
+      XCD_TICK(9)
+      for (int p = NVW - 1 - v; 16 * p < B; p += NVW) {     // h1 = relu(W x1[row]), 16 rows per wave     graphsage.py:412
+        PieceX P;
+        load_piece_x(S.x1, row0 + 16 * p, min(16, B - 16 * p), lane, P);
+        f4 h[XNT];
+        piece_fwd(P, WB, h);
+#pragma unroll
+        for (int t = 0; t < XNT; ++t)
+#pragma unroll
+          for (int vv = 0; vv < 4; ++vv) {
+            const int i = 16 * p + 4 * lg + vv, ch = 16 * t + la;
+            if (i < B && ch < D) S.h1[(int64_t)(row0 + i) * D + ch] = fmaxf(h[t][vv], 0.0f);
+          }
+      }
+    }
+    XCD_TICK(0)
+    XCD_BARRIER()
+    XCD_TICK(1)
+
+    // ================================================================ R: positions of combined_all (k_loss_pos_ck of step.hip)
+    for (int vw = rank; vw < NVWG; vw += G) {
+      for (int q = vw + NVWG * wid; q < B; q += NVW) {
+        const int pr = (piped && q == v0) ? posv : pos_rec(row0 + q);
+        const int meta = ri(pr, 0);
+        const int src = meta >> 2, y = meta & 1;
+        const bool from_gen = (meta & 2) != 0;
+        const int row = row0 + q;
+        const int qa = ri(pr, 1), nq = ri(pr, 2), rq = ri(pr, 3), sa = ri(pr, 4), ns = ri(pr, 5), rs = ri(pr, 6);
+        const float hs_r = cld(S.h1 + (int64_t)src * D + d);
+        float totq = 0.0f, tots = 0.0f;
+        constexpr int PF = 16;                                      // piece order; loads in flight from clamped indices
+        {
+          float vq[PF], vs[PF];
+#pragma unroll
+          for (int k = 0; k < PF; ++k) {
+            vq[k] = cld(S.chunk_part + (int64_t)(qa + min(k, max(nq - 1, 0))) * 64 + lane);
+            vs[k] = cld(S.chunk_part + (int64_t)(ns > 0 ? sa + min(k, ns - 1) : qa) * 64 + lane);
+          }
+#pragma unroll
+          for (int k = 0; k < PF; ++k) {
+            totq += (k < nq) ? vq[k] : 0.0f;
+            tots += (k < ns) ? vs[k] : 0.0f;
+          }
+        }
+        for (int c0 = PF; c0 < nq; c0 += 2 * PF) {                  // hub rows: 32 partials per round trip
+          float vq[2 * PF];
+#pragma unroll
+          for (int k = 0; k < 2 * PF; ++k) vq[k] = cld(S.chunk_part + (int64_t)(qa + min(c0 + k, nq - 1)) * 64 + lane);
+#pragma unroll
+          for (int k = 0; k < 2 * PF; ++k) totq += (c0 + k < nq) ? vq[k] : 0.0f;
+        }
+        for (int c0 = PF; c0 < ns; c0 += 2 * PF) {
+          float vs[2 * PF];
+#pragma unroll
+          for (int k = 0; k < 2 * PF; ++k) vs[k] = cld(S.chunk_part + (int64_t)(sa + min(c0 + k, ns - 1)) * 64 + lane);
+#pragma unroll
+          for (int k = 0; k < 2 * PF; ++k) tots += (c0 + k < ns) ? vs[k] : 0.0f;
+        }
+        const float nb_r = (1.0f / (float)rq) * totq;                                            // mask_row = mask / rowsum  graphsage.py:317
+        if (on) S.nbar[(int64_t)row * D + lane] = nb_r;                                          // to_feats_neigh[q, :]
+        float c_r = hs_r;                                                                        // combined_all[:, q] = h1[src] ...
+        if (from_gen) {                                                                          // ... or gen[src] = relu(fc nbar[src])  :428-430
+          const float nbm = on ? (1.0f / (float)rs) * tots : 0.0f;
+          float a = 0.0f;
+          for (int d2 = 0; d2 < D; ++d2) a = fmaf(fct[d2 * FCS + d], rl(nbm, d2), a);
+          c_r = fmaxf(a, 0.0f);
+          if (on) S.gen[(int64_t)src * D + lane] = c_r;
+        }
+        const float wd = on ? wd_r : 0.0f, c = on ? c_r : 0.0f, nb = on ? nb_r : 0.0f;
+        const float hs = (on && from_gen) ? hs_r : 0.0f;
+        const PosVals pv = eval_position(wd, c, nb);
+        float recn_ = 0.0f;
+        if (from_gen) { const float dl2 = hs - c; recn_ = sqrtf(wave_sum_fast(dl2 * dl2)); }     // recon2   graphsage.py:197-198
+        const float o0 = (1.0f - (float)y) * pv.s - log_sigmoid(pv.s);                           // BCEWithLogits, pos_weight 1 :246
+        const float sv = lane == 0 ? pv.s : lane == 1 ? pv.aff : lane == 2 ? pv.na : lane == 3 ? pv.nbn : recn_;
+        if (lane < 5) A.pos_scal[(int64_t)q * 8 + lane] = sv;
+        const float ov = lane == 0 ? o0 : lane == 1 ? (y == 0 ? pv.aff : 0.0f) : lane == 2 ? (y == 1 ? pv.aff : 0.0f)
+                       : lane == 3 ? recn_ : lane == 4 ? (y == 0 ? 1.0f : 0.0f) : (y == 1 ? 1.0f : 0.0f);
+        if (lane < 6) A.pos_o[(int64_t)lane * A.ld_o + q] = ov;
+      }
+    }
+    XCD_TICK(2)
+    XCD_BARRIER()
+    XCD_TICK(3)
+
+    // ================================================================ C: loss scalars, row coefficients per piece, dW partial
+    auto row_load = [&](int rv) {                         // what the coefficients of a piece's row read (written in phases A / R)
+      RowIn in;
+      const int row = ri(rv, 0) >> 6, q1 = ri(rv, 4), m2 = ri(rv, 5);
+      const int i = row - row0;
+      const int64_t off = (int64_t)row * D + d;
+      in.H1 = cld(S.h1 + off);
+      in.NB = cld(S.nbar + off);
+      in.Gl = cld(S.gen + off);
+      in.p1v = cld(A.pos_scal + (int64_t)q1 * 8 + l8);
+      in.p2v = cld(A.pos_scal + (int64_t)i * 8 + l8);
+      in.nbq = cld(S.nbar + (int64_t)(row0 + q1) * D + d);
+      in.c2 = cld(((m2 & 2) ? S.gen : S.h1) + (int64_t)(m2 >> 2) * D + d);
+      return in;
+    };
+    RowIn inc[XPC];
+    if (piped) {
+#pragma unroll
+      for (int j = 0; j < XPC; ++j) inc[j] = row_load(v0 + j * NVW < nck ? recv[j] : recv[0]);   // in flight across the reduction below
+    }
+    if (wid == 0) {                                         // the reduction tree of k_loss_pos_ck (groups of 4) + k_loss_rows
+      const int nwg = loss_nwg(B);
+      float tv = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        float v = 0.0f;
+        for (int g = lane; g < nwg; g += GGAD_WAVE) {
+          const float *po = A.pos_o + (int64_t)k * A.ld_o + 4 * g;
+          const float o0 = cld(po), o1 = 4 * g + 1 < B ? cld(po + 1) : 0.0f;
+          const float o2 = 4 * g + 2 < B ? cld(po + 2) : 0.0f, o3 = 4 * g + 3 < B ? cld(po + 3) : 0.0f;
+          v += (o0 + o1) + (o2 + o3);
+        }
+        const float tk = wave_sum_fast(v);
+        tv = lane == k ? tk : tv;
+      }
+      if (lane < 6) t_lds[lane] = tv;
+    }
+    const bool more = piped && b + 1 < A.n_batches;
+    if (more) issue_recs(b + 1, recn, posn);                // next step's records: behind this phase's own loads
+    if (threadIdx.x == XT - 1) {                            // Adam scalars of this step (double pow: off the critical path here)
+      const double ts = (double)(step0 + b + 1);
+      const double bc1 = 1.0 - pow(0.9, ts), bc2 = 1.0 - pow(0.999, ts);
+      sc[0] = (float)((double)S.lr / bc1);                 // step_size
+      sc[1] = (float)sqrt(bc2);                            // bias_correction2_sqrt
+    }
+    __syncthreads();
+    XCD_TICK(10)
+    float t[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) t[k] = t_lds[k];
+    const float fB = (float)B;
+    const float cls = t[0] / fB;
+    const float an = t[1] / t[4], ab = t[2] / t[5];
+    const float mg = 1.0f - (an - ab);                                     // confidence_margin = 1      graphsage.py:236-240
+    const float active = (mg >= 0.0f) ? 1.0f : 0.0f;                       // clamp_min backward: pass where x >= min
+    const float rec_coef = 0.1f / t[5];
+    const int n0 = (int)t[4], n1 = (int)t[5];
+    for (int j = threadIdx.x; j < min(n1, XRA); j += XT) ra_lds[j] = S.pos_meta[row0 + n0 + j] >> 2;   // for phase E
+    if (rank == 0 && threadIdx.x == 0) {
+      const float margin = fmaxf(mg, 0.0f), rec = t[3] / t[5];
+      log8[0] = cls + margin + 0.1f * rec;                                 // graphsage.py:258
+      log8[1] = cls; log8[2] = margin; log8[3] = rec;
+      log8[4] = rec_coef; log8[5] = active; log8[6] = t[4]; log8[7] = t[5];
+      *S.step_counter = step0 + b + 1;
+    }
+    // backward coefficients of a piece's row (k_loss_rows of step.hip); first piece of the row: its wave also owns the row's x1
+    // item, dz and the d w term
+    auto row_coefs = [&](int rv, const RowIn &in, float &cg, float &ca) {
+      const int row = ri(rv, 0) >> 6, fl2 = ri(rv, 2), r = ri(rv, 3);
+      const int y = fl2 & 1, y1 = (fl2 >> 2) & 1;
+      const bool first = (fl2 & 2) != 0;
+      const int i = row - row0;
+      const int64_t off = (int64_t)row * D + d;
+      const float H1 = in.H1, NB = in.NB, Gl = in.Gl, p1v = in.p1v, p2v = in.p2v, nbq = in.nbq, c2 = in.c2;
+      const float s1 = rl(p1v, 0), aff1 = rl(p1v, 1), na1 = rl(p1v, 2), nbn1 = rl(p1v, 3), recn_ = rl(p1v, 4);
+      const float aff2 = rl(p2v, 1), na2 = rl(p2v, 2), nbn2 = rl(p2v, 3);
+      const float Gv = (y == 1) ? Gl : 0.0f;
+      const float Cc = (y == 1) ? Gv : H1;                                 // this row's column of combined_all
+      const float wd = on ? wd_r : 0.0f;
+      const float nac1 = fmaxf(na1, 1e-8f), nbc1 = fmaxf(nbn1, 1e-8f);
+      const float ds = (1.0f / (1.0f + expf(-s1)) - (float)y1) / fB;
+      const float gq1 = active * (y1 == 0 ? -1.0f / t[4] : 1.0f / t[5]);
+      const float cA = na1 > 0.0f ? Cc / na1 : 0.0f;
+      const float dC = ds * wd + gq1 * ((nbq / nbc1) / nac1 - (aff1 / nac1) * cA);
+      float gH = dC, gG = 0.0f;
+      if (y == 1) {                                                        // recon term 0.1 * mean_i |h1_i - gen_i|  graphsage.py:258
+        const float tt = rec_coef * ((H1 - Gv) / recn_);
+        gH = tt; gG = dC - tt;
+      }
+      const float nac2 = fmaxf(na2, 1e-8f), nbc2 = fmaxf(nbn2, 1e-8f);
+      const float gq2 = active * (y == 0 ? -1.0f / t[4] : 1.0f / t[5]);
+      const float cb = nbn2 > 0.0f ? NB / nbn2 : 0.0f;
+      float dNb = gq2 * ((c2 / nac2) / nbc2 - (aff2 / nbc2) * cb);
+      if (y == 1) {
+        const float dZ = (Gv > 0.0f) ? gG : 0.0f;                          // relu(fc(.))
+        if (first && on) S.dz[off] = dZ;
+        const float dZm = on ? dZ : 0.0f;
+        float a = 0.0f;
+        for (int dd = 0; dd < D; ++dd) a = fmaf(fct[d * FCS + dd], rl(dZm, dd), a);   // fc^T dZ: fc[dd][d] = fct[d][dd]
+        dNb += a;
+      }
+      ca = (on && H1 > 0.0f) ? gH : 0.0f;
+      cg = on ? dNb * (1.0f / (float)r) : 0.0f;
+      if (first) A.gw_row[(int64_t)i * GGAD_WAVE + lane] = on ? ds * Cc : 0.0f;       // d w = sum_q ds_q * combined_all[:, q]
+    };
+    for (int vw = rank; vw < NVWG; vw += G) {
+      const int v = vw + NVWG * wid;
+      f4 dacc[XNT];                                         // dW[16 t + 4 g + v'][f = a], f < 16
+      float d16[XNT], accr[XFT];                            // dW[16 t + a][16] (partial over the lane group), row items (lane = channel)
+#pragma unroll
+      for (int t4 = 0; t4 < XNT; ++t4) { dacc[t4] = f4{0.0f, 0.0f, 0.0f, 0.0f}; d16[t4] = 0.0f; }
+#pragma unroll
+      for (int f = 0; f < XFT; ++f) accr[f] = 0.0f;
+      auto bwd_piece = [&](int rv, const RowIn &in, const PieceX &P) {
+        float cg, ca;
+        row_coefs(rv, in, cg, ca);
+        f4 h[XNT];
+        piece_fwd(P, WB, h);                                // h2 recomputed exactly as in phase A: the relu mask
+        float x16[4];
+#pragma unroll
+        for (int vv = 0; vv < 4; ++vv) x16[vv] = __shfl(P.a[XKS - 1], 4 * lg + vv, GGAD_WAVE);   // X[4 g + v][16] (lanes 0..15 of k-step 4)
+#pragma unroll
+        for (int t4 = 0; t4 < XNT; ++t4) {
+          const float cgt = __shfl(cg, 16 * t4 + la, GGAD_WAVE);
+#pragma unroll
+          for (int vv = 0; vv < 4; ++vv) {
+            const float cf = h[t4][vv] > 0.0f ? cgt : 0.0f;                                  // [h2 > 0] * coef_g[row][ch]
+            dacc[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(cf, P.b[vv], dacc[t4], 0, 0, 0);
+            d16[t4] = fmaf(cf, x16[vv], d16[t4]);
+          }
+        }
+        if (ri(rv, 2) & 2) {                                // the row's own item: coef_a (x) x1[row]
+          const float x1v = S.x1[(int64_t)(ri(rv, 0) >> 6) * XFT + fl];
+#pragma unroll
+          for (int f = 0; f < XFT; ++f) accr[f] = fmaf(ca, rl(x1v, f), accr[f]);
+        }
+      };
+#pragma unroll
+      for (int j = 0; j < XPC; ++j) {
+        const int w = v + j * NVW;
+        if (w < nck) {
+          if (!piped) {
+            recv[j] = piece_rec(ck0 + w);
+            issue_ops(recv[j], xc[j]);
+            inc[j] = row_load(recv[j]);
+          }
+          bwd_piece(recv[j], inc[j], xc[j]);
+        }
+        if (j == 0 && more) {                               // next step's operands: requested while this step's pieces are worked on
+#pragma unroll
+          for (int jj = 0; jj < XPC; ++jj) issue_ops(recn[jj], xn[jj]);
+        }
+      }
+      for (int w = v + XPC * NVW; w < nck; w += NVW) {
+        const int rv = piece_rec(ck0 + w);
+        PieceX P;
+        issue_ops(rv, P);
+        const RowIn in = row_load(rv);
+        bwd_piece(rv, in, P);
+      }
+      // dW partial of the virtual workgroup: its 8 waves in a fixed tree
+      XCD_TICK(11)
+      __syncthreads();
+      XCD_TICK(12)
+      float *mine = accw[wid];
+#pragma unroll
+      for (int t4 = 0; t4 < XNT; ++t4) {
+#pragma unroll
+        for (int vv = 0; vv < 4; ++vv) mine[dw_pos(la, 16 * t4 + 4 * lg + vv)] = dacc[t4][vv];
+        float s16 = d16[t4];
+        s16 += __shfl_xor(s16, 16, GGAD_WAVE);
+        s16 += __shfl_xor(s16, 32, GGAD_WAVE);
+        if (lg == 0) mine[dw_pos(16, 16 * t4 + la)] = s16;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int f = 0; f < XFT; ++f) mine[dw_pos(f, lane)] += accr[f];
+      __syncthreads();
+      float *out = A.dw_part + (int64_t)vw * XFT * GGAD_WAVE;
+      for (int i = threadIdx.x; i < XFT * GGAD_WAVE; i += XT) {
+        const int p = dw_pos(i >> 6, i & 63);
+        out[i] = ((accw[0][p] + accw[1][p]) + (accw[2][p] + accw[3][p])) + ((accw[4][p] + accw[5][p]) + (accw[6][p] + accw[7][p]));
+      }
+    }
+    XCD_TICK(4)
+    XCD_BARRIER()
+    XCD_TICK(5)
+
+    // ================================================================ E: gradient reduction, [exchange,] Adam
+    // virtual workgroup vw owns  W[:, f = vw] (vw < 17),  w (vw == 17),  fc[2 vw], fc[2 vw + 1];  wave = sub-reducer
+    for (int vw = rank; vw < NVWG; vw += G) {
+      float gW = 0.0f, gw = 0.0f, g0 = 0.0f, g1 = 0.0f;
+      const int dd0 = 2 * vw, dd1 = 2 * vw + 1;
+      int pidx = -1, sel = 0;
+      if (wid == 0 && vw < XFT && on) { pidx = L.o_W() + lane * XFT + vw; sel = 0; }
+      if (wid == 1 && vw == XFT && on) { pidx = lane; sel = 64; }
+      if (wid == 2 && dd0 < D && on) { pidx = L.o_fc() + dd0 * D + lane; sel = 128; }
+      if (wid == 3 && dd1 < D && on) { pidx = L.o_fc() + dd1 * D + lane; sel = 192; }
+      // every load of the wave first (one round trip), then the arithmetic: label-1 rows wid, wid + 8, ... in blocks of EU;
+      // the optimiser state of the parameter this thread owns comes with them (through the L2: the 128-byte lines of params /
+      // exp_avg / exp_avg_sq hold words owned by other compute units -- W is strided by F)
+      constexpr int EU = 8;
+      float pw[NVWG / XW];
+      if (vw < XFT) {
+#pragma unroll
+        for (int k = 0; k < NVWG / XW; ++k) pw[k] = cld(A.dw_part + (int64_t)(wid * (NVWG / XW) + k) * XFT * GGAD_WAVE + vw * GGAD_WAVE + lane);
+      }
+      const int pl = pidx >= 0 ? pidx : 0;
+      const float ap = cld(params + pl), am = cld(S.exp_avg + pl), av = cld(S.exp_avg_sq + pl);
+      if (dd0 < D) {
+        for (int j0 = wid; j0 < n1; j0 += XW * EU) {         // label-1 rows = sources of the last n1 columns, in order
+          float dzr[EU], nbr[EU];
+#pragma unroll
+          for (int u = 0; u < EU; ++u) {
+            const int j = min(j0 + u * XW, n1 - 1);
+            const int ra = j < XRA ? ra_lds[j] : (S.pos_meta[row0 + n0 + j] >> 2);
+            dzr[u] = cld(S.dz + (int64_t)ra * D + d);
+            nbr[u] = cld(S.nbar + (int64_t)ra * D + d);
+          }
+#pragma unroll
+          for (int u = 0; u < EU; ++u) {
+            if (j0 + u * XW < n1) {
+              const float dzm = on ? dzr[u] : 0.0f;
+              g0 = fmaf(rl(dzm, dd0), nbr[u], g0);            // d fc[dd][d2] = sum_i dZ_i[dd] * nbar_i[d2]
+              g1 = fmaf(rl(dzm, dd1 < D ? dd1 : dd0), nbr[u], g1);
+            }
+          }
+        }
+      }
+      if (vw < XFT) {
+#pragma unroll
+        for (int k = 0; k < NVWG / XW; ++k) gW += pw[k];
+      } else if (vw == XFT) {
+        for (int i0 = wid; i0 < B; i0 += XW * EU) {
+          float gr[EU];
+#pragma unroll
+          for (int u = 0; u < EU; ++u) gr[u] = cld(A.gw_row + (int64_t)min(i0 + u * XW, B - 1) * GGAD_WAVE + lane);
+#pragma unroll
+          for (int u = 0; u < EU; ++u) gw += (i0 + u * XW < B) ? gr[u] : 0.0f;
+        }
+      }
+      __syncthreads();
+      accw[wid][lane] = gW; accw[wid][64 + lane] = gw; accw[wid][128 + lane] = g0; accw[wid][192 + lane] = g1;
+      __syncthreads();
+      if (pidx >= 0) {
+        float g = 0.0f;
+#pragma unroll
+        for (int k = 0; k < XW; ++k) g += accw[k][sel + lane];              // fixed order
+        S.grads[pidx] = g;
+        if (MODE == 2) g = xchg_sum(A.X, A.xstep0 + (uint32_t)b + 1u, pidx, g) * A.grad_scale;
+        adam_apply(params, S.exp_avg, S.exp_avg_sq, L, pidx, ap, am, av, g, S.weight_decay, sc[0], sc[1]);
+      }
+    }
+    XCD_TICK(6)
+    XCD_BARRIER()
+    XCD_TICK(7)
+    if (more) {                                             // step b + 1's records and operands become the current ones
+#pragma unroll
+      for (int j = 0; j < XPC; ++j) { recv[j] = recn[j]; xc[j] = xn[j]; }
+      posv = posn;
+    }
+  }
+  if (rank == 0 && threadIdx.x == 0) C->done = 1;
+}
+
+// ------------------------------------------------------------------ records + entry-complete x2 (once per chunk, whole chip)
+struct XcdPrepArgs {
+  const int32_t *batch_ptr, *ent_ptr, *row_ck_ptr, *ck_rc, *ck_e0, *ent_own, *labels, *pos_meta, *row_pos;
+  float *x2;
+  int32_t *ck_rec, *pos_rec;
+  int n_batches, n_rows, n_pieces, n_ents;
+};
+__global__ void __launch_bounds__(256) k_xcd_prep(XcdPrepArgs P) {
+  const int tid = blockIdx.x * 256 + threadIdx.x;
+  auto batch_row0 = [&](int row) {                       // first row of the batch that holds `row`
+    int lo = 0, hi = P.n_batches;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (P.batch_ptr[mid] <= row) lo = mid; else hi = mid; }
+    return P.batch_ptr[lo];
+  };
+  if (tid < P.n_pieces) {
+    const int c = tid;
+    const int rc = P.ck_rc[c], row = rc >> 6;
+    const int row0 = batch_row0(row);
+    const int q1 = P.row_pos[row];
+    int32_t *o = P.ck_rec + (int64_t)c * REC;
+    o[0] = rc;
+    o[1] = P.ck_e0[c];
+    o[2] = (P.labels[row] & 1) | ((c == P.row_ck_ptr[row]) ? 2 : 0) | ((P.pos_meta[row0 + q1] & 1) << 2);
+    o[3] = P.ent_ptr[row + 1] - P.ent_ptr[row];
+    o[4] = q1;
+    o[5] = P.pos_meta[row];
+    o[6] = 0; o[7] = 0;
+  }
+  if (tid < P.n_rows) {
+    const int row = tid;
+    const int meta = P.pos_meta[row];
+    int32_t *o = P.pos_rec + (int64_t)row * REC;
+    o[0] = meta;
+    o[1] = P.row_ck_ptr[row];
+    o[2] = P.row_ck_ptr[row + 1] - P.row_ck_ptr[row];
+    o[3] = P.ent_ptr[row + 1] - P.ent_ptr[row];
+    int sa = 0, ns = 0, rs = 1;
+    if (meta & 2) {
+      const int src = meta >> 2;
+      sa = P.row_ck_ptr[src]; ns = P.row_ck_ptr[src + 1] - sa; rs = P.ent_ptr[src + 1] - P.ent_ptr[src];
+    }
+    o[4] = sa; o[5] = ns; o[6] = rs; o[7] = 0;
+  }
+  // x2 is stored at owner entries (the reference's deduplicated unique_nodes_list, graphsage.py:306); the other entries of a
+  // (batch, column) get a copy of their owner's row, so that the rows of a piece are the consecutive entries [e0, e0 + cnt)
+  for (int64_t i = tid; i < (int64_t)P.n_ents * XFT; i += (int64_t)gridDim.x * 256) {
+    const int e = (int)(i / XFT), f = (int)(i - (int64_t)e * XFT);
+    const int o = P.ent_own[e];
+    if (o != e) P.x2[i] = P.x2[(int64_t)o * XFT + f];
+  }
+}
+
+// ------------------------------------------------------------------ L2 warmer
+// The plan's outputs (x2, ent_own, piece / row tables) were written by kernels on the other XCDs: the chunk kernel's first touch
+// of every line is an HBM / Infinity-Cache round trip (1-2 us under the plan's traffic) on a chain of 2-3 DEPENDENT loads per
+// phase.  A few single-wave workgroups of this kernel -- the ones that land on the chunk kernel's XCD -- stay `ahead` steps in
+// front of it and touch every line a step will read (one lane per 128-byte line), so the chunk kernel's loads are served by
+// the shared L2.  It only reads; it never delays the chunk kernel (own waves, own vmcnt) and leaves when that kernel does.
+struct XcdWarmArgs {
+  XcdCtrl *ctrl;
+  const int32_t *batch_ptr, *ent_ptr, *row_ck_ptr, *ck_rc, *ck_e0, *ent_own, *labels, *pos_meta, *row_pos;
+  const float *x1, *x2;
+  int n_batches, ahead;
+  unsigned launch_id;
+  unsigned long long timeout_ticks;
+};
+constexpr int XWARM = 8;              // helper workgroups that stay (one wave each)
+
+__device__ __forceinline__ void warm_range(const void *base, int64_t byte0, int64_t byte1, int r, int lane) {
+  const char *p = reinterpret_cast<const char *>(base);
+  const int64_t l0 = byte0 >> 7, l1 = (byte1 + 127) >> 7;             // 128-byte lines [l0, l1)
+  for (int64_t l = l0 + r + (int64_t)XWARM * lane; l < l1; l += (int64_t)XWARM * GGAD_WAVE) {
+    const int v = *reinterpret_cast<const volatile int *>(p + (l << 7));
+    asm volatile("" ::"v"(v));
+  }
+}
+
+__global__ void __launch_bounds__(GGAD_WAVE) k_xcd_warm(XcdWarmArgs P) {
+  XcdCtrl *C = P.ctrl;
+  const int lane = lane_id();
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  xcc &= 7u;
+  const unsigned long long t0 = wall_clock64();
+  while (__hip_atomic_load(&C->placed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != P.launch_id) {
+    __builtin_amdgcn_s_sleep(8);
+    if (cldu(&C->done) != 0 || cldu(&C->err) != 0 || wall_clock64() - t0 > P.timeout_ticks) return;
+  }
+  if (cldu(&C->xcc) != xcc) return;
+  int r = 0;
+  if (lane == 0) r = (int)__hip_atomic_fetch_add(&C->helpers, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  r = __builtin_amdgcn_readfirstlane(r);
+  if (r >= XWARM) return;
+  for (int s = 0; s < P.n_batches; ++s) {
+    while ((int)(cldu(&C->slot[0]) >> 2) < s - P.ahead) {              // 4 barrier rounds per step
+      __builtin_amdgcn_s_sleep(4);
+      if (cldu(&C->done) != 0 || wall_clock64() - t0 > P.timeout_ticks) return;
+    }
+    const int row0 = P.batch_ptr[s], row1 = P.batch_ptr[s + 1];
+    const int64_t e0 = P.ent_ptr[row0], e1 = P.ent_ptr[row1];
+    const int64_t c0 = P.row_ck_ptr[row0], c1 = P.row_ck_ptr[row1];
+    warm_range(P.x2, e0 * XFT * 4, e1 * XFT * 4, r, lane);
+    warm_range(P.ent_own, e0 * 4, e1 * 4, r, lane);
+    warm_range(P.ck_rc, c0 * 4, c1 * 4, r, lane);
+    warm_range(P.ck_e0, c0 * 4, c1 * 4, r, lane);
+    warm_range(P.x1, (int64_t)row0 * XFT * 4, (int64_t)row1 * XFT * 4, r, lane);
+    warm_range(P.labels, (int64_t)row0 * 4, (int64_t)row1 * 4, r, lane);
+    warm_range(P.pos_meta, (int64_t)row0 * 4, (int64_t)row1 * 4, r, lane);
+    warm_range(P.row_pos, (int64_t)row0 * 4, (int64_t)row1 * 4, r, lane);
+    warm_range(P.ent_ptr, (int64_t)row0 * 4, (int64_t)row1 * 4 + 4, r, lane);
+    warm_range(P.row_ck_ptr, (int64_t)row0 * 4, (int64_t)row1 * 4 + 4, r, lane);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t ggad_mb_xcd_grid(void) { return 8 * NVWG; }
+
+int64_t ggad_mb_xcd_workspace_elems(int32_t max_rows, int32_t D, int32_t F, int64_t rows_cap, int64_t pieces_cap) {
+  if (max_rows < 1 || D < 1 || F < 1 || rows_cap < 0 || pieces_cap < 0) return 0;
+  const int64_t ld = ((int64_t)max_rows + 3) / 4 * 4;
+  return 256 + (int64_t)max_rows * 8 + 8 * ld + (int64_t)max_rows * GGAD_WAVE + (int64_t)NVWG * F * GGAD_WAVE +
+         (rows_cap + pieces_cap + 2) * REC;
+}
+
+/* The dense steps of a whole chunk as ONE launch resident on one XCD (see the header of this file).  tmpl as for
+ * ggad_mb_train_chunk (row_ck_ptr / ck_rc / ck_e0 / chunk_part REQUIRED, F == 17); batch_ptr: DEVICE int32[n_batches + 1];
+ * workspace: float[ggad_mb_xcd_workspace_elems(largest batch, D, F)], 16-byte aligned; xchg NULL = single GPU. */
+int ggad_mb_train_chunk_xcd(const ggad_mb_step *tmpl, int32_t n_batches, const int32_t *batch_ptr_dev, int32_t max_rows,
+                            int32_t n_rows, int32_t n_pieces, int32_t n_ents, int64_t rows_cap, int64_t pieces_cap, float *loss_log,
+                            int32_t log_base, float *workspace, float grad_scale, ggad_xchg *xchg, ggad_stream_t stream) {
+  GGAD_REQUIRE(tmpl && batch_ptr_dev && loss_log && workspace && n_batches >= 0 && log_base >= 0 && max_rows >= 1);
+  GGAD_REQUIRE(n_rows >= 0 && n_pieces >= 0 && n_ents >= 0 && n_rows <= rows_cap && n_pieces <= pieces_cap);
+  const ggad_mb_step &s = *tmpl;
+  GGAD_REQUIRE(s.params && s.exp_avg && s.exp_avg_sq && s.grads && s.step_counter && s.x1 && s.x2 && s.ent_ptr && s.ent_own &&
+               s.labels && s.pos_meta && s.row_pos && s.h1 && s.nbar && s.gen && s.dz && s.row_ck_ptr && s.ck_rc && s.ck_e0 &&
+               s.chunk_part);
+  GGAD_REQUIRE(s.F == XFT && s.D >= 1 && s.D <= GGAD_MAX_D && ((uintptr_t)workspace & 15) == 0);
+  if (n_batches == 0) return GGAD_OK;
+  XcdArgs A;
+  A.s = s;
+  A.batch_ptr = batch_ptr_dev;
+  A.n_batches = n_batches; A.log_base = log_base;
+  A.ld_o = (max_rows + 3) / 4 * 4;
+  A.loss_log = loss_log;
+  A.ctrl = reinterpret_cast<XcdCtrl *>(workspace);
+  A.pos_scal = workspace + 256;
+  A.pos_o = A.pos_scal + (int64_t)max_rows * 8;
+  A.gw_row = A.pos_o + (int64_t)8 * A.ld_o;
+  A.dw_part = A.gw_row + (int64_t)max_rows * GGAD_WAVE;
+  int32_t *recs = reinterpret_cast<int32_t *>(A.dw_part + (int64_t)NVWG * XFT * GGAD_WAVE);
+  A.pos_rec = recs;
+  A.ck_rec = recs + (rows_cap + 1) * REC;
+  A.grad_scale = grad_scale;
+  static const unsigned long long timeout = [] {            // barrier time-out in seconds (wall clock, 100 MHz ticks)
+    const char *e = getenv("GGAD_XCD_TIMEOUT_S");
+    const double sec = e ? atof(e) : 10.0;
+    return (unsigned long long)((sec > 0.001 ? sec : 0.001) * 1e8);
+  }();
+  A.timeout_ticks = timeout;
+  static unsigned launch_seq = 0;
+  A.launch_id = ++launch_seq ? launch_seq : ++launch_seq;      // never 0 (the cleared control block)
+  hipStream_t st = as_stream(stream);
+  // registration counters, barrier slots and the error word start from zero on every launch (profile clocks too)
+  if (hipMemsetAsync(workspace, 0, sizeof(XcdCtrl), st) != hipSuccess) return GGAD_E_LAUNCH;
+  {  // records + entry-complete x2: one whole-chip launch per chunk (the plan's tables are read-only for everybody else)
+    XcdPrepArgs Q;
+    Q.batch_ptr = batch_ptr_dev; Q.ent_ptr = s.ent_ptr; Q.row_ck_ptr = s.row_ck_ptr; Q.ck_rc = s.ck_rc; Q.ck_e0 = s.ck_e0;
+    Q.ent_own = s.ent_own; Q.labels = s.labels; Q.pos_meta = s.pos_meta; Q.row_pos = s.row_pos;
+    Q.x2 = const_cast<float *>(s.x2);
+    Q.ck_rec = const_cast<int32_t *>(A.ck_rec); Q.pos_rec = const_cast<int32_t *>(A.pos_rec);
+    Q.n_batches = n_batches; Q.n_rows = n_rows; Q.n_pieces = n_pieces; Q.n_ents = n_ents;
+    const int64_t work = std::max<int64_t>(std::max<int64_t>(n_rows, n_pieces), ((int64_t)n_ents * XFT + 3) / 4);
+    const unsigned blocks = (unsigned)std::min<int64_t>((work + 255) / 256, 8192);
+    k_xcd_prep<<<dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st>>>(Q);
+    GGAD_CHECK_LAUNCH("mb_train_chunk_xcd (records)");
+  }
+  // the L2 warmer runs BESIDE the chunk kernel on a stream of its own: it starts once the control block is cleared (ev0) and the
+  // caller's stream continues only after it has left (ev1: it reads the plan's buffers)
+  static const int warm_ahead = [] { const char *e = getenv("GGAD_XCD_WARM"); return e ? atoi(e) : 0; }();   // off: measured without effect
+  struct Side { hipStream_t st; hipEvent_t ev0, ev1; };
+  static Side side[GGAD_MAX_DEVICES] = {};
+  Side *sd = nullptr;
+  if (warm_ahead > 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < GGAD_MAX_DEVICES) {
+      sd = &side[dev];
+      if (!sd->st) {
+        if (hipStreamCreateWithFlags(&sd->st, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&sd->ev0, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&sd->ev1, hipEventDisableTiming) != hipSuccess) {
+          sd->st = nullptr;
+          sd = nullptr;
+        }
+      }
+    }
+    if (sd && (hipEventRecord(sd->ev0, st) != hipSuccess || hipStreamWaitEvent(sd->st, sd->ev0, 0) != hipSuccess)) sd = nullptr;
+    (void)hipGetLastError();
+  }
+  if (xchg) {
+    GGAD_REQUIRE(xchg->view.n >= s.D + s.D * s.F + s.D * s.D);
+    for (int q = 0; q < xchg->view.world; ++q) GGAD_REQUIRE(xchg->view.peer[q] != nullptr);
+    A.X = xchg->view;
+    A.xstep0 = xchg->step;
+    xchg->step += (uint32_t)n_batches;
+    k_train_chunk_xcd<2><<<dim3(8 * NVWG), dim3(XT), 0, st>>>(A);
+  } else {
+    A.X = ggad_xchg_view{};
+    A.xstep0 = 0;
+    k_train_chunk_xcd<1><<<dim3(8 * NVWG), dim3(XT), 0, st>>>(A);
+  }
+  GGAD_CHECK_LAUNCH("mb_train_chunk_xcd");
+  if (sd) {
+    XcdWarmArgs W;
+    W.ctrl = A.ctrl;
+    W.batch_ptr = batch_ptr_dev; W.ent_ptr = s.ent_ptr; W.row_ck_ptr = s.row_ck_ptr; W.ck_rc = s.ck_rc; W.ck_e0 = s.ck_e0;
+    W.ent_own = s.ent_own; W.labels = s.labels; W.pos_meta = s.pos_meta; W.row_pos = s.row_pos;
+    W.x1 = s.x1; W.x2 = s.x2;
+    W.n_batches = n_batches; W.ahead = warm_ahead; W.launch_id = A.launch_id; W.timeout_ticks = timeout;
+    k_xcd_warm<<<dim3(8 * 2 * XWARM), dim3(GGAD_WAVE), 0, sd->st>>>(W);
+    if (hipGetLastError() == hipSuccess && hipEventRecord(sd->ev1, sd->st) == hipSuccess) (void)hipStreamWaitEvent(st, sd->ev1, 0);
+    (void)hipGetLastError();
+  }
+  return GGAD_OK;
+}
+
+/* Control words of the LAST launch that used `workspace` (device -> host copy on `stream`, synchronises it):
+ * out[0] error (0 ok, 1 barrier time-out, 2 registration time-out), out[1] workgroups that stayed, out[2] their XCD,
+ * out[3..10] phase clocks of rank 0 in 10 ns ticks (A, barrier, R, barrier, C, barrier, E, barrier). */
+int ggad_mb_xcd_status(const float *workspace, int64_t *out19, ggad_stream_t stream) {
+  GGAD_REQUIRE(workspace && out19);
+  int64_t *out11 = out19;
+  XcdCtrl h;
+  hipStream_t st = as_stream(stream);
+  if (hipMemcpyAsync(&h, workspace, sizeof(XcdCtrl), hipMemcpyDeviceToHost, st) != hipSuccess) return GGAD_E_LAUNCH;
+  if (hipStreamSynchronize(st) != hipSuccess) return GGAD_E_LAUNCH;
+  out11[0] = h.err; out11[1] = h.survivors; out11[2] = h.xcc;
+  for (int k = 0; k < 16; ++k) out11[3 + k] = (int64_t)h.prof[k];
+  return GGAD_OK;
+}
+
+}  // extern "C"

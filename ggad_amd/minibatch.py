@@ -294,13 +294,26 @@ class MiniBatchEngine:
     """Parameters, optimiser state and the per-batch kernel chain."""
 
     def __init__(self, feat_dim: int, embed_dim: int, device, lr: float = 1e-3, weight_decay: float = 0.007,
-                 chain: int = 0):
+                 chain: int = 0, resident: Optional[bool] = None):
+        """`resident`: run the dense steps of a chunk as ONE launch resident on one XCD (`ggad_mb_train_chunk_xcd`,
+        csrc/step_xcd.hip) instead of 5 launches per step.  None = whenever the kernel supports the shapes (F == 17,
+        D <= 64, chain 0) and GGAD_XCD is not 0."""
         self.lib = _lib.load()
         # 0: fused-forward step (5 launches, F == 17); 2: always the generic 6 launches (project -> fwd_rows -> ...)
         self.chain = int(chain)
         if self.chain not in (0, 2):
             raise ValueError("chain must be 0 or 2")
         self.F, self.D = int(feat_dim), int(embed_dim)
+        import os
+        can = int(feat_dim) == 17 and int(embed_dim) <= 64 and self.chain == 0
+        if resident is None:
+            resident = can and os.environ.get("GGAD_XCD", "1") != "0"
+        elif resident and not can:
+            raise ValueError("the XCD-resident chunk kernel needs F == 17, D <= 64 and chain 0")
+        self.resident = bool(resident)
+        self.xcd_ws = None
+        self._xcd_rows = 0
+        self._xcd_caps = (0, 0)
         if self.D > self.lib.ggad_max_embed_dim():
             raise ValueError(f"emb_size {self.D} > {self.lib.ggad_max_embed_dim()} is not supported by the HIP step kernels")
         self.dev = torch.device(device)
@@ -351,6 +364,12 @@ class MiniBatchEngine:
         need = int(self.lib.ggad_mb_dw_part_elems(max_rows, self.D, self.F))
         if self.dw_part.numel() < need:
             self.dw_part = torch.zeros(need, dtype=torch.float32, device=self.dev)
+        if self.resident and (self.xcd_ws is None or self._xcd_rows < max_rows or self._xcd_caps[0] < ch.n_rows
+                              or self._xcd_caps[1] < ch.n_chunks):
+            self._xcd_rows = max(256, int(max_rows * 1.25), self._xcd_rows)
+            self._xcd_caps = (max(int(ch.n_rows * 1.25) + 64, self._xcd_caps[0]), max(int(ch.n_chunks * 1.25) + 64, self._xcd_caps[1]))
+            self.xcd_ws = torch.zeros(int(self.lib.ggad_mb_xcd_workspace_elems(self._xcd_rows, self.D, self.F, *self._xcd_caps)),
+                                      dtype=torch.float32, device=self.dev)
         if self.loss_log.numel() < 8 * log_slots:
             new = torch.zeros(8 * max(log_slots, 2 * (self.loss_log.numel() // 8)), dtype=torch.float32, device=self.dev)
             new[:self.loss_log.numel()].copy_(self.loss_log)
@@ -394,6 +413,15 @@ class MiniBatchEngine:
         no host call in the loop) or `allreduce` (a callable, e.g. RCCL through torch.distributed, served by a callback)."""
         self.ensure_capacity(ch, log_base + ch.n_batches)
         stream = _lib.current_stream()
+        if self.resident and allreduce is None and (world_size == 1 or exchange is not None) \
+                and getattr(ch, "row_ck_ptr", None) is not None:
+            s = self.step_desc(ch, 0, log_base)
+            _lib.check(self.lib.ggad_mb_train_chunk_xcd(ctypes.byref(s), ch.n_batches, ptr(ch.batch_ptr), self._xcd_rows,
+                                                         ch.n_rows, ch.n_chunks, ch.n_ents, self._xcd_caps[0], self._xcd_caps[1],
+                                                         self.loss_log.data_ptr(), log_base, ptr(self.xcd_ws), 1.0 / world_size,
+                                                         exchange.handle if exchange is not None else None, stream),
+                       "ggad_mb_train_chunk_xcd")
+            return
         if exchange is not None:
             s = self.step_desc(ch, 0, log_base)
             bp, ep, mr = ch._bp_host, ch._bep_host, ch._bmr_host
@@ -432,6 +460,25 @@ class MiniBatchEngine:
         if err:
             raise err[0]
         _lib.check(rc, "ggad_mb_train_chunk_dp")
+
+    def xcd_status(self) -> dict:
+        """Control words of the last XCD-resident launch (synchronises the current stream): error code, surviving workgroups,
+        their XCD, and rank 0's wall time per phase in microseconds (A, barrier, R, barrier, C, barrier, E, barrier)."""
+        if self.xcd_ws is None:
+            raise RuntimeError("no XCD-resident launch has run")
+        out = (ctypes.c_int64 * 19)()
+        _lib.check(self.lib.ggad_mb_xcd_status(ptr(self.xcd_ws), out, _lib.current_stream()), "ggad_mb_xcd_status")
+        names = ("A", "bar1", "R", "bar2", "C", "bar3", "E", "bar4")
+        return dict(error=int(out[0]), workgroups=int(out[1]), xcc=int(out[2]),
+                    phase_us={n: out[3 + k] / 100.0 for k, n in enumerate(names)},
+                    sub_us=[out[11 + k] / 100.0 for k in range(8)])
+
+    def check_resident(self) -> None:
+        """Raise if the last XCD-resident launch timed out at a barrier (it leaves instead of hanging the GPU)."""
+        if self.xcd_ws is not None:
+            st = self.xcd_status()
+            if st["error"]:
+                raise RuntimeError(f"ggad_amd: XCD-resident chunk kernel timed out (code {st['error']}, {st['workgroups']} workgroups)")
 
     def forward_batch(self, ch: BatchChunk, b: int) -> None:
         """project + fwd_rows only (layered API / tests): fills ch.h1, ch.nbar, ch.gen for batch b."""

@@ -248,7 +248,7 @@ def test_fused_forward_chain_equals_six_launch_chain(d, bsz, n_ano):
             grads.append(eng.grads.cpu().numpy().copy())
             eng.adam_step()
         res[chain] = (np.stack(grads), eng.losses(3).copy(), eng.params.cpu().numpy().copy())
-        eng2 = MiniBatchEngine(17, d, DEV, chain=chain)      # Adam fused into the last launch
+        eng2 = MiniBatchEngine(17, d, DEV, chain=chain, resident=False)      # Adam fused into the last launch
         eng2.load_params(w, W, fc)
         eng2.train_chunk(ch)
         np.testing.assert_array_equal(eng2.params.cpu().numpy(), res[chain][2])
@@ -265,6 +265,46 @@ def test_fused_forward_chain_equals_six_launch_chain(d, bsz, n_ano):
     np.testing.assert_allclose(res[2][1][0], [tot.item(), cls.item(), mar.item(), rec.item()], atol=1e-5, rtol=0)
     with pytest.raises(ValueError):
         MiniBatchEngine(17, d, DEV, chain=1)
+
+
+@pytest.mark.parametrize("d,bsz,n_ano,hub", [(64, 200, 50, True), (64, 150, 50, False), (32, 333, 77, True), (48, 23, 5, False)])
+def test_xcd_resident_chunk_equals_launch_chain(d, bsz, n_ano, hub):
+    """The dense steps of a chunk as ONE launch resident on one XCD (`ggad_mb_train_chunk_xcd`) against the 5-launch chain:
+    same per-entry fma order, same piece order per row, same loss reduction tree -> the FIRST step's losses are bit-equal when the
+    chain takes its chunk-parallel forward (batch 0 holds the graph's hub row); gradients are grouped by piece instead of by flat stripes -> weights and
+    later losses agree to fp32 round-off.  The launch is deterministic and reports its placement."""
+    g, batches, labels = _random_case(n=12000, n_entries=150000, f=17, d=d, seed=131 + d + bsz, nb=6, bsz=bsz, n_ano=n_ano)
+    torch.manual_seed(d)
+    w = torch.nn.init.xavier_uniform_(torch.empty(1, d))
+    W = torch.nn.init.xavier_uniform_(torch.empty(d, 17))
+    fc = torch.nn.init.xavier_uniform_(torch.empty(d, d))
+    res = {}
+    for key, resident in (("chain", False), ("xcd", True), ("xcd2", True)):
+        graph, feat, ch = _setup(g, max_batches=len(batches), hop2="ldsw")
+        eng = MiniBatchEngine(17, d, DEV, resident=resident)
+        assert eng.resident == resident
+        eng.load_params(w, W, fc)
+        ch.build(batches, labels)
+        eng.train_chunk(ch)
+        torch.cuda.synchronize()
+        res[key] = (eng.params.cpu().numpy().copy(), eng.losses(len(batches)).copy(), eng.exp_avg.cpu().numpy().copy(),
+                    int(eng.step_counter.item()), int(ch.batch_max_row[0]))
+        if resident:
+            st = eng.xcd_status()
+            assert st["error"] == 0 and st["workgroups"] == 32, st
+    assert res["xcd"][3] == res["chain"][3] == len(batches)
+    np.testing.assert_array_equal(res["xcd"][0], res["xcd2"][0])                 # deterministic
+    np.testing.assert_array_equal(res["xcd"][1], res["xcd2"][1])
+    if hub and res["chain"][4] > 256:
+        np.testing.assert_array_equal(res["xcd"][1][0], res["chain"][1][0])      # same forward / loss arithmetic
+    np.testing.assert_allclose(res["xcd"][1], res["chain"][1], atol=2e-6, rtol=0)
+    np.testing.assert_allclose(res["xcd"][0], res["chain"][0], atol=2e-6, rtol=0)
+    np.testing.assert_allclose(res["xcd"][2], res["chain"][2], atol=2e-6, rtol=1e-4)
+    # and the oracle on the first step
+    p = O.MiniParams(w.clone().requires_grad_(), W.clone().requires_grad_(), fc.clone().requires_grad_())
+    agg = O.aggregate_batch(g["rowptr"], g["col"], g["feat"], batches[0], True)
+    tot, cls, mar, rec = O.batch_loss(p, agg, labels[0])
+    np.testing.assert_allclose(res["xcd"][1][0], [tot.item(), cls.item(), mar.item(), rec.item()], atol=1e-5, rtol=0)
 
 
 def test_rebuild_reuses_clean_slots():
@@ -285,7 +325,7 @@ def test_fused_adam_chunk_equals_stepwise():
     outs = []
     for fused in (True, False):
         graph, feat, ch = _setup(g, max_batches=4)
-        eng = MiniBatchEngine(17, 64, DEV)
+        eng = MiniBatchEngine(17, 64, DEV, resident=False)
         eng.load_params(w, W, fc)
         ch.build(batches, labels)
         if fused:
