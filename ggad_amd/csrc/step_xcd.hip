@@ -12,12 +12,13 @@
 // 2 KB hand-offs + barrier + 3 remote reads; zero stale words under skewed arrivals and HBM noise; a device-scope counter
 // barrier over the chip: 3-7 us).  The other seven XCDs stay free for the plan kernels of the next chunk.
 //
-// Placement.  HIP cannot place workgroups, so the launch does not assume it: every workgroup reads HW_REG_XCC_ID, registers
-// in a per-XCD counter and waits until the whole grid has registered; the XCD with the most registrations (lowest id on ties) is
-// picked by everyone from the same final counts, its workgroups take ranks in registration order, all others exit.  Work is
-// dealt to NVWG = 32 VIRTUAL workgroups of 8 waves; the G survivors loop over them (G = 32 on a 256-workgroup grid: one each), so
-// every floating-point sum has the same order for any G and the results do not depend on the placement.  A barrier wait is
-// bounded (wall clock); on a time-out the error word is set and the kernel leaves instead of hanging the GPU.
+// Placement.  HIP cannot place workgroups, but the dispatcher deals the workgroups of a launch to the eight XCDs in strict
+// rotation (exactly grid / 8 each, whatever the stream's CU mask: scripts/xcd_block_map.hip), so the launch has 8 nv workgroups:
+// every workgroup reads HW_REG_XCC_ID; the ones that are not on the host-chosen XCD leave at once; the nv on it take ranks in
+// registration order and wait (bounded) until all nv are there.  If the rotation ever were not exact the launch would not hang
+// or compute garbage: the wait times out, the error word is set, every workgroup leaves, and the host raises at its next
+// check (ggad_mb_xcd_status).  nv <= 32 is a launch parameter (the trainer leaves a few CUs of the XCD to the plan stream).
+// A barrier wait is bounded the same way.
 //
 // Phases of one step (4 barriers), lane = embedding channel d, F = 17:
 //   A   pieces (<= 16 consecutive entries of ONE row, tables of the plan): partial sums of relu(W x2[own(e)]) -> chunk_part;
@@ -53,11 +54,12 @@ namespace {
 constexpr int GGAD_MAX_DEVICES = 16;
 constexpr int XW = 8;                 // waves per workgroup
 constexpr int XT = XW * GGAD_WAVE;    // threads per workgroup
-constexpr int NVWG = 32;              // virtual workgroups (= CUs of an XCD)
-constexpr int NVW = NVWG * XW;        // virtual waves
+constexpr int XMAXWG = 32;            // workgroups of a launch that stay (CUs of an XCD)
+constexpr int XMINWG = 18;            // 17 columns of W + w need one owner each in phase E
 constexpr int XFT = 17;               // feature width (DGraph-Fin)
 
 constexpr int XPC = 2;                // pieces per virtual wave whose records / operands are fetched a step ahead and kept in registers
+constexpr int XHUB = 32;              // pieces from which a row's partial sums are added by the whole workgroup (phase R)
 constexpr int XRA = 512;              // label-1 rows of a batch listed in LDS for phase E
 constexpr int XBT = 256;              // batches whose offsets are staged in LDS at launch (later ones are read per step)
 constexpr int FCS = GGAD_MAX_D + 1;   // row stride of fc^T in LDS (conflict-free for both access patterns)
@@ -79,14 +81,22 @@ struct XcdArgs {
   XcdCtrl *ctrl;
   float *pos_scal, *pos_o, *gw_row, *dw_part;
   const int32_t *ck_rec, *pos_rec;    // records of k_xcd_prep (8 ints per piece / per position)
+  const int32_t *batch_n0;            // label-0 positions per batch (k_xcd_prep)
   ggad_xchg_view X;
   uint32_t xstep0;
   float grad_scale;
   unsigned long long timeout_ticks;
   unsigned launch_id;
+  int dbg;
+  int nv, want_xcd;                    // workgroups that stay, the XCD they stay on
 };
 
 __device__ __forceinline__ float cld(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+struct f2 { float x, y; };
+__device__ __forceinline__ f2 cld2(const float *p) {          // 8-byte aligned pair, one L1-bypassing load
+  const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return f2{__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32))};
+}
 __device__ __forceinline__ unsigned cldu(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float rl(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
@@ -143,7 +153,7 @@ struct PieceX {
 // (clamped address, select afterwards): 9 loads in flight per piece.
 __device__ __forceinline__ void load_piece_x(const float *__restrict__ x, int base, int n, int lane, PieceX &P) {
   const int a = lane & 15, g = lane >> 4;
-  const int64_t ra = base + min(a, n - 1);
+  const unsigned ra = base + min(a, n - 1);
 #pragma unroll
   for (int j = 0; j < XKS; ++j) {
     const int f = 4 * j + g;
@@ -153,7 +163,7 @@ __device__ __forceinline__ void load_piece_x(const float *__restrict__ x, int ba
 #pragma unroll
   for (int v = 0; v < 4; ++v) {
     const int e = 4 * g + v;
-    const float xv = x[(int64_t)(base + min(e, n - 1)) * XFT + a];
+    const float xv = x[(unsigned)(base + min(e, n - 1)) * XFT + a];
     P.b[v] = e < n ? xv : 0.0f;
   }
 }
@@ -173,7 +183,7 @@ __device__ __forceinline__ void piece_fwd(const PieceX &P, const float (&WB)[XKS
 //   position q:     [0] pos_meta   [1] first piece of row q   [2] its pieces   [3] entries of row q
 //                   [4] first piece of the source row (generated columns)   [5] its pieces   [6] its entries
 constexpr int REC = 8;
-struct RowIn { float H1, NB, Gl, p1v, p2v, nbq, c2; };
+struct RowIn { float H1, NB, Gl, pp, nbq, c2, xr; };      // pp: lanes 0..7 = scalars of position q1, lanes 8..15 = of position i
 
 // Adam on one parameter whose state is already in registers (torch.optim.Adam's single-tensor update op by op, step_common.h)
 __device__ __forceinline__ void adam_apply(float *__restrict__ params, float *__restrict__ m, float *__restrict__ v, ParamLayout L,
@@ -194,9 +204,9 @@ __device__ __forceinline__ void adam_apply(float *__restrict__ params, float *__
   }
 }
 
-template <int MODE>      // 1: Adam; 2: one-shot data-parallel exchange + Adam
+template <int MODE, int DT>      // MODE 1: Adam; 2: one-shot data-parallel exchange + Adam.  DT: embedding width at compile time (0 = run time)
 __global__ void __launch_bounds__(XT) k_train_chunk_xcd(XcdArgs A) {
-  __shared__ int s_rank, s_G;
+  __shared__ int s_rank;
   __shared__ float wt_lds[XFT * GGAD_MAX_D];            // W^T of this step
   __shared__ float w_lds[GGAD_MAX_D];
   __shared__ float fct[GGAD_MAX_D * FCS];               // fc^T of this step, rows padded
@@ -204,58 +214,55 @@ __global__ void __launch_bounds__(XT) k_train_chunk_xcd(XcdArgs A) {
   __shared__ int ra_lds[XRA];                           // label-1 rows of the batch (sources of the generated columns), phase E
   __shared__ float t_lds[8];
   __shared__ float sc[2];
-  __shared__ int bt_row0[XBT + 1], bt_ck0[XBT + 1];     // row / piece offsets of the first XBT batches (no dependent loads per step)
+  __shared__ int hub_first[2 * XW], hub_n[2 * XW];      // phase R: rows summed by the whole workgroup
+  __shared__ float hub_part[XW][GGAD_WAVE];
+  __shared__ int bt_row0[XBT + 1], bt_ck0[XBT + 1], bt_n0[XBT + 1];   // row / piece offsets, label-0 positions of the first XBT batches
   XcdCtrl *C = A.ctrl;
   // ---------------------------------------------------------------- placement
   if (threadIdx.x == 0) {
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     xcc &= 7u;
-    const unsigned r = __hip_atomic_fetch_add(&C->reg[xcc][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned tot = 0, pick = 0, best = 0;
-    const unsigned long long t0 = wall_clock64();
-    bool ok = true;
-    while (true) {
-      tot = 0; pick = 0; best = 0;
-#pragma unroll
-      for (unsigned k = 0; k < 8; ++k) {
-        const unsigned ck = cldu(&C->reg[k][0]);
-        tot += ck;
-        if (ck > best) { best = ck; pick = k; }             // most registrations, lowest id on ties
+    int r = -1;
+    if ((int)xcc == A.want_xcd) {
+      r = (int)__hip_atomic_fetch_add(&C->reg[xcc][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long t0 = wall_clock64();
+      while (r < A.nv && cldu(&C->reg[xcc][0]) < (unsigned)A.nv) {
+        __builtin_amdgcn_s_sleep(2);
+        if (cldu(&C->err) != 0 || wall_clock64() - t0 > A.timeout_ticks) { C->err = 2; C->done = 1; r = -1; break; }
       }
-      if (tot >= gridDim.x) break;
-      __builtin_amdgcn_s_sleep(2);
-      if (wall_clock64() - t0 > A.timeout_ticks) { ok = false; C->err = 2; C->done = 1; break; }
+      if (r >= A.nv) { C->err = 3; r = -1; }                // more than grid / 8 workgroups on one XCD: not the dealing we rely on
+      if (r == 0) {
+        C->survivors = (unsigned)A.nv; C->xcc = xcc;
+        __hip_atomic_store(&C->placed, A.launch_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
-    s_rank = (ok && xcc == pick) ? (int)r : -1;
-    s_G = (int)min(best, 64u);
-    if (ok && xcc == pick && r == 0) {
-      C->survivors = best; C->xcc = pick;
-      __hip_atomic_store(&C->placed, A.launch_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    s_rank = r;
   }
   __syncthreads();
-  const int rank = s_rank, G = s_G;
-  if (rank < 0 || rank >= 64) return;
+  const int rank = s_rank;
+  if (rank < 0) return;
+  const int nv = A.nv, NVW = nv * XW, G = nv;
 
   const ggad_mb_step &S = A.s;
-  const ParamLayout L{S.D, XFT};
-  const int D = S.D;
+  const int D = DT ? DT : S.D;
+  const ParamLayout L{D, XFT};
   const int lane = lane_id(), wid = threadIdx.x / GGAD_WAVE;
   const int la = lane & 15, lg = lane >> 4;             // (a, g) of the matrix-core layouts
   const int l8 = lane & 7;
   const bool on = lane < D;
   const int d = on ? lane : D - 1;
   const int fl = lane < XFT ? lane : XFT - 1;
-  // one virtual workgroup per workgroup (the normal case): the records and operands of step b + 1 are fetched into registers
-  // during step b; otherwise every phase loads what it needs in place
-  const bool piped = (G == NVWG);
+  // the records and operands of step b + 1 are fetched into registers during step b
+  constexpr bool piped = true;
   float *params = S.params;
   const int step0 = *S.step_counter;
+  for (int i = threadIdx.x; i < GGAD_MAX_D * FCS; i += XT) fct[i] = 0.0f;      // rows / columns beyond D stay zero
   for (int i = threadIdx.x; i <= min(A.n_batches, XBT); i += XT) {
     const int r0 = A.batch_ptr[i];
     bt_row0[i] = r0;
     bt_ck0[i] = S.row_ck_ptr[r0];
+    bt_n0[i] = i < A.n_batches ? A.batch_n0[i] : 0;
   }
   __syncthreads();
   auto batch_info = [&](int bb, int &row0, int &B, int &ck0, int &nck) {
@@ -267,9 +274,9 @@ __global__ void __launch_bounds__(XT) k_train_chunk_xcd(XcdArgs A) {
   };
   // virtual wave of this wave in its first virtual workgroup: pieces / positions v0, v0 + NVW, ...  Consecutive pieces (and
   // positions) go to consecutive WORKGROUPS, so a batch of 358 pieces puts 11-12 on every compute unit
-  const int v0 = rank + NVWG * wid;
-  auto piece_rec = [&](int c) { return A.ck_rec[(int64_t)c * REC + l8]; };
-  auto pos_rec = [&](int row) { return A.pos_rec[(int64_t)row * REC + l8]; };
+  const int v0 = rank + nv * wid;
+  auto piece_rec = [&](int c) { return A.ck_rec[(unsigned)c * REC + l8]; };
+  auto pos_rec = [&](int row) { return A.pos_rec[(unsigned)row * REC + l8]; };
   auto issue_recs = [&](int bb, int (&rv)[XPC], int &pv) {          // records of this wave's pieces / position in step bb
     int r0, Bn, c0, nc;
     batch_info(bb, r0, Bn, c0, nc);
@@ -303,11 +310,28 @@ __global__ void __launch_bounds__(XT) k_train_chunk_xcd(XcdArgs A) {
     batch_info(b, row0, B, ck0, nck);
     float *log8 = A.loss_log + (int64_t)8 * (A.log_base + b);
     // ---------------------------------------------------------------- weights of this step: L2 -> LDS (written by phase E of the previous step)
-    for (int i = threadIdx.x; i < XFT * D; i += XT) wt_lds[i] = cld(params + L.o_Wt() + i);
-    if (threadIdx.x < GGAD_WAVE) w_lds[lane] = on ? cld(params + lane) : 0.0f;
-    for (int i = threadIdx.x; i < D * D; i += XT) {
-      const int r2 = i / D, c2 = i - r2 * D;
-      fct[r2 * FCS + c2] = cld(params + L.o_fcT() + i);
+    if ((D & 1) == 0) {                                   // all three blocks start on even offsets: 8-byte loads
+      for (int i = 2 * threadIdx.x; i < XFT * D; i += 2 * XT) {
+        const f2 v = cld2(params + L.o_Wt() + i);
+        wt_lds[i] = v.x; wt_lds[i + 1] = v.y;
+      }
+      for (int i = 2 * threadIdx.x; i < D * D; i += 2 * XT) {
+        const int r2 = i / D, c2 = i - r2 * D;
+        const f2 v = cld2(params + L.o_fcT() + i);
+        fct[r2 * FCS + c2] = v.x; fct[r2 * FCS + c2 + 1] = v.y;
+      }
+    } else {
+      for (int i = threadIdx.x; i < XFT * D; i += XT) wt_lds[i] = cld(params + L.o_Wt() + i);
+      for (int i = threadIdx.x; i < D * D; i += XT) {
+        const int r2 = i / D, c2 = i - r2 * D;
+        fct[r2 * FCS + c2] = cld(params + L.o_fcT() + i);
+      }
+    }
+    if (threadIdx.x >= XT - GGAD_WAVE) w_lds[lane] = on ? cld(params + lane) : 0.0f;
+    {                                                       // sources of the generated columns (label-1 rows), for phase E
+      const int n0s = b < XBT ? bt_n0[b] : A.batch_n0[b];
+      if (!(A.dbg & 2))
+        for (int j = threadIdx.x; j < min(B - n0s, XRA); j += XT) ra_lds[j] = S.pos_meta[row0 + n0s + j] >> 2;
     }
     __syncthreads();
     float WB[XKS][XNT];                                   // W^T in the B-operand layout: W[16 t + a][4 j + g]
@@ -333,10 +357,10 @@ __global__ void __launch_bounds__(XT) k_train_chunk_xcd(XcdArgs A) {
         st += __shfl_xor(st, 32, GGAD_WAVE);
         out = lg == t ? st : out;                           // lane l = channel 16 (l / 16) + l % 16
       }
-      S.chunk_part[(int64_t)c * 64 + lane] = out;
+      S.chunk_part[(unsigned)c * 64 + lane] = out;
     };
-    for (int vw = rank; vw < NVWG; vw += G) {
-      const int v = vw + NVWG * wid;
+    {
+      const int v = v0;
 #pragma unroll
       for (int j = 0; j < XPC; ++j) {
         const int w = v + j * NVW;
@@ -361,7 +385,7 @@ __global__ void __launch_bounds__(XT) k_train_chunk_xcd(XcdArgs A) {
 #pragma unroll
           for (int vv = 0; vv < 4; ++vv) {
             const int i = 16 * p + 4 * lg + vv, ch = 16 * t + la;
-            if (i < B && ch < D) S.h1[(int64_t)(row0 + i) * D + ch] = fmaxf(h[t][vv], 0.0f);
+            if (i < B && ch < D) S.h1[(unsigned)(row0 + i) * D + ch] = fmaxf(h[t][vv], 0.0f);
           }
       }
     }
@@ -370,53 +394,88 @@ __global__ void __launch_bounds__(XT) k_train_chunk_xcd(XcdArgs A) {
     XCD_TICK(1)
 
     // ================================================================ R: positions of combined_all (k_loss_pos_ck of step.hip)
-    for (int vw = rank; vw < NVWG; vw += G) {
-      for (int q = vw + NVWG * wid; q < B; q += NVW) {
-        const int pr = (piped && q == v0) ? posv : pos_rec(row0 + q);
+    // piece order; groups of 4 loads behind wave-uniform guards (a row has 2-3 pieces), up to 32 in flight
+    auto sum_row = [&](int first, int n, float &tot) {
+      if (n <= 0) return;
+      if (n <= 4) {                                                 // the usual row: no loop, no guards
+        float pv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pv[k] = cld(S.chunk_part + (unsigned)(first + min(k, n - 1)) * 64 + lane);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tot += (k < n) ? pv[k] : 0.0f;
+        return;
+      }
+      constexpr int PF = 32;
+      for (int c0 = 0; c0 < n; c0 += PF) {
+        float pv[PF];
+#pragma unroll
+        for (int g4 = 0; g4 < PF / 4; ++g4) {
+          if (c0 + 4 * g4 < n) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pv[4 * g4 + k] = cld(S.chunk_part + (unsigned)(first + min(c0 + 4 * g4 + k, n - 1)) * 64 + lane);
+          }
+        }
+#pragma unroll
+        for (int g4 = 0; g4 < PF / 4; ++g4) {
+          if (c0 + 4 * g4 < n) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tot += (c0 + 4 * g4 + k < n) ? pv[4 * g4 + k] : 0.0f;
+          }
+        }
+      }
+    };
+    const int xhub = (A.dbg & 1) ? (1 << 30) : XHUB;
+    {
+      const int vw = rank;
+      for (int q0 = vw; q0 < B; q0 += NVW) {                        // (workgroup-uniform trip count: the hub pass below synchronises)
+        const int q = q0 + nv * wid;
+        const bool act = q < B;
+        const int pr = (piped && q == v0) ? posv : pos_rec(row0 + (act ? q : 0));
         const int meta = ri(pr, 0);
         const int src = meta >> 2, y = meta & 1;
         const bool from_gen = (meta & 2) != 0;
         const int row = row0 + q;
-        const int qa = ri(pr, 1), nq = ri(pr, 2), rq = ri(pr, 3), sa = ri(pr, 4), ns = ri(pr, 5), rs = ri(pr, 6);
-        const float hs_r = cld(S.h1 + (int64_t)src * D + d);
+        const int qa = ri(pr, 1), nq = act ? ri(pr, 2) : 0, rq = ri(pr, 3), sa = ri(pr, 4), ns = (act && from_gen) ? ri(pr, 5) : 0, rs = ri(pr, 6);
+        const float hs_r = cld(S.h1 + (unsigned)src * D + d);
+        // a hub row (thousands of entries = hundreds of pieces) is summed by ALL waves of the workgroup, an eighth each, the eight
+        // partial sums added in order; every other row by its own wave
+        if (lane == 0) {
+          hub_first[2 * wid] = qa; hub_n[2 * wid] = nq > xhub ? nq : 0;
+          hub_first[2 * wid + 1] = sa; hub_n[2 * wid + 1] = ns > xhub ? ns : 0;
+        }
         float totq = 0.0f, tots = 0.0f;
-        constexpr int PF = 16;                                      // piece order; loads in flight from clamped indices
-        {
-          float vq[PF], vs[PF];
+        if (nq <= xhub) sum_row(qa, nq, totq);
+        if (ns <= xhub) sum_row(sa, ns, tots);
+        __syncthreads();
+        for (int sidx = 0; sidx < 2 * XW; ++sidx) {
+          const int n = hub_n[sidx];
+          if (n == 0) continue;
+          const int first = hub_first[sidx];
+          const int seg = ((n + XW - 1) / XW + 3) & ~3;
+          const int lo = min(wid * seg, n), hi = min(lo + seg, n);
+          float part = 0.0f;
+          sum_row(first + lo, hi - lo, part);
+          hub_part[wid][lane] = part;
+          __syncthreads();
+          if (wid == (sidx >> 1)) {
+            float tt = 0.0f;
 #pragma unroll
-          for (int k = 0; k < PF; ++k) {
-            vq[k] = cld(S.chunk_part + (int64_t)(qa + min(k, max(nq - 1, 0))) * 64 + lane);
-            vs[k] = cld(S.chunk_part + (int64_t)(ns > 0 ? sa + min(k, ns - 1) : qa) * 64 + lane);
+            for (int u = 0; u < XW; ++u) tt += hub_part[u][lane];
+            if (sidx & 1) tots = tt; else totq = tt;
           }
-#pragma unroll
-          for (int k = 0; k < PF; ++k) {
-            totq += (k < nq) ? vq[k] : 0.0f;
-            tots += (k < ns) ? vs[k] : 0.0f;
-          }
+          __syncthreads();
         }
-        for (int c0 = PF; c0 < nq; c0 += 2 * PF) {                  // hub rows: 32 partials per round trip
-          float vq[2 * PF];
-#pragma unroll
-          for (int k = 0; k < 2 * PF; ++k) vq[k] = cld(S.chunk_part + (int64_t)(qa + min(c0 + k, nq - 1)) * 64 + lane);
-#pragma unroll
-          for (int k = 0; k < 2 * PF; ++k) totq += (c0 + k < nq) ? vq[k] : 0.0f;
-        }
-        for (int c0 = PF; c0 < ns; c0 += 2 * PF) {
-          float vs[2 * PF];
-#pragma unroll
-          for (int k = 0; k < 2 * PF; ++k) vs[k] = cld(S.chunk_part + (int64_t)(sa + min(c0 + k, ns - 1)) * 64 + lane);
-#pragma unroll
-          for (int k = 0; k < 2 * PF; ++k) tots += (c0 + k < ns) ? vs[k] : 0.0f;
-        }
+        if (!act) continue;
         const float nb_r = (1.0f / (float)rq) * totq;                                            // mask_row = mask / rowsum  graphsage.py:317
-        if (on) S.nbar[(int64_t)row * D + lane] = nb_r;                                          // to_feats_neigh[q, :]
+        if (on) S.nbar[(unsigned)row * D + lane] = nb_r;                                          // to_feats_neigh[q, :]
         float c_r = hs_r;                                                                        // combined_all[:, q] = h1[src] ...
         if (from_gen) {                                                                          // ... or gen[src] = relu(fc nbar[src])  :428-430
           const float nbm = on ? (1.0f / (float)rs) * tots : 0.0f;
           float a = 0.0f;
-          for (int d2 = 0; d2 < D; ++d2) a = fmaf(fct[d2 * FCS + d], rl(nbm, d2), a);
+#pragma unroll 16
+          for (int d2 = 0; d2 < GGAD_MAX_D; ++d2) a = fmaf(fct[d2 * FCS + d], rl(nbm, d2), a);
           c_r = fmaxf(a, 0.0f);
-          if (on) S.gen[(int64_t)src * D + lane] = c_r;
+          if (on) S.gen[(unsigned)src * D + lane] = c_r;
         }
         const float wd = on ? wd_r : 0.0f, c = on ? c_r : 0.0f, nb = on ? nb_r : 0.0f;
         const float hs = (on && from_gen) ? hs_r : 0.0f;
@@ -425,10 +484,10 @@ __global__ void __launch_bounds__(XT) k_train_chunk_xcd(XcdArgs A) {
         if (from_gen) { const float dl2 = hs - c; recn_ = sqrtf(wave_sum_fast(dl2 * dl2)); }     // recon2   graphsage.py:197-198
         const float o0 = (1.0f - (float)y) * pv.s - log_sigmoid(pv.s);                           // BCEWithLogits, pos_weight 1 :246
         const float sv = lane == 0 ? pv.s : lane == 1 ? pv.aff : lane == 2 ? pv.na : lane == 3 ? pv.nbn : recn_;
-        if (lane < 5) A.pos_scal[(int64_t)q * 8 + lane] = sv;
+        if (lane < 5) A.pos_scal[(unsigned)q * 8 + lane] = sv;
         const float ov = lane == 0 ? o0 : lane == 1 ? (y == 0 ? pv.aff : 0.0f) : lane == 2 ? (y == 1 ? pv.aff : 0.0f)
                        : lane == 3 ? recn_ : lane == 4 ? (y == 0 ? 1.0f : 0.0f) : (y == 1 ? 1.0f : 0.0f);
-        if (lane < 6) A.pos_o[(int64_t)lane * A.ld_o + q] = ov;
+        if (lane < 6) A.pos_o[(unsigned)lane * A.ld_o + q] = ov;
       }
     }
     XCD_TICK(2)
@@ -438,16 +497,16 @@ __global__ void __launch_bounds__(XT) k_train_chunk_xcd(XcdArgs A) {
     // ================================================================ C: loss scalars, row coefficients per piece, dW partial
     auto row_load = [&](int rv) {                         // what the coefficients of a piece's row read (written in phases A / R)
       RowIn in;
-      const int row = ri(rv, 0) >> 6, q1 = ri(rv, 4), m2 = ri(rv, 5);
+      const int row = ri(rv, 0) >> 6, fl2 = ri(rv, 2), q1 = ri(rv, 4), m2 = ri(rv, 5);
       const int i = row - row0;
-      const int64_t off = (int64_t)row * D + d;
+      const unsigned off = (unsigned)row * D + d;
       in.H1 = cld(S.h1 + off);
       in.NB = cld(S.nbar + off);
-      in.Gl = cld(S.gen + off);
-      in.p1v = cld(A.pos_scal + (int64_t)q1 * 8 + l8);
-      in.p2v = cld(A.pos_scal + (int64_t)i * 8 + l8);
-      in.nbq = cld(S.nbar + (int64_t)(row0 + q1) * D + d);
-      in.c2 = cld(((m2 & 2) ? S.gen : S.h1) + (int64_t)(m2 >> 2) * D + d);
+      in.Gl = (fl2 & 1) ? cld(S.gen + off) : 0.0f;
+      in.pp = cld(A.pos_scal + (unsigned)(lane < 8 ? q1 : i) * 8 + l8);
+      in.nbq = cld(S.nbar + (unsigned)(row0 + q1) * D + d);
+      in.c2 = cld(((m2 & 2) ? S.gen : S.h1) + (unsigned)(m2 >> 2) * D + d);
+      in.xr = (fl2 & 2) ? S.x1[(unsigned)row * XFT + fl] : 0.0f;      // first piece of its row: the row's own item
       return in;
     };
     RowIn inc[XPC];
@@ -462,10 +521,10 @@ __global__ void __launch_bounds__(XT) k_train_chunk_xcd(XcdArgs A) {
       for (int k = 0; k < 6; ++k) {
         float v = 0.0f;
         for (int g = lane; g < nwg; g += GGAD_WAVE) {
-          const float *po = A.pos_o + (int64_t)k * A.ld_o + 4 * g;
-          const float o0 = cld(po), o1 = 4 * g + 1 < B ? cld(po + 1) : 0.0f;
-          const float o2 = 4 * g + 2 < B ? cld(po + 2) : 0.0f, o3 = 4 * g + 3 < B ? cld(po + 3) : 0.0f;
-          v += (o0 + o1) + (o2 + o3);
+          const float *po = A.pos_o + (unsigned)k * A.ld_o + 4 * g;
+          const f2 oa = cld2(po), ob = cld2(po + 2);
+          const float o1 = 4 * g + 1 < B ? oa.y : 0.0f, o2 = 4 * g + 2 < B ? ob.x : 0.0f, o3 = 4 * g + 3 < B ? ob.y : 0.0f;
+          v += (oa.x + o1) + (o2 + o3);
         }
         const float tk = wave_sum_fast(v);
         tv = lane == k ? tk : tv;
@@ -492,7 +551,6 @@ __global__ void __launch_bounds__(XT) k_train_chunk_xcd(XcdArgs A) {
     const float active = (mg >= 0.0f) ? 1.0f : 0.0f;                       // clamp_min backward: pass where x >= min
     const float rec_coef = 0.1f / t[5];
     const int n0 = (int)t[4], n1 = (int)t[5];
-    for (int j = threadIdx.x; j < min(n1, XRA); j += XT) ra_lds[j] = S.pos_meta[row0 + n0 + j] >> 2;   // for phase E
     if (rank == 0 && threadIdx.x == 0) {
       const float margin = fmaxf(mg, 0.0f), rec = t[3] / t[5];
       log8[0] = cls + margin + 0.1f * rec;                                 // graphsage.py:258
@@ -502,55 +560,61 @@ __global__ void __launch_bounds__(XT) k_train_chunk_xcd(XcdArgs A) {
     }
     // backward coefficients of a piece's row (k_loss_rows of step.hip); first piece of the row: its wave also owns the row's x1
     // item, dz and the d w term
+    // (the coefficients use hardware reciprocals, 1 ulp, where the launch chain divides: ~1e-7 relative, inside the tolerance the
+    //  two paths are compared with; the loss values above are computed with true divisions)
+    const float inv_fB = 1.0f / fB, inv_t4 = 1.0f / t[4], inv_t5 = 1.0f / t[5];
+    auto qd = [](float a, float b2) { return a * __frcp_rn(b2); };
     auto row_coefs = [&](int rv, const RowIn &in, float &cg, float &ca) {
       const int row = ri(rv, 0) >> 6, fl2 = ri(rv, 2), r = ri(rv, 3);
       const int y = fl2 & 1, y1 = (fl2 >> 2) & 1;
       const bool first = (fl2 & 2) != 0;
       const int i = row - row0;
-      const int64_t off = (int64_t)row * D + d;
-      const float H1 = in.H1, NB = in.NB, Gl = in.Gl, p1v = in.p1v, p2v = in.p2v, nbq = in.nbq, c2 = in.c2;
-      const float s1 = rl(p1v, 0), aff1 = rl(p1v, 1), na1 = rl(p1v, 2), nbn1 = rl(p1v, 3), recn_ = rl(p1v, 4);
-      const float aff2 = rl(p2v, 1), na2 = rl(p2v, 2), nbn2 = rl(p2v, 3);
+      const unsigned off = (unsigned)row * D + d;
+      const float H1 = in.H1, NB = in.NB, Gl = in.Gl, pp = in.pp, nbq = in.nbq, c2 = in.c2;
+      const float s1 = rl(pp, 0), aff1 = rl(pp, 1), na1 = rl(pp, 2), nbn1 = rl(pp, 3), recn_ = rl(pp, 4);
+      const float aff2 = rl(pp, 9), na2 = rl(pp, 10), nbn2 = rl(pp, 11);
       const float Gv = (y == 1) ? Gl : 0.0f;
       const float Cc = (y == 1) ? Gv : H1;                                 // this row's column of combined_all
       const float wd = on ? wd_r : 0.0f;
       const float nac1 = fmaxf(na1, 1e-8f), nbc1 = fmaxf(nbn1, 1e-8f);
-      const float ds = (1.0f / (1.0f + expf(-s1)) - (float)y1) / fB;
-      const float gq1 = active * (y1 == 0 ? -1.0f / t[4] : 1.0f / t[5]);
-      const float cA = na1 > 0.0f ? Cc / na1 : 0.0f;
-      const float dC = ds * wd + gq1 * ((nbq / nbc1) / nac1 - (aff1 / nac1) * cA);
+      const float ds = (qd(1.0f, 1.0f + __expf(-s1)) - (float)y1) * inv_fB;
+      const float gq1 = active * (y1 == 0 ? -inv_t4 : inv_t5);
+      const float cA = na1 > 0.0f ? qd(Cc, na1) : 0.0f;
+      const float inac1 = __frcp_rn(nac1);
+      const float dC = ds * wd + gq1 * ((nbq * __frcp_rn(nbc1)) * inac1 - (aff1 * inac1) * cA);
       float gH = dC, gG = 0.0f;
       if (y == 1) {                                                        // recon term 0.1 * mean_i |h1_i - gen_i|  graphsage.py:258
-        const float tt = rec_coef * ((H1 - Gv) / recn_);
+        const float tt = rec_coef * qd(H1 - Gv, recn_);
         gH = tt; gG = dC - tt;
       }
       const float nac2 = fmaxf(na2, 1e-8f), nbc2 = fmaxf(nbn2, 1e-8f);
-      const float gq2 = active * (y == 0 ? -1.0f / t[4] : 1.0f / t[5]);
-      const float cb = nbn2 > 0.0f ? NB / nbn2 : 0.0f;
-      float dNb = gq2 * ((c2 / nac2) / nbc2 - (aff2 / nbc2) * cb);
+      const float gq2 = active * (y == 0 ? -inv_t4 : inv_t5);
+      const float cb = nbn2 > 0.0f ? qd(NB, nbn2) : 0.0f;
+      const float inbc2 = __frcp_rn(nbc2);
+      float dNb = gq2 * ((c2 * __frcp_rn(nac2)) * inbc2 - (aff2 * inbc2) * cb);
       if (y == 1) {
         const float dZ = (Gv > 0.0f) ? gG : 0.0f;                          // relu(fc(.))
         if (first && on) S.dz[off] = dZ;
         const float dZm = on ? dZ : 0.0f;
         float a = 0.0f;
-        for (int dd = 0; dd < D; ++dd) a = fmaf(fct[d * FCS + dd], rl(dZm, dd), a);   // fc^T dZ: fc[dd][d] = fct[d][dd]
+#pragma unroll 16
+        for (int dd = 0; dd < GGAD_MAX_D; ++dd) a = fmaf(fct[d * FCS + dd], rl(dZm, dd), a);   // fc^T dZ: fc[dd][d] = fct[d][dd]
         dNb += a;
       }
       ca = (on && H1 > 0.0f) ? gH : 0.0f;
-      cg = on ? dNb * (1.0f / (float)r) : 0.0f;
-      if (first) A.gw_row[(int64_t)i * GGAD_WAVE + lane] = on ? ds * Cc : 0.0f;       // d w = sum_q ds_q * combined_all[:, q]
+      cg = on ? dNb * __frcp_rn((float)r) : 0.0f;
+      if (first) A.gw_row[(unsigned)i * GGAD_WAVE + lane] = on ? ds * Cc : 0.0f;       // d w = sum_q ds_q * combined_all[:, q]
     };
-    for (int vw = rank; vw < NVWG; vw += G) {
-      const int v = vw + NVWG * wid;
+    {
+      const int vw = rank, v = v0;
       f4 dacc[XNT];                                         // dW[16 t + 4 g + v'][f = a], f < 16
-      float d16[XNT], accr[XFT];                            // dW[16 t + a][16] (partial over the lane group), row items (lane = channel)
+      float d16[XNT];                                       // dW[16 t + a][16] (partial over the lane group)
 #pragma unroll
       for (int t4 = 0; t4 < XNT; ++t4) { dacc[t4] = f4{0.0f, 0.0f, 0.0f, 0.0f}; d16[t4] = 0.0f; }
-#pragma unroll
-      for (int f = 0; f < XFT; ++f) accr[f] = 0.0f;
       auto bwd_piece = [&](int rv, const RowIn &in, const PieceX &P) {
         float cg, ca;
         row_coefs(rv, in, cg, ca);
+        XCD_TICK(13)
         f4 h[XNT];
         piece_fwd(P, WB, h);                                // h2 recomputed exactly as in phase A: the relu mask
         float x16[4];
@@ -566,11 +630,18 @@ __global__ void __launch_bounds__(XT) k_train_chunk_xcd(XcdArgs A) {
             d16[t4] = fmaf(cf, x16[vv], d16[t4]);
           }
         }
-        if (ri(rv, 2) & 2) {                                // the row's own item: coef_a (x) x1[row]
-          const float x1v = S.x1[(int64_t)(ri(rv, 0) >> 6) * XFT + fl];
+        if (ri(rv, 2) & 2) {                                // the row's own item coef_a (x) x1[row]: one more k-step, entry slot g = 0
+          const float xb = lg == 0 ? in.xr : 0.0f;           // lanes 0..15 of in.xr = features 0..15, lane 16 = feature 16
+          const float x16r = rl(in.xr, 16);
 #pragma unroll
-          for (int f = 0; f < XFT; ++f) accr[f] = fmaf(ca, rl(x1v, f), accr[f]);
+          for (int t4 = 0; t4 < XNT; ++t4) {
+            const float cat = __shfl(ca, 16 * t4 + la, GGAD_WAVE);
+            const float af = lg == 0 ? cat : 0.0f;
+            dacc[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, xb, dacc[t4], 0, 0, 0);
+            d16[t4] = fmaf(af, x16r, d16[t4]);
+          }
         }
+        XCD_TICK(14)
       };
 #pragma unroll
       for (int j = 0; j < XPC; ++j) {
@@ -583,10 +654,6 @@ __global__ void __launch_bounds__(XT) k_train_chunk_xcd(XcdArgs A) {
           }
           bwd_piece(recv[j], inc[j], xc[j]);
         }
-        if (j == 0 && more) {                               // next step's operands: requested while this step's pieces are worked on
-#pragma unroll
-          for (int jj = 0; jj < XPC; ++jj) issue_ops(recn[jj], xn[jj]);
-        }
       }
       for (int w = v + XPC * NVW; w < nck; w += NVW) {
         const int rv = piece_rec(ck0 + w);
@@ -594,6 +661,10 @@ __global__ void __launch_bounds__(XT) k_train_chunk_xcd(XcdArgs A) {
         issue_ops(rv, P);
         const RowIn in = row_load(rv);
         bwd_piece(rv, in, P);
+      }
+      if (more) {                                           // next step's operands: behind every load of this phase, they land
+#pragma unroll
+        for (int jj = 0; jj < XPC; ++jj) issue_ops(recn[jj], xn[jj]);     // during the combine, the barrier and phase E
       }
       // dW partial of the virtual workgroup: its 8 waves in a fixed tree
       XCD_TICK(11)
@@ -609,15 +680,16 @@ __global__ void __launch_bounds__(XT) k_train_chunk_xcd(XcdArgs A) {
         s16 += __shfl_xor(s16, 32, GGAD_WAVE);
         if (lg == 0) mine[dw_pos(16, 16 * t4 + la)] = s16;
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int f = 0; f < XFT; ++f) mine[dw_pos(f, lane)] += accr[f];
       __syncthreads();
-      float *out = A.dw_part + (int64_t)vw * XFT * GGAD_WAVE;
-      for (int i = threadIdx.x; i < XFT * GGAD_WAVE; i += XT) {
-        const int p = dw_pos(i >> 6, i & 63);
-        out[i] = ((accw[0][p] + accw[1][p]) + (accw[2][p] + accw[3][p])) + ((accw[4][p] + accw[5][p]) + (accw[6][p] + accw[7][p]));
+      float *out = A.dw_part + (unsigned)vw * XFT * GGAD_WAVE;
+      for (int i = 4 * threadIdx.x; i < XFT * GGAD_WAVE; i += 4 * XT) {     // [f][ch], four channels per thread
+        f4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int p = dw_pos(i >> 6, (i & 63) + k);
+          o[k] = ((accw[0][p] + accw[1][p]) + (accw[2][p] + accw[3][p])) + ((accw[4][p] + accw[5][p]) + (accw[6][p] + accw[7][p]));
+        }
+        *reinterpret_cast<f4 *>(out + i) = o;
       }
     }
     XCD_TICK(4)
@@ -625,60 +697,69 @@ __global__ void __launch_bounds__(XT) k_train_chunk_xcd(XcdArgs A) {
     XCD_TICK(5)
 
     // ================================================================ E: gradient reduction, [exchange,] Adam
-    // virtual workgroup vw owns  W[:, f = vw] (vw < 17),  w (vw == 17),  fc[2 vw], fc[2 vw + 1];  wave = sub-reducer
-    for (int vw = rank; vw < NVWG; vw += G) {
-      float gW = 0.0f, gw = 0.0f, g0 = 0.0f, g1 = 0.0f;
-      const int dd0 = 2 * vw, dd1 = 2 * vw + 1;
+    // workgroup vw owns  W[:, f = vw] (vw < 17),  w (vw == 17),  fc[vw], fc[vw + nv], fc[vw + 2 nv];  wave = sub-reducer
+    {
+      const int vw = rank;
+      float gW = 0.0f, gw = 0.0f, gf[3] = {0.0f, 0.0f, 0.0f};
+      int ddk[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) ddk[k] = vw + k * nv;      // (nv >= 22: three rows cover D <= 64)
       int pidx = -1, sel = 0;
       if (wid == 0 && vw < XFT && on) { pidx = L.o_W() + lane * XFT + vw; sel = 0; }
       if (wid == 1 && vw == XFT && on) { pidx = lane; sel = 64; }
-      if (wid == 2 && dd0 < D && on) { pidx = L.o_fc() + dd0 * D + lane; sel = 128; }
-      if (wid == 3 && dd1 < D && on) { pidx = L.o_fc() + dd1 * D + lane; sel = 192; }
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        if (wid == 2 + k && ddk[k] < D && on) { pidx = L.o_fc() + ddk[k] * D + lane; sel = 128 + 64 * k; }
       // every load of the wave first (one round trip), then the arithmetic: label-1 rows wid, wid + 8, ... in blocks of EU;
       // the optimiser state of the parameter this thread owns comes with them (through the L2: the 128-byte lines of params /
       // exp_avg / exp_avg_sq hold words owned by other compute units -- W is strided by F)
-      constexpr int EU = 8;
-      float pw[NVWG / XW];
+      constexpr int EU = 8, PWN = XMAXWG / XW;
+      float pw[PWN];
       if (vw < XFT) {
 #pragma unroll
-        for (int k = 0; k < NVWG / XW; ++k) pw[k] = cld(A.dw_part + (int64_t)(wid * (NVWG / XW) + k) * XFT * GGAD_WAVE + vw * GGAD_WAVE + lane);
+        for (int k = 0; k < PWN; ++k) pw[k] = cld(A.dw_part + (unsigned)min(wid * PWN + k, nv - 1) * XFT * GGAD_WAVE + vw * GGAD_WAVE + lane);
       }
-      const int pl = pidx >= 0 ? pidx : 0;
-      const float ap = cld(params + pl), am = cld(S.exp_avg + pl), av = cld(S.exp_avg_sq + pl);
-      if (dd0 < D) {
+      float ap = 0.0f, am = 0.0f, av = 0.0f;
+      if (wid < 5) {
+        const int pl = pidx >= 0 ? pidx : 0;
+        ap = cld(params + pl); am = cld(S.exp_avg + pl); av = cld(S.exp_avg_sq + pl);
+      }
+      {
         for (int j0 = wid; j0 < n1; j0 += XW * EU) {         // label-1 rows = sources of the last n1 columns, in order
           float dzr[EU], nbr[EU];
 #pragma unroll
           for (int u = 0; u < EU; ++u) {
             const int j = min(j0 + u * XW, n1 - 1);
-            const int ra = j < XRA ? ra_lds[j] : (S.pos_meta[row0 + n0 + j] >> 2);
-            dzr[u] = cld(S.dz + (int64_t)ra * D + d);
-            nbr[u] = cld(S.nbar + (int64_t)ra * D + d);
+            const int ra = (j < XRA && !(A.dbg & 2)) ? ra_lds[j] : (S.pos_meta[row0 + n0 + j] >> 2);
+            dzr[u] = cld(S.dz + (unsigned)ra * D + d);
+            nbr[u] = cld(S.nbar + (unsigned)ra * D + d);
           }
 #pragma unroll
           for (int u = 0; u < EU; ++u) {
             if (j0 + u * XW < n1) {
               const float dzm = on ? dzr[u] : 0.0f;
-              g0 = fmaf(rl(dzm, dd0), nbr[u], g0);            // d fc[dd][d2] = sum_i dZ_i[dd] * nbar_i[d2]
-              g1 = fmaf(rl(dzm, dd1 < D ? dd1 : dd0), nbr[u], g1);
+#pragma unroll
+              for (int k = 0; k < 3; ++k) gf[k] = fmaf(rl(dzm, min(ddk[k], GGAD_MAX_D - 1)), nbr[u], gf[k]);   // d fc[dd][d2] = sum_i dZ_i[dd] * nbar_i[d2]
             }
           }
         }
       }
       if (vw < XFT) {
 #pragma unroll
-        for (int k = 0; k < NVWG / XW; ++k) gW += pw[k];
+        for (int k = 0; k < PWN; ++k) gW += (wid * PWN + k < nv) ? pw[k] : 0.0f;
       } else if (vw == XFT) {
         for (int i0 = wid; i0 < B; i0 += XW * EU) {
           float gr[EU];
 #pragma unroll
-          for (int u = 0; u < EU; ++u) gr[u] = cld(A.gw_row + (int64_t)min(i0 + u * XW, B - 1) * GGAD_WAVE + lane);
+          for (int u = 0; u < EU; ++u) gr[u] = cld(A.gw_row + (unsigned)min(i0 + u * XW, B - 1) * GGAD_WAVE + lane);
 #pragma unroll
           for (int u = 0; u < EU; ++u) gw += (i0 + u * XW < B) ? gr[u] : 0.0f;
         }
       }
       __syncthreads();
-      accw[wid][lane] = gW; accw[wid][64 + lane] = gw; accw[wid][128 + lane] = g0; accw[wid][192 + lane] = g1;
+      accw[wid][lane] = gW; accw[wid][64 + lane] = gw;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) accw[wid][128 + 64 * k + lane] = gf[k];
       __syncthreads();
       if (pidx >= 0) {
         float g = 0.0f;
@@ -705,7 +786,7 @@ __global__ void __launch_bounds__(XT) k_train_chunk_xcd(XcdArgs A) {
 struct XcdPrepArgs {
   const int32_t *batch_ptr, *ent_ptr, *row_ck_ptr, *ck_rc, *ck_e0, *ent_own, *labels, *pos_meta, *row_pos;
   float *x2;
-  int32_t *ck_rec, *pos_rec;
+  int32_t *ck_rec, *pos_rec, *batch_n0;
   int n_batches, n_rows, n_pieces, n_ents;
 };
 __global__ void __launch_bounds__(256) k_xcd_prep(XcdPrepArgs P) {
@@ -743,6 +824,13 @@ __global__ void __launch_bounds__(256) k_xcd_prep(XcdPrepArgs P) {
       sa = P.row_ck_ptr[src]; ns = P.row_ck_ptr[src + 1] - sa; rs = P.ent_ptr[src + 1] - P.ent_ptr[src];
     }
     o[4] = sa; o[5] = ns; o[6] = rs; o[7] = 0;
+    // the columns of combined_all are the label-0 rows, then the label-1 rows (graphsage.py:450; bit 1 = the source row's label;
+    // bit 0 is the label of ROW q in original order, the reference's quirk): n0 = the first column with a label-1 source
+    int lo = 0, hi = P.n_batches;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (P.batch_ptr[mid] <= row) lo = mid; else hi = mid; }
+    const int r0 = P.batch_ptr[lo], r1 = P.batch_ptr[lo + 1];
+    if ((meta & 2) && (row == r0 || !(P.pos_meta[row - 1] & 2))) P.batch_n0[lo] = row - r0;
+    if (!(meta & 2) && row == r1 - 1) P.batch_n0[lo] = r1 - r0;
   }
   // x2 is stored at owner entries (the reference's deduplicated unique_nodes_list, graphsage.py:306); the other entries of a
   // (batch, column) get a copy of their owner's row, so that the rows of a piece are the consecutive entries [e0, e0 + cnt)
@@ -819,13 +907,14 @@ __global__ void __launch_bounds__(GGAD_WAVE) k_xcd_warm(XcdWarmArgs P) {
 
 extern "C" {
 
-int32_t ggad_mb_xcd_grid(void) { return 8 * NVWG; }
+int32_t ggad_mb_xcd_grid(void) { return 8 * XMAXWG; }
 
 int64_t ggad_mb_xcd_workspace_elems(int32_t max_rows, int32_t D, int32_t F, int64_t rows_cap, int64_t pieces_cap) {
   if (max_rows < 1 || D < 1 || F < 1 || rows_cap < 0 || pieces_cap < 0) return 0;
+  // (the per-batch table at the end holds at most rows_cap entries: a batch has at least one row)
   const int64_t ld = ((int64_t)max_rows + 3) / 4 * 4;
-  return 256 + (int64_t)max_rows * 8 + 8 * ld + (int64_t)max_rows * GGAD_WAVE + (int64_t)NVWG * F * GGAD_WAVE +
-         (rows_cap + pieces_cap + 2) * REC;
+  return 256 + (int64_t)max_rows * 8 + 8 * ld + (int64_t)max_rows * GGAD_WAVE + (int64_t)XMAXWG * F * GGAD_WAVE +
+         (rows_cap + pieces_cap + 2) * REC + rows_cap + 1;
 }
 
 /* The dense steps of a whole chunk as ONE launch resident on one XCD (see the header of this file).  tmpl as for
@@ -833,9 +922,10 @@ int64_t ggad_mb_xcd_workspace_elems(int32_t max_rows, int32_t D, int32_t F, int6
  * workspace: float[ggad_mb_xcd_workspace_elems(largest batch, D, F)], 16-byte aligned; xchg NULL = single GPU. */
 int ggad_mb_train_chunk_xcd(const ggad_mb_step *tmpl, int32_t n_batches, const int32_t *batch_ptr_dev, int32_t max_rows,
                             int32_t n_rows, int32_t n_pieces, int32_t n_ents, int64_t rows_cap, int64_t pieces_cap, float *loss_log,
-                            int32_t log_base, float *workspace, float grad_scale, ggad_xchg *xchg, ggad_stream_t stream) {
+                            int32_t log_base, float *workspace, float grad_scale, ggad_xchg *xchg, int32_t n_wg, ggad_stream_t stream) {
   GGAD_REQUIRE(tmpl && batch_ptr_dev && loss_log && workspace && n_batches >= 0 && log_base >= 0 && max_rows >= 1);
   GGAD_REQUIRE(n_rows >= 0 && n_pieces >= 0 && n_ents >= 0 && n_rows <= rows_cap && n_pieces <= pieces_cap);
+  GGAD_REQUIRE((int64_t)n_ents * XFT < ((int64_t)1 << 31) && (int64_t)n_pieces * 64 < ((int64_t)1 << 31));      // 32-bit element offsets
   const ggad_mb_step &s = *tmpl;
   GGAD_REQUIRE(s.params && s.exp_avg && s.exp_avg_sq && s.grads && s.step_counter && s.x1 && s.x2 && s.ent_ptr && s.ent_own &&
                s.labels && s.pos_meta && s.row_pos && s.h1 && s.nbar && s.gen && s.dz && s.row_ck_ptr && s.ck_rc && s.ck_e0 &&
@@ -853,9 +943,10 @@ int ggad_mb_train_chunk_xcd(const ggad_mb_step *tmpl, int32_t n_batches, const i
   A.pos_o = A.pos_scal + (int64_t)max_rows * 8;
   A.gw_row = A.pos_o + (int64_t)8 * A.ld_o;
   A.dw_part = A.gw_row + (int64_t)max_rows * GGAD_WAVE;
-  int32_t *recs = reinterpret_cast<int32_t *>(A.dw_part + (int64_t)NVWG * XFT * GGAD_WAVE);
+  int32_t *recs = reinterpret_cast<int32_t *>(A.dw_part + (int64_t)XMAXWG * XFT * GGAD_WAVE);
   A.pos_rec = recs;
   A.ck_rec = recs + (rows_cap + 1) * REC;
+  A.batch_n0 = recs + (rows_cap + pieces_cap + 2) * REC;
   A.grad_scale = grad_scale;
   static const unsigned long long timeout = [] {            // barrier time-out in seconds (wall clock, 100 MHz ticks)
     const char *e = getenv("GGAD_XCD_TIMEOUT_S");
@@ -863,6 +954,14 @@ int ggad_mb_train_chunk_xcd(const ggad_mb_step *tmpl, int32_t n_batches, const i
     return (unsigned long long)((sec > 0.001 ? sec : 0.001) * 1e8);
   }();
   A.timeout_ticks = timeout;
+  static const int dbg = [] { const char *e = getenv("GGAD_XCD_DEBUG"); return e ? atoi(e) : 0; }();
+  A.dbg = dbg;
+  // workgroups that stay (= compute units of the chosen XCD the stream may use) and the XCD: GGAD_XCD_WGS / GGAD_XCD_ID
+  static const int env_nv = [] { const char *e = getenv("GGAD_XCD_WGS"); return e ? atoi(e) : 0; }();
+  static const int env_xcd = [] { const char *e = getenv("GGAD_XCD_ID"); return e ? atoi(e) : 0; }();
+  A.nv = n_wg > 0 ? n_wg : (env_nv > 0 ? env_nv : XMAXWG);
+  A.want_xcd = env_xcd & 7;
+  GGAD_REQUIRE(A.nv >= XMINWG + 4 && A.nv <= XMAXWG);     // 22..32: three fc rows per workgroup cover 64 channels
   static unsigned launch_seq = 0;
   A.launch_id = ++launch_seq ? launch_seq : ++launch_seq;      // never 0 (the cleared control block)
   hipStream_t st = as_stream(stream);
@@ -874,6 +973,7 @@ int ggad_mb_train_chunk_xcd(const ggad_mb_step *tmpl, int32_t n_batches, const i
     Q.ent_own = s.ent_own; Q.labels = s.labels; Q.pos_meta = s.pos_meta; Q.row_pos = s.row_pos;
     Q.x2 = const_cast<float *>(s.x2);
     Q.ck_rec = const_cast<int32_t *>(A.ck_rec); Q.pos_rec = const_cast<int32_t *>(A.pos_rec);
+    Q.batch_n0 = const_cast<int32_t *>(A.batch_n0);
     Q.n_batches = n_batches; Q.n_rows = n_rows; Q.n_pieces = n_pieces; Q.n_ents = n_ents;
     const int64_t work = std::max<int64_t>(std::max<int64_t>(n_rows, n_pieces), ((int64_t)n_ents * XFT + 3) / 4);
     const unsigned blocks = (unsigned)std::min<int64_t>((work + 255) / 256, 8192);
@@ -908,11 +1008,13 @@ int ggad_mb_train_chunk_xcd(const ggad_mb_step *tmpl, int32_t n_batches, const i
     A.X = xchg->view;
     A.xstep0 = xchg->step;
     xchg->step += (uint32_t)n_batches;
-    k_train_chunk_xcd<2><<<dim3(8 * NVWG), dim3(XT), 0, st>>>(A);
+    if (s.D == 64) k_train_chunk_xcd<2, 64><<<dim3(8 * A.nv), dim3(XT), 0, st>>>(A);
+    else k_train_chunk_xcd<2, 0><<<dim3(8 * A.nv), dim3(XT), 0, st>>>(A);
   } else {
     A.X = ggad_xchg_view{};
     A.xstep0 = 0;
-    k_train_chunk_xcd<1><<<dim3(8 * NVWG), dim3(XT), 0, st>>>(A);
+    if (s.D == 64) k_train_chunk_xcd<1, 64><<<dim3(8 * A.nv), dim3(XT), 0, st>>>(A);
+    else k_train_chunk_xcd<1, 0><<<dim3(8 * A.nv), dim3(XT), 0, st>>>(A);
   }
   GGAD_CHECK_LAUNCH("mb_train_chunk_xcd");
   if (sd) {

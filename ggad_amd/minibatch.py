@@ -312,6 +312,7 @@ class MiniBatchEngine:
             raise ValueError("the XCD-resident chunk kernel needs F == 17, D <= 64 and chain 0")
         self.resident = bool(resident)
         self.xcd_ws = None
+        self.xcd_wgs = 0                 # workgroups of the resident launch that stay (0 = 32: a whole XCD)
         self._xcd_rows = 0
         self._xcd_caps = (0, 0)
         if self.D > self.lib.ggad_max_embed_dim():
@@ -419,7 +420,7 @@ class MiniBatchEngine:
             _lib.check(self.lib.ggad_mb_train_chunk_xcd(ctypes.byref(s), ch.n_batches, ptr(ch.batch_ptr), self._xcd_rows,
                                                          ch.n_rows, ch.n_chunks, ch.n_ents, self._xcd_caps[0], self._xcd_caps[1],
                                                          self.loss_log.data_ptr(), log_base, ptr(self.xcd_ws), 1.0 / world_size,
-                                                         exchange.handle if exchange is not None else None, stream),
+                                                         exchange.handle if exchange is not None else None, int(self.xcd_wgs), stream),
                        "ggad_mb_train_chunk_xcd")
             return
         if exchange is not None:

@@ -331,16 +331,18 @@ int ggad_mb_train_chunk_xchg(const ggad_mb_step *tmpl, int32_t n_batches, const 
  * src/model_handler.py:330-364 (GCNEncoder.forward + GCN.loss src/graphsage.py:395-454,171-258, backward, Adam) -- as ONE
  * launch whose workgroups all stay on one XCD (one shared L2): hand-offs between the phases of a step are plain stores + L2-served
  * loads, barriers are tagged-slot all-gathers inside that L2 (0.43 us), nothing is written back or invalidated between steps.
- * The launch is placement-independent (workgroups register per XCD at run time; the fullest XCD stays, the rest exit) and
- * deterministic for any number of surviving workgroups.  Requirements: F == 17, D <= 64, the row-piece tables of the plan
+ * The launch has 8 n_wg workgroups (n_wg = 22..32, 0 = 32: the compute units of one XCD the stream may use); the dispatcher
+ * deals exactly n_wg to every XCD, the ones on XCD GGAD_XCD_ID (default 0) stay, the rest leave at once.  Results are
+ * deterministic and independent of n_wg's placement; if fewer than n_wg workgroups ever reached that XCD the launch times out
+ * (error 2) instead of hanging.  Requirements: F == 17, D <= 64, the row-piece tables of the plan
  * (row_ck_ptr / ck_rc / ck_e0 / chunk_part of ggad_mb_step).  batch_ptr_dev: DEVICE int32[n_batches + 1] row offsets (the
  * staging block of ggad_mb_plan_build holds them); max_rows: rows of the largest batch; n_rows / n_pieces / n_entries: totals of
  * the chunk (rows_cap / pieces_cap: what the workspace was sized for); workspace:
  * float[ggad_mb_xcd_workspace_elems(max_rows, D, F, rows_cap, pieces_cap)], 16-byte aligned.  A whole-chip launch first
  * flattens the plan's tables into one 32-byte record per piece / per position (in the workspace) and copies the x2 row of every
  * owner entry to the other entries of its (batch, column) -- x2 is written, at non-owner entries only; xchg NULL = single GPU, else the one-shot exchange runs
- * inside the reduction phase of every step (grad_scale = 1 / world size).  The grid is ggad_mb_xcd_grid() workgroups of 512
- * threads: the stream must be able to keep ggad_mb_xcd_grid() / 8 of them resident on one XCD.
+ * inside the reduction phase of every step (grad_scale = 1 / world size).  Workgroups have 512 threads and need a compute unit
+ * each: the stream must be able to keep n_wg of them resident on that XCD (ggad_mb_xcd_grid() = the largest grid, 8 x 32).
  * ggad_mb_xcd_status: control words of the last launch on `workspace` (synchronises `stream`): out[0] error (0 ok, 1 barrier
  * time-out, 2 registration time-out; GGAD_XCD_TIMEOUT_S seconds, default 10), out[1] workgroups that stayed, out[2] their XCD,
  * out[3..10] wall clocks of rank 0 in 10 ns ticks: phase A, barrier, R, barrier, C, barrier, E, barrier; out[11..18] sub-phase
@@ -349,7 +351,7 @@ int32_t ggad_mb_xcd_grid(void);
 int64_t ggad_mb_xcd_workspace_elems(int32_t max_rows, int32_t D, int32_t F, int64_t rows_cap, int64_t pieces_cap);
 int ggad_mb_train_chunk_xcd(const ggad_mb_step *tmpl, int32_t n_batches, const int32_t *batch_ptr_dev, int32_t max_rows,
                             int32_t n_rows, int32_t n_pieces, int32_t n_ents, int64_t rows_cap, int64_t pieces_cap, float *loss_log,
-                            int32_t log_base, float *workspace, float grad_scale, ggad_xchg *xchg, ggad_stream_t stream);
+                            int32_t log_base, float *workspace, float grad_scale, ggad_xchg *xchg, int32_t n_wg, ggad_stream_t stream);
 int ggad_mb_xcd_status(const float *workspace, int64_t *out19, ggad_stream_t stream);
 
 /* Inference embeddings: h[i] = relu(W x1[i])  (GCNEncoder.forward, train_flag False).   graphsage.py:412 */
