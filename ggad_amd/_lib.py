@@ -68,6 +68,7 @@ SIGNATURES = {
     "ggad_xchg_adam": (c_int32, [_P, _P, _P, _P, _I, _I, _F, _F, _F, _P, _P, _P]),
     "ggad_mb_train_chunk_xchg": (c_int32, [_P, _I, _P, _P, _P, _P, _I, c_float, _P, _P]),
     "ggad_mb_xcd_grid": (c_int32, []),
+    "ggad_xcd_first_of_stream": (c_int32, [_P, _P]),
     "ggad_mb_xcd_workspace_elems": (c_int64, [_I, _I, _I, _L, _L]),
     "ggad_mb_train_chunk_xcd": (c_int32, [_P, _I, _P, _I, _I, _I, _I, _L, _L, _P, _I, _P, c_float, _P, _I, _P]),
     "ggad_mb_xcd_status": (c_int32, [_P, _P, _P]),
@@ -155,7 +156,7 @@ class MbPlan(ctypes.Structure):
                                           "seg_cap")]
                 + [(n, c_int32) for n in ("feat_dim", "feat_stride", "max_batches", "rows_cap", "ck_part_stride", "train", "hop2",
                                           "node_major")]
-                + [("mean_nbr_deg", c_float)])
+                + [("mean_nbr_deg", c_float), ("xcd_skip", c_int32)])
 
 
 class MbPlanInfo(ctypes.Structure):

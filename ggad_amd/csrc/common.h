@@ -50,6 +50,23 @@ __device__ __forceinline__ int lower_bound_i32(const int32_t *__restrict__ a, in
   return lo;
 }
 
+// ---- plan launches that leave one XCD alone.  The dispatcher deals the workgroups of a launch to the eight XCDs in strict rotation
+// (block b runs on XCD (first + b) % 8, `first` a constant of the stream: scripts/xcd_block_map.hip).  While the XCD-resident chunk
+// kernel (step_xcd.hip) owns an XCD, the plan kernels of the next chunk run on the other seven: launched with ggad_skip_grid(n)
+// workgroups, every eighth one -- blockIdx.x % 8 == skip, the ones the dispatcher would put on that XCD -- returns at once and the
+// others number themselves 0 .. n' - 1 (n' >= n: every kernel bounds-checks what it derives from the number).  Which blocks are
+// skipped is decided by INDEX, so the results never depend on the placement; only the speed does.  skip < 0: plain launch.
+__device__ __forceinline__ bool ggad_vblock(int skip, unsigned &vb, unsigned &vg) {
+  const unsigned b = blockIdx.x, n = gridDim.x;
+  if (skip < 0) { vb = b; vg = n; return true; }
+  const unsigned sk = (unsigned)skip;
+  if ((b & 7u) == sk) return false;
+  vb = b - ((b >> 3) + ((b & 7u) > sk ? 1u : 0u));
+  vg = n - ((n >> 3) + ((n & 7u) > sk ? 1u : 0u));
+  return true;
+}
+static inline unsigned ggad_skip_grid(unsigned want, int skip) { return skip < 0 ? want : (unsigned)(((uint64_t)(want + 1) * 8 + 6) / 7); }
+
 // ---- internal (C++ linkage) pieces of ggad_mb_plan_build, shared between plan_build.cpp, plan.hip and hop2_ldsw.hip
 // counters[] of a plan: every counter on a 64-byte line of its own.  A device-scope atomic on ONE address (or line) completes every
 // ~7 ns whoever issues it (measured: 43 K wave-level atomics = 313 us of k_build_groups), so the plan kernels reserve storage

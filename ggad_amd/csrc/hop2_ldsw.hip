@@ -58,9 +58,11 @@ constexpr int TW_T = 1024;
 constexpr int TT_SLAB = 128;
 __global__ void __launch_bounds__(256) k_seg_transpose(const int32_t *__restrict__ tile_off, int n_tiles,
                                                        const int32_t *__restrict__ ent_own, const int32_t *__restrict__ ent_col,
-                                                       int n_ents, int64_t seg_stride, int32_t *__restrict__ seg_t) {
+                                                       int n_ents, int64_t seg_stride, int32_t *__restrict__ seg_t, int skip) {
   __shared__ int tl[TT_SLAB][65];
-  const int p0 = blockIdx.x * 64;
+  unsigned vbx, vgx;
+  if (!ggad_vblock(skip, vbx, vgx)) return;
+  const int p0 = vbx * 64;
   if (p0 >= n_ents) return;
   const int lane = lane_id(), wid = threadIdx.x >> 6;
   const int NT1 = n_tiles + 1;
@@ -107,14 +109,18 @@ __device__ __forceinline__ int block_excl_scan_1024(int v, int *warp_buf, int *t
 __global__ void __launch_bounds__(TW_T) k_tile_counts(const int32_t *__restrict__ col, const int32_t *__restrict__ seg_t,
                                                       int64_t n_cap, const int32_t *__restrict__ own_rp,
                                                       const int32_t *__restrict__ batch_ent_ptr,
-                                                      const int32_t *__restrict__ pw_base, uint16_t *__restrict__ pc) {
+                                                      const int32_t *__restrict__ pw_base, uint16_t *__restrict__ pc, int n_tiles,
+                                                      int n_batches, int skip) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
   uint32_t *cnt = lds_u;                                   // TW_TILE / 2 words
   int *offs = reinterpret_cast<int *>(lds_u + TW_TILE / 2);  // TW_MAXOWN + 1
   int *segbeg = offs + TW_MAXOWN + 1;                      // TW_MAXOWN   (index into col[])
   int *dst = segbeg + TW_MAXOWN;                           // TW_MAXOWN   (index into pc[])
   __shared__ int wbuf[16];
-  const int t = blockIdx.x, b = blockIdx.y;
+  unsigned vbx, vgx;
+  if (!ggad_vblock(skip, vbx, vgx)) return;
+  if (vbx >= (unsigned)n_tiles * (unsigned)n_batches) return;
+  const int t = (int)(vbx % (unsigned)n_tiles), b = (int)(vbx / (unsigned)n_tiles);
   const int o0 = batch_ent_ptr[b], o1 = batch_ent_ptr[b + 1];      // "owner slots" = the entries of batch b
   const int n_own_all = o1 - o0;
   const int32_t *seg_lo = seg_t + (int64_t)t * n_cap, *seg_hi = seg_lo + n_cap;
@@ -356,8 +362,10 @@ __global__ void __launch_bounds__(256) k_build_groups(const int32_t *__restrict_
                                                       const int32_t *__restrict__ own_deg, int n_ents,
                                                       int32_t *__restrict__ node_head, const int32_t *__restrict__ own_next,
                                                       int32_t *__restrict__ grp, int32_t *__restrict__ items,
-                                                      int32_t *__restrict__ counters) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
+                                                      int32_t *__restrict__ counters, int skip) {
+  unsigned vbx, vgx;
+  if (!ggad_vblock(skip, vbx, vgx)) return;
+  const int e = vbx * 256 + threadIdx.x;
   const int lane = lane_id();
   int u = 0, m = 0, ng = 0, ns = 0;
   if (e < n_ents && ent_own[e] == e) {
@@ -417,8 +425,10 @@ __global__ void __launch_bounds__(256) k_gather2_items(const int32_t *__restrict
                                                        const int32_t *__restrict__ own_deg, const int32_t *__restrict__ pw_base,
                                                        const uint16_t *__restrict__ pc, const int32_t *__restrict__ grp,
                                                        const int32_t *__restrict__ items, int32_t *__restrict__ counters,
-                                                       float *__restrict__ x2, float *__restrict__ part2) {
+                                                       float *__restrict__ x2, float *__restrict__ part2, int skip) {
   static_assert(ITEM_GRAB == 4 && GRP_W <= 16, "lane layout of the metadata loads: 16 lanes per item of a grab");
+  unsigned vbx, vgx;
+  if (!ggad_vblock(skip, vbx, vgx)) return;
   const int F = FT ? FT : F_rt;
   const int lane = lane_id();
   const int n_items = counters[GGAD_CTR_ITEMS];
@@ -426,7 +436,7 @@ __global__ void __launch_bounds__(256) k_gather2_items(const int32_t *__restrict
   // Guided self-scheduling on ONE cursor: a wave reserves rem / (2 waves) items at a time (64 at most, ITEM_GRAB at least; rem is
   // what its previous reservation saw left), i.e. big bites while there is plenty and single grabs at the end.  A same-address
   // atomic completes every ~7 ns chip-wide: one atomic per 4 items (268 K per 150-batch launch) was 1.9 of the kernel's 2.3 ms.
-  const int n_waves = (int)gridDim.x * 4;
+  const int n_waves = (int)vgx * 4;
   int seen = 0;
   for (;;) {
     const int rem = n_items - seen;
@@ -486,12 +496,14 @@ __global__ void __launch_bounds__(256) k_gather2_items(const int32_t *__restrict
 
 // x2 of multi-slice owners: slices in order (0 + P_0 + P_1 + ...), the per-owner kernel's order.
 __global__ void __launch_bounds__(256) k_gather2_combine(const int32_t *__restrict__ grp, const int32_t *__restrict__ counters,
-                                                         const float *__restrict__ part2, int F, float *__restrict__ x2) {
+                                                         const float *__restrict__ part2, int F, float *__restrict__ x2, int skip) {
+  unsigned vbx, vgx;
+  if (!ggad_vblock(skip, vbx, vgx)) return;
   const int lane = lane_id();
   const int n_groups = counters[GGAD_CTR_GROUPS];
   const int rpi = 64 / F;
   const int g = lane / F, f = lane - g * F;
-  for (int gi = blockIdx.x * 4 + (threadIdx.x >> 6); gi < n_groups; gi += gridDim.x * 4) {
+  for (int gi = vbx * 4 + (threadIdx.x >> 6); gi < n_groups; gi += vgx * 4) {
     const int rv = (lane < GRP_W) ? grp[(int64_t)gi * GRP_W + lane] : -1;
     const int ns = __builtin_amdgcn_readlane(rv, 9);
     if (ns <= 1) continue;
@@ -514,8 +526,10 @@ __global__ void __launch_bounds__(256) k_gather2_w(const int32_t *__restrict__ c
                                                    const int32_t *__restrict__ ent_own, int n_ents,
                                                    const int32_t *__restrict__ own_rp, const int32_t *__restrict__ own_deg,
                                                    const int32_t *__restrict__ pw_base, const uint16_t *__restrict__ pc,
-                                                   float *__restrict__ x2) {
-  const int e0 = blockIdx.x * 4 + (threadIdx.x >> 6);
+                                                   float *__restrict__ x2, int skip) {
+  unsigned vbx, vgx;
+  if (!ggad_vblock(skip, vbx, vgx)) return;
+  const int e0 = vbx * 4 + (threadIdx.x >> 6);
   if (e0 >= n_ents || ent_own[e0] != e0) return;
   const int lane = lane_id();
   const int s = own_rp[e0];
@@ -566,33 +580,35 @@ __global__ void __launch_bounds__(256) k_gather2_w(const int32_t *__restrict__ c
 int ggad_int_ldsw_hop2(const ggad_mb_plan *P, const ggad_plan_view &V, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
   if (V.n_ents == 0 || V.n_batches == 0) return GGAD_OK;
   const int n_tiles = (int)((P->n_nodes + TW_TILE - 1) >> TW_SHIFT);
-  k_seg_transpose<<<dim3((unsigned)((V.n_ents + 63) / 64)), dim3(256), 0, st>>>(P->tile_off, n_tiles, P->ent_own, P->ent_col, V.n_ents,
-                                                                                V.seg_stride, P->seg_t);
+  const int skip = P->xcd_skip >= 0 && P->xcd_skip < 8 ? P->xcd_skip : -1;      // leave one XCD to the resident chunk kernel
+  k_seg_transpose<<<dim3(ggad_skip_grid((unsigned)((V.n_ents + 63) / 64), skip)), dim3(256), 0, st>>>(
+      P->tile_off, n_tiles, P->ent_own, P->ent_col, V.n_ents, V.seg_stride, P->seg_t, skip);
   const size_t lds = (size_t)(TW_TILE / 2) * 4 + (size_t)(3 * TW_MAXOWN + 1) * 4;
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void *)k_tile_counts, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-  k_tile_counts<<<dim3(n_tiles, V.n_batches), dim3(TW_T), lds, st>>>(P->col, P->seg_t, V.seg_stride, P->own_rp, V.batch_ent_ptr,
-                                                                     P->pw_base, P->pc);
+  k_tile_counts<<<dim3(ggad_skip_grid((unsigned)n_tiles * (unsigned)V.n_batches, skip)), dim3(TW_T), lds, st>>>(
+      P->col, P->seg_t, V.seg_stride, P->own_rp, V.batch_ent_ptr, P->pw_base, P->pc, n_tiles, V.n_batches, skip);
   if (ev0) (void)hipEventRecord(ev0, st);
   const int F = P->feat_dim;
   if (P->node_major && F <= 64) {
-    k_build_groups<<<dim3((unsigned)((V.n_ents + 255) / 256)), dim3(256), 0, st>>>(P->ent_own, P->ent_col, P->own_deg, V.n_ents,
-                                                                                   P->node_head, P->own_next, P->grp, P->items,
-                                                                                   P->counters);
+    k_build_groups<<<dim3(ggad_skip_grid((unsigned)((V.n_ents + 255) / 256), skip)), dim3(256), 0, st>>>(
+        P->ent_own, P->ent_col, P->own_deg, V.n_ents, P->node_head, P->own_next, P->grp, P->items, P->counters, skip);
     // waves take ITEM_GRAB work items at a time from a cursor: enough workgroups to fill the chip, no more than there can be items
     const int64_t max_items = (int64_t)V.n_ents + P->pair_cap / SLICE;
     const unsigned wgs = (unsigned)std::min<int64_t>((max_items + 4 * ITEM_GRAB - 1) / (4 * ITEM_GRAB), 256 * 8);
     if (F == 17)
-      k_gather2_items<17><<<dim3(wgs), dim3(256), 0, st>>>(P->col, P->feat, F, P->feat_stride, P->own_rp, P->own_deg, P->pw_base,
-                                                           P->pc, P->grp, P->items, P->counters, P->x2, P->part2);
+      k_gather2_items<17><<<dim3(ggad_skip_grid(wgs, skip)), dim3(256), 0, st>>>(P->col, P->feat, F, P->feat_stride, P->own_rp, P->own_deg,
+                                                                                 P->pw_base, P->pc, P->grp, P->items, P->counters, P->x2,
+                                                                                 P->part2, skip);
     else
-      k_gather2_items<0><<<dim3(wgs), dim3(256), 0, st>>>(P->col, P->feat, F, P->feat_stride, P->own_rp, P->own_deg, P->pw_base,
-                                                          P->pc, P->grp, P->items, P->counters, P->x2, P->part2);
+      k_gather2_items<0><<<dim3(ggad_skip_grid(wgs, skip)), dim3(256), 0, st>>>(P->col, P->feat, F, P->feat_stride, P->own_rp, P->own_deg,
+                                                                                P->pw_base, P->pc, P->grp, P->items, P->counters, P->x2,
+                                                                                P->part2, skip);
     const unsigned cg = (unsigned)std::min<int64_t>(((int64_t)V.n_ents + 3) / 4, 16384);        // ~2 groups per wave: every group costs a dependent load of its record
-    k_gather2_combine<<<dim3(cg), dim3(256), 0, st>>>(P->grp, P->counters, P->part2, F, P->x2);
+    k_gather2_combine<<<dim3(ggad_skip_grid(cg, skip)), dim3(256), 0, st>>>(P->grp, P->counters, P->part2, F, P->x2, skip);
   } else {
-    k_gather2_w<<<dim3((unsigned)((V.n_ents + 3) / 4)), dim3(256), 0, st>>>(P->col, P->feat, F, P->feat_stride, P->ent_own, V.n_ents,
-                                                                           P->own_rp, P->own_deg, P->pw_base, P->pc, P->x2);
+    k_gather2_w<<<dim3(ggad_skip_grid((unsigned)((V.n_ents + 3) / 4), skip)), dim3(256), 0, st>>>(
+        P->col, P->feat, F, P->feat_stride, P->ent_own, V.n_ents, P->own_rp, P->own_deg, P->pw_base, P->pc, P->x2, skip);
   }
   if (ev1) (void)hipEventRecord(ev1, st);
   GGAD_CHECK_LAUNCH("mb_plan_build (ldsw 2-hop)");

@@ -135,9 +135,11 @@ __global__ void __launch_bounds__(256) k_expand(const int32_t *__restrict__ rowp
                                                 const int32_t *__restrict__ ck_e0, int n_chunks, int64_t n_nodes,
                                                 int32_t *__restrict__ ent_col, int32_t *__restrict__ ent_slot,
                                                 int32_t *__restrict__ ent_row, int32_t *__restrict__ cnt1,
-                                                int32_t *__restrict__ own1, int32_t *__restrict__ counters) {
-  if (blockIdx.x == 0 && threadIdx.x < GGAD_PLAN_COUNTERS && counters != nullptr) counters[threadIdx.x] = 0;
-  const int ck = (int)((blockIdx.x * 256u + threadIdx.x) >> 4);
+                                                int32_t *__restrict__ own1, int32_t *__restrict__ counters, int skip) {
+  unsigned vbx, vgx;
+  if (!ggad_vblock(skip, vbx, vgx)) return;
+  if (vbx == 0 && threadIdx.x < GGAD_PLAN_COUNTERS && counters != nullptr) counters[threadIdx.x] = 0;
+  const int ck = (int)((vbx * 256u + threadIdx.x) >> 4);
   const int i = threadIdx.x & 15;
   if (ck >= n_chunks) return;
   const int rc = ck_rc[ck];
@@ -185,8 +187,10 @@ __global__ void __launch_bounds__(256) k_gather1c(const float *__restrict__ feat
                                                   float *__restrict__ x1, const int32_t *__restrict__ rowptr,
                                                   int32_t *__restrict__ own_deg, int32_t *__restrict__ own_rp,
                                                   int32_t *__restrict__ pw_base, int32_t *__restrict__ node_head,
-                                                  int32_t *__restrict__ own_next, int32_t *__restrict__ counters, int ldsw) {
-  const int wave = (int)((blockIdx.x * 256u + threadIdx.x) >> 6);
+                                                  int32_t *__restrict__ own_next, int32_t *__restrict__ counters, int ldsw, int skip) {
+  unsigned vbx, vgx;
+  if (!ggad_vblock(skip, vbx, vgx)) return;
+  const int wave = (int)((vbx * 256u + threadIdx.x) >> 6);
   const int lane = lane_id();
   const int ck = wave * 4 + (lane >> 4), i = lane & 15;
   int len = 0, row = 0, e = 0;
@@ -300,14 +304,16 @@ __global__ void __launch_bounds__(256) k_combine1_reset(int row_blocks, int n_ro
                                                         float *__restrict__ x1, int do_reset, int n_ents,
                                                         const int32_t *__restrict__ ent_col,
                                                         const int32_t *__restrict__ ent_slot, int64_t n_nodes,
-                                                        int32_t *__restrict__ cnt1) {
-  if ((int)blockIdx.x >= row_blocks) {
+                                                        int32_t *__restrict__ cnt1, int skip) {
+  unsigned vbx, vgx;
+  if (!ggad_vblock(skip, vbx, vgx)) return;
+  if ((int)vbx >= row_blocks) {
     if (!do_reset) return;
-    const int e = (blockIdx.x - row_blocks) * 256 + threadIdx.x;
+    const int e = (vbx - row_blocks) * 256 + threadIdx.x;
     if (e < n_ents) cnt1[(int64_t)ent_slot[e] * n_nodes + ent_col[e]] = 0;
     return;
   }
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int row = vbx * 4 + (threadIdx.x >> 6);
   if (row >= n_rows) return;
   const int c0 = row_ck_ptr[row];
   const int nck = row_ck_ptr[row + 1] - c0;
@@ -439,17 +445,18 @@ __global__ void __launch_bounds__(256) k_plan_reset(const int32_t *__restrict__ 
 int ggad_int_hop1(const ggad_mb_plan *P, const ggad_plan_view &V, int ldsw, int reset_now, hipStream_t st) {
   if (V.n_chunks == 0) return GGAD_OK;
   const unsigned eb = (unsigned)((V.n_chunks + 15) / 16);       // 16 pieces (4 waves x 4) per workgroup
-  k_expand<<<dim3(eb), dim3(256), 0, st>>>(P->rowptr, P->col, V.nodes, V.row_slot, V.ent_ptr, V.ck_rc, V.ck_e0, V.n_chunks,
-                                            P->n_nodes, P->ent_col, P->ent_slot, P->ent_row, P->cnt1, P->own1, P->counters);
-  k_gather1c<<<dim3(eb), dim3(256), 0, st>>>(P->feat, P->feat_dim, P->feat_stride, V.row_slot, V.ent_ptr, V.row_ck_ptr, V.ck_rc,
+  const int skip = P->xcd_skip >= 0 && P->xcd_skip < 8 ? P->xcd_skip : -1;
+  k_expand<<<dim3(ggad_skip_grid(eb, skip)), dim3(256), 0, st>>>(P->rowptr, P->col, V.nodes, V.row_slot, V.ent_ptr, V.ck_rc, V.ck_e0, V.n_chunks,
+                                            P->n_nodes, P->ent_col, P->ent_slot, P->ent_row, P->cnt1, P->own1, P->counters, skip);
+  k_gather1c<<<dim3(ggad_skip_grid(eb, skip)), dim3(256), 0, st>>>(P->feat, P->feat_dim, P->feat_stride, V.row_slot, V.ent_ptr, V.row_ck_ptr, V.ck_rc,
                                               V.ck_e0, V.n_chunks, P->n_nodes, P->cnt1, P->own1, P->ent_col, P->ent_own, P->ent_c1,
                                               P->ck_part, P->ck_part_stride, P->x1, P->rowptr, P->own_deg, P->own_rp, P->pw_base,
-                                              P->node_head, P->own_next, P->counters, ldsw);
+                                              P->node_head, P->own_next, P->counters, ldsw, skip);
   const int row_blocks = (V.n_rows + 3) / 4;
   const int ent_blocks = reset_now ? (V.n_ents + 255) / 256 : 0;
-  k_combine1_reset<<<dim3((unsigned)(row_blocks + ent_blocks)), dim3(256), 0, st>>>(
+  k_combine1_reset<<<dim3(ggad_skip_grid((unsigned)(row_blocks + ent_blocks), skip)), dim3(256), 0, st>>>(
       row_blocks, V.n_rows, V.row_ck_ptr, P->ck_part, P->ck_part_stride, P->feat_dim, P->x1, reset_now, V.n_ents, P->ent_col,
-      P->ent_slot, P->n_nodes, P->cnt1);
+      P->ent_slot, P->n_nodes, P->cnt1, skip);
   GGAD_CHECK_LAUNCH("mb_plan_build (1-hop)");
   return GGAD_OK;
 }

@@ -905,9 +905,36 @@ __global__ void __launch_bounds__(GGAD_WAVE) k_xcd_warm(XcdWarmArgs P) {
 
 }  // namespace
 
+__global__ void k_xcd_probe(int32_t *out) {
+  if (threadIdx.x == 0) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    out[blockIdx.x] = (int32_t)(xcc & 7u);
+  }
+}
+
 extern "C" {
 
 int32_t ggad_mb_xcd_grid(void) { return 8 * XMAXWG; }
+
+int ggad_xcd_first_of_stream(int32_t *first_host, ggad_stream_t stream) {
+  GGAD_REQUIRE(first_host);
+  int32_t *d = nullptr;
+  if (hipMalloc(&d, 16 * sizeof(int32_t)) != hipSuccess) return GGAD_E_LAUNCH;
+  hipStream_t st = as_stream(stream);
+  int32_t h[16];
+  int rc = GGAD_OK;
+  k_xcd_probe<<<dim3(16), dim3(GGAD_WAVE), 0, st>>>(d);
+  if (hipGetLastError() != hipSuccess || hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess)
+    rc = GGAD_E_LAUNCH;
+  (void)hipFree(d);
+  if (rc != GGAD_OK) return rc;
+  for (int b = 0; b < 16; ++b)
+    if (h[b] != ((h[0] + b) & 7)) return GGAD_E_INVALID;      // not the rotation the skipping launches rely on
+  *first_host = h[0];
+  return GGAD_OK;
+}
 
 int64_t ggad_mb_xcd_workspace_elems(int32_t max_rows, int32_t D, int32_t F, int64_t rows_cap, int64_t pieces_cap) {
   if (max_rows < 1 || D < 1 || F < 1 || rows_cap < 0 || pieces_cap < 0) return 0;

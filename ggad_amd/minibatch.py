@@ -60,7 +60,9 @@ class BatchChunk:
         if hop2 not in self.HOP2_MODES:
             raise ValueError("hop2 must be 'ldsw' (LDS counting, default) or 'global' (device atomics)")
         self.hop2 = hop2
-        self.node_major = bool(node_major)      # ldsw: all occurrences of a node in the chunk share one pass over its rows
+        self.node_major = bool(node_major)
+             # ldsw: all occurrences of a node in the chunk share one pass over its rows
+        self.xcd_skip = -1              # 0..7: the plan kernels leave the workgroups of one XCD out (the resident chunk kernel's)
         self.D = int(embed_dim)
         self.dev = feat.device
         self.train = bool(train)
@@ -191,6 +193,7 @@ class BatchChunk:
         P.ck_part_stride = self.part_stride
         P.train, P.hop2, P.node_major = int(self.train), self.HOP2_MODES[self.hop2], int(self.node_major)
         P.mean_nbr_deg = float(g.mean_nbr_deg)
+        P.xcd_skip = int(getattr(self, "xcd_skip", -1))
 
     # ---- build
     def build(self, batches: Sequence[np.ndarray], labels: Optional[Sequence[np.ndarray]] = None) -> None:
@@ -223,6 +226,7 @@ class BatchChunk:
         if rows > self.rows_cap:
             self._alloc(rows, 0, 0, 0, 0, 0, 0, 0)
         P, I = self.plan, self.info
+        P.xcd_skip = int(self.xcd_skip)
         if self.gather2_events is not None:
             P.ev_gather0, P.ev_gather1 = self.gather2_events
         else:

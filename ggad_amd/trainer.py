@@ -134,10 +134,20 @@ class DGraphTrainer:
         if self.overlap:
             self.chunks.append(BatchChunk(graph, table, embed_dim, self.chunk_batches, rows, ent_cap, train=True, feat_dim=f,
                                           hop2=hop2))
+            # XCD-resident dense steps (MiniBatchEngine.resident): the chunk kernel owns `xcd_wgs` compute units of XCD 0, the plan
+            # kernels of the next chunk run on the other seven XCDs (they skip the workgroups the dispatcher would put on XCD 0)
+            self.resident_split = bool(self.engine.resident) and self.world == 1 or (bool(self.engine.resident) and self.exchange is not None)
+            import os
+            if os.environ.get("GGAD_XCD_SPLIT", "1") == "0":
+                self.resident_split = False
+            if dense_cus is not None and not 22 <= int(dense_cus) <= 31:
+                self.resident_split = False              # an explicit split of the chip: the cross-XCD stream pair of round 2
             if dense_cus is None:
-                dense_cus = 64
+                dense_cus = 28 if self.resident_split else 64
             self.dense_cus = int(dense_cus)
             self.side, self.hi = self._make_streams(feat.device, int(dense_cus))
+            if self.resident_split and not getattr(self, "_xcd_ready", False):
+                self.resident_split = False
         self.steps_done = 0
         self.prefetch = bool(prefetch)
         self._stream = None
@@ -200,7 +210,16 @@ class DGraphTrainer:
                 # every 8th bit = one whole XCD for the dense chain -> 79 us/step), so a contiguous range spreads the dense
                 # chain over all XCDs
                 dense = set(range(dense_cus))
-                for members in (set(range(n_cu)) - dense, dense):
+                plan = set(range(n_cu)) - dense
+                if getattr(self, "resident_split", False):
+                    # mask bit i = CU i // 8 of XCD i % 8.  Chunk kernel: CUs 0 .. dense_cus-1 of XCD 0 (+ the last CU of every
+                    # other XCD, where its workgroups only pass through); plan: the rest
+                    if not 22 <= dense_cus <= 31:
+                        raise ValueError("with the XCD-resident chunk kernel dense_cus is 22..31 compute units of one XCD")
+                    per = n_cu // 8
+                    dense = {8 * cu for cu in range(dense_cus)} | {8 * (per - 1) + x for x in range(1, 8)}
+                    plan = set(range(n_cu)) - dense
+                for members in (plan, dense):
                     mask = (ctypes.c_uint32 * words)()
                     for cu in members:
                         mask[cu // 32] |= 1 << (cu % 32)
@@ -210,6 +229,12 @@ class DGraphTrainer:
                     raw.append(h.value)
                     out.append(torch.cuda.ExternalStream(h.value, device=device))
             self._raw_streams = raw
+            if getattr(self, "resident_split", False):
+                first = ctypes.c_int32(-1)
+                _lib.check(lib.ggad_xcd_first_of_stream(ctypes.byref(first), raw[0]), "ggad_xcd_first_of_stream")
+                skip = (0 - int(first.value)) % 8               # blocks b with (first + b) % 8 == 0 would run on XCD 0
+                self._xcd_skip = skip
+                self._xcd_ready = True
             return out[0], out[1]
         except ValueError:
             raise
@@ -317,7 +342,10 @@ class DGraphTrainer:
             ch.build(bn, bl) if gather_hook is None else gather_hook(ch, bn, bl)
 
         nodes_seen, done = 0, 0
+        split = getattr(self, "resident_split", False)
         if not self.overlap or len(sizes) == 1:
+            if split:                                  # nothing runs beside the chunk kernel: it takes a whole XCD, the plan the chip
+                self.chunk.xcd_skip, self.engine.xcd_wgs = -1, 0
             for k in sizes:
                 bn, bl = take(k)
                 build(self.chunk, bn, bl)
@@ -325,6 +353,10 @@ class DGraphTrainer:
                 nodes_seen += sum(len(b) for b in bn)
                 done += k
         else:
+            if split:
+                for ch in self.chunks:
+                    ch.xcd_skip = self._xcd_skip
+                self.engine.xcd_wgs = self.dense_cus
             outer = torch.cuda.current_stream()
             main = self.hi
             main.wait_stream(outer)

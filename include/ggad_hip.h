@@ -118,6 +118,9 @@ typedef struct ggad_mb_plan {
   int32_t hop2;              /* 1: LDS counting ("ldsw"), 2: device atomics ("global") */
   int32_t node_major;        /* ldsw gather: occurrences of a node in the chunk share the fetch of its neighbour rows */
   float mean_nbr_deg;        /* sum deg^2 / sum deg (memset vs walk when the global counters are cleared) */
+  int32_t xcd_skip;          /* -1: plain launches.  0..7: the plan kernels leave one XCD to the XCD-resident chunk kernel: the
+                                workgroups with blockIdx % 8 == xcd_skip return at once (ggad_xcd_first_of_stream tells which
+                                residue the stream's dispatcher puts on which XCD); results do not depend on it */
 } ggad_mb_plan;
 
 typedef struct ggad_mb_plan_info {
@@ -348,6 +351,9 @@ int ggad_mb_train_chunk_xchg(const ggad_mb_step *tmpl, int32_t n_batches, const 
  * out[3..10] wall clocks of rank 0 in 10 ns ticks: phase A, barrier, R, barrier, C, barrier, E, barrier; out[11..18] sub-phase
  * clocks (diagnostics: they are INCLUDED in the phase that follows them). */
 int32_t ggad_mb_xcd_grid(void);
+/* XCD on which block 0 of a launch on `stream` runs (block b then runs on XCD (first + b) % 8; a constant of the stream's
+ * hardware queue, measured by a one-wave probe launch; synchronises the stream). */
+int ggad_xcd_first_of_stream(int32_t *first_host, ggad_stream_t stream);
 int64_t ggad_mb_xcd_workspace_elems(int32_t max_rows, int32_t D, int32_t F, int64_t rows_cap, int64_t pieces_cap);
 int ggad_mb_train_chunk_xcd(const ggad_mb_step *tmpl, int32_t n_batches, const int32_t *batch_ptr_dev, int32_t max_rows,
                             int32_t n_rows, int32_t n_pieces, int32_t n_ents, int64_t rows_cap, int64_t pieces_cap, float *loss_log,
