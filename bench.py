@@ -140,7 +140,10 @@ def main():
     trainer = DGraphTrainer(graph, feat, a.emb, sched, lr=1e-3, weight_decay=0.007, chunk_batches=a.chunk, rank=rank,
                             world_size=world, allreduce=allreduce, hop2=a.hop2, overlap=not a.no_overlap, chain=a.chain,
                             dense_cus=(None if a.dense_cus < 0 else a.dense_cus),
-                            ramp=([int(x) for x in a.ramp.split(",") if x] if a.ramp else None), exchange=exchange)
+                            ramp=([int(x) for x in a.ramp.split(",") if x] if a.ramp else None), exchange=exchange,
+                            # ranks that share a device (the 1-GPU tests of the launch line) cannot both keep a chunk kernel
+                            # resident on the same XCD: they take the launch chain
+                            resident=(False if world > torch.cuda.device_count() else None))
     a.dense_cus = getattr(trainer, "dense_cus", 0 if a.dense_cus < 0 else a.dense_cus)
     if a.dp_path and world == 1:
         # the data-parallel step chain on one GPU: backward -> k_xchg_adam with a world of one (publish to itself, flag, wait,
@@ -208,7 +211,7 @@ def main():
     nodes_local = trainer.run_steps(a.steps, prepared=timed, gather_hook=timed_build)
     barrier()
     elapsed = time.perf_counter() - t1
-    trainer.check_exchange()
+    trainer.check_exchange(dist if world > 1 else None)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -351,6 +354,9 @@ def main():
                        "graph": f"{a.graph_kind}(alpha=2.1,max_degree={a.max_degree})", "chunk_batches": trainer.chunk_batches,
                        "chunks_of_timed_region": sizes[:16], "hop2": a.hop2, "overlap": overlapped,
                        "dense_cus": (a.dense_cus if overlapped else 0), "chain": a.chain,
+                       "dense_steps": ("XCD-resident chunk kernel: one launch per chunk on %d CUs of one XCD%s" %
+                                       (trainer.engine.xcd_wgs or 32, ", plan kernels of the next chunk on the other 7 XCDs" if overlapped else "")
+                                       if trainer.engine.resident else "launch chain: 5 launches per step"),
                        "parallelism": f"dp{world}", "optimizer": "adam(lr=1e-3,wd=0.007)",
                        "gradient_exchange": (None if world == 1 else ("oneshot peer writes + in-kernel sum" if trainer.exchange is not None
                                                                       else "rccl all-reduce"))},

@@ -92,6 +92,7 @@ struct ggad_xchg_view {                          // what the kernel needs, passe
   int32_t rank, world;
   int64_t n;                                     // floats per slot
   int32_t *err;                                  // device word: set when a wait timed out
+  unsigned long long timeout_ticks;              // bound of a wait in 100 MHz wall-clock ticks (GGAD_XCHG_TIMEOUT_S, default 20 s)
 };
 struct ggad_xchg {
   ggad_xchg_view view;

@@ -8,6 +8,7 @@
 // ranks' buffers, reads the W granules of its own buffer until they carry this step's number, sums them in rank order
 // (bit-identical on every rank) and applies Adam -- no extra launch, no flag, no fence, no host involvement, no collective
 // library call inside the step loop.
+#include <cstdlib>
 #include <cstring>
 
 #include "common.h"
@@ -29,6 +30,11 @@ int ggad_xchg_create(int32_t rank, int32_t world, int64_t n_floats, ggad_xchg **
   x->view.n = n_floats;
   x->view.peer[rank] = static_cast<float *>(x->local);
   x->view.err = reinterpret_cast<int32_t *>(static_cast<char *>(x->local) + x->bytes - 64);
+  {                                                         // a slow peer (checkpoint, first touch) is not a lost peer: seconds, not spins
+    const char *ev = getenv("GGAD_XCHG_TIMEOUT_S");
+    const double sec = ev ? atof(ev) : 20.0;
+    x->view.timeout_ticks = (unsigned long long)((sec > 0.001 ? sec : 0.001) * 1e8);
+  }
   *out = x;
   return GGAD_OK;
 }

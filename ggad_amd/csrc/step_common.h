@@ -75,7 +75,7 @@ __device__ __forceinline__ void adam_update(float *__restrict__ params, float *_
 // threads: the data is its own "ready" signal (the layout RCCL's low-latency protocol uses).  The W values are added in rank
 // order -- the same order on every rank, so all replicas stay bit-identical.  Two parities: a rank cannot finish step s + 1
 // before every peer has published s + 1, i.e. finished reading s, so it never overwrites a slot that is still being read.  A wait
-// is bounded: a lost peer sets *err instead of hanging the GPU.
+// is bounded by the wall clock: a lost peer sets *err instead of hanging the GPU.
 __device__ __forceinline__ float xchg_sum(const ggad_xchg_view &X, uint32_t xstep, int i, float g) {
   const int W = X.world, par = (int)(xstep & 1u);
   const int64_t n = X.n;
@@ -86,12 +86,15 @@ __device__ __forceinline__ float xchg_sum(const ggad_xchg_view &X, uint32_t xste
   }
   const uint64_t *src = reinterpret_cast<const uint64_t *>(X.peer[X.rank]) + (int64_t)par * W * n + i;
   float s = 0.0f;
+  const unsigned long long t0 = wall_clock64();                            // 100 MHz
   for (int q = 0; q < W; ++q) {
     uint64_t gr = __hip_atomic_load(src + (int64_t)q * n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     int spins = 0;
     while ((uint32_t)(gr >> 32) != xstep) {
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > (1 << 24)) { *X.err = 1; break; }                   // ~ seconds: a peer is gone
+      // wall-clock bound (X.timeout_ticks, GGAD_XCHG_TIMEOUT_S): a peer busy with rank-0-only host work is waited for, a lost
+      // one sets the error word that every rank agrees on at its next check (DGraphTrainer.check_exchange: all-reduce MAX)
+      if ((++spins & 255) == 0 && wall_clock64() - t0 > X.timeout_ticks) { *X.err = 1; break; }
       gr = __hip_atomic_load(src + (int64_t)q * n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     const float gq = __uint_as_float((uint32_t)gr);

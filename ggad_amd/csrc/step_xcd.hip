@@ -988,7 +988,8 @@ int ggad_mb_train_chunk_xcd(const ggad_mb_step *tmpl, int32_t n_batches, const i
   static const int env_xcd = [] { const char *e = getenv("GGAD_XCD_ID"); return e ? atoi(e) : 0; }();
   A.nv = n_wg > 0 ? n_wg : (env_nv > 0 ? env_nv : XMAXWG);
   A.want_xcd = env_xcd & 7;
-  GGAD_REQUIRE(A.nv >= XMINWG + 4 && A.nv <= XMAXWG);     // 22..32: three fc rows per workgroup cover 64 channels
+  GGAD_REQUIRE(A.nv >= XMINWG + 4 && A.nv <= XMAXWG && A.nv % 4 == 0);     // 24 / 28 / 32: three fc rows per workgroup cover 64 channels; the
+                                                                            // XCD's four shader engines get the same number of workgroups
   static unsigned launch_seq = 0;
   A.launch_id = ++launch_seq ? launch_seq : ++launch_seq;      // never 0 (the cleared control block)
   hipStream_t st = as_stream(stream);

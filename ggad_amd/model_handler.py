@@ -124,7 +124,13 @@ class ModelHandler(object):
             def allreduce(t):
                 dist.all_reduce(t, op=dist.ReduceOp.SUM)
         exchange = None
-        if world > 1 and os.environ.get("GGAD_EXCHANGE", "oneshot") == "oneshot":
+        want_oneshot = os.environ.get("GGAD_EXCHANGE", "oneshot") == "oneshot"
+        if world > 1:                                   # rank 0's choice holds for everybody (the hand-shake below is collective)
+            flag = torch.tensor([int(want_oneshot)], dtype=torch.int32,
+                                device=features.weight.device if dist.get_backend() == "nccl" else "cpu")
+            dist.broadcast(flag, src=0)
+            want_oneshot = bool(flag.item())
+        if world > 1 and want_oneshot:
             # one-shot peer-write exchange inside the gradient / Adam launch; every rank agrees on whether
             # it is usable, else all of them keep the all-reduce
             from .exchange import OneShotExchange
@@ -153,7 +159,7 @@ class ModelHandler(object):
             t0 = time.time()
             trainer.run_steps(steps_per_epoch * n_ep)
             torch.cuda.synchronize()
-            trainer.check_exchange()
+            trainer.check_exchange(dist if world > 1 else None)
             block_time = time.time() - t0
             lall = engine.losses(steps_per_epoch * n_ep).astype(np.float64)
             for j in range(n_ep):

@@ -87,7 +87,8 @@ class DGraphTrainer:
                  world_size: int = 1, allreduce: Optional[Callable[[torch.Tensor], None]] = None,
                  engine: Optional[MiniBatchEngine] = None, hop2: str = "ldsw",
                  overlap: bool = True, prefetch: bool = True, chain: int = 0, dense_cus: Optional[int] = None,
-                 ramp: Optional[Sequence[int]] = None, exchange=None, own_stream: bool = False):
+                 ramp: Optional[Sequence[int]] = None, exchange=None, own_stream: bool = False,
+                 resident: Optional[bool] = None):
         """`feat` is the plain (N, F) table.  hop2 = "ldsw" (default): 2-hop counts in LDS per (tile, batch), per-pair
         counts streamed to the gather, feature rows padded to one 128-byte line; "global": per-batch counter slots in HBM +
         device atomics (the fallback the LDS path takes by itself when a chunk exceeds its limits).
@@ -116,7 +117,10 @@ class DGraphTrainer:
         self.sched_rank, self.sched_world = (0, 1) if own_stream else (self.rank, self.world)
         self.allreduce = allreduce if self.world > 1 else None
         self.exchange = exchange if (self.world > 1 and exchange is not None and exchange.ok) else None
-        self.engine = engine or MiniBatchEngine(feat.shape[1], embed_dim, feat.device, lr, weight_decay, chain=chain)
+        # `resident`: the dense steps of a chunk as one launch resident on one XCD (None = whenever supported).  Ranks that SHARE a
+        # device (tests) must pass False: two resident kernels cannot both hold the same XCD
+        self.engine = engine or MiniBatchEngine(feat.shape[1], embed_dim, feat.device, lr, weight_decay, chain=chain,
+                                                resident=(None if resident is None or resident else False))
         self.chunk_batches = int(chunk_batches)
         self.ramp = None if ramp is None else [int(k) for k in ramp]
         f = int(feat.shape[1])
@@ -130,35 +134,67 @@ class DGraphTrainer:
         ent_cap = int(rows * (mean_deg + 1) * 1.5) + 1024
         self.chunk = BatchChunk(graph, table, embed_dim, self.chunk_batches, rows, ent_cap, train=True, feat_dim=f, hop2=hop2)
         self.overlap = bool(overlap) and feat.device.type == "cuda"
+        self.dense_cus = 0
+        self.resident_split = False
+        if dense_cus is not None and int(dense_cus) not in (0, 24, 28):
+            self.engine.resident = False                 # an explicit split of the chip: the launch chain of round 2
         self.chunks = [self.chunk]
         if self.overlap:
             self.chunks.append(BatchChunk(graph, table, embed_dim, self.chunk_batches, rows, ent_cap, train=True, feat_dim=f,
                                           hop2=hop2))
             # XCD-resident dense steps (MiniBatchEngine.resident): the chunk kernel owns `xcd_wgs` compute units of XCD 0, the plan
-            # kernels of the next chunk run on the other seven XCDs (they skip the workgroups the dispatcher would put on XCD 0)
-            self.resident_split = bool(self.engine.resident) and self.world == 1 or (bool(self.engine.resident) and self.exchange is not None)
+            # kernels of the next chunk run on the other seven XCDs (they skip the workgroups the dispatcher would put on XCD 0).
+            # dense_cus 24 / 28 (default 28): CU-masked streams; 0: plain streams (the skipping launches alone keep the plan off
+            # XCD 0); any other explicit value: the cross-XCD stream pair of round 2 with the 5-launch chain
             import os
-            if os.environ.get("GGAD_XCD_SPLIT", "1") == "0":
+            self.resident_split = bool(self.engine.resident) and (self.world == 1 or self.exchange is not None) \
+                and os.environ.get("GGAD_XCD_SPLIT", "1") != "0"
+            if dense_cus is not None and int(dense_cus) not in (0, 24, 28):
                 self.resident_split = False
-            if dense_cus is not None and not 22 <= int(dense_cus) <= 31:
-                self.resident_split = False              # an explicit split of the chip: the cross-XCD stream pair of round 2
             if dense_cus is None:
                 dense_cus = 28 if self.resident_split else 64
             self.dense_cus = int(dense_cus)
             self.side, self.hi = self._make_streams(feat.device, int(dense_cus))
             if self.resident_split and not getattr(self, "_xcd_ready", False):
                 self.resident_split = False
+            if not self.resident_split:
+                self.engine.resident = False             # (a masked stream without a whole XCD cannot hold the chunk kernel)
+        if self.engine.resident:
+            # the same workgroup count with and without overlap: results are bit-identical across the two paths
+            self.engine.xcd_wgs = self.dense_cus if (self.overlap and self.dense_cus in (24, 28)) else 28
         self.steps_done = 0
         self.prefetch = bool(prefetch)
         self._stream = None
         self._pending = ([], [])        # batches taken from the sampler stream but not consumed yet
 
-    def check_exchange(self) -> None:
-        """Raise if a one-shot exchange step timed out waiting for a peer (the kernel's bounded spin sets an error word instead of
-        hanging).  Reads device memory: call after a synchronisation point (end of a run / before a validation sweep)."""
-        if self.exchange is not None and self.exchange.error() != 0:
-            raise RuntimeError("ggad_amd: one-shot gradient exchange timed out waiting for a peer rank (weights are no longer "
-                               "in step across the ranks)")
+    def plan_stream_first_xcd(self) -> int:
+        """XCD on which block 0 of a launch on the plan stream runs right now (diagnostics: the index-skipping plan launches were
+        calibrated with this value when the streams were made)."""
+        import ctypes
+        from . import _lib
+        first = ctypes.c_int32(-1)
+        _lib.check(_lib.load().ggad_xcd_first_of_stream(ctypes.byref(first), self._raw_streams[0]), "ggad_xcd_first_of_stream")
+        return int(first.value)
+
+    def check_exchange(self, dist=None) -> None:
+        """Raise if a one-shot exchange step timed out waiting for a peer (the kernel's bounded wait sets an error word instead of
+        hanging), or if the XCD-resident chunk kernel did.  Reads device memory: call after a synchronisation point (end of a run
+        / before a validation sweep).  With `dist` (torch.distributed, initialised) the error words are all-reduced (MAX) first, so
+        EVERY rank raises together instead of one rank raising while its peers walk into the next collective."""
+        err = 0
+        if self.exchange is not None:
+            err = int(self.exchange.error() != 0)
+        if self.engine.xcd_ws is not None and self.engine.xcd_status()["error"]:
+            err |= 2
+        if dist is not None and self.world > 1 and dist.is_available() and dist.is_initialized():
+            t = torch.tensor([err], dtype=torch.int32, device=self.feat.device if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            err = int(t.item())
+        if err & 1:
+            raise RuntimeError("ggad_amd: one-shot gradient exchange timed out waiting for a peer rank (on this or another rank; "
+                               "weights are no longer in step across the ranks)")
+        if err & 2:
+            raise RuntimeError("ggad_amd: the XCD-resident chunk kernel timed out (placement or barrier; see MiniBatchEngine.xcd_status)")
 
     def default_ramp(self, n_steps: int) -> List[int]:
         """Chunk sizes of a run of n optimiser steps.  With overlap the first plan is exposed and the last chunk's dense steps
@@ -190,9 +226,18 @@ class DGraphTrainer:
     def _make_streams(self, device, dense_cus: int):
         """(plan stream, dense stream).  dense_cus > 0: CU-masked HIP streams (dense chain on CUs [0, dense_cus), plan on
         the rest); dense_cus == 0: plain torch streams, dense chain on the high-priority queue."""
-        if dense_cus <= 0:
-            return torch.cuda.Stream(device=device, priority=0), torch.cuda.Stream(device=device, priority=-1)
         import ctypes
+        if dense_cus <= 0:
+            side, hi = torch.cuda.Stream(device=device, priority=0), torch.cuda.Stream(device=device, priority=-1)
+            if getattr(self, "resident_split", False):
+                from . import _lib
+                first = ctypes.c_int32(-1)
+                with torch.cuda.device(device):
+                    _lib.check(_lib.load().ggad_xcd_first_of_stream(ctypes.byref(first), side.cuda_stream), "ggad_xcd_first_of_stream")
+                self._raw_streams = [side.cuda_stream, hi.cuda_stream]
+                self._xcd_skip = (0 - int(first.value)) % 8
+                self._xcd_ready = True
+            return side, hi
         import warnings
         from . import _lib
         lib = _lib.load()
@@ -214,8 +259,11 @@ class DGraphTrainer:
                 if getattr(self, "resident_split", False):
                     # mask bit i = CU i // 8 of XCD i % 8.  Chunk kernel: CUs 0 .. dense_cus-1 of XCD 0 (+ the last CU of every
                     # other XCD, where its workgroups only pass through); plan: the rest
-                    if not 22 <= dense_cus <= 31:
-                        raise ValueError("with the XCD-resident chunk kernel dense_cus is 22..31 compute units of one XCD")
+                    # (multiples of 4 only: the XCD deals workgroups to its four shader engines in rotation, and a workgroup waits
+                    #  for a compute unit of ITS engine -- with 26 or 30 enabled CUs one engine gets more workgroups than it has CUs
+                    #  and the launch never becomes resident: measured, the registration wait times out)
+                    if dense_cus not in (24, 28):
+                        raise ValueError("with the XCD-resident chunk kernel dense_cus is 24 or 28 compute units of one XCD")
                     per = n_cu // 8
                     dense = {8 * cu for cu in range(dense_cus)} | {8 * (per - 1) + x for x in range(1, 8)}
                     plan = set(range(n_cu)) - dense
@@ -344,8 +392,8 @@ class DGraphTrainer:
         nodes_seen, done = 0, 0
         split = getattr(self, "resident_split", False)
         if not self.overlap or len(sizes) == 1:
-            if split:                                  # nothing runs beside the chunk kernel: it takes a whole XCD, the plan the chip
-                self.chunk.xcd_skip, self.engine.xcd_wgs = -1, 0
+            if split:                                  # nothing runs beside the chunk kernel: the plan takes the whole chip
+                self.chunk.xcd_skip = -1
             for k in sizes:
                 bn, bl = take(k)
                 build(self.chunk, bn, bl)
@@ -356,7 +404,6 @@ class DGraphTrainer:
             if split:
                 for ch in self.chunks:
                     ch.xcd_skip = self._xcd_skip
-                self.engine.xcd_wgs = self.dense_cus
             outer = torch.cuda.current_stream()
             main = self.hi
             main.wait_stream(outer)

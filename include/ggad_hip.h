@@ -334,7 +334,7 @@ int ggad_mb_train_chunk_xchg(const ggad_mb_step *tmpl, int32_t n_batches, const 
  * src/model_handler.py:330-364 (GCNEncoder.forward + GCN.loss src/graphsage.py:395-454,171-258, backward, Adam) -- as ONE
  * launch whose workgroups all stay on one XCD (one shared L2): hand-offs between the phases of a step are plain stores + L2-served
  * loads, barriers are tagged-slot all-gathers inside that L2 (0.43 us), nothing is written back or invalidated between steps.
- * The launch has 8 n_wg workgroups (n_wg = 22..32, 0 = 32: the compute units of one XCD the stream may use); the dispatcher
+ * The launch has 8 n_wg workgroups (n_wg = 24, 28 or 32, 0 = 32: the compute units of one XCD the stream may use, the same number on each of its four shader engines); the dispatcher
  * deals exactly n_wg to every XCD, the ones on XCD GGAD_XCD_ID (default 0) stay, the rest leave at once.  Results are
  * deterministic and independent of n_wg's placement; if fewer than n_wg workgroups ever reached that XCD the launch times out
  * (error 2) instead of hanging.  Requirements: F == 17, D <= 64, the row-piece tables of the plan

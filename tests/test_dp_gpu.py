@@ -60,7 +60,8 @@ def _worker(rank, world, port, steps, out_dir, oneshot=False, own_stream=False):
         exchange = OneShotExchange(rank, world, 64 + 64 * 17 + 64 * 64, "cuda:0")
         assert exchange.connect(dist), "one-shot exchange: IPC hand-shake or self-test failed"
     tr = DGraphTrainer(graph, ft, 64, sched, chunk_batches=3, rank=rank, world_size=world,
-                       allreduce=lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM), exchange=exchange, own_stream=own_stream)
+                       allreduce=lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM), exchange=exchange, own_stream=own_stream,
+                       resident=False)      # the ranks share ONE device: two XCD-resident chunk kernels cannot both hold XCD 0
     assert tr.overlap and (tr.exchange is not None) == oneshot
     tr.engine.load_params(w, W, fc)
     tr.run_steps(steps)
@@ -88,6 +89,38 @@ def test_one_shot_exchange_two_processes_one_gpu_bit_equal_to_allreduce(tmp_path
     p0, p1 = np.load(a / "params_0.npy"), np.load(a / "params_1.npy")
     np.testing.assert_array_equal(p0, p1)
     np.testing.assert_array_equal(p0, np.load(b / "params_0.npy"))
+
+
+def test_exchange_inside_the_resident_chunk_kernel_world_one():
+    """The one-shot exchange code path INSIDE the XCD-resident chunk kernel (phase E: publish the granule, poll, rank-order sum,
+    Adam x 1/W) at world size 1 -- granule stores and polls on the rank's own fine-grained buffer -- gives bit for bit the weights
+    of the same kernel without exchange, and reports no time-out.  (Two ranks cannot share a device with this kernel; over xGMI the
+    peers' buffers are the same kind of mapping.)"""
+    from ggad_amd.exchange import OneShotExchange
+    from ggad_amd.graph import DeviceGraph
+    from ggad_amd.minibatch import BatchChunk, MiniBatchEngine
+    from ggad_amd.sampler import PyCompatRandom
+    from ggad_amd.trainer import BatchSchedule
+    rowptr, col, feat, labels, train, pool, (w, W, fc) = _inputs()
+    graph = DeviceGraph(rowptr, col, "cuda:0")
+    ft = torch.from_numpy(feat).to("cuda:0")
+    sched = BatchSchedule(train.copy(), pool.copy(), labels, 90, PyCompatRandom(72), n_pseudo=30, batches_per_epoch=7)
+    bn, bl = sched.next_batches(6, 0, 1)
+    res = []
+    for use_x in (False, True):
+        eng = MiniBatchEngine(17, 64, "cuda:0", resident=True)
+        eng.load_params(w, W, fc)
+        ch = BatchChunk(graph, ft, 64, max_batches=6, rows_cap=64, ent_cap=64, train=True, hop2="ldsw")
+        ch.build(bn, bl)
+        x = OneShotExchange(0, 1, 64 + 64 * 17 + 64 * 64, "cuda:0") if use_x else None
+        eng.train_chunk(ch, exchange=x)
+        torch.cuda.synchronize()
+        assert eng.xcd_status()["error"] == 0
+        if x is not None:
+            assert x.error() == 0
+        res.append((eng.params.cpu().numpy().copy(), eng.losses(6).copy()))
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    np.testing.assert_array_equal(res[0][1], res[1][1])
 
 
 def test_rank_owned_streams_keep_the_ranks_in_step(tmp_path):

@@ -485,7 +485,10 @@ def test_overlapped_chunks_equal_serial_execution():
     W = torch.nn.init.xavier_uniform_(torch.empty(64, 17))
     fc = torch.nn.init.xavier_uniform_(torch.empty(64, 64))
     outs = []
-    for overlap, prefetch, dense_cus in ((False, False, 32), (True, False, 32), (True, False, 0), (False, True, 32)):
+    # (None: the XCD-resident chunk kernel, plan kernels skipping its XCD when overlapped; 32: the launch chain on a cross-XCD
+    #  stream pair -- the two families agree to round-off, each is bit-identical across its scheduling variants)
+    for overlap, prefetch, dense_cus in ((False, False, None), (True, False, None), (True, False, 0), (False, True, None),
+                                         (True, False, 24)):
         graph = DeviceGraph(rowptr, col, DEV)
         feat = torch.from_numpy(feat_np).to(DEV)
         sched = BatchSchedule(train.copy(), pool.copy(), labels, 60, PyCompatRandom(72), n_pseudo=20, batches_per_epoch=5)
@@ -495,9 +498,25 @@ def test_overlapped_chunks_equal_serial_execution():
         tr.run_steps(11)                                   # chunks of 3,3,3,2 -> both buffers reused
         torch.cuda.synchronize()
         outs.append((tr.engine.params.cpu().numpy().copy(), tr.engine.losses(11).copy()))
-    for o in outs[1:]:        # side-stream planning (CU-masked or plain streams) and the sampler thread change nothing
+    for o in outs[1:4]:       # side-stream planning (CU-masked or plain streams) and the sampler thread change nothing
         np.testing.assert_array_equal(outs[0][0], o[0])
         np.testing.assert_array_equal(outs[0][1], o[1])
+    np.testing.assert_allclose(outs[4][0], outs[0][0], atol=2e-6, rtol=0)      # 24 instead of 28 workgroups: another summation order
+    chain = []
+    for overlap, dense_cus in ((False, 32), (True, 32)):
+        graph = DeviceGraph(rowptr, col, DEV)
+        feat = torch.from_numpy(feat_np).to(DEV)
+        sched = BatchSchedule(train.copy(), pool.copy(), labels, 60, PyCompatRandom(72), n_pseudo=20, batches_per_epoch=5)
+        tr = DGraphTrainer(graph, feat, 64, sched, chunk_batches=3, overlap=overlap, prefetch=False, dense_cus=dense_cus)
+        assert not tr.engine.resident
+        tr.engine.load_params(w, W, fc)
+        tr.run_steps(11)
+        torch.cuda.synchronize()
+        chain.append((tr.engine.params.cpu().numpy().copy(), tr.engine.losses(11).copy()))
+    np.testing.assert_array_equal(chain[0][0], chain[1][0])
+    np.testing.assert_array_equal(chain[0][1], chain[1][1])
+    np.testing.assert_allclose(chain[0][0], outs[0][0], atol=2e-6, rtol=0)
+    np.testing.assert_allclose(chain[0][1], outs[0][1], atol=2e-6, rtol=0)
 
 
 def test_chunk_parallel_forward_on_hub_batches_equals_six_launch_chain():
