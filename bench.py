@@ -70,6 +70,8 @@ def parse():
                     "skipped when --steps is already >= this)")
     ap.add_argument("--e2e-steps", type=int, default=3000, help="extra leg: steps timed with the reference-exact sampler inside the window (0 = skip)")
     ap.add_argument("--fullgraph-epochs", type=int, default=30, help="extra leg: epochs timed per full-graph config (0 = skip)")
+    ap.add_argument("--sparse-entries", type=int, default=8_600_000, help="extra leg: directed entries of the public-degree DGraph regime (0 = skip)")
+    ap.add_argument("--cpu-fullgraph-budget", type=float, default=12.0, help="seconds of CPU time per variant and full-graph config of the cpu_baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="only the timed region (no steady-state / e2e / full-graph / CPU legs)")
     ap.add_argument("--exchange", default="oneshot", choices=["oneshot", "rccl"],
                     help="multi-GPU gradient exchange: oneshot = peer-mapped buffers written inside the Adam launch (falls back to "
@@ -78,6 +80,108 @@ def parse():
                     "launch with a world of one) to measure what the multi-GPU step costs without the xGMI hop")
     ap.add_argument("--seed", type=int, default=72)
     return ap.parse_args()
+
+
+def cpu_fullgraph_baseline(name, budget_s):
+    """The reference's timing window `run.py:146 -> 214` (forward, loss block, backward, Adam) on the host cores of this box, for one
+    full-graph config at its published size: the oracle's CSR step on 24 threads (`sparse_variant`) and, where
+    the dense operands fit and finish (Reddit / Photo / Amazon), the dense-faithful restatement of the reference's N x N products
+    (`dense_variant`).  >= 3 warm-up + >= 10 timed epochs unless `budget_s` seconds per variant run out first (the counts are reported)."""
+    import random as _random
+    import scipy.sparse as sp
+    from ggad_amd.fullgraph_bench import make_dataset
+    from ggad_amd.utils import normalize_adj
+    from oracle import ggad_oracle as O
+    threads = min(24, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    state = _random.getstate()
+    _random.seed(0)
+    np.random.seed(0)
+    ds = make_dataset(name, 0)
+    _random.setstate(state)
+    n, f, h = ds["n"], ds["f"], 300
+    an = (normalize_adj(ds["adj"]) + sp.eye(n)).tocsr()
+    an.sort_indices()
+    rw = (ds["adj"] + sp.eye(n)).tocsr()
+    rw.sort_indices()
+    adjn = (an.indptr, an.indices, an.data.astype(np.float32))
+    raw = (rw.indptr, rw.indices, rw.data.astype(np.float32))
+    gen = torch.Generator().manual_seed(0)
+    shapes = {"gcn1.bias": (h,), "gcn1.fc.weight": (h, f), "gcn1.act.weight": (1,), "gcn2.bias": (h,), "gcn2.fc.weight": (h, h),
+              "gcn2.act.weight": (1,), "fc1.weight": (h // 2, h), "fc2.weight": (h // 4, h // 2), "fc3.weight": (1, h // 4), "fc4.weight": (h, h)}
+    feat_t = torch.from_numpy(ds["features"])
+    abn, nrm = ds["abn_idx"], ds["normal_idx"]
+
+    def fresh():
+        P = {}
+        for k in O.FULL_PARAM_ORDER:
+            shp = shapes[k]
+            t = torch.full(shp, 0.25) if k.endswith("act.weight") else (torch.zeros(shp) if k.endswith("bias") else
+                                                                       torch.randn(shp, generator=gen) * (1.0 / np.sqrt(shp[-1])))
+            P[k] = t.requires_grad_()
+        return P, O.make_adam(list(P.values()), 1e-3, 0.0)
+
+    def run(step, P, adam):
+        ts, warm, t_all = [], 0, time.perf_counter()
+        while True:
+            t0 = time.perf_counter()
+            adam.zero_grad()
+            noise = torch.randn(len(abn), h) * ds["var"] + ds["mean"]
+            loss = step(P, noise)
+            loss.backward()
+            adam.step()
+            dt = time.perf_counter() - t0
+            if warm < 3 and (warm == 0 or time.perf_counter() - t_all < 0.3 * budget_s):
+                warm += 1
+            else:
+                ts.append(dt)
+            if len(ts) >= 10 or (len(ts) >= 3 and time.perf_counter() - t_all > budget_s) or (len(ts) >= 1 and time.perf_counter() - t_all > 3 * budget_s):
+                break
+        return {"epoch_ms": 1e3 * float(np.median(ts)), "nodes_per_s": n / float(np.median(ts)), "warmup_epochs": warm, "epochs_timed": len(ts)}
+
+    out = {"cores": threads, "kind": "port", "window": "run.py:146-214 (forward, loss block, backward, Adam), noise drawn per epoch"}
+    P, adam = fresh()
+    out["sparse_variant"] = run(lambda P, noise: _sparse_step(O, P, feat_t, adjn, raw, abn, nrm, noise), P, adam)
+    if (name != "t_finance") and n <= 16000:
+        A = torch.from_numpy(np.asarray(an.todense(), dtype=np.float32))
+        Rw = torch.from_numpy(np.asarray(rw.todense(), dtype=np.float32))
+        P, adam = fresh()
+        out["dense_variant"] = run(lambda P, noise: O.full_step_dense(P, feat_t, A, Rw, abn, nrm, noise), P, adam)
+    else:
+        out["dense_variant"] = None      # 39,357^2 floats x 2 operands and ~5 TFLOP per epoch: not run (BASELINE.md section 3)
+    return out
+
+
+def _sparse_step(O, P, feat_t, adjn, raw, abn, nrm, noise):
+    emb, comb, logits, con, eab = O.full_forward(P, feat_t, adjn, abn, nrm, noise, True)
+    return O.full_loss(emb, logits, con, eab, raw, abn, nrm, by_column=True)[0]
+
+
+def sparse_regime_leg(a, dev, feat, sp, w, W, fc):
+    """Steady-state throughput on a DGraph-size graph with the PUBLIC degree (about 8.6 M directed entries, average 2.3): its own
+    graph, plans and trainer; same features, split and batch schedule shape as the headline run."""
+    import random as _random
+    from ggad_amd import synth
+    from ggad_amd.graph import DeviceGraph
+    from ggad_amd.sampler import PyCompatRandom
+    from ggad_amd.trainer import BatchSchedule, DGraphTrainer
+    rp, ci = synth.make_graph_torch(a.nodes, a.sparse_entries, a.seed + 1, dev, max_degree=a.max_degree)
+    g2 = DeviceGraph(rp, ci, dev)
+    sched = BatchSchedule(sp["idx_train"], sp["idx_anomaly"], sp["labels"], 150, PyCompatRandom.from_python_state(_random.getstate()))
+    tr = DGraphTrainer(g2, feat, a.emb, sched, lr=1e-3, weight_decay=0.007, chunk_batches=a.chunk, overlap=not a.no_overlap, chain=a.chain,
+                       dense_cus=(None if a.dense_cus_arg < 0 else a.dense_cus_arg))
+    tr.engine.load_params(w, W, fc)
+    batch = sched.next_batches(a.steady_steps)
+    tr.run_steps(min(300, a.steady_steps), prepared=(batch[0][:300], batch[1][:300]))      # warm-up: allocations, first plans
+    torch.cuda.synchronize()
+    ts = time.perf_counter()
+    nn = tr.run_steps(a.steady_steps, prepared=batch)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - ts
+    tr.check_exchange()
+    return {"directed_entries": int(g2.nnz), "steps": a.steady_steps, "value": nn / dt, "unit": "nodes/s", "ms_per_step": 1e3 * dt / a.steady_steps,
+            "dense_steps": "XCD-resident chunk kernel" if tr.engine.resident else "launch chain",
+            "note": "steady-state run of this many steps (schedule prepared beforehand, plans inside) on the public-degree graph"}
 
 
 def main():
@@ -144,6 +248,7 @@ def main():
                             # ranks that share a device (the 1-GPU tests of the launch line) cannot both keep a chunk kernel
                             # resident on the same XCD: they take the launch chain
                             resident=(False if world > torch.cuda.device_count() else None))
+    a.dense_cus_arg = a.dense_cus
     a.dense_cus = getattr(trainer, "dense_cus", 0 if a.dense_cus < 0 else a.dense_cus)
     if a.dp_path and world == 1:
         # the data-parallel step chain on one GPU: backward -> k_xchg_adam with a world of one (publish to itself, flag, wait,
@@ -236,9 +341,9 @@ def main():
     mode = trainer.chunk.last_hop2
     sizes = trainer.default_ramp(a.steps)
     overlapped = bool(trainer.overlap and len(sizes) > 1)
-    # algorithmic bytes per gathered neighbour (per occurrence): the feature row (4 F) + the column id (4) [+ the streamed
-    # 2-byte pair count in "ldsw"]
-    per_nbr = 4 * a.feat + 4 + (2 if mode == "ldsw" else 0)
+    # algorithmic bytes per gathered neighbour (per occurrence), SURVEY.md section 8d: the feature row (4 F) + the column id (4) =
+    # 72 B at F = 17.  (The 2-byte per-pair count "ldsw" streams besides is this implementation's traffic, not the algorithm's.)
+    per_nbr = 4 * a.feat + 4
     alg_bytes = [per_nbr * nb for nb in gather_nbrs]
     ach = (sum(alg_bytes) / 1e9) / (sum(gather_ms) / 1e3) if gather_ms and sum(gather_ms) > 0 else None
     kname = ("k_build_groups + k_gather2_items + k_gather2_combine (node-major 2-hop gather-aggregate: work items of <= 8 occurrences "
@@ -246,17 +351,19 @@ def main():
     # HBM-side bytes per gathered neighbour from the rocprofv3 PMC passes of this command (profiles/, FETCH_SIZE doubled as
     # MI355X_MICROARCH prescribes for gfx950), keyed by batches per launch; nearest measured chunk size, else null
     traffic = hbm_per_nbr = hbm_src = None
-    pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_gather2_items.json")
+    pmc_path = os.path.join(ROOT, "profiles", "r03_pmc_gather2_items.json")
     if mode == "ldsw" and os.path.exists(pmc_path) and gather_nbrs:
         with open(pmc_path) as fh:
-            table = json.load(fh).get("by_batches_per_launch", {})
+            pmc_doc = json.load(fh)
+            table = pmc_doc.get("by_batches_per_launch", {})
+            pmc_commit = pmc_doc.get("commit", "unknown")
         if table:
             mean_b = float(np.mean(gather_batches))
             key = min(table, key=lambda k: abs(float(k) - mean_b))
             if abs(float(key) - mean_b) <= 0.5 * mean_b:
                 hbm_per_nbr = float(table[key]["hbm_bytes_per_neighbour"])
                 traffic = hbm_per_nbr * float(np.mean(gather_nbrs))
-                hbm_src = f"profiles/r02_pmc_gather2_items.json[{key} batches per launch]"
+                hbm_src = f"profiles/r03_pmc_gather2_items.json[{key} batches per launch] (PMC passes of build {pmc_commit})"
     avg_ms = float(np.mean(gather_ms)) if gather_ms else None
     roofline = {"kernel": kname, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": traffic,
@@ -298,12 +405,27 @@ def main():
             extras["e2e_with_sampler"] = {"steps": n_e2e, "value": n_nodes / dt, "unit": "nodes/s", "ms_per_step": 1e3 * dt / n_e2e,
                                           "note": "batch schedule generated inside the window by the reference-exact sampler thread "
                                                   "(CPython random.shuffle of the 55k pool per batch, 1.05M train list per epoch)"}
+        if a.sparse_entries > 0 and a.steady_steps > a.steps:
+            # BASELINE.md section 3 quotes DGraph-Fin in two degree regimes: 73.1 M entries (the headline run above) and the
+            # public graph's ~8.6 M directed entries (average degree 2.3): same nodes, same schedule, its own graph and plans
+            try:
+                extras["dgraph_sparse_regime"] = sparse_regime_leg(a, dev, feat, split, w, W, fc)
+            except Exception as exc:
+                extras["dgraph_sparse_regime"] = {"error": repr(exc)}
         if a.fullgraph_epochs > 0:
             try:
                 from ggad_amd.fullgraph_bench import bench_fullgraph
                 extras["fullgraph"] = bench_fullgraph(dev, a.fullgraph_epochs)
             except Exception as exc:          # the extra leg must never take the headline line down
                 extras["fullgraph"] = {"error": repr(exc)}
+            if a.cpu_batches > 0 and isinstance(extras["fullgraph"], dict) and "error" not in extras["fullgraph"]:
+                for name in list(extras["fullgraph"].keys()):
+                    try:
+                        extras["fullgraph"][name]["cpu_baseline"] = cpu_fullgraph_baseline(name, a.cpu_fullgraph_budget)
+                        ep = extras["fullgraph"][name]["cpu_baseline"]["sparse_variant"]["epoch_ms"]
+                        extras["fullgraph"][name]["gpu_over_cpu_sparse"] = ep / extras["fullgraph"][name]["epoch_ms"]
+                    except Exception as exc:
+                        extras["fullgraph"][name]["cpu_baseline"] = {"error": repr(exc)}
 
     # ---------------- CPU baseline: dense-faithful port of the reference's step, bounded sample
     cpu = None

@@ -524,6 +524,39 @@ def _full_loss_by_column(emb, logits, emb_con, emb_abnormal, raw, abn_idx, norma
     return l_margin + l_bce + l_rec, l_margin, l_bce, l_rec, aff
 
 
+def full_step_dense(P: Dict[str, torch.Tensor], feat: torch.Tensor, adj: torch.Tensor, raw: torch.Tensor, abn_idx, normal_idx,
+                    noise: torch.Tensor, margin_c: float = 0.7):
+    """One training forward + loss of `run.py:146-210` with the DENSE N x N operands the reference holds (`adj` = normalize_adj(A) + I,
+    `raw` = A + I as (N, N) float tensors): `torch.bmm(adj, seq_fts)` per GCN layer (`model.py:26-35`), `adj[0, abn, :] @ emb`
+    (`model.py:151-156`), the N x N similarity `emb_n @ emb_n.T * raw_adj` and its column sums (`run.py:177-188`).  Same arithmetic as
+    full_forward + full_loss, other association; used as the dense-faithful CPU baseline of bench.py.  Returns the total loss."""
+    def gcn(x, pre):
+        t = x.mm(P[pre + ".fc.weight"].t())                               # `model.py:27`
+        out = torch.bmm(adj[None], t[None])[0] + P[pre + ".bias"]         # `:31-33`
+        return F.prelu(out, P[pre + ".act.weight"])                       # `:35`
+    emb = gcn(gcn(feat, "gcn1"), "gcn2")
+    abn = torch.as_tensor(np.asarray(abn_idx), dtype=torch.long)
+    nrm = torch.as_tensor(np.asarray(normal_idx), dtype=torch.long)
+    emb_abnormal = emb[abn] + noise                                       # `model.py:141-144`
+    emb_con = F.relu(adj[abn, :].mm(emb).mm(P["fc4.weight"].t()))         # `:151-156`
+    emb_combine = torch.cat((emb[nrm], emb_con), 0)                       # `:159`
+    logits = F.relu(F.relu(emb_combine.mm(P["fc1.weight"].t())).mm(P["fc2.weight"].t())).mm(P["fc3.weight"].t())[:, 0]
+    emb = emb.index_copy(0, abn, emb_con)                                 # `:182`
+    lbl = torch.cat((torch.zeros(len(normal_idx)), torch.ones(emb_con.shape[0])))
+    l_bce = torch.mean(F.binary_cross_entropy_with_logits(logits, lbl, reduction="none", pos_weight=torch.tensor([1])))
+    inv = torch.pow(torch.norm(emb, dim=-1, keepdim=True), -1)            # `run.py:177-181`
+    inv = torch.where(torch.isinf(inv), torch.zeros_like(inv), inv)
+    en = emb * inv
+    sim = en.mm(en.t()) * raw                                             # `:182-184`
+    r_inv = torch.pow(raw.sum(0), -1)
+    r_inv = torch.where(torch.isinf(r_inv), torch.zeros_like(r_inv), r_inv)
+    aff = sim.sum(0) * r_inv                                              # `:185-188`
+    l_margin = (margin_c - (torch.mean(aff[nrm]) - torch.mean(aff[abn]))).clamp_min(min=0)
+    diff = torch.pow(emb_con - emb_abnormal.unsqueeze(0), 2)
+    l_rec = torch.mean(torch.sqrt(torch.sum(diff, 1)))                    # quirk 4: reduces over the outlier axis
+    return l_margin + l_bce + l_rec
+
+
 # ----------------------------------------------------------------------------------
 # TAM comparison model (`tam.py`, `model_tam.py`, `utils_tam.py`): truncated affinity maximisation
 # ----------------------------------------------------------------------------------

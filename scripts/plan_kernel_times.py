@@ -32,5 +32,6 @@ for k in sizes:
         bn, bl = sched.next_batches(k)
         ch.build(bn, bl)
         torch.cuda.synchronize()
-        print("chunk", k, "rows", ch.n_rows, "entries", ch.n_ents, "items", int(ch.counters[1]), "groups", int(ch.counters[0]),
-              "partial slots", int(ch.counters[2]), "pairs", int(ch.counters[4]), flush=True)
+        c = ch.counters.cpu().numpy()[::16]           # one counter per 64-byte line (GGAD_CTR_STRIDE): groups, items, partial slots, cursor, pairs
+        print("chunk", k, "rows", ch.n_rows, "entries", ch.n_ents, "items", int(c[1]), "groups", int(c[0]),
+              "partial slots", int(c[2]), "pairs", int(c[4]), flush=True)

@@ -777,7 +777,7 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     if a.part == "all":
         env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
-        for p in ("full", "mini", "baselines", "ocgnn", "ingest"):
+        for p in ("full", "mini", "baselines", "ocgnn", "ingest", "sage", "pcgnn", "tam"):
             cmd = [sys.executable, os.path.abspath(__file__), "--part", p] + (["--no-handler"] if a.no_handler else [])
             subprocess.check_call(cmd, env=env)
     elif a.part == "full":
