@@ -82,6 +82,7 @@ struct XcdArgs {
   float *pos_scal, *pos_o, *gw_row, *dw_part;
   const int32_t *ck_rec, *pos_rec;    // records of k_xcd_prep (8 ints per piece / per position)
   const int32_t *batch_n0;            // label-0 positions per batch (k_xcd_prep)
+  const float *adam_sc;               // Adam's step_size / sqrt(bias_correction2) per batch of the chunk (k_xcd_prep: double pow)
   ggad_xchg_view X;
   uint32_t xstep0;
   float grad_scale;
@@ -296,8 +297,9 @@ __global__ void __launch_bounds__(XT) k_train_chunk_xcd(XcdArgs A) {
   }
   unsigned round = 0;
   unsigned long long t_prev = wall_clock64();
+  const bool prof_on = (A.dbg & 4) != 0;                 // phase clocks cost rank 0's polling wave a global read-modify-write each
 #define XCD_TICK(slot)                                                         \
-  if (rank == 0 && threadIdx.x == 0) {                                         \
+  if (prof_on && rank == 0 && threadIdx.x == 0) {                              \
     const unsigned long long t_now = wall_clock64();                           \
     C->prof[slot] += t_now - t_prev;                                           \
     t_prev = t_now;                                                            \
@@ -533,11 +535,9 @@ __global__ void __launch_bounds__(XT) k_train_chunk_xcd(XcdArgs A) {
     }
     const bool more = piped && b + 1 < A.n_batches;
     if (more) issue_recs(b + 1, recn, posn);                // next step's records: behind this phase's own loads
-    if (threadIdx.x == XT - 1) {                            // Adam scalars of this step (double pow: off the critical path here)
-      const double ts = (double)(step0 + b + 1);
-      const double bc1 = 1.0 - pow(0.9, ts), bc2 = 1.0 - pow(0.999, ts);
-      sc[0] = (float)((double)S.lr / bc1);                 // step_size
-      sc[1] = (float)sqrt(bc2);                            // bias_correction2_sqrt
+    if (threadIdx.x == XT - 1) {                            // Adam scalars of this step: double pow(), evaluated by k_xcd_prep for every
+      sc[0] = A.adam_sc[2 * b];                            // batch of the chunk (300 f64 instructions in one wave per step stalled its
+      sc[1] = A.adam_sc[2 * b + 1];                        // whole workgroup at the barrier below for > 1 us)
     }
     __syncthreads();
     XCD_TICK(10)
@@ -787,6 +787,9 @@ struct XcdPrepArgs {
   const int32_t *batch_ptr, *ent_ptr, *row_ck_ptr, *ck_rc, *ck_e0, *ent_own, *labels, *pos_meta, *row_pos;
   float *x2;
   int32_t *ck_rec, *pos_rec, *batch_n0;
+  float *adam_sc;
+  const int32_t *step_counter;
+  float lr;
   int n_batches, n_rows, n_pieces, n_ents;
 };
 __global__ void __launch_bounds__(256) k_xcd_prep(XcdPrepArgs P) {
@@ -796,6 +799,12 @@ __global__ void __launch_bounds__(256) k_xcd_prep(XcdPrepArgs P) {
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (P.batch_ptr[mid] <= row) lo = mid; else hi = mid; }
     return P.batch_ptr[lo];
   };
+  if (tid < P.n_batches) {                               // adam_scalars of step.hip for optimiser step step0 + tid + 1
+    const double ts = (double)(*P.step_counter + tid + 1);
+    const double bc1 = 1.0 - pow(0.9, ts), bc2 = 1.0 - pow(0.999, ts);
+    P.adam_sc[2 * tid] = (float)((double)P.lr / bc1);       // step_size
+    P.adam_sc[2 * tid + 1] = (float)sqrt(bc2);              // bias_correction2_sqrt
+  }
   if (tid < P.n_pieces) {
     const int c = tid;
     const int rc = P.ck_rc[c], row = rc >> 6;
@@ -941,7 +950,7 @@ int64_t ggad_mb_xcd_workspace_elems(int32_t max_rows, int32_t D, int32_t F, int6
   // (the per-batch table at the end holds at most rows_cap entries: a batch has at least one row)
   const int64_t ld = ((int64_t)max_rows + 3) / 4 * 4;
   return 256 + (int64_t)max_rows * 8 + 8 * ld + (int64_t)max_rows * GGAD_WAVE + (int64_t)XMAXWG * F * GGAD_WAVE +
-         (rows_cap + pieces_cap + 2) * REC + rows_cap + 1;
+         (rows_cap + pieces_cap + 2) * REC + 3 * (rows_cap + 1);
 }
 
 /* The dense steps of a whole chunk as ONE launch resident on one XCD (see the header of this file).  tmpl as for
@@ -974,6 +983,7 @@ int ggad_mb_train_chunk_xcd(const ggad_mb_step *tmpl, int32_t n_batches, const i
   A.pos_rec = recs;
   A.ck_rec = recs + (rows_cap + 1) * REC;
   A.batch_n0 = recs + (rows_cap + pieces_cap + 2) * REC;
+  A.adam_sc = reinterpret_cast<const float *>(A.batch_n0 + rows_cap + 1);
   A.grad_scale = grad_scale;
   static const unsigned long long timeout = [] {            // barrier time-out in seconds (wall clock, 100 MHz ticks)
     const char *e = getenv("GGAD_XCD_TIMEOUT_S");
@@ -1002,6 +1012,7 @@ int ggad_mb_train_chunk_xcd(const ggad_mb_step *tmpl, int32_t n_batches, const i
     Q.x2 = const_cast<float *>(s.x2);
     Q.ck_rec = const_cast<int32_t *>(A.ck_rec); Q.pos_rec = const_cast<int32_t *>(A.pos_rec);
     Q.batch_n0 = const_cast<int32_t *>(A.batch_n0);
+    Q.adam_sc = const_cast<float *>(A.adam_sc); Q.step_counter = s.step_counter; Q.lr = s.lr;
     Q.n_batches = n_batches; Q.n_rows = n_rows; Q.n_pieces = n_pieces; Q.n_ents = n_ents;
     const int64_t work = std::max<int64_t>(std::max<int64_t>(n_rows, n_pieces), ((int64_t)n_ents * XFT + 3) / 4);
     const unsigned blocks = (unsigned)std::min<int64_t>((work + 255) / 256, 8192);

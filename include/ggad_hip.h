@@ -348,7 +348,7 @@ int ggad_mb_train_chunk_xchg(const ggad_mb_step *tmpl, int32_t n_batches, const 
  * each: the stream must be able to keep n_wg of them resident on that XCD (ggad_mb_xcd_grid() = the largest grid, 8 x 32).
  * ggad_mb_xcd_status: control words of the last launch on `workspace` (synchronises `stream`): out[0] error (0 ok, 1 barrier
  * time-out, 2 registration time-out; GGAD_XCD_TIMEOUT_S seconds, default 10), out[1] workgroups that stayed, out[2] their XCD,
- * out[3..10] wall clocks of rank 0 in 10 ns ticks: phase A, barrier, R, barrier, C, barrier, E, barrier; out[11..18] sub-phase
+ * out[3..10] (only with GGAD_XCD_DEBUG=4, else 0) wall clocks of rank 0 in 10 ns ticks: phase A, barrier, R, barrier, C, barrier, E, barrier; out[11..18] sub-phase
  * clocks (diagnostics: they are INCLUDED in the phase that follows them). */
 int32_t ggad_mb_xcd_grid(void);
 /* XCD on which block 0 of a launch on `stream` runs (block b then runs on XCD (first + b) % 8; a constant of the stream's

@@ -1,6 +1,7 @@
 """Dense steps of a chunk: the XCD-resident launch (csrc/step_xcd.hip) against the 5-launch chain, alone on the chip, DGraph-size
 graph.  Prints us per step for both, the phase clocks of the resident kernel, and the largest |difference| of losses / weights.
 Usage (GPU box): python scripts/xcd_step_time.py [batches ...]"""
+import os
 import random
 import sys
 import time
@@ -30,6 +31,7 @@ torch.manual_seed(0)
 w0 = (torch.nn.init.xavier_uniform_(torch.empty(1, 64)), torch.nn.init.xavier_uniform_(torch.empty(64, 17)),
       torch.nn.init.xavier_uniform_(torch.empty(64, 64)))
 sizes = [int(a) for a in sys.argv[1:]] or [20, 150]
+# GGAD_XCD_DEBUG=4 turns the kernel's phase clocks on (they cost ~1 us per step)
 for k in sizes:
     bn, bl = sched.next_batches(k)
     tr.chunk.build(bn, bl)
