@@ -98,6 +98,7 @@ SIGNATURES = {
     "ggad_spmm_csr_f32": (c_int32, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _L, _I, _P, _P, _P, _L, _P, _P, _P]),
     "ggad_spmm_sliced_workspace_elems": (c_int64, [_L, _I]),
     "ggad_spmm_sliced_seg_len": (c_int32, []),
+    "ggad_spmm_panel_available": (c_int32, []),
     "ggad_spmm_panel_rows": (c_int32, []),
     "ggad_spmm_panel_waves": (c_int32, []),
     "ggad_spmm_panel_rounds": (c_int32, []),

@@ -12,6 +12,8 @@
 // One wave per output row; a row of W floats is read as float4 (W % 4 == 0, W <= 1024: W = 300 -> 75 float4,
 // 2 load instructions per neighbour); neighbour ids / values are fetched 64 at a time and broadcast by
 // v_readlane.  Summation order is fixed (CSR order) -> deterministic.
+#include <mutex>
+
 #include "common.h"
 
 namespace {
@@ -492,6 +494,27 @@ __global__ void __launch_bounds__(256) k_prelu_bwd_v4(const float4 *__restrict__
   }
 }
 
+// any width: every thread walks columns c, c + 1024, ... and the S partials of each in order; the slope gradient = the sum of the
+// column sums, added thread by thread through LDS in a fixed tree.  (The single-round kernel below needs W <= 1,024.)
+__global__ void __launch_bounds__(1024) k_prelu_bwd_final_wide(const float *__restrict__ part_db, const float *__restrict__ part_da,
+                                                               int S, int W, float *__restrict__ db, float *__restrict__ da) {
+  __shared__ float qa[1024];
+  float tot_a = 0.f;
+  for (int c = threadIdx.x; c < W; c += 1024) {
+    float b = 0.f, a = 0.f;
+    for (int s0 = 0; s0 < S; ++s0) { b += part_db[(int64_t)s0 * W + c]; a += part_da[(int64_t)s0 * W + c]; }
+    if (db) db[c] = b;
+    tot_a += a;
+  }
+  qa[threadIdx.x] = tot_a;
+  __syncthreads();
+  for (int off = 512; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) qa[threadIdx.x] += qa[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && da) *da = qa[0];
+}
+
 __global__ void __launch_bounds__(1024) k_prelu_bwd_final(const float *__restrict__ part_db, const float *__restrict__ part_da,
                                                           int S, int W, float *__restrict__ db, float *__restrict__ da) {
   // one workgroup of 1,024 threads = G groups of (W rounded up to 64) threads, W <= 1024: group g sums its share of the S
@@ -835,6 +858,27 @@ int ggad_spmm_sliced_f32(const int32_t *col, const float *val, const int32_t *se
   return GGAD_OK;
 }
 
+// k_spmm_panel needs PAN_LDS (159 KB) of dynamic LDS per workgroup: the attribute is set -- and its result checked -- once per DEVICE
+// (0 unknown, 1 ready, -1 not available), under a mutex
+static bool panel_lds_ready() {
+  static std::mutex mu;
+  static int state[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  std::lock_guard<std::mutex> lock(mu);
+  if (state[dev] == 0) {
+    int max_lds = 0;
+    bool ok = hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess;
+    (void)hipGetLastError();
+    // (the attribute reports the default limit on some stacks; the authoritative answer is whether the opt-in succeeds)
+    ok = hipFuncSetAttribute((const void *)k_spmm_panel, hipFuncAttributeMaxDynamicSharedMemorySize, PAN_LDS) == hipSuccess;
+    (void)hipGetLastError();
+    state[dev] = ok ? 1 : -1;
+  }
+  return state[dev] == 1;
+}
+int32_t ggad_spmm_panel_available(void) { return panel_lds_ready() ? 1 : 0; }
+
 int32_t ggad_spmm_panel_rows(void) { return PAN_R; }
 int32_t ggad_spmm_panel_waves(void) { return PAN_WAVES; }
 int32_t ggad_spmm_panel_rounds(void) { return PAN_KR; }
@@ -850,8 +894,7 @@ int ggad_spmm_panel_f32(const int32_t *wg_tab, int32_t n_wg, const uint32_t *dir
   GGAD_REQUIRE(n_chunks == (int32_t)((n_src_rows + PAN_R - 1) / PAN_R));
   if (n_wg == 0) return GGAD_OK;
   hipStream_t st = as_stream(stream_);
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void *)k_spmm_panel, hipFuncAttributeMaxDynamicSharedMemorySize, PAN_LDS); attr = true; }
+  if (!panel_lds_ready()) return GGAD_E_INVALID;          // this device cannot give a workgroup PAN_LDS bytes: callers take the sliced kernel
   const int64_t nt = n_src_rows * S * SPMM_SL;
   k_slice_major<<<dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st>>>(X, ldx, (int)n_src_rows, W, S, col_scale,
                                                                         reinterpret_cast<float4 *>(xs_workspace));
@@ -866,7 +909,7 @@ int32_t ggad_prelu_bwd_splits(int32_t M) { int s = (M + 63) / 64; return s < 1 ?
 
 int ggad_prelu_bwd_f32(const float *g, const float *z, const float *prelu_a, int32_t M, int32_t W, float *dz, float *db,
                        float *da, float *workspace, ggad_stream_t stream) {
-  GGAD_REQUIRE(g && z && prelu_a && dz && workspace && M >= 1 && W >= 1 && W <= 1024);
+  GGAD_REQUIRE(g && z && prelu_a && dz && workspace && M >= 1 && W >= 1);
   const int S = ggad_prelu_bwd_splits(M);
   float *pdb = workspace, *pda = workspace + (int64_t)S * W;
   hipStream_t st = as_stream(stream);
@@ -875,7 +918,10 @@ int ggad_prelu_bwd_f32(const float *g, const float *z, const float *prelu_a, int
                                                   reinterpret_cast<float4 *>(dz), reinterpret_cast<float4 *>(pdb), reinterpret_cast<float4 *>(pda));
   else
     k_prelu_bwd<<<dim3((W + 63) / 64, S), dim3(256), 0, st>>>(g, z, prelu_a, M, W, dz, pdb, pda);
-  k_prelu_bwd_final<<<dim3(1), dim3(1024), 0, st>>>(pdb, pda, S, W, db, da);
+  if (W <= 1024)
+    k_prelu_bwd_final<<<dim3(1), dim3(1024), 0, st>>>(pdb, pda, S, W, db, da);
+  else
+    k_prelu_bwd_final_wide<<<dim3(1), dim3(1024), 0, st>>>(pdb, pda, S, W, db, da);      // layers wider than 1,024 (tam.py --embedding_dim > 512)
   GGAD_CHECK_LAUNCH("prelu_bwd_f32");
   return GGAD_OK;
 }

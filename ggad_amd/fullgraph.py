@@ -420,6 +420,9 @@ def _use_panel(csr: Csr, p, X: torch.Tensor):
     force = os.environ.get("GGAD_SPMM_PANEL")
     if force == "0" or X.shape[0] != csr.shape[1]:
         return None
+    with torch.cuda.device(X.device):
+        if not _lib.load().ggad_spmm_panel_available():          # a device without 159 KB of LDS per workgroup: the sliced kernel
+            return None
     w = X.shape[1]
     nnz = p.get("nnz", csr.nnz)
     if force != "1" and not (w >= 64 and nnz >= 64 * p["n_out"] and nnz >= (1 << 20)):

@@ -125,6 +125,10 @@ class BatchChunk:
     def _alloc(self, rows, ents, chunks, stage, pairs, items, part2, seg) -> None:
         """Grow whatever is smaller than asked (25 % head room on growth); refresh the descriptor handed to the C side."""
         d = self.dev
+        if self.generation > 0 and d.type == "cuda":
+            # a grow replaces the pinned staging block and device buffers that an earlier build's asynchronous upload, or the other
+            # stream's chunk kernels, may still be using; torch's allocators do not see the native copies: drain the device first
+            torch.cuda.synchronize(d)
         grow = lambda need, have: int(need * 1.25) + 64 if need > have else have      # noqa: E731
         rows_cap, ent_cap, ck_cap = grow(rows, self.rows_cap), grow(ents, self.ent_cap), grow(chunks, self.ck_cap)
         stage_need = max(stage, 2 * (self.max_batches + 8) + 7 * (rows_cap + 8) + 2 * (ck_cap + 8))

@@ -444,6 +444,9 @@ int ggad_spmm_panel_fill(const int64_t *rowptr, const int32_t *col, int32_t n_ro
 /* 1: every off-diagonal value[i][j] equals (float)(r[i] * r[j]) to a relative rtol; 0: not; < 0: invalid arguments. */
 int ggad_spmm_panel_values_factor(const int64_t *rowptr, const int32_t *col, const float *val, const double *r, int32_t n_rows,
                                   double rtol, int32_t n_threads);
+/* 1 when the current device can give a workgroup the panel kernel's 159 KB of LDS (queried and opted into once per device), else 0:
+ * ggad_spmm_panel_f32 then returns an error and callers keep the sliced kernel. */
+int32_t ggad_spmm_panel_available(void);
 int32_t ggad_spmm_panel_rows(void);
 int32_t ggad_spmm_panel_waves(void);
 int32_t ggad_spmm_panel_rounds(void);

@@ -105,12 +105,22 @@ def main():
 
     start = time.time()
     print("<<<<<<Start to calculate distance<<<<<")
-    dis_path = "distance_save/dis_array_{}.npy".format(args.dataset_model)
-    if os.path.exists(dis_path) and not args.synthetic:
-        dis_vals = np.load(dis_path)
-        if dis_vals.shape != (raw.nnz,):
-            sys.exit("{} does not belong to this graph ({} values for {} entries)".format(dis_path, dis_vals.shape, raw.nnz))
-    else:
+    # The reference caches a DENSE N x N distance array as distance_save/dis_array_{dataset_model}.npy (tam.py:164-170); here the cache
+    # holds one value per stored entry of A + I and is keyed by the DATASET and its entry count (a file of its own name: a second
+    # dataset, or a cache the reference wrote, is never mistaken for it).  A dense reference cache of the right shape is converted.
+    dis_path = "distance_save/dis_edges_{}_{}.npy".format(args.dataset, raw.nnz)
+    ref_path = "distance_save/dis_array_{}.npy".format(args.dataset_model)
+    dis_vals = None
+    if not args.synthetic and os.path.exists(dis_path):
+        cand = np.load(dis_path)
+        if cand.shape == (raw.nnz,):
+            dis_vals = cand
+    if dis_vals is None and not args.synthetic and os.path.exists(ref_path):
+        cand = np.load(ref_path, mmap_mode="r")
+        if cand.shape == tuple(raw.shape):                             # the reference's dense cache: gather at the stored entries
+            coo = raw.tocoo()
+            dis_vals = np.asarray(cand[coo.row, coo.col], dtype=np.float32)
+    if dis_vals is None:
         dis_vals = T.calc_distance(raw, feats[0])                      # one value per entry of A + I      tam.py:168
         if not args.synthetic:
             os.makedirs("distance_save", exist_ok=True)

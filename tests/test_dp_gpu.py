@@ -91,6 +91,26 @@ def test_one_shot_exchange_two_processes_one_gpu_bit_equal_to_allreduce(tmp_path
     np.testing.assert_array_equal(p0, np.load(b / "params_0.npy"))
 
 
+@pytest.mark.parametrize("world", [4, 8])
+def test_one_shot_exchange_four_and_eight_processes_one_gpu(tmp_path, world):
+    """W = 4 and W = 8 PROCESSES on one device through the one-shot exchange (what a node of 8 GPUs runs, minus the xGMI hop): every
+    rank's buffer holds 2 x W slots, each step is W peer writes + W polls per parameter, bounded by the wall clock.  After 6 steps all
+    ranks hold bit-identical weights, equal to the all-reduce(SUM) + Adam(1 / W) path."""
+    import torch.multiprocessing as mp
+    steps = 6
+    a, b = tmp_path / "oneshot", tmp_path / "allreduce"
+    a.mkdir(); b.mkdir()
+    mp.spawn(_worker, args=(world, _free_port(), steps, str(a), True), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), steps, str(b), False), nprocs=world, join=True)
+    ps = [np.load(a / f"params_{r}.npy") for r in range(world)]
+    for r in range(1, world):
+        np.testing.assert_array_equal(ps[0], ps[r])
+    ref = np.load(b / "params_0.npy")
+    assert np.isfinite(ps[0]).all()
+    # the rank-order sum g0 + g1 + ... + g(W-1) of the exchange against the all-reduce's tree: equal to fp32 round-off of a sum of W terms
+    np.testing.assert_allclose(ps[0], ref, atol=2e-7, rtol=1e-5)
+
+
 def test_exchange_inside_the_resident_chunk_kernel_world_one():
     """The one-shot exchange code path INSIDE the XCD-resident chunk kernel (phase E: publish the granule, poll, rank-order sum,
     Adam x 1/W) at world size 1 -- granule stores and polls on the rank's own fine-grained buffer -- gives bit for bit the weights
