@@ -67,9 +67,10 @@ class ModelHandler(object):
         args = self.args
         if args.model == "SAGE":
             return self._train_sage()
+        if args.model == "PCGNN":
+            return self._train_pcgnn()
         if args.model != "GCN":
-            raise NotImplementedError("models 'GCN' (GGAD) and 'SAGE' are trainable; 'PCGNN' needs three relation graphs and an "
-                                      "undefined `test_pcgnn` in the reference (SURVEY.md §3.2 quirk 7)")
+            raise NotImplementedError("models 'GCN' (GGAD), 'SAGE' and 'PCGNN' are trainable")
         if not torch.cuda.is_available():
             raise RuntimeError("ModelHandler.train needs an MI355X: the GGAD hot path has no CPU fallback")
         dist = torch.distributed if (torch.distributed.is_available() and torch.distributed.is_initialized()) else None
@@ -274,6 +275,114 @@ class ModelHandler(object):
             print("Model path: {}".format(path_saver))
             gnn_model.load_state_dict(torch.load(path_saver))
         return self._test_graphsage(idx_test, y_test, gnn_model, args.batch_size, args.thres)
+
+    def _train_pcgnn(self):
+        """`model: 'PCGNN'`: IntraAgg x 3 -> InterAgg -> PCALayer(2, inter1, alpha) as `src/model_handler.py:269-277,287-288` builds
+        them, trained by the loop of `:310-370` and validated / tested through the `test_pcgnn` call sites of `:392,411`.  The reference
+        cannot run this branch: its handler hands the homogeneous adjacency to `InterAgg`, which indexes three relations
+        (`src/layers.py:43-45`), and `test_pcgnn` is not defined anywhere.  Two repairs, nothing else:
+        (1) `adj_lists` must be a list of THREE relation adjacencies -- config key `relations` (dicts of sets / (rowptr, col) pairs),
+        or `data = ([r1, r2, r3], feat, labels)`; (2) `test_pcgnn` = `test_sage`'s protocol on `PCALayer.to_prob(nodes, labels,
+        train_flag=False)[0][:, 1]` (the class-1 GNN score).  No vectors of the reference exist for this loop (it never ran): the
+        modules are pinned (tests/golden/minibatch_pcgnn.npz), the loop is checked for self-consistency (tests/test_dropin_gpu.py)."""
+        from .fullgraph import FlatAdam
+        from .layers import InterAgg, IntraAgg, PCALayer
+        from . import synth
+        args = self.args
+        if not torch.cuda.is_available():
+            raise RuntimeError("ModelHandler.train needs an MI355X: there is no CPU fallback")
+        dev = torch.device("cuda", int(getattr(args, "device", torch.cuda.current_device())))
+        torch.cuda.set_device(dev)
+        feat_data = self.dataset["feat_data"]
+        relations = getattr(args, "relations", None)
+        if relations is None and isinstance(self.dataset["adj_lists"], (list, tuple)) and len(self.dataset["adj_lists"]) == 3 \
+                and not isinstance(self.dataset["adj_lists"][0], np.ndarray):
+            relations = self.dataset["adj_lists"]
+        if relations is None or len(relations) != 3:
+            raise ValueError("model 'PCGNN' needs three relation graphs: config key `relations` = [r1, r2, r3] "
+                             "(dict of neighbour sets, or (rowptr, col)); the reference's branch never ran (its handler passes one)")
+        adjs = [synth.csr_to_adj_lists(r[0], r[1]) if isinstance(r, tuple) else r for r in relations]
+        idx_train = list(self.dataset["idx_train"])
+        idx_valid, y_valid, idx_test, y_test = (self.dataset["idx_test"], self.dataset["y_test"],
+                                                self.dataset["idx_test"], self.dataset["y_test"])   # :260-261
+        n, f = feat_data.shape
+        nn.Embedding(n, f)                                            # RNG consumption of :263
+        features = FeatureTable(torch.FloatTensor(np.asarray(feat_data, dtype=np.float32)))
+        train_pos = [i for i in idx_train if self.dataset["labels"][i] == 1]          # pos_neg_split(idx_train, y_train)[0]
+        rho, alpha = float(getattr(args, "rho", 0.5)), float(getattr(args, "alpha", 2))
+        intras = [IntraAgg(features, f, args.emb_size, train_pos, rho, cuda=True) for _ in range(3)]         # :270-275
+        inter1 = InterAgg(features, f, args.emb_size, train_pos, adjs, intras, inter=args.multi_relation, cuda=True)    # :276-277
+        gnn_model = PCALayer(2, inter1, alpha).to(dev)                 # :288
+        features.to(dev)
+        optimizer = FlatAdam([p for p in gnn_model.parameters() if p.requires_grad], lr=args.lr, weight_decay=args.weight_decay)
+        self.model = gnn_model
+        num_batches = int(getattr(args, "num_batches", 150))           # :317
+        n_pseudo = int(getattr(args, "n_pseudo", 50))
+        idx_anomaly = list(self.dataset["idx_anomaly"])
+        labels = self.dataset["labels"]
+        timestamp = datetime.datetime.fromtimestamp(int(time.time())).strftime("%Y-%m-%d %H-%M-%S")
+        dir_saver = args.save_dir + timestamp
+        path_saver = os.path.join(dir_saver, "{}_{}.pkl".format(args.data_name, args.model))
+        f1_mac_best, auc_best, ep_best = 0, 0, -1
+        self.pcgnn_losses = []
+        for epoch in range(args.num_epochs):
+            random.shuffle(idx_train)                                  # :314
+            loss_sum, con_sum, epoch_time = 0.0, 0.0, 0.0
+            for batch in range(num_batches):
+                t0 = time.time()
+                i0, i1 = batch * args.batch_size, min((batch + 1) * args.batch_size, len(idx_train))
+                batch_nodes = idx_train[i0:i1]
+                random.shuffle(idx_anomaly)                            # :341
+                batch_nodes = batch_nodes + idx_anomaly[:n_pseudo]     # :342,347
+                batch_label = torch.as_tensor(labels[np.array(batch_nodes)], device=dev).long()
+                optimizer.zero_grad()
+                loss, loss_constraint = gnn_model.loss(batch_nodes, batch_label)           # :352-353
+                loss.backward()
+                optimizer.step()
+                epoch_time += time.time() - t0
+                self.pcgnn_losses.append((float(loss.item()), float(loss_constraint.item())))
+                loss_sum += self.pcgnn_losses[-1][0]
+                con_sum += self.pcgnn_losses[-1][1]
+            print(f"Epoch: {epoch}, loss: {loss_sum / num_batches}, loss_constraint: {con_sum / num_batches}, time: {epoch_time}s")
+            if epoch % args.valid_epochs == 0:
+                print("Valid at epoch {}".format(epoch))
+                f1_mac_val, f1_1_val, f1_0_val, auc_val, gmean_val = self._test_pcgnn(idx_valid, y_valid, gnn_model, args.batch_size,
+                                                                                      args.thres)
+                if auc_val > auc_best:
+                    f1_mac_best, auc_best, ep_best = f1_mac_val, auc_val, epoch
+                    if not os.path.exists(dir_saver):
+                        os.makedirs(dir_saver)
+                    print("  Saving model ...")
+                    torch.save(gnn_model.state_dict(), path_saver)
+        if ep_best >= 0:
+            print("Restore model from epoch {}".format(ep_best))
+            print("Model path: {}".format(path_saver))
+            gnn_model.load_state_dict(torch.load(path_saver))
+        return self._test_pcgnn(idx_test, y_test, gnn_model, args.batch_size, args.thres)
+
+    @staticmethod
+    def _test_pcgnn(test_cases, labels, model, batch_size, thres=0.5):
+        """What the undefined `test_pcgnn` of `src/model_handler.py:392,411` has to be for that call to work: `test_sage`'s protocol
+        (`src/utils.py:207-247`) on the class-1 GNN score of `PCALayer.to_prob(nodes, labels, train_flag=False)`."""
+        from .metrics import binary_report
+        test_cases = list(test_cases)
+        labels = np.asarray(labels)
+        probs = []
+        with torch.no_grad():
+            for it in range(int(len(test_cases) / batch_size) + 1):
+                lo, hi = it * batch_size, min((it + 1) * batch_size, len(test_cases))
+                if hi <= lo:
+                    continue
+                chunk = test_cases[lo:hi]
+                dev = next(model.parameters()).device
+                gnn_prob, _ = model.to_prob(chunk, torch.as_tensor(labels[lo:hi], device=dev).long(), train_flag=False)
+                probs.append(gnn_prob[:, 1])
+        probs = torch.cat(probs)
+        r = binary_report(probs, torch.as_tensor(labels, device=probs.device), thres)
+        print(f"   GNN F1-binary-1: {r['f1_1']:.4f}\tF1-binary-0: {r['f1_0']:.4f}" +
+              f"\tF1-macro: {r['f1_macro']:.4f}\tG-Mean: {r['gmean']:.4f}\tAUC: {r['auc']:.4f}")
+        print("Testing AP:", r["ap"])
+        return r["f1_macro"], r["f1_1"], r["f1_0"], r["auc"], r["gmean"]
 
     @staticmethod
     def _test_graphsage(test_cases, labels, model, batch_size, thres=0.5):

@@ -166,3 +166,36 @@ def test_recon(test_cases, labels, model, batch_size, test_attr, thres=0.5, verb
         print("Testing AUC", auc_gnn)
         print("Testing AP:", ap)
     return auc_gnn, ap
+
+
+def aegis_scores(model, test_cases: Sequence[int], batch_size: int, batches_per_launch: int = 512) -> torch.Tensor:
+    """`to_prob` of the AEGIS-style model for every reference batch of `test_cases` (`src/utils.py:184-193`): the aggregation of
+    many batches per plan, the discriminator batch by batch (its batch norm uses the statistics of each batch: the reference never
+    leaves training mode)."""
+    cases = np.asarray(list(test_cases), dtype=np.int64)
+    n_it = int(len(cases) / batch_size) + 1
+    slices = [cases[i * batch_size:min((i + 1) * batch_size, len(cases))] for i in range(n_it)]
+    slices = [s for s in slices if len(s)]
+    enc = model.enc
+    out = []
+    with torch.no_grad():
+        for g0 in range(0, len(slices), batches_per_launch):
+            grp = slices[g0:g0 + batches_per_launch]
+            x_feat, x_noise, bp = enc.aggregator.aggregate(grp, enc.adj_lists, len(grp))
+            for b in range(len(grp)):
+                logits, _, _ = enc.discriminate(x_feat[bp[b]:bp[b + 1]], x_noise[bp[b]:bp[b + 1]])
+                out.append(logits[:int(len(logits) / 2), 0].clone())
+    return torch.cat(out)
+
+
+def test_aegis(test_cases, labels, model, batch_size, thres=0.5, verbose=True):
+    """Reference `test_aegis` (`src/utils.py:175-204`): AP / AUROC of the discriminator's score of the real nodes; same prints.  The
+    reference returns nothing; the two numbers are returned here as well."""
+    from .metrics import average_precision, roc_auc
+    scores = aegis_scores(model, test_cases, batch_size)
+    y = torch.as_tensor(np.asarray(labels), device=scores.device)
+    auc_gnn, ap = roc_auc(scores, y), average_precision(scores, y)
+    if verbose:
+        print("Testing AP:", ap)
+        print("Testing AUC", auc_gnn)
+    return auc_gnn, ap

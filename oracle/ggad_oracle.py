@@ -388,6 +388,38 @@ def baseline_scores(weight, fc_weight, rowptr, col, feat, cases, batch_size: int
     return np.concatenate(out) if out else np.zeros(0, dtype=np.float32)
 
 
+def aegis_mlp(P: Dict[str, torch.Tensor], pre: str, x: torch.Tensor, act, bn_state: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
+    """The 2-layer stack of `torch_geometric.nn.MLP` (2.1.0: Linear -> BatchNorm1d (training mode: batch statistics, eps 1e-5) -> act ->
+    Linear) as `src/graphsage_aegis.py:283-290` instantiates `discriminator2`; parameters named like PyG's state_dict.  PARITY
+    UNPINNED: torch_geometric is absent from the image; this restates its published layer stack, it was never run against it."""
+    h = x.mm(P[pre + ".lins.0.weight"].t()) + P[pre + ".lins.0.bias"]
+    mean, var = h.mean(0), h.var(0, unbiased=False)
+    h = (h - mean) / torch.sqrt(var + 1e-5) * P[pre + ".norms.0.module.weight"] + P[pre + ".norms.0.module.bias"]
+    h = act(h)
+    return h.mm(P[pre + ".lins.1.weight"].t()) + P[pre + ".lins.1.bias"]
+
+
+def aegis_forward(P: Dict[str, torch.Tensor], rowptr, col, feat, noise, nodes):
+    """`GCNEncoder.forward` of `src/graphsage_aegis.py:292-320` from the CSR: the batch's 1-hop aggregate of the feature table and of
+    the noise table (`:194-226`), relu(W agg^T) of both, the discriminator on real ++ noise and on noise alone, sigmoid.
+    Returns (logits_all (2B,), logits_gen (B,), label (2B,))."""
+    a = torch.from_numpy(aggregate_batch(rowptr, col, feat, nodes, False).to_feats)
+    z = torch.from_numpy(aggregate_batch(rowptr, col, noise, nodes, False).to_feats)
+    combined = F.relu(a.mm(P["enc.weight"].t()))
+    combined_noise = F.relu(z.mm(P["enc.weight"].t()))
+    emb_all = torch.cat([combined, combined_noise], 0)
+    label = torch.cat([torch.zeros(len(combined)), torch.ones(len(combined_noise))])
+    logits_all = torch.sigmoid(aegis_mlp(P, "enc.discriminator2", emb_all, torch.sigmoid))[:, 0]
+    logits_gen = torch.sigmoid(aegis_mlp(P, "enc.discriminator2", combined_noise, torch.sigmoid))[:, 0]
+    return logits_all, logits_gen, label
+
+
+def aegis_loss(P, rowptr, col, feat, noise, nodes):
+    """`GCN.loss` (`src/graphsage_aegis.py:167-173`): (BCE(discriminator, real = 0 / noise = 1), BCE(discriminator(noise), 0))."""
+    la, lg, label = aegis_forward(P, rowptr, col, feat, noise, nodes)
+    return F.binary_cross_entropy(la, label), F.binary_cross_entropy(lg, torch.zeros_like(lg))
+
+
 def make_adam(params: Sequence[torch.Tensor], lr: float, weight_decay: float):
     """The optimiser both entry points use (`run.py:118`, `src/model_handler.py:299-300`)."""
     return torch.optim.Adam(list(params), lr=lr, weight_decay=weight_decay)

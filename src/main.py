@@ -54,6 +54,8 @@ def use_handler(name):
         from ggad_amd.model_handler_dominate import ModelHandler as H
     elif name == "anomalydae":
         from ggad_amd.model_handler_anomalydae import ModelHandler as H
+    elif name == "aegis":
+        from ggad_amd.model_handler_aegis import ModelHandler as H
     else:
         H = ModelHandler
     HANDLER = H
@@ -112,7 +114,7 @@ if __name__ == "__main__":
     ap.add_argument("--synthetic_entries", type=int, default=73105508, help="directed entries of the synthetic graph "
                     "(73.1 M = BASELINE's figure; 8600000 = the public dataset's average degree 2.3)")
     ap.add_argument("--num_epochs", type=int, default=None, help="override the config's num_epochs")
-    ap.add_argument("--handler", choices=["ggad", "dominant", "anomalydae"], default="ggad",
+    ap.add_argument("--handler", choices=["ggad", "dominant", "anomalydae", "aegis"], default="ggad",
                     help="which ModelHandler drives the run: GGAD (default) or one of the mini-batch comparison models")
     a = ap.parse_args()
     with open(a.config, "r") as fh:

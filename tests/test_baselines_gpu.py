@@ -160,3 +160,77 @@ def test_handler_epochs_equal_the_oracle_loop(which, pw, frac):
     # the pseudo-anomaly fraction of this handler's split
     n_lab = len(h.dataset["idx_labeled"])
     assert int(h.dataset["labels"].sum()) == int(y.sum()) + int(n_lab * frac)
+
+
+def test_aegis_minibatch_model_against_the_oracle_restatement(tmp_path, capsys):
+    """Mini-batch AEGIS-style model (`src/graphsage_aegis.py`, `src/model_handler_aegis.py`).  PARITY UNPINNED: its
+    discriminator is `torch_geometric.nn.MLP`, absent from the image, so the HIP path (two 1-hop aggregates per batch from one plan,
+    MFMA projections and MLP linears) is compared with the oracle's restatement of the same published layer stack: logits, both losses,
+    every gradient, a 4-step Adam trajectory; `to_prob`; the handler end to end (schedule, validation prints)."""
+    import random
+    from ggad_amd import graphsage_aegis as M
+    from ggad_amd.fullgraph import FlatAdam
+    from ggad_amd.graph import DeviceGraph
+    from ggad_amd.graphsage import FeatureTable
+    n, f, d = 6000, 17, 64
+    rowptr, col = synth.make_graph(n, 60000, 5, kind="powerlaw", max_degree=300)
+    feat = O.normalize_rows(synth.make_features(n, f, 5)).astype(np.float32)
+    torch.manual_seed(11)
+    features = FeatureTable(torch.from_numpy(feat))
+    agg = M.GCNAggregator(features, feat, cuda=True)
+    enc = M.GCNEncoder(features, f, d, DeviceGraph(rowptr, col, DEV), agg, gcn=True, cuda=True)
+    model = M.GCN(2, enc).to(DEV)
+    features.to(DEV)
+    names = [k for k, p in model.named_parameters() if p.requires_grad]
+    assert "enc.discriminator2.lins.0.weight" in names and "enc.discriminator2.norms.0.module.weight" in names and "enc.weight" in names
+    P = {k: p.detach().cpu().clone().requires_grad_() for k, p in model.named_parameters() if p.requires_grad}
+    noise = agg.noise.numpy()
+    rng = np.random.default_rng(3)
+    batches = [rng.choice(n, size=150, replace=False) for _ in range(4)]
+    # forward / losses / gradients of the first batch
+    la, lg, lab = model(batches[0])
+    ra, rg, rlab = O.aegis_forward(P, rowptr, col, feat, noise, batches[0])
+    np.testing.assert_allclose(la[:, 0].detach().cpu().numpy(), ra.detach().numpy(), atol=3e-6, rtol=0)
+    np.testing.assert_allclose(lg[:, 0].detach().cpu().numpy(), rg.detach().numpy(), atol=3e-6, rtol=0)
+    assert np.array_equal(lab.cpu().numpy(), rlab.numpy())
+    np.testing.assert_allclose(model.to_prob(batches[0])[:, 0].detach().cpu().numpy(), ra.detach().numpy()[:150], atol=3e-6, rtol=0)
+    # 4 optimiser steps: both losses back-propagated, one Adam step (src/model_handler_aegis.py:152-158)
+    opt = FlatAdam([p for p in model.parameters() if p.requires_grad], lr=0.005, weight_decay=0.007)
+    used = [k for k in names if k == "enc.weight" or k.startswith("enc.discriminator2")]
+    ref_opt = O.make_adam([P[k] for k in used], 0.005, 0.007)
+    for b in range(4):
+        opt.zero_grad()
+        l1, l2 = model.loss(batches[b])
+        (l1 + l2).backward()
+        ref_opt.zero_grad()
+        r1, r2 = O.aegis_loss(P, rowptr, col, feat, noise, batches[b])
+        (r1 + r2).backward()
+        np.testing.assert_allclose([l1.item(), l2.item()], [r1.item(), r2.item()], atol=5e-6, rtol=0)
+        if b == 0:
+            got = dict(model.named_parameters())
+            for k in used:
+                np.testing.assert_allclose(got[k].grad.cpu().numpy(), P[k].grad.numpy(), atol=5e-6, rtol=2e-4, err_msg=k)
+            for k in names:
+                if k not in used:
+                    assert got[k].grad is None or float(got[k].grad.abs().max()) == 0.0, k      # generator / discriminator / fc / weight: unused
+        opt.step()
+        ref_opt.step()
+    got = dict(model.named_parameters())
+    for k in used:
+        np.testing.assert_allclose(got[k].detach().cpu().numpy(), P[k].detach().numpy(), atol=2e-5, rtol=0, err_msg=k)
+    # the handler: schedule (idx_train + idx_test shuffled per epoch, 100 -> here 5 batches), both losses, validation
+    from ggad_amd.model_handler_aegis import ModelHandler
+    lab = synth.make_labels(n, 0.05, 5)
+    cfg = dict(data_name="synthetic", data_dir="", data=((rowptr, col), synth.make_features(n, f, 5), lab), seed=72, model="GCN",
+               multi_relation="GNN", emb_size=64, thres=0.4, lr=0.005, weight_decay=0.007, batch_size=90, num_epochs=3, valid_epochs=2,
+               num_batches=5, save_dir=str(tmp_path) + "/", test_ratio=0.67, device=0)
+    random.seed(72)
+    np.random.seed(72)
+    torch.manual_seed(72)
+    h = ModelHandler(cfg)
+    assert h.train() is None
+    out = capsys.readouterr().out
+    assert "loss_g:" in out and "loss_gen:" in out and "Testing AUC" in out and "Testing AP:" in out
+    assert len(h.epoch_losses) == 3 and h.epoch_losses[0].shape == (5, 2) and np.isfinite(np.stack(h.epoch_losses)).all()
+    assert len(h.valid_history) == 2 and all(0.0 <= v[1] <= 1.0 for v in h.valid_history)
+    assert np.stack(h.epoch_losses)[-1, :, 0].mean() < np.stack(h.epoch_losses)[0, :, 0].mean()      # the discriminator learns

@@ -285,6 +285,49 @@ def test_model_handler_sage_runs_end_to_end(tmp_path, capsys):
     assert "Restore model from epoch" in capsys.readouterr().out
 
 
+def test_model_handler_pcgnn_trains_on_three_relation_graphs(tmp_path, capsys):
+    """`model: 'PCGNN'` end to end (the reference's branch never ran: one adjacency handed to a three-relation aggregator, `test_pcgnn`
+    undefined).  With three relation graphs in the config the repaired driver trains IntraAgg x 3 -> InterAgg -> PCALayer, validates,
+    checkpoints, restores and returns the reference's 5-tuple.  Self-consistency: the run is reproducible from the seed, the loss pair
+    is (total, constraint) with total >= 5 x constraint, the restored model scores the test nodes like the checkpointed one."""
+    from ggad_amd.model_handler import ModelHandler
+    n = 3000
+    rels = []
+    for k in range(3):
+        rp, ci = synth.make_graph(n, 20000 + 5000 * k, 11 + k, kind="powerlaw", max_degree=150)
+        rels.append(synth.csr_to_adj_lists(rp, ci))
+    rp0, ci0 = synth.make_graph(n, 30000, 3, kind="powerlaw", max_degree=200)
+    feat = synth.make_features(n, 17, 3)
+    lab = synth.make_labels(n, 0.05, 3)
+    outs = []
+    for rep in range(2):
+        cfg = dict(data_name="synthetic", data_dir="", data=(synth.csr_to_adj_lists(rp0, ci0), feat, lab.copy()), relations=rels, seed=72,
+                   model="PCGNN", multi_relation="GNN", emb_size=64, thres=0.4, lr=0.005, weight_decay=0.007, batch_size=60,
+                   num_epochs=3, valid_epochs=2, num_batches=5, n_pseudo=20, save_dir=str(tmp_path) + f"/{rep}/", test_ratio=0.67,
+                   device=0, rho=0.5, alpha=2)
+        random.seed(72)
+        np.random.seed(72)
+        torch.manual_seed(72)
+        h = ModelHandler(cfg)
+        res = h.train()
+        assert len(res) == 5 and all(np.isfinite(r) for r in res[:4]) and 0.0 <= res[3] <= 1.0
+        ls = np.array(h.pcgnn_losses)
+        assert ls.shape == (15, 2) and np.isfinite(ls).all() and (ls[:, 0] >= 5 * ls[:, 1] - 1e-5).all()
+        outs.append((res, ls, {k: v.detach().cpu().numpy().copy() for k, v in h.model.state_dict().items()}))
+    out = capsys.readouterr().out
+    assert "Restore model from epoch" in out and "loss_constraint" in out
+    np.testing.assert_allclose(outs[0][1], outs[1][1], atol=1e-6, rtol=0)              # reproducible from the seed
+    for k in outs[0][2]:
+        np.testing.assert_allclose(outs[0][2][k], outs[1][2][k], atol=1e-6, rtol=0)
+    for k in ("inter1.intra_agg1.weight", "inter1.intra_agg2.weight", "inter1.intra_agg3.weight", "inter1.weight", "weight"):
+        assert k in outs[0][2]                                                          # the reference's parameter names
+    with pytest.raises(ValueError):
+        cfg2 = dict(cfg)
+        cfg2.pop("relations")
+        random.seed(72)
+        ModelHandler(cfg2).train()
+
+
 def test_pcgnn_inter_aggregator_and_pca_layer_vs_reference_golden():
     """PC-GNN skeleton (`InterAgg`, `PCALayer`; src/layers.py:11-153, src/model.py:8-48) on three relation graphs against the
     imported reference classes (tests/golden/minibatch_pcgnn.npz): embeddings, affinity, both loss values, the gradient of every

@@ -257,3 +257,21 @@ def test_ocgnn_forward_loss_trajectory():
     with torch.no_grad():
         _, sc = O.ocgnn_loss(O.ocgnn_forward(P, feat, adjn))
     np.testing.assert_allclose(sc.numpy(), g["eval_score"], atol=5e-5)
+
+
+def test_aegis_mlp_restatement_equals_torch_layers():
+    """The oracle's restatement of torch_geometric.nn.MLP's 2-layer stack (Linear -> BatchNorm1d in training mode -> act -> Linear;
+    parity with the absent library itself is UNPINNED) against torch's own layers with the same parameters."""
+    import torch.nn as nn
+    torch.manual_seed(5)
+    lin0, bn, lin1 = nn.Linear(64, 64), nn.BatchNorm1d(64), nn.Linear(64, 1)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.2, 0.2)
+    P = {"d.lins.0.weight": lin0.weight, "d.lins.0.bias": lin0.bias, "d.norms.0.module.weight": bn.weight,
+         "d.norms.0.module.bias": bn.bias, "d.lins.1.weight": lin1.weight, "d.lins.1.bias": lin1.bias}
+    x = torch.randn(300, 64)
+    bn.train()
+    ref = lin1(torch.sigmoid(bn(lin0(x))))
+    got = O.aegis_mlp(P, "d", x, torch.sigmoid)
+    np.testing.assert_allclose(got.detach().numpy(), ref.detach().numpy(), atol=2e-6, rtol=0)
