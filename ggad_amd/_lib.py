@@ -96,6 +96,10 @@ SIGNATURES = {
     "ggad_gemm_f32": (c_int32, [_P, _P, _P, _I, _I, _I, _L, _L, _L, _L, _L, _P, _I, _P, _P]),
     "ggad_spmm_seg_len": (c_int32, []),
     "ggad_spmm_csr_f32": (c_int32, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _L, _I, _P, _P, _P, _L, _P, _P, _P]),
+    "ggad_spmm_rowslice_group": (c_int32, []),
+    "ggad_spmm_rowslice_short": (c_int32, []),
+    "ggad_spmm_rowslice_long": (c_int32, []),
+    "ggad_spmm_rowslice_f32": (c_int32, [_P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _I, _P, _L, _I, _P, _P, _P, _L, _P, _P]),
     "ggad_spmm_sliced_workspace_elems": (c_int64, [_L, _I]),
     "ggad_spmm_sliced_seg_len": (c_int32, []),
     "ggad_spmm_panel_available": (c_int32, []),

@@ -110,6 +110,130 @@ __global__ void __launch_bounds__(256) k_spmm_seg(const int32_t *__restrict__ co
   }
 }
 
+// ---- column-sliced kernel for SPARSE neighbourhoods (Reddit, Photo: ~17 entries per row, W = 300, operand 9-13 MB) -----------
+// The wave-per-segment kernel above gathers 1,200-byte rows from an operand no XCD's 4 MB L2 holds (every fetch comes from the
+// Infinity Cache: 4 nnz H = 215 MB per Reddit product for 28 MB of compulsory traffic), its second load instruction of a row carries
+// 11 of 64 lanes, and rows of more than 64 entries need a second launch.  Here a workgroup owns ONE slice of RS_W = 40 columns --
+// slice = blockIdx % n_slices, 8 slices at W = 300, i.e. one per XCD: each L2 then serves N x 160 B = 1.8 MB, resident after the
+// first touch -- and a wave works on SIX rows at once: lane (g, q) = (lane / 10, lane % 10) accumulates float4 q of the slice for row
+// g of the unit, walking that row's entries sequentially (rows of a unit have similar lengths: the host sorts them by degree), so a
+// load instruction carries 60 of 64 lanes, there is no cross-lane reduction and every row is finished by one lane group (epilogue in
+// place, no partial sums, no combine launch).  Rows of more than RS_LONG entries (hubs) take a whole wave: six entries per load,
+// the six partial sums added by shuffles.  Summation order: CSR order inside a row (short rows), six interleaved running sums
+// combined in group order (long rows): deterministic.
+constexpr int RS_W = 40, RS_Q = RS_W / 4, RS_G = 6;
+constexpr int RS_U = 8;                  // loads in flight per lane: the walk of a row is a chain of memory round trips
+constexpr int RS_SHORT = 32;             // rows of <= 32 entries: one lane group each (<= 4 round trips)
+constexpr int RS_LONG = 192;             // rows of <= 192 entries: one wave each, 48 entries per round trip; longer (hubs): a workgroup
+
+// entries e0, e0 + step, ... < t of one row, RS_U per round trip, accumulated into acc (this lane's float4 of the slice).  The ten
+// lanes of a group fetch the next ten (column, value) pairs with ONE load each and hand them round by shuffles: per 8 entries the
+// vector-memory path sees 8 + 2 instructions instead of 24 (it accepts one wave-wide load per ~17 clocks per CU whatever it carries)
+__device__ __forceinline__ void rs_walk(const int32_t *__restrict__ col, const float *__restrict__ val, const float *__restrict__ X,
+                                        int64_t ldx, int vic, int e0, int step, int t, bool lane_on, int g, int q, float4 &acc) {
+  static_assert(RS_U <= RS_Q, "a group's lanes hold one round of (column, value) pairs");
+  const int gbase = g * RS_Q;
+  int eq = min(e0 + q * step, max(t - 1, 0));
+  int ce = col[eq];                                                 // (column, value) pairs of the first round
+  float ve = (lane_on && e0 + q * step < t) ? (val ? val[eq] : 1.0f) : 0.0f;
+  for (int e = e0; e < t; e += RS_U * step) {
+    int c[RS_U]; float v[RS_U]; float4 x[RS_U];
+#pragma unroll
+    for (int k = 0; k < RS_U; ++k) {
+      c[k] = __shfl(ce, gbase + k, GGAD_WAVE);
+      v[k] = __shfl(ve, gbase + k, GGAD_WAVE);
+    }
+#pragma unroll
+    for (int k = 0; k < RS_U; ++k) x[k] = reinterpret_cast<const float4 *>(X + (int64_t)c[k] * ldx)[vic];
+    const int en = e + RS_U * step;                                 // the next round's pairs travel with this round's rows
+    eq = min(en + q * step, t - 1);
+    ce = col[eq];
+    ve = (lane_on && en + q * step < t) ? (val ? val[eq] : 1.0f) : 0.0f;
+#pragma unroll
+    for (int k = 0; k < RS_U; ++k) {
+      acc.x = fmaf(v[k], x[k].x, acc.x); acc.y = fmaf(v[k], x[k].y, acc.y);
+      acc.z = fmaf(v[k], x[k].z, acc.z); acc.w = fmaf(v[k], x[k].w, acc.w);
+    }
+  }
+}
+
+// blocks [0, n_slices * ublocks): 4 units each (a unit = 6 short rows, or one medium row); then n_slices blocks per hub row
+__global__ void __launch_bounds__(256) k_spmm_rowslice(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                       const float *__restrict__ val, const int32_t *__restrict__ unit_rows,
+                                                       const int32_t *__restrict__ unit_out, int n_units,
+                                                       const int32_t *__restrict__ long_rows, const int32_t *__restrict__ long_out,
+                                                       int n_long, const int32_t *__restrict__ hub_rows,
+                                                       const int32_t *__restrict__ hub_out, int n_hub, int n_slices,
+                                                       const float *__restrict__ X, int64_t ldx, int W,
+                                                       const float *__restrict__ bias, const float *__restrict__ prelu_a,
+                                                       float *__restrict__ out, int64_t ldo, float *__restrict__ out_pre) {
+  __shared__ float4 hub_part[4][RS_Q];
+  const int slice = blockIdx.x % n_slices;
+  const int ub = blockIdx.x / n_slices, wid = threadIdx.x >> 6;
+  const int ublocks = (n_units + n_long + 3) / 4;
+  const int lane = lane_id();
+  const int g = lane / RS_Q, q = lane - g * RS_Q;
+  const int vi = slice * RS_Q + q;                                 // float4 index inside a row of X / out
+  const bool lane_on = g < RS_G;
+  const int vic = vi < (W >> 2) ? vi : 0;
+  const int gc = lane_on ? g : 0;
+  const float a = prelu_a ? *prelu_a : 1.0f;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ub < ublocks) {
+    const int u = ub * 4 + wid;
+    if (u >= n_units + n_long) return;
+    if (u < n_units) {                                             // six short rows, one per lane group
+      const int row = lane_on ? unit_rows[u * RS_G + g] : -1;
+      int e = 0, t = 0;
+      if (row >= 0) { e = rowptr[row]; t = rowptr[row + 1]; }
+      rs_walk(col, val, X, ldx, vic, e, 1, t, lane_on, gc, q, acc);
+      if (row >= 0 && vi < (W >> 2)) {
+        const int orow = unit_out[u * RS_G + g];
+        spmm_epilogue_store(acc, vi, bias, prelu_a, a, out + (int64_t)orow * ldo, out_pre ? out_pre + (int64_t)orow * ldo : nullptr);
+      }
+      return;
+    }
+    const int lr = u - n_units;                                    // a medium row: the six lane groups take every sixth entry
+    const int row = long_rows[lr];
+    rs_walk(col, val, X, ldx, vic, rowptr[row] + gc, RS_G, rowptr[row + 1], lane_on, gc, q, acc);
+    if (!lane_on) acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 tot = acc;                                              // group 0 + 1 + ... + 5, in that order
+#pragma unroll
+    for (int k = 1; k < RS_G; ++k) {
+      const int src = q + k * RS_Q;
+      tot.x += __shfl(acc.x, src, GGAD_WAVE); tot.y += __shfl(acc.y, src, GGAD_WAVE);
+      tot.z += __shfl(acc.z, src, GGAD_WAVE); tot.w += __shfl(acc.w, src, GGAD_WAVE);
+    }
+    if (g == 0 && vi < (W >> 2)) {
+      const int orow = long_out[lr];
+      spmm_epilogue_store(tot, vi, bias, prelu_a, a, out + (int64_t)orow * ldo, out_pre ? out_pre + (int64_t)orow * ldo : nullptr);
+    }
+    return;
+  }
+  // a hub row: the 24 lane groups of the workgroup take every 24th entry; waves combined through LDS in wave order
+  const int hr = ub - ublocks;
+  if (hr >= n_hub) return;
+  const int row = hub_rows[hr];
+  rs_walk(col, val, X, ldx, vic, rowptr[row] + wid * RS_G + gc, 4 * RS_G, rowptr[row + 1], lane_on, gc, q, acc);
+  if (!lane_on) acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 tot = acc;
+#pragma unroll
+  for (int k = 1; k < RS_G; ++k) {
+    const int src = q + k * RS_Q;
+    tot.x += __shfl(acc.x, src, GGAD_WAVE); tot.y += __shfl(acc.y, src, GGAD_WAVE);
+    tot.z += __shfl(acc.z, src, GGAD_WAVE); tot.w += __shfl(acc.w, src, GGAD_WAVE);
+  }
+  if (g == 0) hub_part[wid][q] = tot;
+  __syncthreads();
+  if (wid == 0 && g == 0 && vi < (W >> 2)) {
+    float4 r = hub_part[0][q];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) { const float4 p2 = hub_part[k][q]; r.x += p2.x; r.y += p2.y; r.z += p2.z; r.w += p2.w; }
+    const int orow = hub_out[hr];
+    spmm_epilogue_store(r, vi, bias, prelu_a, a, out + (int64_t)orow * ldo, out_pre ? out_pre + (int64_t)orow * ldo : nullptr);
+  }
+}
+
 // ---- XCD-sliced variant for dense neighbourhoods (T-Finance: 470 neighbours per row, X = 47 MB) -----------------------
 // Measured on MI355X (scripts/spmm_locality_probe.py): the vector-memory path accepts ONE wave-wide load instruction per
 // ~17 clocks per CU whatever its number of active lanes (W = 260 costs what W = 512 costs), and a 47 MB operand that every
@@ -824,6 +948,28 @@ int ggad_spmm_csr_f32(const int32_t *col, const float *val, const int32_t *seg_b
     k_spmm_combine<<<dim3((n_multi + 3) / 4), dim3(256), 0, st>>>(multi_row, multi_first, multi_count, n_multi, part, W, bias,
                                                                  prelu_a, out, ldo, out_pre);
   GGAD_CHECK_LAUNCH("spmm_csr_f32");
+  return GGAD_OK;
+}
+
+int32_t ggad_spmm_rowslice_group(void) { return RS_G; }
+int32_t ggad_spmm_rowslice_short(void) { return RS_SHORT; }
+int32_t ggad_spmm_rowslice_long(void) { return RS_LONG; }
+
+int ggad_spmm_rowslice_f32(const int32_t *rowptr, const int32_t *col, const float *val, const int32_t *unit_rows,
+                           const int32_t *unit_out, int32_t n_units, const int32_t *long_rows, const int32_t *long_out, int32_t n_long,
+                           const int32_t *hub_rows, const int32_t *hub_out, int32_t n_hub, const float *X, int64_t ldx, int32_t W,
+                           const float *bias, const float *prelu_a, float *out, int64_t ldo, float *out_pre, ggad_stream_t stream) {
+  GGAD_REQUIRE(rowptr && col && X && out && W >= 4 && (W & 3) == 0 && n_units >= 0 && n_long >= 0 && n_hub >= 0);
+  GGAD_REQUIRE((n_units == 0 || (unit_rows && unit_out)) && (n_long == 0 || (long_rows && long_out)) && (n_hub == 0 || (hub_rows && hub_out)));
+  GGAD_REQUIRE((ldx & 3) == 0 && (ldo & 3) == 0 && ldx >= W && ldo >= W);
+  if (n_units + n_long + n_hub == 0) return GGAD_OK;
+  const int n_slices = (W + RS_W - 1) / RS_W;
+  const int64_t blocks = (int64_t)n_slices * ((n_units + n_long + 3) / 4 + n_hub);
+  GGAD_REQUIRE(blocks < (1ll << 31));
+  k_spmm_rowslice<<<dim3((unsigned)blocks), dim3(256), 0, as_stream(stream)>>>(rowptr, col, val, unit_rows, unit_out, n_units, long_rows,
+                                                                            long_out, n_long, hub_rows, hub_out, n_hub, n_slices, X,
+                                                                            ldx, W, bias, prelu_a, out, ldo, out_pre);
+  GGAD_CHECK_LAUNCH("spmm_rowslice_f32");
   return GGAD_OK;
 }
 

@@ -117,6 +117,35 @@ class Csr:
             self._plans[key] = p
         return p
 
+    def rowslice_plan(self, p):
+        """Units of the column-sliced kernel for sparse neighbourhoods (k_spmm_rowslice) for the rows of segment plan `p` (whole
+        matrix or a row subset): rows sorted by length into groups of 6, rows of more than `ggad_spmm_rowslice_long()` entries apart.
+        Cached on the plan."""
+        rs = p.get("rowslice")
+        if rs is not None:
+            return rs
+        lib = _lib.load()
+        G, SHORT, LONG = int(lib.ggad_spmm_rowslice_group()), int(lib.ggad_spmm_rowslice_short()), int(lib.ggad_spmm_rowslice_long())
+        rp = self.host.indptr.astype(np.int64)
+        rows = np.arange(self.shape[0], dtype=np.int64) if p.get("rows") is None else np.asarray(p["rows"], dtype=np.int64)
+        outr = np.arange(len(rows), dtype=np.int64)
+        deg = rp[rows + 1] - rp[rows]
+        is_short, is_hub = deg <= SHORT, deg > LONG
+        is_med = ~is_short & ~is_hub
+        order = np.argsort(-deg[is_short], kind="stable")
+        sr, so = rows[is_short][order], outr[is_short][order]
+        n_units = (len(sr) + G - 1) // G
+        ur = np.full(n_units * G, -1, dtype=np.int64)
+        uo = np.zeros(n_units * G, dtype=np.int64)
+        ur[:len(sr)], uo[:len(so)] = sr, so
+        mo = np.argsort(-deg[is_med], kind="stable")                    # longest first: they start first
+        dev = self.dev
+        rs = dict(unit_rows=_dev_i32(ur, dev), unit_out=_dev_i32(uo, dev), n_units=int(n_units),
+                  long_rows=_dev_i32(rows[is_med][mo], dev), long_out=_dev_i32(outr[is_med][mo], dev), n_long=int(is_med.sum()),
+                  hub_rows=_dev_i32(rows[is_hub], dev), hub_out=_dev_i32(outr[is_hub], dev), n_hub=int(is_hub.sum()))
+        p["rowslice"] = rs
+        return rs
+
     def value_factors(self):
         """(rs, cs, diag) such that value[i][j] = rs[i] * cs[j] off the diagonal (to fp32 round-off) and value[i][i] = diag[i] --
         the shape `normalize_adj` (`utils.py:47-54`: D^-1/2 A D^-1/2 of a 0/1 matrix, with or without self loops, `+ I`
@@ -414,6 +443,16 @@ def _use_sliced(csr: Csr, p, X: torch.Tensor) -> bool:
     return w >= 64 and X.shape[0] * w * 4 >= (6 << 20) and p["n_seg"] > 0 and p.get("nnz", csr.nnz) >= 24 * p["n_seg"]
 
 
+def _use_rowslice(csr: Csr, p, X: torch.Tensor) -> bool:
+    """Sparse neighbourhoods gathered from a wide operand that no XCD's L2 holds (Reddit, Photo): the column-sliced six-rows-per-wave
+    kernel (k_spmm_rowslice).  GGAD_SPMM_ROWSLICE=0 / 1 forces the choice (A/B measurements)."""
+    force = os.environ.get("GGAD_SPMM_ROWSLICE")
+    if force is not None:
+        return force == "1"
+    w = X.shape[1]
+    return w >= 160 and X.shape[0] * w * 4 >= (4 << 20)
+
+
 def _use_panel(csr: Csr, p, X: torch.Tensor):
     """Products with dense neighbourhoods and factoring values (whole matrix, or a row subset of a matrix without separate
     diagonal): the LDS-panel kernel (k_spmm_panel).  Returns its plan or None.  GGAD_SPMM_PANEL=0 turns it off, =1 forces it wherever a plan can be built."""
@@ -478,6 +517,10 @@ def spmm(csr: Csr, X: torch.Tensor, plan=None, bias=None, prelu_a=None, want_pre
         call("ggad_spmm_sliced_f32", ptr(csr.col), ptr(csr.val), ptr(p["seg_beg"]), ptr(p["seg_end"]), ptr(p["seg_out"]),
              p["n_seg"], ptr(p["multi_row"]), ptr(p["multi_first"]), ptr(p["multi_count"]), p["n_multi"], ptr(X), W, W, X.shape[0],
              ptr(xs), *opt, ptr(part) if part is not None else 0)
+    elif _use_rowslice(csr, p, X):
+        rs = csr.rowslice_plan(p)
+        call("ggad_spmm_rowslice_f32", ptr(csr.rowptr), ptr(csr.col), ptr(csr.val), ptr(rs["unit_rows"]), ptr(rs["unit_out"]), rs["n_units"],
+             ptr(rs["long_rows"]), ptr(rs["long_out"]), rs["n_long"], ptr(rs["hub_rows"]), ptr(rs["hub_out"]), rs["n_hub"], ptr(X), W, W, *opt)
     else:
         part = _part_buffer(p, W, X.device)
         call("ggad_spmm_csr_f32", ptr(csr.col), ptr(csr.val), ptr(p["seg_beg"]), ptr(p["seg_end"]), ptr(p["seg_out"]), p["n_seg"],

@@ -403,6 +403,21 @@ int ggad_spmm_csr_f32(const int32_t *col, const float *val, const int32_t *seg_b
                       const int32_t *multi_count, int32_t n_multi, const float *X, int64_t ldx, int32_t W, const float *bias,
                       const float *prelu_a, float *out, int64_t ldo, float *out_pre, float *part, ggad_stream_t stream);
 
+/* Same product for SPARSE neighbourhoods with a wide operand (Reddit / Photo: ~17 entries per row, W = 300; model.py:31 on those
+ * configs): a workgroup owns one slice of 40 columns (8 slices at W = 300: one per XCD, whose L2 then holds its slice of X); every
+ * row is finished in place by whoever owns it (no partial sums, no second launch): rows of <= ggad_spmm_rowslice_short() entries by one
+ * lane group -- ggad_spmm_rowslice_group() = 6 rows per wave, unit_rows / unit_out: int32[n_units x 6] CSR rows and output rows, -1 =
+ * empty slot, the caller groups rows of similar length --, rows of <= ggad_spmm_rowslice_long() entries by one wave (long_rows /
+ * long_out), longer ones (hubs) by one workgroup (hub_rows / hub_out).  rowptr: the CSR row pointers (DEVICE).  Same epilogue as
+ * ggad_spmm_csr_f32; results agree with it to fp32 round-off. */
+int32_t ggad_spmm_rowslice_group(void);
+int32_t ggad_spmm_rowslice_short(void);
+int32_t ggad_spmm_rowslice_long(void);
+int ggad_spmm_rowslice_f32(const int32_t *rowptr, const int32_t *col, const float *val, const int32_t *unit_rows,
+                           const int32_t *unit_out, int32_t n_units, const int32_t *long_rows, const int32_t *long_out, int32_t n_long,
+                           const int32_t *hub_rows, const int32_t *hub_out, int32_t n_hub, const float *X, int64_t ldx, int32_t W,
+                           const float *bias, const float *prelu_a, float *out, int64_t ldo, float *out_pre, ggad_stream_t stream);
+
 /* Same product for dense neighbourhoods (hundreds of neighbours per row, X larger than an XCD's 4 MB L2): X is first
  * re-laid slice-major into xs_workspace (ggad_spmm_sliced_workspace_elems(n_src_rows, W) floats; column slices of 32 floats =
  * one cache line per row), then every workgroup gathers ONE slice, chosen by the XCD it runs on, 8 neighbours per load.  n_src_rows = rows of X.  Same
