@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(XT) k_train_chunk_xcd(XcdArgs A) {
   __shared__ int ra_lds[XRA];                           // label-1 rows of the batch (sources of the generated columns), phase E
   __shared__ float t_lds[8];
   __shared__ float sc[2];
-  __shared__ int hub_first[2 * XW], hub_n[2 * XW];      // phase R: rows summed by the whole workgroup
+  __shared__ int hub_first[2 * XW], hub_n[2 * XW], hub_any;   // phase R: rows summed by the whole workgroup
   __shared__ float hub_part[XW][GGAD_WAVE];
   __shared__ int bt_row0[XBT + 1], bt_ck0[XBT + 1], bt_n0[XBT + 1];   // row / piece offsets, label-0 positions of the first XBT batches
   XcdCtrl *C = A.ctrl;
@@ -259,6 +259,7 @@ __global__ void __launch_bounds__(XT) k_train_chunk_xcd(XcdArgs A) {
   float *params = S.params;
   const int step0 = *S.step_counter;
   for (int i = threadIdx.x; i < GGAD_MAX_D * FCS; i += XT) fct[i] = 0.0f;      // rows / columns beyond D stay zero
+  if (threadIdx.x == 0) hub_any = 0;
   for (int i = threadIdx.x; i <= min(A.n_batches, XBT); i += XT) {
     const int r0 = A.batch_ptr[i];
     bt_row0[i] = r0;
@@ -441,15 +442,18 @@ __global__ void __launch_bounds__(XT) k_train_chunk_xcd(XcdArgs A) {
         const float hs_r = cld(S.h1 + (unsigned)src * D + d);
         // a hub row (thousands of entries = hundreds of pieces) is summed by ALL waves of the workgroup, an eighth each, the eight
         // partial sums added in order; every other row by its own wave
+        const bool my_hub = nq > xhub || ns > xhub;
         if (lane == 0) {
           hub_first[2 * wid] = qa; hub_n[2 * wid] = nq > xhub ? nq : 0;
           hub_first[2 * wid + 1] = sa; hub_n[2 * wid + 1] = ns > xhub ? ns : 0;
+          if (my_hub) hub_any = 1;
         }
         float totq = 0.0f, tots = 0.0f;
         if (nq <= xhub) sum_row(qa, nq, totq);
         if (ns <= xhub) sum_row(sa, ns, tots);
         __syncthreads();
-        for (int sidx = 0; sidx < 2 * XW; ++sidx) {
+        const int any_hub = hub_any;                                 // (most batches: no hub row in this workgroup, nothing to walk)
+        for (int sidx = 0; any_hub && sidx < 2 * XW; ++sidx) {
           const int n = hub_n[sidx];
           if (n == 0) continue;
           const int first = hub_first[sidx];
@@ -466,6 +470,10 @@ __global__ void __launch_bounds__(XT) k_train_chunk_xcd(XcdArgs A) {
             if (sidx & 1) tots = tt; else totq = tt;
           }
           __syncthreads();
+        }
+        if (any_hub) {                                               // clear for the next use (all waves have read it)
+          __syncthreads();
+          if (threadIdx.x == 0) hub_any = 0;
         }
         if (!act) continue;
         const float nb_r = (1.0f / (float)rq) * totq;                                            // mask_row = mask / rowsum  graphsage.py:317
@@ -516,22 +524,18 @@ __global__ void __launch_bounds__(XT) k_train_chunk_xcd(XcdArgs A) {
 #pragma unroll
       for (int j = 0; j < XPC; ++j) inc[j] = row_load(v0 + j * NVW < nck ? recv[j] : recv[0]);   // in flight across the reduction below
     }
-    if (wid == 0) {                                         // the reduction tree of k_loss_pos_ck (groups of 4) + k_loss_rows
-      const int nwg = loss_nwg(B);
-      float tv = 0.0f;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        float v = 0.0f;
-        for (int g = lane; g < nwg; g += GGAD_WAVE) {
-          const float *po = A.pos_o + (unsigned)k * A.ld_o + 4 * g;
-          const f2 oa = cld2(po), ob = cld2(po + 2);
-          const float o1 = 4 * g + 1 < B ? oa.y : 0.0f, o2 = 4 * g + 2 < B ? ob.x : 0.0f, o3 = 4 * g + 3 < B ? ob.y : 0.0f;
-          v += (oa.x + o1) + (o2 + o3);
-        }
-        const float tk = wave_sum_fast(v);
-        tv = lane == k ? tk : tv;
+    if (wid < 6) {                                          // the reduction tree of k_loss_pos_ck (groups of 4) + k_loss_rows, one
+      const int nwg = loss_nwg(B);                         // scalar per wave: two loads and one wave sum on the critical path
+      const int k = wid;
+      float v = 0.0f;
+      for (int g = lane; g < nwg; g += GGAD_WAVE) {
+        const float *po = A.pos_o + (unsigned)k * A.ld_o + 4 * g;
+        const f2 oa = cld2(po), ob = cld2(po + 2);
+        const float o1 = 4 * g + 1 < B ? oa.y : 0.0f, o2 = 4 * g + 2 < B ? ob.x : 0.0f, o3 = 4 * g + 3 < B ? ob.y : 0.0f;
+        v += (oa.x + o1) + (o2 + o3);
       }
-      if (lane < 6) t_lds[lane] = tv;
+      const float tk = wave_sum_fast(v);
+      if (lane == 0) t_lds[k] = tk;
     }
     const bool more = piped && b + 1 < A.n_batches;
     if (more) issue_recs(b + 1, recn, posn);                // next step's records: behind this phase's own loads
