@@ -349,19 +349,26 @@ __global__ void __launch_bounds__(XT) k_train_chunk_xcd(XcdArgs A) {
     XCD_TICK(8)
 
     // ================================================================ A: piece partials of relu(W x2), rows' h1
-    auto fwd_piece = [&](int c, const PieceX &P) {
+    auto fwd_piece = [&](int c, const PieceX &P) -> unsigned {
       f4 h[XNT];
       piece_fwd(P, WB, h);
       float out = 0.0f;
+      unsigned pos = 0;                                    // [h2 > 0] of this lane's 16 outputs: phase C's relu mask
 #pragma unroll
-      for (int t = 0; t < XNT; ++t) {                      // relu(W x2[u])   graphsage.py:419 ; entries beyond cnt are zero rows
+      for (int t = 0; t < XNT; ++t) {
+#pragma unroll
+        for (int vv = 0; vv < 4; ++vv) pos |= (h[t][vv] > 0.0f ? 1u : 0u) << (4 * t + vv);                      // relu(W x2[u])   graphsage.py:419 ; entries beyond cnt are zero rows
         float st = (fmaxf(h[t][0], 0.0f) + fmaxf(h[t][1], 0.0f)) + (fmaxf(h[t][2], 0.0f) + fmaxf(h[t][3], 0.0f));
         st += __shfl_xor(st, 16, GGAD_WAVE);
         st += __shfl_xor(st, 32, GGAD_WAVE);
         out = lg == t ? st : out;                           // lane l = channel 16 (l / 16) + l % 16
       }
       S.chunk_part[(unsigned)c * 64 + lane] = out;
+      return pos;
     };
+    unsigned hpos[XPC];
+#pragma unroll
+    for (int j = 0; j < XPC; ++j) hpos[j] = 0;
     {
       const int v = v0;
 #pragma unroll
@@ -369,7 +376,7 @@ __global__ void __launch_bounds__(XT) k_train_chunk_xcd(XcdArgs A) {
         const int w = v + j * NVW;
         if (w < nck) {
           if (!piped) { recv[j] = piece_rec(ck0 + w); issue_ops(recv[j], xc[j]); }
-          fwd_piece(ck0 + w, xc[j]);
+          hpos[j] = fwd_piece(ck0 + w, xc[j]);
         }
       }
       for (int w = v + XPC * NVW; w < nck; w += NVW) {     // more than XPC pieces per wave (a batch of > 8,000 entries)
@@ -615,12 +622,10 @@ __global__ void __launch_bounds__(XT) k_train_chunk_xcd(XcdArgs A) {
       float d16[XNT];                                       // dW[16 t + a][16] (partial over the lane group)
 #pragma unroll
       for (int t4 = 0; t4 < XNT; ++t4) { dacc[t4] = f4{0.0f, 0.0f, 0.0f, 0.0f}; d16[t4] = 0.0f; }
-      auto bwd_piece = [&](int rv, const RowIn &in, const PieceX &P) {
+      auto bwd_piece = [&](int rv, const RowIn &in, const PieceX &P, unsigned pos) {
         float cg, ca;
         row_coefs(rv, in, cg, ca);
         XCD_TICK(13)
-        f4 h[XNT];
-        piece_fwd(P, WB, h);                                // h2 recomputed exactly as in phase A: the relu mask
         float x16[4];
 #pragma unroll
         for (int vv = 0; vv < 4; ++vv) x16[vv] = __shfl(P.a[XKS - 1], 4 * lg + vv, GGAD_WAVE);   // X[4 g + v][16] (lanes 0..15 of k-step 4)
@@ -629,7 +634,7 @@ __global__ void __launch_bounds__(XT) k_train_chunk_xcd(XcdArgs A) {
           const float cgt = __shfl(cg, 16 * t4 + la, GGAD_WAVE);
 #pragma unroll
           for (int vv = 0; vv < 4; ++vv) {
-            const float cf = h[t4][vv] > 0.0f ? cgt : 0.0f;                                  // [h2 > 0] * coef_g[row][ch]
+            const float cf = ((pos >> (4 * t4 + vv)) & 1u) ? cgt : 0.0f;                     // [h2 > 0] * coef_g[row][ch]
             dacc[t4] = __builtin_amdgcn_mfma_f32_16x16x4f32(cf, P.b[vv], dacc[t4], 0, 0, 0);
             d16[t4] = fmaf(cf, x16[vv], d16[t4]);
           }
@@ -656,7 +661,7 @@ __global__ void __launch_bounds__(XT) k_train_chunk_xcd(XcdArgs A) {
             issue_ops(recv[j], xc[j]);
             inc[j] = row_load(recv[j]);
           }
-          bwd_piece(recv[j], inc[j], xc[j]);
+          bwd_piece(recv[j], inc[j], xc[j], hpos[j]);
         }
       }
       for (int w = v + XPC * NVW; w < nck; w += NVW) {
@@ -664,7 +669,14 @@ __global__ void __launch_bounds__(XT) k_train_chunk_xcd(XcdArgs A) {
         PieceX P;
         issue_ops(rv, P);
         const RowIn in = row_load(rv);
-        bwd_piece(rv, in, P);
+        f4 h[XNT];
+        piece_fwd(P, WB, h);                                // beyond the XPC masks kept from phase A: h2 again, exactly as there
+        unsigned pos = 0;
+#pragma unroll
+        for (int t4 = 0; t4 < XNT; ++t4)
+#pragma unroll
+          for (int vv = 0; vv < 4; ++vv) pos |= (h[t4][vv] > 0.0f ? 1u : 0u) << (4 * t4 + vv);
+        bwd_piece(rv, in, P, pos);
       }
       if (more) {                                           // next step's operands: behind every load of this phase, they land
 #pragma unroll
