@@ -177,6 +177,24 @@ __device__ __forceinline__ void piece_fwd(const PieceX &P, const float (&WB)[XKS
     for (int t = 0; t < XNT; ++t) h[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(P.a[j], WB[j][t], h[t], 0, 0, 0);
 }
 
+// ---- sum_k m[k * stride] * v[lane k], k = 0..63 in order (one FMA chain: the order of the launch chain's kernels).  Sixteen LDS
+// reads in flight per group: left to itself the compiler waits for every ds_read before the next (64 x ~100 clocks on the
+// critical path of every generated position and label-1 piece).
+__device__ __forceinline__ float lds_matvec(const float *m, int stride, float v) {
+  float a = 0.0f;
+#pragma unroll
+  for (int c = 0; c < GGAD_MAX_D; c += 16) {
+    float fv[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) fv[k] = m[(c + k) * stride];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) a = fmaf(fv[k], rl(v, c + k), a);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  return a;
+}
+
 // ---- records (k_xcd_prep, once per chunk): everything a step needs to know about a piece / a position in ONE 32-byte line,
 // so that no phase walks a chain of dependent table look-ups (row -> label / position -> position's label, source row -> its pieces)
 //   piece c:        [0] (row << 6) | entries   [1] first entry   [2] label | first piece of its row << 1 | label of position q1 << 2
@@ -298,11 +316,15 @@ __global__ void __launch_bounds__(XT) k_train_chunk_xcd(XcdArgs A) {
   }
   unsigned round = 0;
   unsigned long long t_prev = wall_clock64();
-  const bool prof_on = (A.dbg & 4) != 0;                 // phase clocks cost rank 0's polling wave a global read-modify-write each
+  const int prof_rank = A.dbg >> 8;                      // GGAD_XCD_DEBUG = 4 + 16 * wave + 256 * rank: whose clocks
+  const int prof_thread = ((A.dbg >> 4) & 7) * GGAD_WAVE;
+  const bool prof_on = (A.dbg & 4) != 0;                 // phase clocks: accumulated in LDS by one thread, written out at the end
+  __shared__ unsigned long long prof_lds[16];
+  if (threadIdx.x < 16) prof_lds[threadIdx.x] = 0;
 #define XCD_TICK(slot)                                                         \
-  if (prof_on && rank == 0 && threadIdx.x == 0) {                              \
+  if (prof_on && rank == prof_rank && threadIdx.x == prof_thread) {                           \
     const unsigned long long t_now = wall_clock64();                           \
-    C->prof[slot] += t_now - t_prev;                                           \
+    prof_lds[slot] += t_now - t_prev;                                          \
     t_prev = t_now;                                                            \
   }
 #define XCD_BARRIER()                                                          \
@@ -482,6 +504,7 @@ __global__ void __launch_bounds__(XT) k_train_chunk_xcd(XcdArgs A) {
           __syncthreads();
           if (threadIdx.x == 0) hub_any = 0;
         }
+        XCD_TICK(15)
         if (!act) continue;
         const float nb_r = (1.0f / (float)rq) * totq;                                            // mask_row = mask / rowsum  graphsage.py:317
         if (on) S.nbar[(unsigned)row * D + lane] = nb_r;                                          // to_feats_neigh[q, :]
@@ -489,16 +512,17 @@ __global__ void __launch_bounds__(XT) k_train_chunk_xcd(XcdArgs A) {
         if (from_gen) {                                                                          // ... or gen[src] = relu(fc nbar[src])  :428-430
           const float nbm = on ? (1.0f / (float)rs) * tots : 0.0f;
           float a = 0.0f;
-#pragma unroll 16
-          for (int d2 = 0; d2 < GGAD_MAX_D; ++d2) a = fmaf(fct[d2 * FCS + d], rl(nbm, d2), a);
+          a = lds_matvec(fct + d, FCS, nbm);
           c_r = fmaxf(a, 0.0f);
           if (on) S.gen[(unsigned)src * D + lane] = c_r;
         }
+        XCD_TICK(13)
         const float wd = on ? wd_r : 0.0f, c = on ? c_r : 0.0f, nb = on ? nb_r : 0.0f;
         const float hs = (on && from_gen) ? hs_r : 0.0f;
         const PosVals pv = eval_position(wd, c, nb);
         float recn_ = 0.0f;
         if (from_gen) { const float dl2 = hs - c; recn_ = sqrtf(wave_sum_fast(dl2 * dl2)); }     // recon2   graphsage.py:197-198
+        XCD_TICK(14)
         const float o0 = (1.0f - (float)y) * pv.s - log_sigmoid(pv.s);                           // BCEWithLogits, pos_weight 1 :246
         const float sv = lane == 0 ? pv.s : lane == 1 ? pv.aff : lane == 2 ? pv.na : lane == 3 ? pv.nbn : recn_;
         if (lane < 5) A.pos_scal[(unsigned)q * 8 + lane] = sv;
@@ -608,8 +632,7 @@ __global__ void __launch_bounds__(XT) k_train_chunk_xcd(XcdArgs A) {
         if (first && on) S.dz[off] = dZ;
         const float dZm = on ? dZ : 0.0f;
         float a = 0.0f;
-#pragma unroll 16
-        for (int dd = 0; dd < GGAD_MAX_D; ++dd) a = fmaf(fct[d * FCS + dd], rl(dZm, dd), a);   // fc^T dZ: fc[dd][d] = fct[d][dd]
+        a = lds_matvec(fct + d * FCS, 1, dZm);                                                  // fc^T dZ: fc[dd][d] = fct[d][dd]
         dNb += a;
       }
       ca = (on && H1 > 0.0f) ? gH : 0.0f;
@@ -625,7 +648,7 @@ __global__ void __launch_bounds__(XT) k_train_chunk_xcd(XcdArgs A) {
       auto bwd_piece = [&](int rv, const RowIn &in, const PieceX &P, unsigned pos) {
         float cg, ca;
         row_coefs(rv, in, cg, ca);
-        XCD_TICK(13)
+        //XCD_TICK(13)
         float x16[4];
 #pragma unroll
         for (int vv = 0; vv < 4; ++vv) x16[vv] = __shfl(P.a[XKS - 1], 4 * lg + vv, GGAD_WAVE);   // X[4 g + v][16] (lanes 0..15 of k-step 4)
@@ -650,7 +673,7 @@ __global__ void __launch_bounds__(XT) k_train_chunk_xcd(XcdArgs A) {
             d16[t4] = fmaf(af, x16r, d16[t4]);
           }
         }
-        XCD_TICK(14)
+        //XCD_TICK(14)
       };
 #pragma unroll
       for (int j = 0; j < XPC; ++j) {
@@ -795,6 +818,8 @@ __global__ void __launch_bounds__(XT) k_train_chunk_xcd(XcdArgs A) {
       posv = posn;
     }
   }
+  if (prof_on && rank == prof_rank && threadIdx.x == prof_thread)
+    for (int k = 0; k < 16; ++k) C->prof[k] = prof_lds[k];
   if (rank == 0 && threadIdx.x == 0) C->done = 1;
 }
 

@@ -54,7 +54,7 @@ for k in sizes:
         if resident:
             st = eng.xcd_status()
             ph = "  ".join(f"{a} {b / k:.2f}" for a, b in st["phase_us"].items())
-            line += f"  | wgs {st['workgroups']} xcc {st['xcc']} err {st['error']} | us/step by phase: {ph} | sub: " + " ".join(f"{x / k:.2f}" for x in st["sub_us"][:7])
+            line += f"  | wgs {st['workgroups']} xcc {st['xcc']} err {st['error']} | us/step by phase: {ph} | sub: " + " ".join(f"{x / k:.2f}" for x in st["sub_us"][:8])
         print(line, flush=True)
     dl = np.abs(out["xcd"][1][:, :4] - out["chain"][1][:, :4]).max()
     dw = np.abs(out["xcd"][0] - out["chain"][0]).max()
