@@ -38,6 +38,8 @@ SIGNATURES = {
     "ggad_mb_chunk_len": (c_int32, []),
     "ggad_mb_slice_len": (c_int32, []),
     "ggad_mb_group_words": (c_int32, []),
+    "ggad_mb_item_words": (c_int32, []),
+    "ggad_mb_set_gather_options": (c_int32, [c_int32, c_int32]),
     "ggad_mb_plan_counter_elems": (c_int32, []),
     "ggad_mb_plan_build": (c_int32, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
     "ggad_event_create": (c_int32, [_I, _P]),

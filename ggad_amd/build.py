@@ -21,7 +21,7 @@ SOURCES = ["runtime.cpp", "plan_build.cpp", "exchange.cpp", "sampler.cpp", "samp
 HOST_ONLY = {"sampler.cpp", "sampler_x86.cpp", "spmm_panel_build.cpp"}      # plain C++ (x86 intrinsics behind a run-time CPU check), no device pass
 HEADERS = ["common.h", "step_common.h", os.path.join("..", "..", "include", "ggad_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-fno-fast-math",
-         "-Wall", "-Wno-unused-function"]
+         "-Wall", "-Wno-unused-function"] + os.environ.get("GGAD_EXTRA_HIPFLAGS", "").split()      # e.g. -DGGAD_G2_PROF (scripts/g2_phase_clocks.py)
 
 
 def _hipcc() -> str:

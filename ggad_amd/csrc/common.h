@@ -73,8 +73,13 @@ static inline unsigned ggad_skip_grid(unsigned want, int skip) { return skip < 0
 // once per WORKGROUP (wg_reserve below), not once per wave, and the work-item cursor of the 2-hop gather is bumped by big grabs.
 constexpr int GGAD_CTR_STRIDE = 16;
 constexpr int GGAD_CTR_GROUPS = 0 * GGAD_CTR_STRIDE, GGAD_CTR_ITEMS = 1 * GGAD_CTR_STRIDE, GGAD_CTR_PART = 2 * GGAD_CTR_STRIDE,
-              GGAD_CTR_CURSOR = 3 * GGAD_CTR_STRIDE, GGAD_CTR_PC = 4 * GGAD_CTR_STRIDE;
-constexpr int GGAD_PLAN_COUNTERS = 8 * GGAD_CTR_STRIDE;      // ints of ggad_mb_plan::counters
+              GGAD_CTR_CURSOR = 3 * GGAD_CTR_STRIDE, GGAD_CTR_PC = 4 * GGAD_CTR_STRIDE,
+              GGAD_CTR_BIG = 5 * GGAD_CTR_STRIDE,          // groups of range-partitioned owners (hop2_ldsw.hip)
+              GGAD_CTR_RANGE0 = 6 * GGAD_CTR_STRIDE,       // .. 13: the work cursor of each of the eight id ranges
+              GGAD_CTR_PROF = 14 * GGAD_CTR_STRIDE;        // 14, 15: phase clocks of a -DGGAD_G2_PROF build (16 x 64 bits)
+constexpr int GGAD_RANGES = 8;            // id ranges of the 2-hop gather: one per XCD, so that each L2 keeps an eighth of the hot rows
+constexpr int GGAD_RANGE_DEG = 256;       // owners with more neighbours than this are gathered range by range
+constexpr int GGAD_PLAN_COUNTERS = 16 * GGAD_CTR_STRIDE;      // ints of ggad_mb_plan::counters
 
 struct ggad_plan_view {      // device views into the staging block of ONE build + its exact sizes (known on the host)
   const int32_t *batch_ptr, *batch_ent_ptr, *nodes, *row_slot, *ent_ptr, *row_ck_ptr, *ck_rc, *ck_e0;

@@ -23,10 +23,28 @@
 // wave WAS the gather's fixed 0.35 ms on small chunks).  Summation order per owner: slices ascending, inside a slice the
 // CSR order -- independent of grouping, chunk composition and launch geometry: bit-reproducible.
 #include <algorithm>
+#include <atomic>
+#include <climits>
 
 #include "common.h"
 
 namespace {
+
+// Phase clocks of k_gather2_items (a build with -DGGAD_G2_PROF only; scripts/g2_phase_clocks.py): every mark first drains the
+// wave's memory counters, so the time a wave spends waiting for each kind of load is attributed to the phase that issued it.
+// Totals per launch in counters[GGAD_CTR_PROF ...] as 64-bit words: 0 cursor, 1 item metadata, 2 first ids / counts of a slice,
+// 3 rows (issue + wait), 4 weights + fma, 5 stores, 6 whole kernel per wave.
+#ifdef GGAD_G2_PROF
+struct G2Prof { unsigned long long a[8], t; };
+#define G2_ARG , G2Prof &prof
+#define G2_PASS , prof
+#define G2_MARK(i) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = wall_clock64(); \
+                        prof.a[i] += t_ - prof.t; prof.t = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define G2_ARG
+#define G2_PASS
+#define G2_MARK(i)
+#endif
 
 constexpr int SLICE = 256;              // neighbours per work item
 constexpr int GRP_W = 10;               // ints per group record: 8 owner entries (-1 = empty), partial-slot base, slices
@@ -250,7 +268,7 @@ __global__ void __launch_bounds__(TW_T) k_tile_counts(const int32_t *__restrict_
 template <int G, int FT>
 __device__ __forceinline__ void gather_slice(const int32_t *__restrict__ col, const float *__restrict__ feat, int F_rt, int stride,
                                              int s, int n0, int n1, float inv_sr, int n_occ, const int (&pb)[8],
-                                             const uint16_t *__restrict__ pc, int lane, float (&tot)[G]) {
+                                             const uint16_t *__restrict__ pc, int lane, float (&tot)[G] G2_ARG) {
   const int F = FT ? FT : F_rt;
   const int rpi = 64 / F;
   const int g = lane / F, f = lane - g * F;
@@ -277,6 +295,7 @@ __device__ __forceinline__ void gather_slice(const int32_t *__restrict__ col, co
 #pragma unroll
     for (int j = 0; j < G; ++j) c_nx[j] = pc[pb[j] + ix];
   }
+  G2_MARK(2);
   for (int blk = n0; blk < n1; blk += 64) {
     const bool mine = blk + lane < n1;
     const int k = mine ? k_nx : 0;
@@ -298,6 +317,7 @@ __device__ __forceinline__ void gather_slice(const int32_t *__restrict__ col, co
 #pragma unroll
         for (int j = 0; j < G; ++j) c_nx[j] = pc[pb[j] + ix];
       }
+      G2_MARK(3);
 #pragma unroll
       for (int t = 0; t < IT; ++t) {
         const int src = t * 3 + g;
@@ -308,6 +328,7 @@ __device__ __forceinline__ void gather_slice(const int32_t *__restrict__ col, co
           acc[j] = fmaf((src < count) ? ws : 0.0f, xv, acc[j]);
         }
       }
+      G2_MARK(4);
     } else {
       const int iters = (count + rpi - 1) / rpi;
       int tt = 0;
@@ -354,51 +375,152 @@ __device__ __forceinline__ void gather_slice(const int32_t *__restrict__ col, co
   }
 }
 
+// ---- the same slice on the matrix cores (F = 17, rows padded to 32 floats = one 128-byte line: the trainer's table).
+//   x2[j][f] += sum_k w[j][k] x[k][f]  is a (8 occurrences x 64 neighbours) . (64 x 32) product per block:
+//   v_mfma_f32_16x16x4_f32, lane (a = l % 16, g = l / 16) holds A[a][g], B[g][a], D[4 g + v][a].  K-step i takes the neighbours
+//   {i, 16 + i, 32 + i, 48 + i} of the block (k = g), A[a][g] = w[occurrence a][16 g + i], B[g][a] = the features (2 a, 2 a + 1) of
+//   that neighbour: ONE 8-byte load per lane and k-step = 4 rows x 128 bytes per instruction, 16 load instructions per block
+//   instead of 22, and two products per k-step (even / odd features; columns >= 17 are the zero padding of the rows).
+//   Ids and weights change layout (lane = neighbour -> lane = (occurrence | feature pair, neighbour group)) through a
+//   wave-private piece of LDS: 1 + G stores and 8 16-byte reads per block.  The VALU version spends 22 G ds_bpermute + 22 G fma
+//   per block on the weights: 41 % of the wave time of a 150-batch launch (scripts/g2_phase_clocks.py).
+//   Order of the sum per (occurrence, feature): k-step i ascending, inside a step g ascending; blocks ascending: fixed.
+constexpr int MF_WS = 68;                                   // floats per weight row in LDS (16-byte reads of 8 rows: conflict-free)
+constexpr int MF_LDS = 8 * MF_WS + 64;                      // floats per wave
+typedef float mf4 __attribute__((ext_vector_type(4)));
+typedef float mf2 __attribute__((ext_vector_type(2)));
+typedef int mi4 __attribute__((ext_vector_type(4)));
+
+template <int G>
+__device__ __forceinline__ void gather_slice_mfma(const int32_t *__restrict__ col, const float *__restrict__ feat, int s, int n0, int n1,
+                                                  float inv_sr, int n_occ, const int (&pb)[8], const uint16_t *__restrict__ pc,
+                                                  int lane, float *lw, float (&tot)[G] G2_ARG) {
+  const int a = lane & 15, g = lane >> 4;
+  const char *fb = reinterpret_cast<const char *>(feat) + a * 8;
+  int *lids = reinterpret_cast<int *>(lw + 8 * MF_WS);
+  const int aa = a < G ? a : 0;
+  mf4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
+  const int last = max(n1 - 1, 0);
+  int k_nx;
+  uint32_t c_nx[G];
+  {
+    const int ix = min(n0 + lane, last);
+    k_nx = col[s + ix];                                      // clamped: always the id of a neighbour of this slice
+#pragma unroll
+    for (int j = 0; j < G; ++j) c_nx[j] = pc[pb[j] + ix];
+  }
+  G2_MARK(2);
+  for (int blk = n0; blk < n1; blk += 64) {
+    const bool mine = blk + lane < n1;
+    lids[lane] = k_nx;
+#pragma unroll
+    for (int j = 0; j < G; ++j)
+      lw[j * MF_WS + lane] = (j < n_occ && mine) ? inv_sr / sqrtf((float)c_nx[j]) : 0.0f;     // .div(row).div(col)  graphsage.py:348
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int id[16];
+    float wa[16];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const mi4 iv = *reinterpret_cast<const mi4 *>(lids + 16 * g + 4 * c);
+      const mf4 wv = *reinterpret_cast<const mf4 *>(lw + aa * MF_WS + 16 * g + 4 * c);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { id[4 * c + q] = iv[q]; wa[4 * c + q] = a < G ? wv[q] : 0.0f; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    mf2 x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = *reinterpret_cast<const mf2 *>(fb + ((uint32_t)id[i] << 7));
+    {
+      const int ix = min(blk + 64 + lane, last);
+      k_nx = col[s + ix];
+#pragma unroll
+      for (int j = 0; j < G; ++j) c_nx[j] = pc[pb[j] + ix];
+    }
+    G2_MARK(3);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[i], x[i].x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[i], x[i].y, acc1, 0, 0, 0);
+    }
+    G2_MARK(4);
+  }
+  // D[j][f]: tile f & 1, column f >> 1, i.e. lane (f >> 1) + 16 (j >> 2), register j & 3  ->  lane f of tot[j]
+#pragma unroll
+  for (int j = 0; j < G; ++j) {
+    const int src = (lane >> 1) + 16 * (j >> 2);
+    const float v0 = __shfl(acc0[j & 3], src & 63, GGAD_WAVE), v1 = __shfl(acc1[j & 3], src & 63, GGAD_WAVE);
+    tot[j] = (lane & 1) ? v1 : v0;
+  }
+}
+
 // One thread per entry.  The owner entry that was linked LAST into its node's list (k_gather1c) acts for the node: it cuts
-// the list into groups of <= 8 occurrences, every group into ceil(deg / SLICE) work items, and reserves the partial-sum
-// slots of multi-slice owners; the three cursors are bumped once per WAVE (prefix sums over the lanes).  Groups and items
-// of one node are adjacent (their waves run side by side and find each other's rows in L2).  Clears node_head[u].
+// the list into groups of <= 8 occurrences and reserves the partial-sum slots of owners that are summed in parts; the cursors are
+// bumped once per WORKGROUP (prefix sums over the lanes, wave totals through LDS).  Clears node_head[u].
+//   deg <= range_deg (always, unless ggad_mb_set_gather_options turns the ranges on: measured slower): every group
+//                          becomes ceil(deg / SLICE) work items of the common list (any XCD takes them);
+//   deg >  range_deg:      the group goes on the `big` list with the node's GGAD_RANGES + 1 range boundaries (positions inside its
+//                          CSR row where the neighbour ids cross an eighth of the tile range: tile_off[u][tile(r)]).  The waves of
+//                          XCD x walk that list for range x, so an L2 only ever sees an eighth of the id space from these owners
+//                          (84 % of the pairs of the bench graph) and keeps an eighth of the hot rows: scripts/gather_range_bench.hip
+//                          measures 72.6 against 46.2 G rows/s for this access pattern.  The GGAD_RANGES partial sums of an
+//                          occurrence are added in range order (k_gather2_combine): fixed by the ids, not by the launch.
+// Groups of one node are adjacent in both lists (their waves run side by side and find each other's rows in L2).
+__device__ __forceinline__ int range_tile(int r, int n_tiles) { return (int)(((int64_t)r * n_tiles) / GGAD_RANGES); }
+
 __global__ void __launch_bounds__(256) k_build_groups(const int32_t *__restrict__ ent_own, const int32_t *__restrict__ ent_col,
                                                       const int32_t *__restrict__ own_deg, int n_ents,
                                                       int32_t *__restrict__ node_head, const int32_t *__restrict__ own_next,
+                                                      const int32_t *__restrict__ tile_off, int n_tiles,
                                                       int32_t *__restrict__ grp, int32_t *__restrict__ items,
-                                                      int32_t *__restrict__ counters, int skip) {
+                                                      int32_t *__restrict__ big, int32_t *__restrict__ gbnd,
+                                                      int32_t *__restrict__ counters, int range_deg, int skip) {
   unsigned vbx, vgx;
   if (!ggad_vblock(skip, vbx, vgx)) return;
   const int e = vbx * 256 + threadIdx.x;
   const int lane = lane_id();
-  int u = 0, m = 0, ng = 0, ns = 0;
+  int u = 0, m = 0, ng = 0, ns = 0, deg = 0;
   if (e < n_ents && ent_own[e] == e) {
     u = ent_col[e];
     if (node_head[u] == e + 1) {
       for (int cur = e + 1; cur != 0; cur = own_next[cur - 1]) ++m;
       ng = (m + 7) >> 3;
-      const int deg = own_deg[e];
-      ns = deg > SLICE ? (deg + SLICE - 1) / SLICE : 1;
+      deg = own_deg[e];
+      ns = deg > range_deg ? GGAD_RANGES : (deg > SLICE ? (deg + SLICE - 1) / SLICE : 1);
     }
   }
-  int v0 = ng, v1 = ng * ns, v2 = ns > 1 ? m * ns : 0;        // inclusive prefix sums over the wave
+  const bool is_big = deg > range_deg;
+  const int c1 = is_big ? 0 : ng * ns, c2 = ns > 1 ? m * ns : 0, c3 = is_big ? ng : 0;
+  int v0 = ng, v1 = c1, v2 = c2, v3 = c3;                       // inclusive prefix sums over the wave
 #pragma unroll
   for (int off = 1; off < GGAD_WAVE; off <<= 1) {
-    const int t0 = __shfl_up(v0, off, GGAD_WAVE), t1 = __shfl_up(v1, off, GGAD_WAVE), t2 = __shfl_up(v2, off, GGAD_WAVE);
-    if (lane >= off) { v0 += t0; v1 += t1; v2 += t2; }
+    const int t0 = __shfl_up(v0, off, GGAD_WAVE), t1 = __shfl_up(v1, off, GGAD_WAVE), t2 = __shfl_up(v2, off, GGAD_WAVE),
+              t3 = __shfl_up(v3, off, GGAD_WAVE);
+    if (lane >= off) { v0 += t0; v1 += t1; v2 += t2; v3 += t3; }
   }
   // one reservation per WORKGROUP (the four waves' totals meet in LDS): same-address atomics are serialised chip-wide
-  __shared__ int wg_tot[3][5];
+  __shared__ int wg_tot[4][5];
   const int wid = threadIdx.x >> 6;
-  if (lane == GGAD_WAVE - 1) { wg_tot[0][wid] = v0; wg_tot[1][wid] = v1; wg_tot[2][wid] = v2; }
+  if (lane == GGAD_WAVE - 1) { wg_tot[0][wid] = v0; wg_tot[1][wid] = v1; wg_tot[2][wid] = v2; wg_tot[3][wid] = v3; }
   __syncthreads();
-  if (threadIdx.x < 3) {
+  if (threadIdx.x < 4) {
     const int k = threadIdx.x;
     int sum = 0;
     for (int w = 0; w < 4; ++w) { const int t = wg_tot[k][w]; wg_tot[k][w] = sum; sum += t; }
-    int32_t *ctr = counters + (k == 0 ? GGAD_CTR_GROUPS : (k == 1 ? GGAD_CTR_ITEMS : GGAD_CTR_PART));
+    int32_t *ctr = counters + (k == 0 ? GGAD_CTR_GROUPS : (k == 1 ? GGAD_CTR_ITEMS : (k == 2 ? GGAD_CTR_PART : GGAD_CTR_BIG)));
     wg_tot[k][4] = sum > 0 ? atomicAdd(ctr, sum) : 0;
   }
   __syncthreads();
-  const int b0 = wg_tot[0][4] + wg_tot[0][wid], b1 = wg_tot[1][4] + wg_tot[1][wid], b2 = wg_tot[2][4] + wg_tot[2][wid];
+  const int b0 = wg_tot[0][4] + wg_tot[0][wid], b1 = wg_tot[1][4] + wg_tot[1][wid], b2 = wg_tot[2][4] + wg_tot[2][wid],
+            b3 = wg_tot[3][4] + wg_tot[3][wid];
   if (ng == 0) return;
-  const int gbase = b0 + v0 - ng, ibase = b1 + v1 - ng * ns, pbase = b2 + v2 - (ns > 1 ? m * ns : 0);
+  const int gbase = b0 + v0 - ng, ibase = b1 + v1 - c1, pbase = b2 + v2 - c2, bbase = b3 + v3 - c3;
+  int bnd[GGAD_RANGES + 1];
+  if (is_big) {
+    const int32_t *row = tile_off + (int64_t)u * (n_tiles + 1);
+#pragma unroll
+    for (int r = 0; r <= GGAD_RANGES; ++r) bnd[r] = row[range_tile(r, n_tiles)];      // bnd[0] = 0, bnd[GGAD_RANGES] = deg
+  }
   int cur = e + 1;
   for (int g = 0; g < ng; ++g) {
     int32_t *rec = grp + (int64_t)(gbase + g) * GRP_W;
@@ -410,41 +532,76 @@ __global__ void __launch_bounds__(256) k_build_groups(const int32_t *__restrict_
     }
     rec[8] = pbase + g * 8 * ns;
     rec[9] = ns;
-    for (int sl = 0; sl < ns; ++sl) {        // slice-major: consecutive items = the same neighbour rows for the node's groups
-      int32_t *it = items + (int64_t)(ibase + sl * ng + g) * 2;
-      it[0] = gbase + g;
-      it[1] = sl;
+    if (is_big) {
+      big[bbase + g] = gbase + g;
+      int32_t *bo = gbnd + (int64_t)(bbase + g) * (GGAD_RANGES + 1);
+#pragma unroll
+      for (int r = 0; r <= GGAD_RANGES; ++r) bo[r] = bnd[r];
+    } else {
+      for (int sl = 0; sl < ns; ++sl) {        // slice-major: consecutive items = the same neighbour rows for the node's groups
+        int32_t *it = items + (int64_t)(ibase + sl * ng + g) * 2;
+        it[0] = gbase + g;
+        it[1] = sl;
+      }
     }
   }
   node_head[u] = 0;
 }
 
-template <int FT>
+template <int FT, bool MF>
 __global__ void __launch_bounds__(256) k_gather2_items(const int32_t *__restrict__ col, const float *__restrict__ feat, int F_rt,
                                                        int stride, const int32_t *__restrict__ own_rp,
                                                        const int32_t *__restrict__ own_deg, const int32_t *__restrict__ pw_base,
                                                        const uint16_t *__restrict__ pc, const int32_t *__restrict__ grp,
-                                                       const int32_t *__restrict__ items, int32_t *__restrict__ counters,
-                                                       float *__restrict__ x2, float *__restrict__ part2, int skip) {
-  static_assert(ITEM_GRAB == 4 && GRP_W <= 16, "lane layout of the metadata loads: 16 lanes per item of a grab");
+                                                       const int32_t *__restrict__ items, const int32_t *__restrict__ big,
+                                                       const int32_t *__restrict__ gbnd, int32_t *__restrict__ counters,
+                                                       float *__restrict__ x2, float *__restrict__ part2, int affine, int skip) {
+  static_assert(ITEM_GRAB == 4 && GRP_W <= 10, "lane layout of the metadata loads: 16 lanes per item of a grab (10, 11: range bounds)");
   unsigned vbx, vgx;
   if (!ggad_vblock(skip, vbx, vgx)) return;
   const int F = FT ? FT : F_rt;
   const int lane = lane_id();
-  const int n_items = counters[GGAD_CTR_ITEMS];
+  __shared__ __attribute__((aligned(16))) float mf_lds[MF ? 4 * MF_LDS : 4];
+  float *lw = mf_lds + (MF ? (threadIdx.x >> 6) * MF_LDS : 0);
+  const int n_small = counters[GGAD_CTR_ITEMS], n_big = counters[GGAD_CTR_BIG];
   const int q_l = lane >> 4, r_l = lane & 15;                 // metadata phase: lane = (item of the grab, word)
-  // Guided self-scheduling on ONE cursor: a wave reserves rem / (2 waves) items at a time (64 at most, ITEM_GRAB at least; rem is
-  // what its previous reservation saw left), i.e. big bites while there is plenty and single grabs at the end.  A same-address
-  // atomic completes every ~7 ns chip-wide: one atomic per 4 items (268 K per 150-batch launch) was 1.9 of the kernel's 2.3 ms.
-  const int n_waves = (int)vgx * 4;
-  int seen = 0;
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  xcc &= GGAD_RANGES - 1;
+  if (!affine) xcc = (vbx / GGAD_RANGES) & (GGAD_RANGES - 1);      // (experiment: the same work items without the XCD binding)
+  // Work lists in the order a wave visits them: range `xcc` of the big list (the rows of that eighth of the id space stay in
+  // THIS XCD's L2), the common list of the small owners, then the other ranges -- whatever their XCDs have not finished (an XCD
+  // left to the resident step kernel has no waves here: its range is taken by everybody at the end).
+  // Guided self-scheduling on the cursor of a list: a wave reserves rem / (2 waves) items at a time (64 at most, ITEM_GRAB at
+  // least; rem is what its previous reservation saw left), i.e. big bites while there is plenty and single grabs at the end.  A
+  // same-address atomic completes every ~7 ns chip-wide: one atomic per 4 items (268 K per 150-batch launch) was 1.9 of the
+  // kernel's 2.3 ms; a list that is already exhausted is recognised by a plain load.
+  const int n_waves_all = (int)vgx * 4;
+#ifdef GGAD_G2_PROF
+  G2Prof prof = {};
+  const unsigned long long t_begin = wall_clock64();
+  prof.t = t_begin;
+#endif
+  for (int ph = 0; ph <= GGAD_RANGES; ++ph) {
+    const int cls = ph == 0 ? (int)xcc : (ph == 1 ? GGAD_RANGES : (int)((xcc + ph - 1) & (GGAD_RANGES - 1)));
+    const bool bigc = cls < GGAD_RANGES;
+    const int n_items = bigc ? n_big : n_small;
+    if (n_items == 0) continue;
+    int32_t *cursor = counters + (bigc ? GGAD_CTR_RANGE0 + cls * GGAD_CTR_STRIDE : GGAD_CTR_CURSOR);
+    const int n_waves = ph == 0 ? max(n_waves_all / GGAD_RANGES, 1) : n_waves_all;
+    int seen = 0;
+    if (ph != 0) {
+      seen = __hip_atomic_load(cursor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (seen >= n_items) continue;
+    }
   for (;;) {
     const int rem = n_items - seen;
     int take = (rem / (2 * n_waves)) & ~(ITEM_GRAB - 1);
     take = take < ITEM_GRAB ? ITEM_GRAB : (take > 64 ? 64 : take);
     int first = 0;
-    if (lane == 0) first = atomicAdd(&counters[GGAD_CTR_CURSOR], take);
+    if (lane == 0) first = atomicAdd(cursor, take);
     first = __builtin_amdgcn_readfirstlane(first);
+    G2_MARK(0);
     if (first >= n_items) break;
     seen = first + take;
     const int last = min(n_items, first + take);
@@ -452,12 +609,16 @@ __global__ void __launch_bounds__(256) k_gather2_items(const int32_t *__restrict
     for (int base = first; base < last; base += ITEM_GRAB) {
     // three dependent loads for the FOUR items of the grab (item -> group record -> owner metadata) instead of three per item
     const bool it_ok = base + q_l < last;
-    const int iv = (it_ok && r_l < 2) ? items[(int64_t)(base + q_l) * 2 + r_l] : 0;           // r 0: group, r 1: slice
+    int iv;                                                   // r 0: group, r 1: slice (common list) / range (big list)
+    if (bigc) iv = r_l == 0 ? (it_ok ? big[base + q_l] : 0) : cls;
+    else iv = (it_ok && r_l < 2) ? items[(int64_t)(base + q_l) * 2 + r_l] : 0;
+    const int bv = (bigc && it_ok && (r_l == 10 || r_l == 11)) ? gbnd[(int64_t)(base + q_l) * (GGAD_RANGES + 1) + cls + (r_l - 10)] : 0;
     const int gi_l = __shfl(iv, q_l * 16, GGAD_WAVE);
     const int rv = (it_ok && r_l < GRP_W) ? grp[(int64_t)gi_l * GRP_W + r_l] : -1;
     const int pbv = (r_l < 8 && rv >= 0) ? pw_base[rv] : 0;
     const int rpv = (it_ok && r_l == 0) ? own_rp[rv] : 0;
     const int dgv = (it_ok && r_l == 0) ? own_deg[rv] : 0;
+    G2_MARK(1);
 #pragma unroll 1
     for (int q = 0; q < ITEM_GRAB; ++q) {
       if (base + q >= last) break;
@@ -474,14 +635,23 @@ __global__ void __launch_bounds__(256) k_gather2_items(const int32_t *__restrict
       const int s = __builtin_amdgcn_readlane(rpv, q * 16);
       const int deg = __builtin_amdgcn_readlane(dgv, q * 16);
       const float inv_sr = 1.0f / sqrtf((float)deg);        // deg = 0 -> inf * 0 = NaN, as the dense 0/0 row (quirk 3)
-      const int n0 = sl * SLICE, n1 = min(deg, n0 + SLICE);
+      const int n0 = bigc ? __builtin_amdgcn_readlane(bv, q * 16 + 10) : sl * SLICE;
+      const int n1 = bigc ? __builtin_amdgcn_readlane(bv, q * 16 + 11) : min(deg, n0 + SLICE);
       float tot[8];
-      if (n == 1) { float t1[1]; gather_slice<1, FT>(col, feat, F, stride, s, n0, n1, inv_sr, n, pb, pc, lane, t1); tot[0] = t1[0]; }
-      else if (n == 2) { float t2[2]; gather_slice<2, FT>(col, feat, F, stride, s, n0, n1, inv_sr, n, pb, pc, lane, t2); tot[0] = t2[0]; tot[1] = t2[1]; }
-      else if (n <= 4) { float t4[4]; gather_slice<4, FT>(col, feat, F, stride, s, n0, n1, inv_sr, n, pb, pc, lane, t4);
+      if (MF) {
+        if (n == 1) { float t1[1]; gather_slice_mfma<1>(col, feat, s, n0, n1, inv_sr, n, pb, pc, lane, lw, t1 G2_PASS); tot[0] = t1[0]; }
+        else if (n == 2) { float t2[2]; gather_slice_mfma<2>(col, feat, s, n0, n1, inv_sr, n, pb, pc, lane, lw, t2 G2_PASS); tot[0] = t2[0]; tot[1] = t2[1]; }
+        else if (n <= 4) { float t4[4]; gather_slice_mfma<4>(col, feat, s, n0, n1, inv_sr, n, pb, pc, lane, lw, t4 G2_PASS);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) tot[j] = t4[j]; }
+        else gather_slice_mfma<8>(col, feat, s, n0, n1, inv_sr, n, pb, pc, lane, lw, tot G2_PASS);
+      } else
+      if (n == 1) { float t1[1]; gather_slice<1, FT>(col, feat, F, stride, s, n0, n1, inv_sr, n, pb, pc, lane, t1 G2_PASS); tot[0] = t1[0]; }
+      else if (n == 2) { float t2[2]; gather_slice<2, FT>(col, feat, F, stride, s, n0, n1, inv_sr, n, pb, pc, lane, t2 G2_PASS); tot[0] = t2[0]; tot[1] = t2[1]; }
+      else if (n <= 4) { float t4[4]; gather_slice<4, FT>(col, feat, F, stride, s, n0, n1, inv_sr, n, pb, pc, lane, t4 G2_PASS);
 #pragma unroll
         for (int j = 0; j < 4; ++j) tot[j] = t4[j]; }
-      else gather_slice<8, FT>(col, feat, F, stride, s, n0, n1, inv_sr, n, pb, pc, lane, tot);
+      else gather_slice<8, FT>(col, feat, F, stride, s, n0, n1, inv_sr, n, pb, pc, lane, tot G2_PASS);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         if (j < n && lane < F) {
@@ -489,12 +659,21 @@ __global__ void __launch_bounds__(256) k_gather2_items(const int32_t *__restrict
           else part2[((int64_t)pbase + (int64_t)j * ns + sl) * F + lane] = tot[j];
         }
       }
+      G2_MARK(5);
     }
     }
   }
+  }
+#ifdef GGAD_G2_PROF
+  if (lane == 0) {
+    prof.a[6] = wall_clock64() - t_begin;
+    unsigned long long *out = reinterpret_cast<unsigned long long *>(counters + GGAD_CTR_PROF);
+    for (int k = 0; k < 7; ++k) atomicAdd(out + k, prof.a[k]);
+  }
+#endif
 }
 
-// x2 of multi-slice owners: slices in order (0 + P_0 + P_1 + ...), the per-owner kernel's order.
+// x2 of owners summed in parts: slices / ranges in order (0 + P_0 + P_1 + ...).
 __global__ void __launch_bounds__(256) k_gather2_combine(const int32_t *__restrict__ grp, const int32_t *__restrict__ counters,
                                                          const float *__restrict__ part2, int F, float *__restrict__ x2, int skip) {
   unsigned vbx, vgx;
@@ -539,10 +718,13 @@ __global__ void __launch_bounds__(256) k_gather2_w(const int32_t *__restrict__ c
   if (F <= 64) {
     const int pb[8] = {pb0, 0, 0, 0, 0, 0, 0, 0};
     float total = 0.0f;
+#ifdef GGAD_G2_PROF
+    G2Prof prof = {};
+#endif
     for (int n0 = 0; n0 < deg; n0 += SLICE) {
       float t1[1];
-      if (F == 17) gather_slice<1, 17>(col, feat, F, stride, s, n0, min(deg, n0 + SLICE), inv_sr, 1, pb, pc, lane, t1);
-      else gather_slice<1, 0>(col, feat, F, stride, s, n0, min(deg, n0 + SLICE), inv_sr, 1, pb, pc, lane, t1);
+      if (F == 17) gather_slice<1, 17>(col, feat, F, stride, s, n0, min(deg, n0 + SLICE), inv_sr, 1, pb, pc, lane, t1 G2_PASS);
+      else gather_slice<1, 0>(col, feat, F, stride, s, n0, min(deg, n0 + SLICE), inv_sr, 1, pb, pc, lane, t1 G2_PASS);
       total += t1[0];
     }
     if (deg == 0) total = inv_sr * 0.0f;
@@ -575,6 +757,10 @@ __global__ void __launch_bounds__(256) k_gather2_w(const int32_t *__restrict__ c
   }
 }
 
+// process-wide options of the 2-hop gather (ggad_mb_set_gather_options): the environment gives the defaults
+std::atomic<int> g_mfma_batches{[] { const char *e = getenv("GGAD_GATHER_MFMA_BATCHES"); return e ? atoi(e) : 96; }()};
+std::atomic<int> g_range_deg{[] { const char *e = getenv("GGAD_RANGE_DEG"); return e ? atoi(e) : 0; }()};
+
 }  // namespace
 
 int ggad_int_ldsw_hop2(const ggad_mb_plan *P, const ggad_plan_view &V, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
@@ -591,19 +777,32 @@ int ggad_int_ldsw_hop2(const ggad_mb_plan *P, const ggad_plan_view &V, hipStream
   if (ev0) (void)hipEventRecord(ev0, st);
   const int F = P->feat_dim;
   if (P->node_major && F <= 64) {
+    // ggad_mb_plan::items holds 12 * item_cap ints: [0, 2 cap) the common work items, [2 cap, 3 cap) the big list (group ids),
+    // [3 cap, 12 cap) its range boundaries (GGAD_RANGES + 1 per big group; groups <= entries <= item_cap)
+    const int range_deg = g_range_deg.load() > 0 ? std::max(g_range_deg.load(), GGAD_RANGE_DEG) : INT32_MAX;
+    static const int affine = [] { const char *e = getenv("GGAD_RANGE_AFFINE"); return e ? atoi(e) : 1; }();
+    int32_t *big = P->items + 2 * (int64_t)P->item_cap, *gbnd = P->items + 3 * (int64_t)P->item_cap;
     k_build_groups<<<dim3(ggad_skip_grid((unsigned)((V.n_ents + 255) / 256), skip)), dim3(256), 0, st>>>(
-        P->ent_own, P->ent_col, P->own_deg, V.n_ents, P->node_head, P->own_next, P->grp, P->items, P->counters, skip);
+        P->ent_own, P->ent_col, P->own_deg, V.n_ents, P->node_head, P->own_next, P->tile_off, n_tiles, P->grp, P->items, big, gbnd,
+        P->counters, range_deg, skip);
     // waves take ITEM_GRAB work items at a time from a cursor: enough workgroups to fill the chip, no more than there can be items
     const int64_t max_items = (int64_t)V.n_ents + P->pair_cap / SLICE;
     const unsigned wgs = (unsigned)std::min<int64_t>((max_items + 4 * ITEM_GRAB - 1) / (4 * ITEM_GRAB), 256 * 8);
-    if (F == 17)
-      k_gather2_items<17><<<dim3(ggad_skip_grid(wgs, skip)), dim3(256), 0, st>>>(P->col, P->feat, F, P->feat_stride, P->own_rp, P->own_deg,
-                                                                                 P->pw_base, P->pc, P->grp, P->items, P->counters, P->x2,
-                                                                                 P->part2, skip);
+    // the trainer's table (rows padded to one 128-byte line), launches of many batches: the matrix-core slice.  Measured on the
+    // bench graph (plan alone): 20 batches 640 against 551 us (groups of 1-2 occurrences: 32 MFMA per block for one row of weights),
+    // 64 batches 915 / 833, 96 batches 1,320 / 1,360, 150 batches 1,735 / 1,950 us.
+    if (F == 17 && P->feat_stride == 32 && V.n_batches >= g_mfma_batches.load())
+      k_gather2_items<17, true><<<dim3(ggad_skip_grid(wgs, skip)), dim3(256), 0, st>>>(P->col, P->feat, F, P->feat_stride, P->own_rp, P->own_deg,
+                                                                                       P->pw_base, P->pc, P->grp, P->items, big, gbnd, P->counters,
+                                                                                       P->x2, P->part2, affine, skip);
+    else if (F == 17)
+      k_gather2_items<17, false><<<dim3(ggad_skip_grid(wgs, skip)), dim3(256), 0, st>>>(P->col, P->feat, F, P->feat_stride, P->own_rp, P->own_deg,
+                                                                                 P->pw_base, P->pc, P->grp, P->items, big, gbnd, P->counters,
+                                                                                 P->x2, P->part2, affine, skip);
     else
-      k_gather2_items<0><<<dim3(ggad_skip_grid(wgs, skip)), dim3(256), 0, st>>>(P->col, P->feat, F, P->feat_stride, P->own_rp, P->own_deg,
-                                                                                P->pw_base, P->pc, P->grp, P->items, P->counters, P->x2,
-                                                                                P->part2, skip);
+      k_gather2_items<0, false><<<dim3(ggad_skip_grid(wgs, skip)), dim3(256), 0, st>>>(P->col, P->feat, F, P->feat_stride, P->own_rp, P->own_deg,
+                                                                                P->pw_base, P->pc, P->grp, P->items, big, gbnd, P->counters,
+                                                                                P->x2, P->part2, affine, skip);
     const unsigned cg = (unsigned)std::min<int64_t>(((int64_t)V.n_ents + 3) / 4, 16384);        // ~2 groups per wave: every group costs a dependent load of its record
     k_gather2_combine<<<dim3(ggad_skip_grid(cg, skip)), dim3(256), 0, st>>>(P->grp, P->counters, P->part2, F, P->x2, skip);
   } else {
@@ -621,6 +820,12 @@ int ggad_mb_ldsw_tile_shift(void) { return TW_SHIFT; }
 int ggad_mb_ldsw_max_owners(void) { return TW_MAXOWN; }
 int32_t ggad_mb_slice_len(void) { return SLICE; }
 int32_t ggad_mb_group_words(void) { return GRP_W; }
+int ggad_mb_set_gather_options(int32_t mfma_min_batches, int32_t range_deg) {
+  if (mfma_min_batches >= 0) g_mfma_batches.store(mfma_min_batches);
+  if (range_deg >= 0) g_range_deg.store(range_deg);
+  return GGAD_OK;
+}
+int32_t ggad_mb_item_words(void) { return 3 + GGAD_RANGES + 1; }      // ints of ggad_mb_plan::items per unit of item_cap
 int32_t ggad_mb_plan_counter_elems(void) { return GGAD_PLAN_COUNTERS; }
 int64_t ggad_mb_tile_offsets_elems(int64_t n_nodes, int32_t tile_shift) {
   return n_nodes * (((n_nodes + (1LL << tile_shift) - 1) >> tile_shift) + 1);

@@ -129,7 +129,9 @@ int ggad_mb_plan_build(const ggad_mb_plan *P, const int64_t *nodes_host, const i
   if (mode == 1) {
     info->need_pairs = bound;
     info->need_items = n_ents + bound / SL;
-    info->need_part2 = 2 * (bound / SL) + 8;                       // slots of feat_dim floats (owners with > SL neighbours)
+    // slots of feat_dim floats: ceil(deg / SL) <= 2 deg / SL per occurrence of an owner with > SL neighbours, GGAD_RANGES per
+    // occurrence of one with > GGAD_RANGE_DEG
+    info->need_part2 = (2 + (int64_t)GGAD_RANGES * SL / GGAD_RANGE_DEG) * (bound / SL) + 8;
     info->need_seg = n_tiles1 * seg_stride;
   }
   info->need_cnt2 = (mode == 2 && P->cnt2 == nullptr) ? 1 : 0;

@@ -165,7 +165,7 @@ class BatchChunk:
                 self.pc = torch.empty(self.pair_cap, dtype=torch.int16, device=d)      # uint16 per-pair counts (raw storage)
             if items > self.item_cap:
                 self.item_cap = int(items * 1.25) + 1024
-                self.items = _i32(2 * self.item_cap, d)
+                self.items = _i32(int(self.lib.ggad_mb_item_words()) * self.item_cap, d)
             if part2 > self.part2_cap:
                 self.part2_cap = int(part2 * 1.25) + 64
                 self.part2 = _f32(self.part2_cap * self.F, d)

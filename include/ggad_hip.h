@@ -137,6 +137,14 @@ typedef struct ggad_mb_plan_info {
 int32_t ggad_mb_chunk_len(void);          /* 16 */
 int32_t ggad_mb_slice_len(void);          /* neighbours per work item of the 2-hop gather */
 int32_t ggad_mb_group_words(void);        /* ints per record of grp[] */
+/* Options of the node-major 2-hop gather, process-wide (a negative value leaves an option as it is):
+ *   mfma_min_batches  builds of at least this many batches take the matrix-core slice when feat_dim = 17 and feat_stride = 32
+ *                     (default 96, GGAD_GATHER_MFMA_BATCHES; 0 = always, INT32_MAX = never).  The two slices add the same
+ *                     products in different fixed orders: x2 agrees to ~1e-7 relative, not bit for bit.
+ *   range_deg         owners with more neighbours are gathered by eighths of the id space, one per XCD (default 0 = off,
+ *                     GGAD_RANGE_DEG; values below 256 mean 256).  Measured slower than slices of 256. */
+int ggad_mb_set_gather_options(int32_t mfma_min_batches, int32_t range_deg);
+int32_t ggad_mb_item_words(void);         /* ints of items[] per unit of item_cap: work items, the list of range-partitioned groups, their range bounds */
 int32_t ggad_mb_plan_counter_elems(void); /* ints of ggad_mb_plan::counters (one counter per 64-byte line) */
 /* nodes_host: the batches back to back; batch_ptr_host[nb+1]; labels_host (0/1, NULL for inference plans).  Host outputs
  * (each may be NULL): ent_ptr_host_out[R+1], batch_ent_ptr_host_out[nb+1], batch_max_row_host_out[nb]. */

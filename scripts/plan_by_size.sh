@@ -4,5 +4,5 @@ R=$GRAFT_REPO_ROOT
 TAG=${1:-plan}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/q0
-rocprofv3 --kernel-trace -d /tmp/q0 -o t -- python $R/scripts/plan_kernel_times.py 20,150 2 > /tmp/q0.log 2>&1
+rocprofv3 --kernel-trace -d /tmp/q0 -o t -- python $R/scripts/plan_kernel_times.py ${SIZES:-20,150} 2 > /tmp/q0.log 2>&1
 python $R/scripts/rocpd_by_size.py $(find /tmp/q0 -name "*.db" | head -1) | tee $R/gpurun_out/${TAG}_by_size.csv
