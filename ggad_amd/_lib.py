@@ -122,6 +122,12 @@ SIGNATURES = {
     "ggad_rowdot_f32": (c_int32, [_P, _P, _P, _I, _I, _P, _P, _P]),
     "ggad_edge_dist_f32": (c_int32, [_P, _P, _P, _I, _I, _P, _P]),
     "ggad_rows_scale_f32": (c_int32, [_P, _P, _P, _I, _I, _I, _P, _P]),
+    "ggad_full_loss_bwd_scale_f32": (c_int32, [_P, _P, _P, _P, _P, _I, _L, _P, _P, _P, _P, _P]),
+    "ggad_head_gather_f32": (c_int32, [_P, _P, _P, _I, _I, _P, _P]),
+    "ggad_head_combine_f32": (c_int32, [_P, _P, _I, _P, _I, _I, _P, _P]),
+    "ggad_head_emb_out_f32": (c_int32, [_P, _P, _P, _I, _I, _P, _P]),
+    "ggad_head_con_grad_f32": (c_int32, [_P, _P, _P, _P, _P, _I, _I, _P, _P]),
+    "ggad_head_emb_grad_f32": (c_int32, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P]),
     "ggad_full_loss_workspace_elems": (c_int64, [_I, _I]),
     "ggad_full_loss_f32": (c_int32, [_P, _P, _I, _I, _P, _P, _I, _F, _P, _P, _P, _P, _P, _P]),
     "ggad_adam_f32": (c_int32, [_P, _P, _P, _P, _L, _F, _F, _P, _I, _P]),

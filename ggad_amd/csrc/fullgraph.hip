@@ -776,6 +776,85 @@ __global__ void __launch_bounds__(256) k_rows_scale(const float *__restrict__ X,
   }
 }
 
+// ---- the head of the training forward from `emb` on (model.py:140-182) as ONE autograd node (fullgraph.py GgadHeadFn): the
+// index_select / add / cat / index_copy glue of the reference and the gradient accumulation autograd does for the five consumers
+// of `emb` were ~35 full-tensor torch kernels per epoch.  Wave per row, W columns.
+// out[p] = X[idx[p]] (+ add[p])                                                        emb[abn] + noise     model.py:141-145
+__global__ void __launch_bounds__(256) k_head_gather(const float *__restrict__ X, const int32_t *__restrict__ idx,
+                                                     const float *__restrict__ add, int n, int W, float *__restrict__ out) {
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= n) return;
+  const int lane = lane_id();
+  const float *x = X + (int64_t)idx[p] * W;
+  for (int c = lane; c < W; c += 64) out[(int64_t)p * W + c] = x[c] + (add ? add[(int64_t)p * W + c] : 0.0f);
+}
+// out = [X[nrm]; con]                                                                   cat((emb[normal], emb_con))  :159
+__global__ void __launch_bounds__(256) k_head_combine(const float *__restrict__ X, const int32_t *__restrict__ nrm, int n_nrm,
+                                                      const float *__restrict__ con, int n_con, int W, float *__restrict__ out) {
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= n_nrm + n_con) return;
+  const int lane = lane_id();
+  const float *x = p < n_nrm ? X + (int64_t)nrm[p] * W : con + (int64_t)(p - n_nrm) * W;
+  for (int c = lane; c < W; c += 64) out[(int64_t)p * W + c] = x[c];
+}
+// out[i] = abn_pos[i] >= 0 ? con[abn_pos[i]] : X[i]                                     emb[:, abn, :] = emb_con      :182
+__global__ void __launch_bounds__(256) k_head_emb_out(const float *__restrict__ X, const int32_t *__restrict__ abn_pos,
+                                                      const float *__restrict__ con, int n, int W, float *__restrict__ out) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const int lane = lane_id();
+  const int q = abn_pos[i];
+  const float *x = q >= 0 ? con + (int64_t)q * W : X + (int64_t)i * W;
+  for (int c = lane; c < W; c += 64) out[(int64_t)i * W + c] = x[c];
+}
+// dz[p] = [y[p] > 0] * (g_con[p] + g_out[abn[p]] + g_tail[p]): the three gradients that reach emb_con = relu(fc4(.)) (the loss, the
+// rows written back into emb, the tail of emb_combine) and the relu in one pass; absent terms are null
+__global__ void __launch_bounds__(256) k_head_con_grad(const float *__restrict__ g_con, const float *__restrict__ g_out,
+                                                       const int32_t *__restrict__ abn, const float *__restrict__ g_tail,
+                                                       const float *__restrict__ y, int n, int W, float *__restrict__ dz) {
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= n) return;
+  const int lane = lane_id();
+  const int64_t o = (int64_t)p * W, r = g_out ? (int64_t)abn[p] * W : 0;
+  for (int c = lane; c < W; c += 64) {
+    float t = g_con ? g_con[o + c] : 0.0f;
+    if (g_out) t += g_out[r + c];
+    if (g_tail) t += g_tail[o + c];
+    dz[o + c] = y[o + c] > 0.0f ? t : 0.0f;
+  }
+}
+// d emb[i] = [i not in abn] g_out[i] + [i in normal] g_comb[nrm_pos[i]] + [i in abn] g_abn[abn_pos[i]] + sp[i]
+// (index_copy, index_select x 2, the rows product A_hat[abn, :] emb: every consumer of emb in one pass; absent terms are null)
+__global__ void __launch_bounds__(256) k_head_emb_grad(const float *__restrict__ g_out, const int32_t *__restrict__ abn_pos,
+                                                       const int32_t *__restrict__ nrm_pos, const float *__restrict__ g_comb,
+                                                       const float *__restrict__ g_abn, const float *__restrict__ sp, int n, int W,
+                                                       float *__restrict__ out) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const int lane = lane_id();
+  const int qa = abn_pos[i], qn = nrm_pos[i];
+  const int64_t o = (int64_t)i * W;
+  for (int c = lane; c < W; c += 64) {
+    float t = (g_out && qa < 0) ? g_out[o + c] : 0.0f;
+    if (g_comb && qn >= 0) t += g_comb[(int64_t)qn * W + c];
+    if (g_abn && qa >= 0) t += g_abn[(int64_t)qa * W + c];
+    if (sp) t += sp[o + c];
+    out[o + c] = t;
+  }
+}
+
+// backward of the loss block: every product with the incoming d total in one launch (autograd: five tiny torch kernels)
+//   c = g_aff r_inv_J g     d logits = d_logits g     d emb_con = dD g     d emb_abnormal = -dD g
+__global__ void __launch_bounds__(256) k_loss_bwd_scale(const float *__restrict__ g_total, const float *__restrict__ g_aff,
+                                                        const float *__restrict__ r_inv_j, const float *__restrict__ d_logits,
+                                                        const float *__restrict__ dD, int L, int64_t n_rec, float *__restrict__ c,
+                                                        float *__restrict__ dl, float *__restrict__ d_con, float *__restrict__ d_abn) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const float g = g_total[0];
+  if (i < L) { c[i] = (g_aff[i] * r_inv_j[i]) * g; dl[i] = d_logits[i] * g; }
+  if (i < n_rec) { const float v = dD[i] * g; d_con[i] = v; d_abn[i] = -v; }
+}
+
 __device__ __forceinline__ float block_sum_1024(float v, float *red) {
   v = wave_sum(v);
   const int lane = lane_id(), wid = threadIdx.x >> 6;
@@ -1080,6 +1159,46 @@ int ggad_relu_bwd_f32(const float *g, const float *y, int64_t n, float *dz, ggad
   return GGAD_OK;
 }
 
+int ggad_head_gather_f32(const float *X, const int32_t *idx, const float *add, int32_t n, int32_t W, float *out, ggad_stream_t stream) {
+  GGAD_REQUIRE(X && idx && out && n >= 0 && W >= 1);
+  if (n == 0) return GGAD_OK;
+  k_head_gather<<<dim3((n + 3) / 4), dim3(256), 0, as_stream(stream)>>>(X, idx, add, n, W, out);
+  GGAD_CHECK_LAUNCH("head_gather_f32");
+  return GGAD_OK;
+}
+int ggad_head_combine_f32(const float *X, const int32_t *nrm, int32_t n_nrm, const float *con, int32_t n_con, int32_t W, float *out,
+                          ggad_stream_t stream) {
+  GGAD_REQUIRE(X && out && n_nrm >= 0 && n_con >= 0 && W >= 1 && (n_nrm == 0 || nrm) && (n_con == 0 || con));
+  if (n_nrm + n_con == 0) return GGAD_OK;
+  k_head_combine<<<dim3((n_nrm + n_con + 3) / 4), dim3(256), 0, as_stream(stream)>>>(X, nrm, n_nrm, con, n_con, W, out);
+  GGAD_CHECK_LAUNCH("head_combine_f32");
+  return GGAD_OK;
+}
+int ggad_head_emb_out_f32(const float *X, const int32_t *abn_pos, const float *con, int32_t n, int32_t W, float *out,
+                          ggad_stream_t stream) {
+  GGAD_REQUIRE(X && abn_pos && con && out && n >= 0 && W >= 1);
+  if (n == 0) return GGAD_OK;
+  k_head_emb_out<<<dim3((n + 3) / 4), dim3(256), 0, as_stream(stream)>>>(X, abn_pos, con, n, W, out);
+  GGAD_CHECK_LAUNCH("head_emb_out_f32");
+  return GGAD_OK;
+}
+int ggad_head_con_grad_f32(const float *g_con, const float *g_out, const int32_t *abn, const float *g_tail, const float *y, int32_t n,
+                           int32_t W, float *dz, ggad_stream_t stream) {
+  GGAD_REQUIRE(y && dz && n >= 0 && W >= 1 && (!g_out || abn));
+  if (n == 0) return GGAD_OK;
+  k_head_con_grad<<<dim3((n + 3) / 4), dim3(256), 0, as_stream(stream)>>>(g_con, g_out, abn, g_tail, y, n, W, dz);
+  GGAD_CHECK_LAUNCH("head_con_grad_f32");
+  return GGAD_OK;
+}
+int ggad_head_emb_grad_f32(const float *g_out, const int32_t *abn_pos, const int32_t *nrm_pos, const float *g_comb, const float *g_abn,
+                           const float *sp, int32_t n, int32_t W, float *out, ggad_stream_t stream) {
+  GGAD_REQUIRE(abn_pos && nrm_pos && out && n >= 0 && W >= 1);
+  if (n == 0) return GGAD_OK;
+  k_head_emb_grad<<<dim3((n + 3) / 4), dim3(256), 0, as_stream(stream)>>>(g_out, abn_pos, nrm_pos, g_comb, g_abn, sp, n, W, out);
+  GGAD_CHECK_LAUNCH("head_emb_grad_f32");
+  return GGAD_OK;
+}
+
 int ggad_prelu_fwd_f32(const float *z, const float *prelu_a, int64_t n, float *out, ggad_stream_t stream) {
   GGAD_REQUIRE(z && prelu_a && out && n >= 0);
   if (n == 0) return GGAD_OK;
@@ -1145,6 +1264,17 @@ int ggad_full_loss_f32(const float *logits, const float *aff, int32_t n_normal, 
   k_rec_part<<<dim3(nb), dim3(256), 0, st>>>(emb_con, emb_abn, n_out, H, workspace);
   k_rec_apply<<<dim3(nb), dim3(256), 0, st>>>(emb_con, emb_abn, n_out, H, workspace, nb, dD, losses4);
   GGAD_CHECK_LAUNCH("full_loss_f32");
+  return GGAD_OK;
+}
+
+int ggad_full_loss_bwd_scale_f32(const float *g_total, const float *g_aff, const float *r_inv_j, const float *d_logits, const float *dD,
+                                 int32_t L, int64_t n_rec, float *c, float *dl, float *d_con, float *d_abn, ggad_stream_t stream) {
+  GGAD_REQUIRE(g_total && g_aff && r_inv_j && d_logits && dD && c && dl && d_con && d_abn && L >= 0 && n_rec >= 0);
+  const int64_t n = std::max<int64_t>(L, n_rec);
+  if (n == 0) return GGAD_OK;
+  k_loss_bwd_scale<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream)>>>(g_total, g_aff, r_inv_j, d_logits, dD, L, n_rec,
+                                                                                         c, dl, d_con, d_abn);
+  GGAD_CHECK_LAUNCH("full_loss_bwd_scale_f32");
   return GGAD_OK;
 }
 

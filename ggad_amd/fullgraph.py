@@ -362,6 +362,7 @@ class FullGraphAdj:
         self.r_inv_host = r_inv
         self._abn: Dict[tuple, tuple] = {}
         self._loss: Dict[tuple, tuple] = {}
+        self._head: Dict[tuple, object] = {}
         self._ax: Dict[str, object] = {}                         # cached A_hat X of the constant input layer (`cached_aggregate`)
         self._devc: Dict[str, torch.Tensor] = {}                 # small per-node device vectors (`r_inv_dev`, `arange_dev`)
 
@@ -396,6 +397,32 @@ class FullGraphAdj:
             s = (self.A.plan(idx, key=("rows", key)), Csr(sub.T.tocsr(), self.dev))
             self._abn[key] = s
         return s
+
+    def head_structs(self, normal_idx, abn_idx):
+        """Device index lists of the training head (`model.py:140-182`) and their inverse maps (position of node i in the list, -1 if
+        absent) for `GgadHeadFn`; None when a list holds a node twice (the fused head assumes duplicate-free lists, as `run.py` draws them)."""
+        nrm = np.ascontiguousarray(np.asarray(normal_idx, dtype=np.int64))         # C-speed key: no per-element Python work per forward
+        abn = np.ascontiguousarray(np.asarray(abn_idx, dtype=np.int64))
+        key = (nrm.size, abn.size, hash(nrm.tobytes()), hash(abn.tobytes()))
+        s = self._head.get(key)
+        if s is not None and s is not False and not (np.array_equal(s["nrm_host"], nrm) and np.array_equal(s["abn_host"], abn)):
+            s = None                                                                 # (hash collision)
+        if s is None:
+            if len(np.unique(nrm)) != len(nrm) or len(np.unique(abn)) != len(abn) or len(abn) == 0:
+                s = False
+            else:
+                nrm_pos = np.full(self.n, -1, dtype=np.int32)
+                abn_pos = np.full(self.n, -1, dtype=np.int32)
+                nrm_pos[nrm] = np.arange(len(nrm), dtype=np.int32)
+                abn_pos[abn] = np.arange(len(abn), dtype=np.int32)
+                rows_plan, sub_t = self.abn_structs(abn_idx)
+                s = dict(nrm=_dev_i32(nrm, self.dev), abn=_dev_i32(abn, self.dev), nrm_pos=_dev_i32(nrm_pos, self.dev),
+                         abn_pos=_dev_i32(abn_pos, self.dev), n_nrm=len(nrm), n_abn=len(abn), rows_plan=rows_plan, sub_t=sub_t,
+                         nrm_host=nrm, abn_host=abn)
+            if len(self._head) >= 8:
+                self._head.clear()
+            self._head[key] = s
+        return s or None
 
     def loss_structs(self, normal_idx, abn_idx):
         """J = normal_idx ++ abn_idx (the rows whose affinity the loss reads) and R[:, J] as an N x |J| CSR."""
@@ -634,6 +661,82 @@ class SpmmRowsFn(torch.autograd.Function):
         return spmm(ctx.sub_t, g.contiguous()), None, None, None
 
 
+class GgadHeadFn(torch.autograd.Function):
+    """The training forward from `emb` on (`model.py:140-182`) as ONE autograd node:
+
+        emb_abnormal = emb[abn] + noise                                   :141-145
+        emb_con      = relu(fc4(A_hat[abn, :] emb))                       :151-156
+        emb_combine  = cat(emb[normal], emb_con)                          :159
+        f_3          = fc3(relu(fc2(relu(fc1(emb_combine)))))             :176-180
+        emb_out      = emb with rows abn replaced by emb_con              :182
+
+    Same products as the op-by-op path (`Model._head_unfused`: `LinearFn`, `SpmmRowsFn`, torch indexing); what is fused is the glue
+    -- gather / add / cat / index_copy forward, and in the backward the gradient accumulation over the five consumers of `emb` and
+    the three of `emb_con`, which autograd does with one full-tensor kernel per term (~35 launches of 5 us per Reddit epoch).
+    The sums of gradient terms are formed in one fixed order (`k_head_con_grad`, `k_head_emb_grad`); autograd's order is another,
+    so the two paths agree to fp32 round-off, not bit for bit (tests/test_fullgraph_gpu.py)."""
+
+    @staticmethod
+    def forward(ctx, emb, noise, w4, w1, w2, w3, adj: FullGraphAdj, hs):
+        emb = emb.contiguous()
+        n, h = emb.shape
+        dev = emb.device
+        na, nn_ = hs["n_abn"], hs["n_nrm"]
+        noise = noise.reshape(na, h).contiguous() if noise is not None else None
+        emb_abn = torch.empty(na, h, dtype=torch.float32, device=dev)
+        call("ggad_head_gather_f32", ptr(emb), ptr(hs["abn"]), ptr(noise), na, h, ptr(emb_abn))
+        con_pre = spmm(adj.A, emb, plan=hs["rows_plan"])
+        emb_con = gemm(con_pre, w4, False, True, relu=True)
+        comb = torch.empty(nn_ + na, h, dtype=torch.float32, device=dev)
+        call("ggad_head_combine_f32", ptr(emb), ptr(hs["nrm"]), nn_, ptr(emb_con), na, h, ptr(comb))
+        f1 = gemm(comb, w1, False, True, relu=True)
+        f2 = gemm(f1, w2, False, True, relu=True)
+        f3 = gemm(f2, w3, False, True)
+        emb_out = torch.empty_like(emb)
+        call("ggad_head_emb_out_f32", ptr(emb), ptr(hs["abn_pos"]), ptr(emb_con), n, h, ptr(emb_out))
+        ctx.save_for_backward(con_pre, emb_con, comb, f1, f2, w4, w1, w2, w3)
+        ctx.hs, ctx.shape = hs, (n, h)
+        ctx.set_materialize_grads(False)
+        return emb_out, comb, f3, emb_con, emb_abn
+
+    @staticmethod
+    def backward(ctx, g_out, g_comb, g_f3, g_con, g_abn):
+        con_pre, emb_con, comb, f1, f2, w4, w1, w2, w3 = ctx.saved_tensors
+        hs = ctx.hs
+        n, h = ctx.shape
+        na, nn_ = hs["n_abn"], hs["n_nrm"]
+        dev = emb_con.device
+        c = lambda t: t.contiguous() if t is not None else None          # noqa: E731
+        g_out, g_comb, g_f3, g_con, g_abn = c(g_out), c(g_comb), c(g_f3), c(g_con), c(g_abn)
+        dw1 = dw2 = dw3 = None
+        d_comb = g_comb
+        if g_f3 is not None:                                               # scorer MLP, as LinearFn.backward three times
+            dw3 = gemm(g_f3, f2, True, False)
+            df2 = gemm(g_f3, w3, False, False)
+            dz2 = torch.empty_like(df2)
+            call("ggad_relu_bwd_f32", ptr(df2), ptr(f2), df2.numel(), ptr(dz2))
+            dw2 = gemm(dz2, f1, True, False)
+            df1 = gemm(dz2, w2, False, False)
+            dz1 = torch.empty_like(df1)
+            call("ggad_relu_bwd_f32", ptr(df1), ptr(f1), df1.numel(), ptr(dz1))
+            dw1 = gemm(dz1, comb, True, False)
+            d_comb = gemm(dz1, w1, False, False)
+            if g_comb is not None:
+                d_comb = d_comb + g_comb
+        dz4 = torch.empty(na, h, dtype=torch.float32, device=dev)
+        tail = d_comb[nn_:] if d_comb is not None else None              # rows of emb_combine that are emb_con (contiguous slice)
+        call("ggad_head_con_grad_f32", ptr(g_con), ptr(g_out), ptr(hs["abn"]), ptr(tail), ptr(emb_con), na, h, ptr(dz4))
+        dw4 = gemm(dz4, con_pre, True, False)
+        g_emb = None
+        if ctx.needs_input_grad[0]:
+            d_pre = gemm(dz4, w4, False, False)
+            sp = spmm(hs["sub_t"], d_pre)
+            g_emb = torch.empty(n, h, dtype=torch.float32, device=dev)
+            call("ggad_head_emb_grad_f32", ptr(g_out), ptr(hs["abn_pos"]), ptr(hs["nrm_pos"]), ptr(d_comb), ptr(g_abn), ptr(sp), n, h,
+                 ptr(g_emb))
+        return g_emb, None, dw4, dw1, dw2, dw3, None, None
+
+
 class GgadLossFn(torch.autograd.Function):
     """(total, margin, bce, rec) of `run.py:165-210`; only `total` is differentiable."""
 
@@ -674,7 +777,11 @@ class GgadLossFn(torch.autograd.Function):
         J, L, nn_ = ls["J"], int(ls["J"].numel()), ls["n_normal"]
         if g_total is None:
             return None, None, None, None, None, None, None
-        c = g_aff * ls["r_inv_J"] * g_total                                               # d total / d (e_hat_j . S_j)
+        c, dl = torch.empty_like(g_aff), torch.empty_like(d_logits)                       # c = d total / d (e_hat_j . S_j)
+        d_con, d_abn = torch.empty_like(dD), torch.empty_like(dD)
+        g_total = g_total.to(torch.float32).reshape(1).contiguous()
+        call("ggad_full_loss_bwd_scale_f32", ptr(g_total), ptr(g_aff), ptr(ls["r_inv_J"]), ptr(d_logits), ptr(dD), L, dD.numel(),
+             ptr(c), ptr(dl), ptr(d_con), ptr(d_abn))
         xc = torch.empty(L, h, dtype=torch.float32, device=en.device)
         call("ggad_rows_scale_f32", ptr(en), ptr(J), ptr(c), L, h, 0, ptr(xc))            # c_j e_hat_j
         den = spmm(ls["RJ"], xc)                                                          # sum_j R_ij c_j e_hat_j
@@ -684,7 +791,14 @@ class GgadLossFn(torch.autograd.Function):
              ptr(den))
         d_emb = torch.empty_like(en)
         call("ggad_rownorm_bwd_f32", ptr(en), ptr(inv), ptr(den), n, h, ptr(d_emb))
-        return d_emb, d_logits * g_total, dD * g_total, -dD * g_total, None, None, None
+        return d_emb, dl, d_con, d_abn, None, None, None
+
+
+def ggad_loss(emb, logits, emb_con, emb_abnormal, adj: FullGraphAdj, ls, margin: float):
+    """`GgadLossFn` on what `Model.forward` returns ((1, N, H), (1, L, 1), (A, H), (1, A, H)): the 2-D views are reshapes, whose
+    backward is a view again -- `emb[0]` / `logits[0, :, 0]` cost a zero-fill and a copy of the whole tensor each in autograd."""
+    h = emb.shape[-1]
+    return GgadLossFn.apply(emb.reshape(-1, h), logits.reshape(-1), emb_con, emb_abnormal.reshape(-1, h), adj, ls, margin)
 
 
 class FlatAdam:

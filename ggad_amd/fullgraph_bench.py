@@ -90,7 +90,7 @@ def bench_one(name: str, dev, epochs: int = 30, seed: int = 0, h: int = 300) -> 
     def train_epoch():
         opt.zero_grad()
         emb, emb_combine, logits, emb_con, emb_abnormal = model(feats, full, abn, nrm, True, args)
-        out = FG.GgadLossFn.apply(emb[0], logits[0, :, 0], emb_con, emb_abnormal[0], full, ls, 0.7)
+        out = FG.ggad_loss(emb, logits, emb_con, emb_abnormal, full, ls, 0.7)
         out[0].backward()
         opt.step()
         return out

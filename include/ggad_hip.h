@@ -488,6 +488,23 @@ int ggad_prelu_fwd_f32(const float *z, const float *prelu_a, int64_t n, float *o
 /* dz = g * [y > 0] */
 int ggad_relu_bwd_f32(const float *g, const float *y, int64_t n, float *dz, ggad_stream_t stream);
 
+/* The head of the training forward from `emb` (N x W) on -- model.py:140-182 -- and its backward, the glue between the products:
+ *   head_gather    out[p] = X[idx[p]] (+ add[p])                          emb[abn] + noise                       model.py:141-145
+ *   head_combine   out = [X[nrm]; con]                                    torch.cat((emb[normal], emb_con))      :159
+ *   head_emb_out   out[i] = abn_pos[i] >= 0 ? con[abn_pos[i]] : X[i]      emb[:, abn, :] = emb_con               :182
+ *   head_con_grad  dz = [y > 0] (g_con + g_out[abn] + g_tail)             every gradient that reaches emb_con = relu(fc4(.)), :156
+ *   head_emb_grad  d emb[i] = [i not in abn] g_out[i] + [i in normal] g_comb[nrm_pos[i]] + [i in abn] g_abn[abn_pos[i]] + sp[i]
+ * abn_pos / nrm_pos: position of node i in the (duplicate-free) index list, -1 if absent.  Gradient terms may be null. */
+int ggad_head_gather_f32(const float *X, const int32_t *idx, const float *add, int32_t n, int32_t W, float *out, ggad_stream_t stream);
+int ggad_head_combine_f32(const float *X, const int32_t *nrm, int32_t n_nrm, const float *con, int32_t n_con, int32_t W, float *out,
+                          ggad_stream_t stream);
+int ggad_head_emb_out_f32(const float *X, const int32_t *abn_pos, const float *con, int32_t n, int32_t W, float *out,
+                          ggad_stream_t stream);
+int ggad_head_con_grad_f32(const float *g_con, const float *g_out, const int32_t *abn, const float *g_tail, const float *y, int32_t n,
+                           int32_t W, float *dz, ggad_stream_t stream);
+int ggad_head_emb_grad_f32(const float *g_out, const int32_t *abn_pos, const int32_t *nrm_pos, const float *g_comb, const float *g_abn,
+                           const float *sp, int32_t n, int32_t W, float *out, ggad_stream_t stream);
+
 /* Row L2 normalisation e_hat = e / |e| with 1/0 -> 0 (run.py:177-180) and its vector-Jacobian product. */
 int ggad_rownorm_f32(const float *X, int32_t M, int32_t W, float *inv, float *Xn, ggad_stream_t stream);
 int ggad_rownorm_bwd_f32(const float *Xn, const float *inv, const float *dXn, int32_t M, int32_t W, float *dX,
@@ -509,6 +526,10 @@ int64_t ggad_full_loss_workspace_elems(int32_t n_out, int32_t H);   /* floats of
 int ggad_full_loss_f32(const float *logits, const float *aff, int32_t n_normal, int32_t n_out, const float *emb_con,
                        const float *emb_abn, int32_t H, float margin, float *losses4, float *d_logits, float *g_aff,
                        float *dD, float *workspace, ggad_stream_t stream);
+/* Backward of the loss block, every product with the incoming d total (a device scalar) in one launch:
+ *   c = g_aff r_inv_J g (what ggad_rows_scale_f32 needs next), d logits = d_logits g, d emb_con = dD g, d emb_abnormal = -dD g. */
+int ggad_full_loss_bwd_scale_f32(const float *g_total, const float *g_aff, const float *r_inv_j, const float *d_logits, const float *dD,
+                                 int32_t L, int64_t n_rec, float *c, float *dl, float *d_con, float *d_abn, ggad_stream_t stream);
 
 /* torch.optim.Adam.step on a flat fp32 block; uses step index *step_counter + 1 and (bump_after != 0) advances it. */
 int ggad_adam_f32(float *params, float *exp_avg, float *exp_avg_sq, const float *grads, int64_t n, float lr,

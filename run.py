@@ -21,7 +21,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from ggad_amd import synth  # noqa: E402
-from ggad_amd.fullgraph import FlatAdam, FullGraphAdj, GgadLossFn  # noqa: E402
+from ggad_amd.fullgraph import FlatAdam, FullGraphAdj, ggad_loss  # noqa: E402
 from ggad_amd.metrics import average_precision, roc_auc  # noqa: E402
 from ggad_amd.model import Model  # noqa: E402
 from ggad_amd.utils import load_mat, normalize_adj, preprocess_features, split_nodes  # noqa: E402
@@ -115,7 +115,7 @@ def main():
     def train_epoch():
         optimiser.zero_grad()
         emb, emb_combine, logits, emb_con, emb_abnormal = model(feats, full, abnormal_label_idx, normal_label_idx, True, args)
-        out = GgadLossFn.apply(emb[0], logits[0, :, 0], emb_con, emb_abnormal[0], full, ls, 0.7)
+        out = ggad_loss(emb, logits, emb_con, emb_abnormal, full, ls, 0.7)
         out[0].backward()
         optimiser.step()
         return out

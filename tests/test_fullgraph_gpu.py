@@ -62,8 +62,11 @@ def test_preprocessing_matches_reference(name):
     np.testing.assert_array_equal(fa.A.val.cpu().numpy(), ref.data.astype(np.float32))
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("name", ["fullgraph_reddit_like.npz", "fullgraph_amazon_like.npz"])
-def test_model_forward_loss_backward_trajectory(name):
+def test_model_forward_loss_backward_trajectory(name, fused):
+    """The reference's own tensors, losses, gradients and weights (tests/golden/make_golden.py) -- with the head of the forward as
+    one autograd node (`GgadHeadFn`, the default) and op by op."""
     g = load_golden(name)
     fa = _adj(g)
     f, h = int(g["f"]), int(g["n_h"])
@@ -73,11 +76,13 @@ def test_model_forward_loss_backward_trajectory(name):
     assert sorted(sd.keys()) == sorted(model.state_dict().keys())        # same parameter names as the reference
     model.load_state_dict(sd)
     model.to(DEV)
+    model.fused_head = fused
     opt = FG.FlatAdam(model.parameters(), lr=1e-3, weight_decay=0.0)
     feats = torch.from_numpy(g["features"])[None].to(DEV)
     abn, nrm = g["abn_idx"].tolist(), g["normal_idx"].tolist()
     args = types.SimpleNamespace(mean=float(g["mean"]), var=float(g["var"]))
     ls = fa.loss_structs(nrm, abn)
+    assert (fa.head_structs(nrm, abn) is not None) and fa.head_structs(nrm + nrm[:1], abn) is None      # duplicate-free lists only
     for step in range(len(g["losses"])):
         model.train()
         opt.zero_grad()
