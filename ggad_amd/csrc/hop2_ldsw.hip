@@ -84,16 +84,28 @@ __global__ void __launch_bounds__(256) k_seg_transpose(const int32_t *__restrict
   if (p0 >= n_ents) return;
   const int lane = lane_id(), wid = threadIdx.x >> 6;
   const int NT1 = n_tiles + 1;
+  // lane j of every wave knows entry p0 + j (owner?, node); a wave then has the 32 row loads of its 16 entries in flight at once
+  // (every load unconditional: clamped column, node 0 for non-owners, the value selected afterwards) -- one entry at a time
+  // the kernel ran at the latency of two dependent loads per entry (286 us per 150-batch plan for 0.56 GB)
+  int u_l = 0, own_l = 0;
+  if (p0 + lane < n_ents) { own_l = ent_own[p0 + lane] == p0 + lane ? 1 : 0; u_l = own_l ? ent_col[p0 + lane] : 0; }
   for (int t0 = 0; t0 < NT1; t0 += TT_SLAB) {
-    for (int j = wid; j < 64; j += 4) {
-      const int p = p0 + j;
-      if (p < n_ents) {
-        const bool own = ent_own[p] == p;
-        const int u = ent_col[p];
-        const int32_t *row = tile_off + (int64_t)u * NT1 + t0;
-        if (t0 + lane < NT1) tl[lane][j] = own ? row[lane] : 0;
-        if (t0 + 64 + lane < NT1) tl[64 + lane][j] = own ? row[64 + lane] : 0;
-      }
+    int v0[16], v1[16];
+    const int c0 = min(t0 + lane, NT1 - 1), c1 = min(t0 + 64 + lane, NT1 - 1);
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+      const int j = wid + 4 * jj;
+      const int u = __shfl(u_l, j, GGAD_WAVE);
+      const int32_t *row = tile_off + (int64_t)u * NT1;
+      v0[jj] = row[c0];
+      v1[jj] = row[c1];
+    }
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+      const int j = wid + 4 * jj;
+      const int own = __shfl(own_l, j, GGAD_WAVE);
+      if (t0 + lane < NT1) tl[lane][j] = own ? v0[jj] : 0;
+      if (t0 + 64 + lane < NT1) tl[64 + lane][j] = own ? v1[jj] : 0;
     }
     __syncthreads();
     const int nt = min(TT_SLAB, NT1 - t0);
@@ -157,11 +169,18 @@ __global__ void __launch_bounds__(TW_T) k_tile_counts(const int32_t *__restrict_
       if (pass == 0 || n_slabs > 1) {
         // segment of every owner inside this tile; exclusive scan of the lengths (IPT owners per thread).
         // The four table reads are coalesced (thread-contiguous owners), staged through LDS for the per-thread scan.
-        for (int i = threadIdx.x; i < n_own; i += TW_T) {
-          const int lo = seg_lo[ob0 + i], hi = seg_hi[ob0 + i];
-          offs[i] = hi - lo;
-          segbeg[i] = own_rp[ob0 + i] + lo;
-          dst[i] = pw_base[ob0 + i] + lo;
+        {                                                       // all 4 IPT loads of a thread in flight (clamped, unconditional):
+          int lo_[IPT], hi_[IPT], rp_[IPT], pb_[IPT];           // one iteration at a time this phase was IPT dependent round trips
+#pragma unroll
+          for (int q = 0; q < IPT; ++q) {
+            const int i = min((int)threadIdx.x + q * TW_T, n_own - 1);
+            lo_[q] = seg_lo[ob0 + i]; hi_[q] = seg_hi[ob0 + i]; rp_[q] = own_rp[ob0 + i]; pb_[q] = pw_base[ob0 + i];
+          }
+#pragma unroll
+          for (int q = 0; q < IPT; ++q) {
+            const int i = (int)threadIdx.x + q * TW_T;
+            if (i < n_own) { offs[i] = hi_[q] - lo_[q]; segbeg[i] = rp_[q] + lo_[q]; dst[i] = pb_[q] + lo_[q]; }
+          }
         }
         __syncthreads();
         int len[IPT];
@@ -244,11 +263,13 @@ __global__ void __launch_bounds__(TW_T) k_tile_counts(const int32_t *__restrict_
 #pragma unroll
           for (int q = 0; q < 4; ++q) pp[q] = min(p0 + q * TW_T + (int)threadIdx.x, P - 1);
           locate4(pp, own, j);
+          int k4[4];
 #pragma unroll
+          for (int q = 0; q < 4; ++q) k4[q] = col[segbeg[own[q]] + j[q]];      // (pairs clamped to P - 1: unconditional, all four in flight;
+#pragma unroll                                                               //  eight per trip measured slower)
           for (int q = 0; q < 4; ++q) {
             if (p0 + q * TW_T + (int)threadIdx.x < P) {
-              const int k = col[segbeg[own[q]] + j[q]];
-              const int loc = k & (TW_TILE - 1);
+              const int loc = k4[q] & (TW_TILE - 1);
               if (pass == 0) atomicAdd(&cnt[loc >> 1], 1u << ((loc & 1) << 4));
               else pc[(int64_t)dst[own[q]] + j[q]] = (uint16_t)((cnt[loc >> 1] >> ((loc & 1) << 4)) & 0xFFFFu);
             }
