@@ -238,12 +238,10 @@ __global__ void __launch_bounds__(TW_T) k_tile_counts(const int32_t *__restrict_
               locate4(pp, own, j);
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
-                kc[g4 + q] = segbeg[own[q]] + j[q];             // index into col[] for now
+                kc[g4 + q] = col[segbeg[own[q]] + j[q]];        // requested now: in flight while the next four pairs are located
                 dc[g4 + q] = dst[own[q]] + j[q];
               }
             }
-#pragma unroll
-            for (int it = 0; it < CACHE_IT; ++it) kc[it] = col[kc[it]];
 #pragma unroll
             for (int it = 0; it < CACHE_IT; ++it) {
               const bool on = it * TW_T + (int)threadIdx.x < P;
@@ -289,7 +287,7 @@ __global__ void __launch_bounds__(TW_T) k_tile_counts(const int32_t *__restrict_
 template <int G, int FT>
 __device__ __forceinline__ void gather_slice(const int32_t *__restrict__ col, const float *__restrict__ feat, int F_rt, int stride,
                                              int s, int n0, int n1, float inv_sr, int n_occ, const int (&pb)[8],
-                                             const uint16_t *__restrict__ pc, int lane, float (&tot)[G] G2_ARG) {
+                                             const uint16_t *__restrict__ pc, int lane, int k_first, float (&tot)[G] G2_ARG) {
   const int F = FT ? FT : F_rt;
   const int rpi = 64 / F;
   const int g = lane / F, f = lane - g * F;
@@ -307,12 +305,14 @@ __device__ __forceinline__ void gather_slice(const int32_t *__restrict__ col, co
   // 64 neighbours instead of two); the weights of a block are formed from its counts before the request for the next block
   // re-uses their registers.  EVERY load is unconditional (indices clamped into the slice, node 0 for padding lanes, weight
   // 0 for what must not count): a guarded load compiles to a branch + s_waitcnt each and serialises the wave.
+  // The ids of the first block come from the caller (requested while the previous work item was being summed); the counts are
+  // requested here and only waited for AFTER the block's row loads have been issued: a slice starts with ONE memory round trip
+  // (rows; counts beside them), not three (ids, counts, rows).
   const int last = max(n1 - 1, 0);
-  int k_nx;
+  int k_nx = k_first;
   uint32_t c_nx[G];
   {
     const int ix = min(n0 + lane, last);
-    k_nx = col[s + ix];
 #pragma unroll
     for (int j = 0; j < G; ++j) c_nx[j] = pc[pb[j] + ix];
   }
@@ -322,8 +322,10 @@ __device__ __forceinline__ void gather_slice(const int32_t *__restrict__ col, co
     const int k = mine ? k_nx : 0;
     const int count = min(64, n1 - blk);
     float w[G];
+    if (FT != 17) {
 #pragma unroll
-    for (int j = 0; j < G; ++j) w[j] = (j < n_occ && mine) ? inv_sr / sqrtf((float)c_nx[j]) : 0.0f;   // .div(row).div(col)  graphsage.py:348
+      for (int j = 0; j < G; ++j) w[j] = (j < n_occ && mine) ? inv_sr / sqrtf((float)c_nx[j]) : 0.0f;   // .div(row).div(col)  graphsage.py:348
+    }
     if (FT == 17) {
       constexpr int IT = 22;                                   // ceil(64 / 3)
       float x[IT];
@@ -332,6 +334,8 @@ __device__ __forceinline__ void gather_slice(const int32_t *__restrict__ col, co
         const int kk = __shfl(k, (t * 3 + gl) & 63, GGAD_WAVE);   // a valid id or 0: always a readable row
         x[t] = row_elem(kk);
       }
+#pragma unroll
+      for (int j = 0; j < G; ++j) w[j] = (j < n_occ && mine) ? inv_sr / sqrtf((float)c_nx[j]) : 0.0f;   // .div(row).div(col)  graphsage.py:348
       {
         const int ix = min(blk + 64 + lane, last);
         k_nx = col[s + ix];
@@ -415,43 +419,50 @@ typedef int mi4 __attribute__((ext_vector_type(4)));
 template <int G>
 __device__ __forceinline__ void gather_slice_mfma(const int32_t *__restrict__ col, const float *__restrict__ feat, int s, int n0, int n1,
                                                   float inv_sr, int n_occ, const int (&pb)[8], const uint16_t *__restrict__ pc,
-                                                  int lane, float *lw, float (&tot)[G] G2_ARG) {
+                                                  int lane, float *lw, int k_first, float (&tot)[G] G2_ARG) {
   const int a = lane & 15, g = lane >> 4;
   const char *fb = reinterpret_cast<const char *>(feat) + a * 8;
   int *lids = reinterpret_cast<int *>(lw + 8 * MF_WS);
   const int aa = a < G ? a : 0;
   mf4 acc0 = {0.0f, 0.0f, 0.0f, 0.0f}, acc1 = {0.0f, 0.0f, 0.0f, 0.0f};
   const int last = max(n1 - 1, 0);
-  int k_nx;
+  int k_nx = k_first;                                        // (clamped by the caller: always the id of a neighbour of this slice)
   uint32_t c_nx[G];
   {
     const int ix = min(n0 + lane, last);
-    k_nx = col[s + ix];                                      // clamped: always the id of a neighbour of this slice
 #pragma unroll
     for (int j = 0; j < G; ++j) c_nx[j] = pc[pb[j] + ix];
   }
   G2_MARK(2);
   for (int blk = n0; blk < n1; blk += 64) {
     const bool mine = blk + lane < n1;
+    // ids first: their LDS round trip and the 16 row requests do not wait for the counts
     lids[lane] = k_nx;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int id[16];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const mi4 iv = *reinterpret_cast<const mi4 *>(lids + 16 * g + 4 * c);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) id[4 * c + q] = iv[q];
+    }
+    mf2 x[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = *reinterpret_cast<const mf2 *>(fb + ((uint32_t)id[i] << 7));
 #pragma unroll
     for (int j = 0; j < G; ++j)
       lw[j * MF_WS + lane] = (j < n_occ && mine) ? inv_sr / sqrtf((float)c_nx[j]) : 0.0f;     // .div(row).div(col)  graphsage.py:348
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    int id[16];
     float wa[16];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const mi4 iv = *reinterpret_cast<const mi4 *>(lids + 16 * g + 4 * c);
       const mf4 wv = *reinterpret_cast<const mf4 *>(lw + aa * MF_WS + 16 * g + 4 * c);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { id[4 * c + q] = iv[q]; wa[4 * c + q] = a < G ? wv[q] : 0.0f; }
+      for (int q = 0; q < 4; ++q) wa[4 * c + q] = a < G ? wv[q] : 0.0f;
     }
     __builtin_amdgcn_wave_barrier();
-    mf2 x[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) x[i] = *reinterpret_cast<const mf2 *>(fb + ((uint32_t)id[i] << 7));
     {
       const int ix = min(blk + 64 + lane, last);
       k_nx = col[s + ix];
@@ -640,6 +651,17 @@ __global__ void __launch_bounds__(256) k_gather2_items(const int32_t *__restrict
     const int rpv = (it_ok && r_l == 0) ? own_rp[rv] : 0;
     const int dgv = (it_ok && r_l == 0) ? own_deg[rv] : 0;
     G2_MARK(1);
+    // neighbour range of item q of the grab (CSR row start, [n0, n1), degree)
+    auto item_span = [&](int q, int &s_, int &n0_, int &n1_, int &deg_) {
+      s_ = __builtin_amdgcn_readlane(rpv, q * 16);
+      deg_ = __builtin_amdgcn_readlane(dgv, q * 16);
+      const int sl_ = __builtin_amdgcn_readlane(iv, q * 16 + 1);
+      n0_ = bigc ? __builtin_amdgcn_readlane(bv, q * 16 + 10) : sl_ * SLICE;
+      n1_ = bigc ? __builtin_amdgcn_readlane(bv, q * 16 + 11) : min(deg_, n0_ + SLICE);
+    };
+    auto first_ids = [&](int s_, int n0_, int n1_) { return col[s_ + min(n0_ + lane, max(n1_ - 1, 0))]; };
+    int k_ahead = 0;                                           // ids of the first block of the NEXT item: in flight while this one is summed
+    { int s_, a_, b_, d_; item_span(0, s_, a_, b_, d_); k_ahead = first_ids(s_, a_, b_); }
 #pragma unroll 1
     for (int q = 0; q < ITEM_GRAB; ++q) {
       if (base + q >= last) break;
@@ -653,26 +675,30 @@ __global__ void __launch_bounds__(256) k_gather2_items(const int32_t *__restrict
       }
       const int pbase = __builtin_amdgcn_readlane(rv, q * 16 + 8), ns = __builtin_amdgcn_readlane(rv, q * 16 + 9);
       const int sl = __builtin_amdgcn_readlane(iv, q * 16 + 1);
-      const int s = __builtin_amdgcn_readlane(rpv, q * 16);
-      const int deg = __builtin_amdgcn_readlane(dgv, q * 16);
+      int s, n0, n1, deg;
+      item_span(q, s, n0, n1, deg);
       const float inv_sr = 1.0f / sqrtf((float)deg);        // deg = 0 -> inf * 0 = NaN, as the dense 0/0 row (quirk 3)
-      const int n0 = bigc ? __builtin_amdgcn_readlane(bv, q * 16 + 10) : sl * SLICE;
-      const int n1 = bigc ? __builtin_amdgcn_readlane(bv, q * 16 + 11) : min(deg, n0 + SLICE);
+      const int k_first = k_ahead;
+      if (q + 1 < ITEM_GRAB && base + q + 1 < last) {
+        int s_, a_, b_, d_;
+        item_span(q + 1, s_, a_, b_, d_);
+        k_ahead = first_ids(s_, a_, b_);
+      }
       float tot[8];
       if (MF) {
-        if (n == 1) { float t1[1]; gather_slice_mfma<1>(col, feat, s, n0, n1, inv_sr, n, pb, pc, lane, lw, t1 G2_PASS); tot[0] = t1[0]; }
-        else if (n == 2) { float t2[2]; gather_slice_mfma<2>(col, feat, s, n0, n1, inv_sr, n, pb, pc, lane, lw, t2 G2_PASS); tot[0] = t2[0]; tot[1] = t2[1]; }
-        else if (n <= 4) { float t4[4]; gather_slice_mfma<4>(col, feat, s, n0, n1, inv_sr, n, pb, pc, lane, lw, t4 G2_PASS);
+        if (n == 1) { float t1[1]; gather_slice_mfma<1>(col, feat, s, n0, n1, inv_sr, n, pb, pc, lane, lw, k_first, t1 G2_PASS); tot[0] = t1[0]; }
+        else if (n == 2) { float t2[2]; gather_slice_mfma<2>(col, feat, s, n0, n1, inv_sr, n, pb, pc, lane, lw, k_first, t2 G2_PASS); tot[0] = t2[0]; tot[1] = t2[1]; }
+        else if (n <= 4) { float t4[4]; gather_slice_mfma<4>(col, feat, s, n0, n1, inv_sr, n, pb, pc, lane, lw, k_first, t4 G2_PASS);
 #pragma unroll
           for (int j = 0; j < 4; ++j) tot[j] = t4[j]; }
-        else gather_slice_mfma<8>(col, feat, s, n0, n1, inv_sr, n, pb, pc, lane, lw, tot G2_PASS);
+        else gather_slice_mfma<8>(col, feat, s, n0, n1, inv_sr, n, pb, pc, lane, lw, k_first, tot G2_PASS);
       } else
-      if (n == 1) { float t1[1]; gather_slice<1, FT>(col, feat, F, stride, s, n0, n1, inv_sr, n, pb, pc, lane, t1 G2_PASS); tot[0] = t1[0]; }
-      else if (n == 2) { float t2[2]; gather_slice<2, FT>(col, feat, F, stride, s, n0, n1, inv_sr, n, pb, pc, lane, t2 G2_PASS); tot[0] = t2[0]; tot[1] = t2[1]; }
-      else if (n <= 4) { float t4[4]; gather_slice<4, FT>(col, feat, F, stride, s, n0, n1, inv_sr, n, pb, pc, lane, t4 G2_PASS);
+      if (n == 1) { float t1[1]; gather_slice<1, FT>(col, feat, F, stride, s, n0, n1, inv_sr, n, pb, pc, lane, k_first, t1 G2_PASS); tot[0] = t1[0]; }
+      else if (n == 2) { float t2[2]; gather_slice<2, FT>(col, feat, F, stride, s, n0, n1, inv_sr, n, pb, pc, lane, k_first, t2 G2_PASS); tot[0] = t2[0]; tot[1] = t2[1]; }
+      else if (n <= 4) { float t4[4]; gather_slice<4, FT>(col, feat, F, stride, s, n0, n1, inv_sr, n, pb, pc, lane, k_first, t4 G2_PASS);
 #pragma unroll
         for (int j = 0; j < 4; ++j) tot[j] = t4[j]; }
-      else gather_slice<8, FT>(col, feat, F, stride, s, n0, n1, inv_sr, n, pb, pc, lane, tot G2_PASS);
+      else gather_slice<8, FT>(col, feat, F, stride, s, n0, n1, inv_sr, n, pb, pc, lane, k_first, tot G2_PASS);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         if (j < n && lane < F) {
@@ -744,8 +770,9 @@ __global__ void __launch_bounds__(256) k_gather2_w(const int32_t *__restrict__ c
 #endif
     for (int n0 = 0; n0 < deg; n0 += SLICE) {
       float t1[1];
-      if (F == 17) gather_slice<1, 17>(col, feat, F, stride, s, n0, min(deg, n0 + SLICE), inv_sr, 1, pb, pc, lane, t1 G2_PASS);
-      else gather_slice<1, 0>(col, feat, F, stride, s, n0, min(deg, n0 + SLICE), inv_sr, 1, pb, pc, lane, t1 G2_PASS);
+      const int kf = col[s + min(n0 + lane, max(min(deg, n0 + SLICE) - 1, 0))];
+      if (F == 17) gather_slice<1, 17>(col, feat, F, stride, s, n0, min(deg, n0 + SLICE), inv_sr, 1, pb, pc, lane, kf, t1 G2_PASS);
+      else gather_slice<1, 0>(col, feat, F, stride, s, n0, min(deg, n0 + SLICE), inv_sr, 1, pb, pc, lane, kf, t1 G2_PASS);
       total += t1[0];
     }
     if (deg == 0) total = inv_sr * 0.0f;
@@ -779,7 +806,7 @@ __global__ void __launch_bounds__(256) k_gather2_w(const int32_t *__restrict__ c
 }
 
 // process-wide options of the 2-hop gather (ggad_mb_set_gather_options): the environment gives the defaults
-std::atomic<int> g_mfma_batches{[] { const char *e = getenv("GGAD_GATHER_MFMA_BATCHES"); return e ? atoi(e) : 96; }()};
+std::atomic<int> g_mfma_batches{[] { const char *e = getenv("GGAD_GATHER_MFMA_BATCHES"); return e ? atoi(e) : 0; }()};
 std::atomic<int> g_range_deg{[] { const char *e = getenv("GGAD_RANGE_DEG"); return e ? atoi(e) : 0; }()};
 
 }  // namespace
@@ -809,9 +836,10 @@ int ggad_int_ldsw_hop2(const ggad_mb_plan *P, const ggad_plan_view &V, hipStream
     // waves take ITEM_GRAB work items at a time from a cursor: enough workgroups to fill the chip, no more than there can be items
     const int64_t max_items = (int64_t)V.n_ents + P->pair_cap / SLICE;
     const unsigned wgs = (unsigned)std::min<int64_t>((max_items + 4 * ITEM_GRAB - 1) / (4 * ITEM_GRAB), 256 * 8);
-    // the trainer's table (rows padded to one 128-byte line), launches of many batches: the matrix-core slice.  Measured on the
-    // bench graph (plan alone): 20 batches 640 against 551 us (groups of 1-2 occurrences: 32 MFMA per block for one row of weights),
-    // 64 batches 915 / 833, 96 batches 1,320 / 1,360, 150 batches 1,735 / 1,950 us.
+    // the trainer's table (rows padded to one 128-byte line): the matrix-core slice, at every launch size by default.  Measured on
+    // the bench graph (plan alone, MFMA / VALU slice): 20 batches 562-571 / 559-562 us, 32: 617-645 / 639-672, 48: 750 / 814-840,
+    // 64: 850 / 990, 150: 1,430 / 1,950 us.  (Before the ids of a slice were requested one work item ahead and its rows ahead of
+    // its weights, the VALU slice won below 96 batches.)
     if (F == 17 && P->feat_stride == 32 && V.n_batches >= g_mfma_batches.load())
       k_gather2_items<17, true><<<dim3(ggad_skip_grid(wgs, skip)), dim3(256), 0, st>>>(P->col, P->feat, F, P->feat_stride, P->own_rp, P->own_deg,
                                                                                        P->pw_base, P->pc, P->grp, P->items, big, gbnd, P->counters,

@@ -139,7 +139,7 @@ int32_t ggad_mb_slice_len(void);          /* neighbours per work item of the 2-h
 int32_t ggad_mb_group_words(void);        /* ints per record of grp[] */
 /* Options of the node-major 2-hop gather, process-wide (a negative value leaves an option as it is):
  *   mfma_min_batches  builds of at least this many batches take the matrix-core slice when feat_dim = 17 and feat_stride = 32
- *                     (default 96, GGAD_GATHER_MFMA_BATCHES; 0 = always, INT32_MAX = never).  The two slices add the same
+ *                     (default 0 = always, GGAD_GATHER_MFMA_BATCHES; INT32_MAX = never).  The two slices add the same
  *                     products in different fixed orders: x2 agrees to ~1e-7 relative, not bit for bit.
  *   range_deg         owners with more neighbours are gathered by eighths of the id space, one per XCD (default 0 = off,
  *                     GGAD_RANGE_DEG; values below 256 mean 256).  Measured slower than slices of 256. */

@@ -461,7 +461,7 @@ def test_ldsw_node_major_gather_against_per_owner_kernel(stride, mfma, ranges):
             ch.build(batches, labels)
             torch.cuda.synchronize()
         finally:
-            lib.ggad_mb_set_gather_options(96, 0)
+            lib.ggad_mb_set_gather_options(0, 0)
         assert ch.last_hop2 == "ldsw"
         own = ch.owner_entries()
         outs.append((ch.ent_col[own].clone(), torch.div(own, 1, rounding_mode="floor"), ch.x2.view(-1, 17)[own].clone()))
