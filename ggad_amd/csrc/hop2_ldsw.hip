@@ -40,10 +40,14 @@ struct G2Prof { unsigned long long a[8], t; };
 #define G2_PASS , prof
 #define G2_MARK(i) do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0); const unsigned long long t_ = wall_clock64(); \
                         prof.a[i] += t_ - prof.t; prof.t = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+// k_tile_counts, same build: thread 0's clocks per phase (a barrier before every mark), 64-bit words 8..14 of the same block:
+// zero + tables, scan, pass 0 register-cached pairs, pass 0 beyond them, pass 1 cached, pass 1 beyond, workgroups.
+#define TC_MARK(i) do { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long t_ = wall_clock64(); tcp[i] += t_ - tct; tct = t_; } } while (0)
 #else
 #define G2_ARG
 #define G2_PASS
 #define G2_MARK(i)
+#define TC_MARK(i)
 #endif
 
 constexpr int SLICE = 256;              // neighbours per work item
@@ -140,7 +144,7 @@ __global__ void __launch_bounds__(TW_T) k_tile_counts(const int32_t *__restrict_
                                                       int64_t n_cap, const int32_t *__restrict__ own_rp,
                                                       const int32_t *__restrict__ batch_ent_ptr,
                                                       const int32_t *__restrict__ pw_base, uint16_t *__restrict__ pc, int n_tiles,
-                                                      int n_batches, int skip) {
+                                                      int n_batches, int32_t *__restrict__ counters, int skip) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
   uint32_t *cnt = lds_u;                                   // TW_TILE / 2 words
   int *offs = reinterpret_cast<int *>(lds_u + TW_TILE / 2);  // TW_MAXOWN + 1
@@ -154,6 +158,9 @@ __global__ void __launch_bounds__(TW_T) k_tile_counts(const int32_t *__restrict_
   const int o0 = batch_ent_ptr[b], o1 = batch_ent_ptr[b + 1];      // "owner slots" = the entries of batch b
   const int n_own_all = o1 - o0;
   const int32_t *seg_lo = seg_t + (int64_t)t * n_cap, *seg_hi = seg_lo + n_cap;
+#ifdef GGAD_G2_PROF
+  unsigned long long tcp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tct = wall_clock64();      // phase clocks of thread 0 (TC_MARK)
+#endif
   for (int i = threadIdx.x; i < TW_TILE / 2; i += TW_T) cnt[i] = 0u;
   constexpr int IPT = TW_MAXOWN / TW_T;
   // batches with more owners than the LDS tables hold are walked in slabs of TW_MAXOWN owners (counts accumulate
@@ -183,6 +190,7 @@ __global__ void __launch_bounds__(TW_T) k_tile_counts(const int32_t *__restrict_
           }
         }
         __syncthreads();
+        TC_MARK(0);
         int len[IPT];
         int mysum = 0;
 #pragma unroll
@@ -202,6 +210,7 @@ __global__ void __launch_bounds__(TW_T) k_tile_counts(const int32_t *__restrict_
         }
         if (threadIdx.x == 0) offs[n_own] = P0;               // number of pairs of the slab
         __syncthreads();
+        TC_MARK(1);
       }
       const int P = offs[n_own];
       if (P > 0) {                                             // uniform
@@ -255,6 +264,7 @@ __global__ void __launch_bounds__(TW_T) k_tile_counts(const int32_t *__restrict_
               if (kc[it] >= 0) pc[dc[it]] = (uint16_t)((cnt[kc[it] >> 1] >> ((kc[it] & 1) << 4)) & 0xFFFFu);
           }
           p_start = CACHE_IT * TW_T;
+          TC_MARK(2 + 2 * pass);
         }
         for (int p0 = p_start; p0 < P; p0 += 4 * TW_T) {
           int pp[4], own[4], j[4];
@@ -274,10 +284,18 @@ __global__ void __launch_bounds__(TW_T) k_tile_counts(const int32_t *__restrict_
           }
         }
         (void)locate;
+        TC_MARK(3 + 2 * pass);
       }
       __syncthreads();
     }
   }
+#ifdef GGAD_G2_PROF
+  if (threadIdx.x == 0) {
+    unsigned long long *out = reinterpret_cast<unsigned long long *>(counters + GGAD_CTR_PROF) + 8;
+    for (int k = 0; k < 6; ++k) atomicAdd(out + k, tcp[k]);
+    atomicAdd(out + 6, 1ull);
+  }
+#endif
 }
 
 // ---- the gather.  One SLICE of one owner group: neighbours [n0, n1) of node u (CSR row start s), weights
@@ -821,7 +839,7 @@ int ggad_int_ldsw_hop2(const ggad_mb_plan *P, const ggad_plan_view &V, hipStream
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void *)k_tile_counts, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
   k_tile_counts<<<dim3(ggad_skip_grid((unsigned)n_tiles * (unsigned)V.n_batches, skip)), dim3(TW_T), lds, st>>>(
-      P->col, P->seg_t, V.seg_stride, P->own_rp, V.batch_ent_ptr, P->pw_base, P->pc, n_tiles, V.n_batches, skip);
+      P->col, P->seg_t, V.seg_stride, P->own_rp, V.batch_ent_ptr, P->pw_base, P->pc, n_tiles, V.n_batches, P->counters, skip);
   if (ev0) (void)hipEventRecord(ev0, st);
   const int F = P->feat_dim;
   if (P->node_major && F <= 64) {

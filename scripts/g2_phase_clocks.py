@@ -40,3 +40,8 @@ for k in sizes:
         print(f"chunk {k}: items {int(c[1])} big groups {int(c[5])} groups {int(c[0])} pairs {int(c[4])} | wave-us total {tot:.0f}: " +
               "  ".join(f"{nm} {100 * v / tot:.1f}%" for nm, v in zip(names[:6], prof[:6])) +
               f"  (other {100 * (tot - prof[:6].sum()) / tot:.1f}%)", flush=True)
+        tc = c32[14 * 16:].view(np.int64)[8:15].astype(np.float64)
+        if tc[6] > 0:
+            nm2 = ["zero + tables", "scan", "pass 0 cached", "pass 0 beyond 16 K", "pass 1 cached", "pass 1 beyond 16 K"]
+            print(f"   k_tile_counts: {int(tc[6])} workgroups, {tc[:6].sum() / 100.0 / tc[6]:.1f} us each: " +
+                  "  ".join(f"{n_} {v / 100.0 / tc[6]:.2f} us" for n_, v in zip(nm2, tc[:6])), flush=True)
