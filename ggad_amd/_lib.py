@@ -72,7 +72,9 @@ SIGNATURES = {
     "ggad_mb_xcd_grid": (c_int32, []),
     "ggad_xcd_first_of_stream": (c_int32, [_P, _P]),
     "ggad_mb_xcd_workspace_elems": (c_int64, [_I, _I, _I, _L, _L]),
-    "ggad_mb_train_chunk_xcd": (c_int32, [_P, _I, _P, _I, _I, _I, _I, _L, _L, _P, _I, _P, c_float, _P, _I, _P]),
+    "ggad_mb_train_chunk_xcd": (c_int32, [_P, _I, _P, _I, _I, _I, _I, _L, _L, _P, _I, _P, c_float, _P, _I, _P, _P]),
+    "ggad_mb_xcd_record_elems": (c_int64, [_L, _L]),
+    "ggad_mb_xcd_prepare": (c_int32, [_P, _I, _P, _I, _I, _I, _L, _L, _P, _P]),
     "ggad_mb_xcd_status": (c_int32, [_P, _P, _P]),
     "ggad_mb_param_count": (c_int64, [_I, _I]),
     "ggad_mb_param_block_elems": (c_int64, [_I, _I]),

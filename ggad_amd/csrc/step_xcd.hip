@@ -840,7 +840,7 @@ __global__ void __launch_bounds__(256) k_xcd_prep(XcdPrepArgs P) {
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (P.batch_ptr[mid] <= row) lo = mid; else hi = mid; }
     return P.batch_ptr[lo];
   };
-  if (tid < P.n_batches) {                               // adam_scalars of step.hip for optimiser step step0 + tid + 1
+  if (P.adam_sc && tid < P.n_batches) {                   // adam_scalars of step.hip for optimiser step step0 + tid + 1
     const double ts = (double)(*P.step_counter + tid + 1);
     const double bc1 = 1.0 - pow(0.9, ts), bc2 = 1.0 - pow(0.999, ts);
     P.adam_sc[2 * tid] = (float)((double)P.lr / bc1);       // step_size
@@ -994,12 +994,58 @@ int64_t ggad_mb_xcd_workspace_elems(int32_t max_rows, int32_t D, int32_t F, int6
          (rows_cap + pieces_cap + 2) * REC + 3 * (rows_cap + 1);
 }
 
+int64_t ggad_mb_xcd_record_elems(int64_t rows_cap, int64_t pieces_cap) {
+  if (rows_cap < 0 || pieces_cap < 0) return 0;
+  return (rows_cap + pieces_cap + 2) * REC + (rows_cap + 1);
+}
+
+namespace {
+// layout of a record block: position records, piece records, first generated column per batch
+inline void record_views(int32_t *recs, int64_t rows_cap, int64_t pieces_cap, int32_t *&pos_rec, int32_t *&ck_rec, int32_t *&batch_n0) {
+  pos_rec = recs;
+  ck_rec = recs + (rows_cap + 1) * REC;
+  batch_n0 = recs + (rows_cap + pieces_cap + 2) * REC;
+}
+int launch_records(const ggad_mb_step &s, int32_t n_batches, const int32_t *batch_ptr_dev, int32_t n_rows, int32_t n_pieces, int32_t n_ents,
+                   int32_t *pos_rec, int32_t *ck_rec, int32_t *batch_n0, float *adam_sc, hipStream_t st) {
+  XcdPrepArgs Q;
+  Q.batch_ptr = batch_ptr_dev; Q.ent_ptr = s.ent_ptr; Q.row_ck_ptr = s.row_ck_ptr; Q.ck_rc = s.ck_rc; Q.ck_e0 = s.ck_e0;
+  Q.ent_own = s.ent_own; Q.labels = s.labels; Q.pos_meta = s.pos_meta; Q.row_pos = s.row_pos;
+  Q.x2 = const_cast<float *>(s.x2);
+  Q.ck_rec = ck_rec; Q.pos_rec = pos_rec; Q.batch_n0 = batch_n0;
+  Q.adam_sc = adam_sc; Q.step_counter = s.step_counter; Q.lr = s.lr;
+  Q.n_batches = n_batches; Q.n_rows = n_rows; Q.n_pieces = n_pieces; Q.n_ents = n_ents;
+  const int64_t work = std::max<int64_t>(std::max<int64_t>(std::max<int64_t>(n_rows, n_pieces), ((int64_t)n_ents * XFT + 3) / 4), n_batches);
+  const unsigned blocks = (unsigned)std::min<int64_t>((work + 255) / 256, 8192);
+  k_xcd_prep<<<dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st>>>(Q);
+  GGAD_CHECK_LAUNCH("mb_train_chunk_xcd (records)");
+  return GGAD_OK;
+}
+}  // namespace
+
+/* The records of a chunk (and x2 completed per entry) on a stream of the caller's choice -- the PLAN's: in the overlapped trainer
+ * the chunk kernel's stream owns 28 compute units of one XCD, where this whole-chip pass took 0.45 ms per chunk on its critical
+ * path.  `records`: int32[ggad_mb_xcd_record_elems(rows_cap, pieces_cap)], owned by the chunk (double-buffered with it); hand the
+ * same block to ggad_mb_train_chunk_xcd. */
+int ggad_mb_xcd_prepare(const ggad_mb_step *tmpl, int32_t n_batches, const int32_t *batch_ptr_dev, int32_t n_rows, int32_t n_pieces,
+                        int32_t n_ents, int64_t rows_cap, int64_t pieces_cap, int32_t *records, ggad_stream_t stream) {
+  GGAD_REQUIRE(tmpl && batch_ptr_dev && records && n_batches >= 0 && n_rows >= 0 && n_pieces >= 0 && n_ents >= 0);
+  GGAD_REQUIRE(n_rows <= rows_cap && n_pieces <= pieces_cap && (int64_t)n_ents * XFT < ((int64_t)1 << 31));
+  const ggad_mb_step &s = *tmpl;
+  GGAD_REQUIRE(s.x2 && s.ent_ptr && s.ent_own && s.labels && s.pos_meta && s.row_pos && s.row_ck_ptr && s.ck_rc && s.ck_e0 && s.F == XFT);
+  if (n_batches == 0) return GGAD_OK;
+  int32_t *pos_rec, *ck_rec, *batch_n0;
+  record_views(records, rows_cap, pieces_cap, pos_rec, ck_rec, batch_n0);
+  return launch_records(s, n_batches, batch_ptr_dev, n_rows, n_pieces, n_ents, pos_rec, ck_rec, batch_n0, nullptr, as_stream(stream));
+}
+
 /* The dense steps of a whole chunk as ONE launch resident on one XCD (see the header of this file).  tmpl as for
  * ggad_mb_train_chunk (row_ck_ptr / ck_rc / ck_e0 / chunk_part REQUIRED, F == 17); batch_ptr: DEVICE int32[n_batches + 1];
  * workspace: float[ggad_mb_xcd_workspace_elems(largest batch, D, F)], 16-byte aligned; xchg NULL = single GPU. */
 int ggad_mb_train_chunk_xcd(const ggad_mb_step *tmpl, int32_t n_batches, const int32_t *batch_ptr_dev, int32_t max_rows,
                             int32_t n_rows, int32_t n_pieces, int32_t n_ents, int64_t rows_cap, int64_t pieces_cap, float *loss_log,
-                            int32_t log_base, float *workspace, float grad_scale, ggad_xchg *xchg, int32_t n_wg, ggad_stream_t stream) {
+                            int32_t log_base, float *workspace, float grad_scale, ggad_xchg *xchg, int32_t n_wg, const int32_t *records,
+                            ggad_stream_t stream) {
   GGAD_REQUIRE(tmpl && batch_ptr_dev && loss_log && workspace && n_batches >= 0 && log_base >= 0 && max_rows >= 1);
   GGAD_REQUIRE(n_rows >= 0 && n_pieces >= 0 && n_ents >= 0 && n_rows <= rows_cap && n_pieces <= pieces_cap);
   GGAD_REQUIRE((int64_t)n_ents * XFT < ((int64_t)1 << 31) && (int64_t)n_pieces * 64 < ((int64_t)1 << 31));      // 32-bit element offsets
@@ -1021,10 +1067,16 @@ int ggad_mb_train_chunk_xcd(const ggad_mb_step *tmpl, int32_t n_batches, const i
   A.gw_row = A.pos_o + (int64_t)8 * A.ld_o;
   A.dw_part = A.gw_row + (int64_t)max_rows * GGAD_WAVE;
   int32_t *recs = reinterpret_cast<int32_t *>(A.dw_part + (int64_t)XMAXWG * XFT * GGAD_WAVE);
-  A.pos_rec = recs;
-  A.ck_rec = recs + (rows_cap + 1) * REC;
-  A.batch_n0 = recs + (rows_cap + pieces_cap + 2) * REC;
-  A.adam_sc = reinterpret_cast<const float *>(A.batch_n0 + rows_cap + 1);
+  int32_t *w_pos, *w_ck, *w_n0;
+  record_views(recs, rows_cap, pieces_cap, w_pos, w_ck, w_n0);
+  A.adam_sc = reinterpret_cast<const float *>(w_n0 + rows_cap + 1);
+  if (records) {                                            // prepared by ggad_mb_xcd_prepare (on the plan's stream)
+    int32_t *p, *c, *n0;
+    record_views(const_cast<int32_t *>(records), rows_cap, pieces_cap, p, c, n0);
+    A.pos_rec = p; A.ck_rec = c; A.batch_n0 = n0;
+  } else {
+    A.pos_rec = w_pos; A.ck_rec = w_ck; A.batch_n0 = w_n0;
+  }
   A.grad_scale = grad_scale;
   static const unsigned long long timeout = [] {            // barrier time-out in seconds (wall clock, 100 MHz ticks)
     const char *e = getenv("GGAD_XCD_TIMEOUT_S");
@@ -1046,19 +1098,13 @@ int ggad_mb_train_chunk_xcd(const ggad_mb_step *tmpl, int32_t n_batches, const i
   hipStream_t st = as_stream(stream);
   // registration counters, barrier slots and the error word start from zero on every launch (profile clocks too)
   if (hipMemsetAsync(workspace, 0, sizeof(XcdCtrl), st) != hipSuccess) return GGAD_E_LAUNCH;
-  {  // records + entry-complete x2: one whole-chip launch per chunk (the plan's tables are read-only for everybody else)
-    XcdPrepArgs Q;
-    Q.batch_ptr = batch_ptr_dev; Q.ent_ptr = s.ent_ptr; Q.row_ck_ptr = s.row_ck_ptr; Q.ck_rc = s.ck_rc; Q.ck_e0 = s.ck_e0;
-    Q.ent_own = s.ent_own; Q.labels = s.labels; Q.pos_meta = s.pos_meta; Q.row_pos = s.row_pos;
-    Q.x2 = const_cast<float *>(s.x2);
-    Q.ck_rec = const_cast<int32_t *>(A.ck_rec); Q.pos_rec = const_cast<int32_t *>(A.pos_rec);
-    Q.batch_n0 = const_cast<int32_t *>(A.batch_n0);
-    Q.adam_sc = const_cast<float *>(A.adam_sc); Q.step_counter = s.step_counter; Q.lr = s.lr;
-    Q.n_batches = n_batches; Q.n_rows = n_rows; Q.n_pieces = n_pieces; Q.n_ents = n_ents;
-    const int64_t work = std::max<int64_t>(std::max<int64_t>(n_rows, n_pieces), ((int64_t)n_ents * XFT + 3) / 4);
-    const unsigned blocks = (unsigned)std::min<int64_t>((work + 255) / 256, 8192);
-    k_xcd_prep<<<dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st>>>(Q);
-    GGAD_CHECK_LAUNCH("mb_train_chunk_xcd (records)");
+  {  // records + entry-complete x2: one whole-chip launch per chunk (the plan's tables are read-only for everybody else) -- or,
+     // when the caller prepared them, only the Adam scalars of the chunk's steps (they need the step counter as it is NOW)
+    const int rc = records ? launch_records(s, n_batches, batch_ptr_dev, 0, 0, 0, nullptr, nullptr, nullptr, const_cast<float *>(A.adam_sc), st)
+                           : launch_records(s, n_batches, batch_ptr_dev, n_rows, n_pieces, n_ents, const_cast<int32_t *>(A.pos_rec),
+                                            const_cast<int32_t *>(A.ck_rec), const_cast<int32_t *>(A.batch_n0),
+                                            const_cast<float *>(A.adam_sc), st);
+    if (rc) return rc;
   }
   // the L2 warmer runs BESIDE the chunk kernel on a stream of its own: it starts once the control block is cleared (ev0) and the
   // caller's stream continues only after it has left (ev1: it reads the plan's buffers)

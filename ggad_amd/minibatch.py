@@ -16,6 +16,7 @@ PyTorch is used for device memory and streams only; all arithmetic happens in li
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Callable, Optional, Sequence
 
 import numpy as np
@@ -425,10 +426,15 @@ class MiniBatchEngine:
         if self.resident and allreduce is None and (world_size == 1 or exchange is not None) \
                 and getattr(ch, "row_ck_ptr", None) is not None:
             s = self.step_desc(ch, 0, log_base)
+            # records prepared on the plan's stream (xcd_prepare) for THIS build and with the capacities the launch will use?
+            recs = None
+            if getattr(ch, "xcd_prepared", None) == (ch.build_count, self._xcd_caps):
+                recs = ptr(ch.xcd_recs)
             _lib.check(self.lib.ggad_mb_train_chunk_xcd(ctypes.byref(s), ch.n_batches, ptr(ch.batch_ptr), self._xcd_rows,
                                                          ch.n_rows, ch.n_chunks, ch.n_ents, self._xcd_caps[0], self._xcd_caps[1],
                                                          self.loss_log.data_ptr(), log_base, ptr(self.xcd_ws), 1.0 / world_size,
-                                                         exchange.handle if exchange is not None else None, int(self.xcd_wgs), stream),
+                                                         exchange.handle if exchange is not None else None, int(self.xcd_wgs), recs,
+                                                         stream),
                        "ggad_mb_train_chunk_xcd")
             return
         if exchange is not None:
@@ -469,6 +475,29 @@ class MiniBatchEngine:
         if err:
             raise err[0]
         _lib.check(rc, "ggad_mb_train_chunk_dp")
+
+    def xcd_prepare(self, ch: BatchChunk) -> None:
+        """Records of the chunk for the XCD-resident launch (`ggad_mb_xcd_prepare`: a 32-byte record per piece / position, x2
+        completed per entry) on the CURRENT stream -- the plan's, right behind `ch.build`: a whole-chip pass that took 0.45 ms per
+        chunk on the chunk kernel's 28 compute units.  Without this call `train_chunk` builds them inside its own launch."""
+        if not (self.resident and ch.train and getattr(ch, "row_ck_ptr", None) is not None and ch.n_batches > 0):
+            return
+        if os.environ.get("GGAD_XCD_PREP_ON_PLAN", "1") == "0":       # (A/B switch: records inside the chunk kernel's own launch)
+            return
+        caps = self._xcd_caps
+        if self.xcd_ws is None or caps[0] < ch.n_rows or caps[1] < ch.n_chunks:
+            return        # the launch's workspace has to grow first: `train_chunk` does that on ITS stream (an allocation made here,
+                          # under the plan's stream, could be recycled while the other stream's kernel still uses it)
+        need = int(self.lib.ggad_mb_xcd_record_elems(*caps))
+        recs = getattr(ch, "xcd_recs", None)
+        if recs is None or recs.numel() < need:
+            if recs is not None:
+                torch.cuda.synchronize(self.dev)             # a launch on the other stream may still read the old block
+            ch.xcd_recs = torch.empty(need, dtype=torch.int32, device=self.dev)
+        s = self.step_desc(ch, 0, 0)
+        _lib.check(self.lib.ggad_mb_xcd_prepare(ctypes.byref(s), ch.n_batches, ptr(ch.batch_ptr), ch.n_rows, ch.n_chunks, ch.n_ents,
+                                                caps[0], caps[1], ptr(ch.xcd_recs), _lib.current_stream()), "ggad_mb_xcd_prepare")
+        ch.xcd_prepared = (ch.build_count, caps)
 
     def xcd_status(self) -> dict:
         """Control words of the last XCD-resident launch (synchronises the current stream): error code, surviving workgroups,

@@ -388,6 +388,7 @@ class DGraphTrainer:
 
         def build(ch, bn, bl):
             ch.build(bn, bl) if gather_hook is None else gather_hook(ch, bn, bl)
+            self.engine.xcd_prepare(ch)        # records of the resident chunk kernel: on the plan's stream, not on its 28 CUs
 
         nodes_seen, done = 0, 0
         split = getattr(self, "resident_split", False)

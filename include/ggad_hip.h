@@ -365,7 +365,14 @@ int ggad_xcd_first_of_stream(int32_t *first_host, ggad_stream_t stream);
 int64_t ggad_mb_xcd_workspace_elems(int32_t max_rows, int32_t D, int32_t F, int64_t rows_cap, int64_t pieces_cap);
 int ggad_mb_train_chunk_xcd(const ggad_mb_step *tmpl, int32_t n_batches, const int32_t *batch_ptr_dev, int32_t max_rows,
                             int32_t n_rows, int32_t n_pieces, int32_t n_ents, int64_t rows_cap, int64_t pieces_cap, float *loss_log,
-                            int32_t log_base, float *workspace, float grad_scale, ggad_xchg *xchg, int32_t n_wg, ggad_stream_t stream);
+                            int32_t log_base, float *workspace, float grad_scale, ggad_xchg *xchg, int32_t n_wg, const int32_t *records,
+                            ggad_stream_t stream);
+/* `records` NULL: the launch builds the chunk's records itself, on `stream`.  Otherwise they were built by ggad_mb_xcd_prepare on a
+ * stream of the caller's choice (the plan's: a whole-chip pass that does not belong on the chunk kernel's 28 compute units) into
+ * int32[ggad_mb_xcd_record_elems(rows_cap, pieces_cap)] owned by the chunk; the caller orders the two launches (stream / event). */
+int64_t ggad_mb_xcd_record_elems(int64_t rows_cap, int64_t pieces_cap);
+int ggad_mb_xcd_prepare(const ggad_mb_step *tmpl, int32_t n_batches, const int32_t *batch_ptr_dev, int32_t n_rows, int32_t n_pieces,
+                        int32_t n_ents, int64_t rows_cap, int64_t pieces_cap, int32_t *records, ggad_stream_t stream);
 int ggad_mb_xcd_status(const float *workspace, int64_t *out19, ggad_stream_t stream);
 
 /* Inference embeddings: h[i] = relu(W x1[i])  (GCNEncoder.forward, train_flag False).   graphsage.py:412 */
