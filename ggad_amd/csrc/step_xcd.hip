@@ -884,10 +884,11 @@ __global__ void __launch_bounds__(256) k_xcd_prep(XcdPrepArgs P) {
   }
   // x2 is stored at owner entries (the reference's deduplicated unique_nodes_list, graphsage.py:306); the other entries of a
   // (batch, column) get a copy of their owner's row, so that the rows of a piece are the consecutive entries [e0, e0 + cnt)
-  for (int64_t i = tid; i < (int64_t)P.n_ents * XFT; i += (int64_t)gridDim.x * 256) {
-    const int e = (int)(i / XFT), f = (int)(i - (int64_t)e * XFT);
+  // (half a wave per entry, lane = feature: one read of the owner per entry, not one per float)
+  const int f = threadIdx.x & 31;
+  for (int64_t e = tid >> 5; e < P.n_ents; e += ((int64_t)gridDim.x * 256) >> 5) {
     const int o = P.ent_own[e];
-    if (o != e) P.x2[i] = P.x2[(int64_t)o * XFT + f];
+    if (o != (int)e && f < XFT) P.x2[e * XFT + f] = P.x2[(int64_t)o * XFT + f];
   }
 }
 
@@ -1015,7 +1016,7 @@ int launch_records(const ggad_mb_step &s, int32_t n_batches, const int32_t *batc
   Q.ck_rec = ck_rec; Q.pos_rec = pos_rec; Q.batch_n0 = batch_n0;
   Q.adam_sc = adam_sc; Q.step_counter = s.step_counter; Q.lr = s.lr;
   Q.n_batches = n_batches; Q.n_rows = n_rows; Q.n_pieces = n_pieces; Q.n_ents = n_ents;
-  const int64_t work = std::max<int64_t>(std::max<int64_t>(std::max<int64_t>(n_rows, n_pieces), ((int64_t)n_ents * XFT + 3) / 4), n_batches);
+  const int64_t work = std::max<int64_t>(std::max<int64_t>(std::max<int64_t>(n_rows, n_pieces), (int64_t)n_ents * 8), n_batches);
   const unsigned blocks = (unsigned)std::min<int64_t>((work + 255) / 256, 8192);
   k_xcd_prep<<<dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st>>>(Q);
   GGAD_CHECK_LAUNCH("mb_train_chunk_xcd (records)");
