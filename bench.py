@@ -384,6 +384,10 @@ def main():
     extras = {}
     if rank == 0 and world == 1 and not a.no_extras and not a.dp_path:
         if a.steady_steps > a.steps:
+            # (300 untimed steps first: the buffers of 150-batch chunks grow on first use -- a device synchronisation each --, the
+            #  timed region above only planned 20 batches)
+            wb = sched.next_batches(min(300, a.steady_steps), rank, world)
+            trainer.run_steps(len(wb[0]), prepared=wb)
             batch = sched.next_batches(a.steady_steps, rank, world)
             barrier()
             ts = time.perf_counter()
@@ -391,7 +395,7 @@ def main():
             barrier()
             dt = time.perf_counter() - ts
             extras["steady_state"] = {"steps": a.steady_steps, "value": n_st / dt, "unit": "nodes/s", "ms_per_step": 1e3 * dt / a.steady_steps,
-                                      "note": "one run of this many steps right after the timed region (schedule prepared beforehand, plans inside)"}
+                                      "note": "one run of this many steps after the timed region and 300 untimed steps (schedule prepared beforehand, plans inside)"}
         if a.e2e_steps > 0:
             # the reference's window (src/model_handler.py:332-365) holds the per-batch random.shuffle of the pseudo-anomaly pool:
             # here the bit-exact native sampler produces the batches in its own thread INSIDE the window

@@ -605,7 +605,7 @@ __global__ void __launch_bounds__(256) k_gather2_items(const int32_t *__restrict
                                                        const uint16_t *__restrict__ pc, const int32_t *__restrict__ grp,
                                                        const int32_t *__restrict__ items, const int32_t *__restrict__ big,
                                                        const int32_t *__restrict__ gbnd, int32_t *__restrict__ counters,
-                                                       float *__restrict__ x2, float *__restrict__ part2, int affine, int skip) {
+                                                       float *__restrict__ x2, float *__restrict__ part2, int affine, int take_cap, int skip) {
   static_assert(ITEM_GRAB == 4 && GRP_W <= 10, "lane layout of the metadata loads: 16 lanes per item of a grab (10, 11: range bounds)");
   unsigned vbx, vgx;
   if (!ggad_vblock(skip, vbx, vgx)) return;
@@ -647,7 +647,7 @@ __global__ void __launch_bounds__(256) k_gather2_items(const int32_t *__restrict
   for (;;) {
     const int rem = n_items - seen;
     int take = (rem / (2 * n_waves)) & ~(ITEM_GRAB - 1);
-    take = take < ITEM_GRAB ? ITEM_GRAB : (take > 64 ? 64 : take);
+    take = take < ITEM_GRAB ? ITEM_GRAB : (take > take_cap ? take_cap : take);
     int first = 0;
     if (lane == 0) first = atomicAdd(cursor, take);
     first = __builtin_amdgcn_readfirstlane(first);
@@ -853,7 +853,13 @@ int ggad_int_ldsw_hop2(const ggad_mb_plan *P, const ggad_plan_view &V, hipStream
         P->counters, range_deg, skip);
     // waves take ITEM_GRAB work items at a time from a cursor: enough workgroups to fill the chip, no more than there can be items
     const int64_t max_items = (int64_t)V.n_ents + P->pair_cap / SLICE;
-    const unsigned wgs = (unsigned)std::min<int64_t>((max_items + 4 * ITEM_GRAB - 1) / (4 * ITEM_GRAB), 256 * 8);
+    // as many workgroups as are RESIDENT (4 per CU at 105 VGPRs), reservations of 12 items at most: with 2,048 workgroups the second
+    // thousand only started when the first left -- at the very end -- and the reservation size followed the nominal wave count
+    // (4 items at 20 batches, 32-64 at 150).  Measured (20 / 150 batches): 8 per CU, cap 64: 553 / 1,440 us; 4 per CU, cap 12: 410 / 1,390 us
+    // (3 per CU 418 / 1,660; cap 32: 408 / 1,490-1,540).
+    static const int wg_per_cu = [] { const char *e = getenv("GGAD_G2_WG_PER_CU"); return e ? atoi(e) : 4; }();
+    static const int take_cap = [] { const char *e = getenv("GGAD_G2_TAKE_CAP"); return e ? atoi(e) : 12; }();
+    const unsigned wgs = (unsigned)std::min<int64_t>((max_items + 4 * ITEM_GRAB - 1) / (4 * ITEM_GRAB), 256 * wg_per_cu);
     // the trainer's table (rows padded to one 128-byte line): the matrix-core slice, at every launch size by default.  Measured on
     // the bench graph (plan alone, MFMA / VALU slice): 20 batches 562-571 / 559-562 us, 32: 617-645 / 639-672, 48: 750 / 814-840,
     // 64: 850 / 990, 150: 1,430 / 1,950 us.  (Before the ids of a slice were requested one work item ahead and its rows ahead of
@@ -861,15 +867,15 @@ int ggad_int_ldsw_hop2(const ggad_mb_plan *P, const ggad_plan_view &V, hipStream
     if (F == 17 && P->feat_stride == 32 && V.n_batches >= g_mfma_batches.load())
       k_gather2_items<17, true><<<dim3(ggad_skip_grid(wgs, skip)), dim3(256), 0, st>>>(P->col, P->feat, F, P->feat_stride, P->own_rp, P->own_deg,
                                                                                        P->pw_base, P->pc, P->grp, P->items, big, gbnd, P->counters,
-                                                                                       P->x2, P->part2, affine, skip);
+                                                                                       P->x2, P->part2, affine, take_cap, skip);
     else if (F == 17)
       k_gather2_items<17, false><<<dim3(ggad_skip_grid(wgs, skip)), dim3(256), 0, st>>>(P->col, P->feat, F, P->feat_stride, P->own_rp, P->own_deg,
                                                                                  P->pw_base, P->pc, P->grp, P->items, big, gbnd, P->counters,
-                                                                                 P->x2, P->part2, affine, skip);
+                                                                                 P->x2, P->part2, affine, take_cap, skip);
     else
       k_gather2_items<0, false><<<dim3(ggad_skip_grid(wgs, skip)), dim3(256), 0, st>>>(P->col, P->feat, F, P->feat_stride, P->own_rp, P->own_deg,
                                                                                 P->pw_base, P->pc, P->grp, P->items, big, gbnd, P->counters,
-                                                                                P->x2, P->part2, affine, skip);
+                                                                                P->x2, P->part2, affine, take_cap, skip);
     const unsigned cg = (unsigned)std::min<int64_t>(((int64_t)V.n_ents + 3) / 4, 16384);        // ~2 groups per wave: every group costs a dependent load of its record
     k_gather2_combine<<<dim3(ggad_skip_grid(cg, skip)), dim3(256), 0, st>>>(P->grp, P->counters, P->part2, F, P->x2, skip);
   } else {
