@@ -241,14 +241,19 @@ __global__ void __launch_bounds__(TW_T) k_tile_counts(const int32_t *__restrict_
             // (pairs clamped to P - 1, so every load is unconditional); phase C: the LDS counts
 #pragma unroll
             for (int g4 = 0; g4 < CACHE_IT; g4 += 4) {
-              int pp[4], own[4], j[4];
+              if (g4 * TW_T < P) {                                // (uniform: a group of four trips wholly beyond P is not located)
+                int pp[4], own[4], j[4];
 #pragma unroll
-              for (int q = 0; q < 4; ++q) pp[q] = min((g4 + q) * TW_T + (int)threadIdx.x, P - 1);
-              locate4(pp, own, j);
+                for (int q = 0; q < 4; ++q) pp[q] = min((g4 + q) * TW_T + (int)threadIdx.x, P - 1);
+                locate4(pp, own, j);
 #pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                kc[g4 + q] = col[segbeg[own[q]] + j[q]];        // requested now: in flight while the next four pairs are located
-                dc[g4 + q] = dst[own[q]] + j[q];
+                for (int q = 0; q < 4; ++q) {
+                  kc[g4 + q] = col[segbeg[own[q]] + j[q]];      // requested now: in flight while the next four pairs are located
+                  dc[g4 + q] = dst[own[q]] + j[q];
+                }
+              } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { kc[g4 + q] = 0; dc[g4 + q] = 0; }
               }
             }
 #pragma unroll
