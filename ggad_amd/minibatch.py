@@ -247,7 +247,14 @@ class BatchChunk:
             _check_i32(int(I.need_ents))
             if I.need_cnt2 and self.cnt2 is None:       # the LDS path cannot take this chunk: device-atomic counters
                 self.cnt2 = torch.zeros(self.max_batches * self.g.n, dtype=torch.int32, device=self.dev)
-            self._alloc(I.need_rows, I.need_ents, I.need_chunks, I.need_stage, I.need_pairs, I.need_items, I.need_part2, I.need_seg)
+            # the 2-hop buffers (pair counts, work items, partial sums, segment table) are sized for a build of `max_batches`
+            # batches the first time they have to grow: a grow is a device synchronisation, a reallocation and a second host pass,
+            # and a run that ramps 5 -> 20 -> 150 batches per build paid it inside every one of its first windows
+            f = 1.1 * min(64.0, self.max_batches / max(1, nb)) if nb < self.max_batches else 1.0
+            lim = 1_600_000_000                                   # (int32 offsets into pc[] / items[] / part2[])
+            self._alloc(I.need_rows, I.need_ents, I.need_chunks, I.need_stage, max(int(I.need_pairs), min(lim, int(I.need_pairs * f))),
+                        max(int(I.need_items), min(lim // 16, int(I.need_items * f))),
+                        max(int(I.need_part2), min(lim // 32, int(I.need_part2 * f))), max(int(I.need_seg), int(I.need_seg * min(f, self.ent_cap / max(1, int(I.need_ents))))))
         if rc == -1:
             raise ValueError("ggad_mb_plan_build: a batch node id is out of range, a label is not 0/1, or the plan descriptor is incomplete")
         _lib.check(rc, "ggad_mb_plan_build")
@@ -377,7 +384,9 @@ class MiniBatchEngine:
         if self.resident and (self.xcd_ws is None or self._xcd_rows < max_rows or self._xcd_caps[0] < ch.n_rows
                               or self._xcd_caps[1] < ch.n_chunks):
             self._xcd_rows = max(256, int(max_rows * 1.25), self._xcd_rows)
-            self._xcd_caps = (max(int(ch.n_rows * 1.25) + 64, self._xcd_caps[0]), max(int(ch.n_chunks * 1.25) + 64, self._xcd_caps[1]))
+            # (the chunk's own capacities: a 5-batch warm-up followed by a 20-batch window otherwise re-allocated inside the window)
+            self._xcd_caps = (max(int(ch.n_rows * 1.25) + 64, int(ch.rows_cap), self._xcd_caps[0]),
+                              max(int(ch.n_chunks * 1.25) + 64, int(ch.ck_cap), self._xcd_caps[1]))
             self.xcd_ws = torch.zeros(int(self.lib.ggad_mb_xcd_workspace_elems(self._xcd_rows, self.D, self.F, *self._xcd_caps)),
                                       dtype=torch.float32, device=self.dev)
         if self.loss_log.numel() < 8 * log_slots:
