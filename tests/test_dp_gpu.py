@@ -40,13 +40,15 @@ def _inputs():
     return rowptr, col, feat, labels, train, pool, (w, W, fc)
 
 
-def _worker(rank, world, port, steps, out_dir, oneshot=False, own_stream=False):
+def _worker(rank, world, port, steps, out_dir, oneshot=False, own_stream=False, resident=False):
     import torch.distributed as dist
     from ggad_amd.graph import DeviceGraph
     from ggad_amd.sampler import PyCompatRandom
     from ggad_amd.trainer import BatchSchedule, DGraphTrainer
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    if resident:
+        os.environ["GGAD_XCD_ID"] = str(rank)      # the ranks share ONE device: each rank's chunk kernel on an XCD of its own
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     rowptr, col, feat, labels, train, pool, (w, W, fc) = _inputs()
@@ -59,10 +61,16 @@ def _worker(rank, world, port, steps, out_dir, oneshot=False, own_stream=False):
         from ggad_amd.exchange import OneShotExchange
         exchange = OneShotExchange(rank, world, 64 + 64 * 17 + 64 * 64, "cuda:0")
         assert exchange.connect(dist), "one-shot exchange: IPC hand-shake or self-test failed"
-    tr = DGraphTrainer(graph, ft, 64, sched, chunk_batches=3, rank=rank, world_size=world,
-                       allreduce=lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM), exchange=exchange, own_stream=own_stream,
-                       resident=False)      # the ranks share ONE device: two XCD-resident chunk kernels cannot both hold XCD 0
-    assert tr.overlap and (tr.exchange is not None) == oneshot
+    if resident:
+        # (no overlap: the trainer's CU masks and index-skipping plans are laid out for a chunk kernel on XCD 0)
+        tr = DGraphTrainer(graph, ft, 64, sched, chunk_batches=3, rank=rank, world_size=world, allreduce=None, exchange=exchange,
+                           own_stream=own_stream, overlap=False, resident=True)
+        assert tr.engine.resident and tr.exchange is not None
+    else:
+        tr = DGraphTrainer(graph, ft, 64, sched, chunk_batches=3, rank=rank, world_size=world,
+                           allreduce=lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM), exchange=exchange, own_stream=own_stream,
+                           resident=False)      # the ranks share ONE device: two XCD-resident chunk kernels cannot both hold XCD 0
+        assert tr.overlap and (tr.exchange is not None) == oneshot
     tr.engine.load_params(w, W, fc)
     tr.run_steps(steps)
     torch.cuda.synchronize()
@@ -70,6 +78,9 @@ def _worker(rank, world, port, steps, out_dir, oneshot=False, own_stream=False):
     np.save(os.path.join(out_dir, f"seen_{rank}.npy"), np.array([sched.global_batch]))
     if exchange is not None:
         assert exchange.error() == 0
+    if resident:
+        st = tr.engine.xcd_status()
+        assert st["error"] == 0 and st["xcc"] == rank, st
     dist.barrier()
     if exchange is not None:
         exchange.close()
@@ -89,6 +100,25 @@ def test_one_shot_exchange_two_processes_one_gpu_bit_equal_to_allreduce(tmp_path
     p0, p1 = np.load(a / "params_0.npy"), np.load(a / "params_1.npy")
     np.testing.assert_array_equal(p0, p1)
     np.testing.assert_array_equal(p0, np.load(b / "params_0.npy"))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_one_shot_exchange_inside_resident_chunk_kernels_of_several_ranks(tmp_path, world):
+    """The exchange inside phase E of the XCD-resident chunk kernel (`k_train_chunk_xcd<2>`) between PROCESSES: what `bench.py --gpus N`
+    runs on a node, minus the xGMI hop.  The ranks share one device here, so each rank's chunk kernel takes an XCD of its own
+    (GGAD_XCD_ID = rank).  After 6 steps all ranks hold bit-identical weights, equal to the launch chain + all-reduce path to the
+    tolerance the resident kernel is held to against the chain (2e-6)."""
+    import torch.multiprocessing as mp
+    steps = 6
+    a, b = tmp_path / "resident", tmp_path / "allreduce"
+    a.mkdir(); b.mkdir()
+    mp.spawn(_worker, args=(world, _free_port(), steps, str(a), True, False, True), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), steps, str(b), False), nprocs=world, join=True)
+    ps = [np.load(a / f"params_{r}.npy") for r in range(world)]
+    for r in range(1, world):
+        np.testing.assert_array_equal(ps[0], ps[r])
+    assert np.isfinite(ps[0]).all()
+    np.testing.assert_allclose(ps[0], np.load(b / "params_0.npy"), atol=2e-6, rtol=2e-5)
 
 
 @pytest.mark.parametrize("world", [4, 8])
