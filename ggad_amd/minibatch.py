@@ -35,6 +35,27 @@ def _f32(n, device):
     return torch.empty(int(max(n, 1)), dtype=torch.float32, device=device)
 
 
+def _rows_as_flat(rows):
+    """The rows of a list as ONE flat int64 view when they are consecutive rows of a C-contiguous 2-D int64 matrix (else None)."""
+    try:
+        a, z = rows[0], rows[-1]
+        base = a.base
+        if base is None or z.base is not base or base.ndim != 2 or base.dtype != np.int64 or not base.flags.c_contiguous:
+            return None
+        w = base.shape[1]
+        if a.ndim != 1 or len(a) != w or len(z) != w or a.dtype != np.int64:
+            return None
+        p0, pa, pz = base.ctypes.data, a.ctypes.data, z.ctypes.data
+        r0, nb = (pa - p0) // (8 * w), len(rows)
+        if (pa - p0) % (8 * w) or pz - pa != 8 * w * (nb - 1) or r0 + nb > base.shape[0]:
+            return None
+        if nb > 2 and rows[nb // 2].ctypes.data - pa != 8 * w * (nb // 2):     # (a list that merely starts and ends like one)
+            return None
+        return base[r0:r0 + nb].reshape(-1)
+    except (AttributeError, IndexError, TypeError):
+        return None
+
+
 def _check_i32(x: int) -> None:
     if x >= 2 ** 31:
         raise ValueError("chunk too large for int32 entry indices; use fewer batches per chunk")
@@ -206,6 +227,19 @@ class BatchChunk:
         nb = len(batches)
         if nb > self.max_batches or nb == 0:
             raise ValueError(f"chunk holds 1..{self.max_batches} batches, got {nb}")
+        bp = self._bp_host
+        # what `BatchSchedule.next_batches` hands out: consecutive rows of ONE contiguous int64 matrix (ids) and of another (labels)
+        # -- no copy, no per-batch Python work (24 us per 20-batch build otherwise, on the critical path of a one-chunk run)
+        nodes = _rows_as_flat(batches)
+        if nodes is not None and (not self.train or labels is not None):
+            lab = _rows_as_flat(labels) if self.train else None
+            if not self.train or (lab is not None and len(lab) == len(nodes)):
+                w = len(batches[0])
+                bp[:nb + 1] = np.arange(0, (nb + 1) * w, w, dtype=np.int32) if w > 0 else 0
+                if w == 0:
+                    raise ValueError("empty batch")
+                self.build_arrays(nodes, bp, nb, lab)
+                return
         sizes = np.fromiter((len(b) for b in batches), dtype=np.int64, count=nb)
         if (sizes == 0).any():
             raise ValueError("empty batch")
@@ -217,7 +251,6 @@ class BatchChunk:
             lab = np.concatenate(labels).astype(np.int64, copy=False)
             if len(lab) != len(nodes):
                 raise ValueError("labels / batches length mismatch")
-        bp = self._bp_host
         bp[0] = 0
         np.cumsum(sizes, out=bp[1:nb + 1])
         self.build_arrays(nodes, bp, nb, lab)

@@ -50,3 +50,19 @@ for rep in range(5):
     a3 = time.perf_counter()
     print(f"run_steps(20): host {1e6 * (t1 - t0):7.1f} us, until the GPU is done {1e6 * (t2 - t0):7.1f} us | build() host {1e6 * (a1 - a0):6.1f}, "
           f"train_chunk() host {1e6 * (a2 - a1):6.1f}, wait {1e6 * (a3 - a2):7.1f}, total {1e6 * (a3 - a0):7.1f} us", flush=True)
+
+# GPU-side view of the same window: an event recorded at t0 (the stream is idle: it completes at once) and one behind the chunk
+# kernel -- their distance minus the kernels' own time is what the GPU waited for the host before its first kernel
+for rep in range(4):
+    bn, bl = sched.next_batches(20)
+    ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ea.record()
+    tr.run_steps(20, prepared=(bn, bl))
+    eb.record()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print(f"window: host returns after {1e6 * (t1 - t0):6.1f} us, GPU from the t0 marker to the end of the chunk kernel {1e3 * ea.elapsed_time(eb):7.1f} us, "
+          f"wall until synchronize returns {1e6 * (t2 - t0):7.1f} us", flush=True)

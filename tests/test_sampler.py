@@ -114,3 +114,18 @@ def test_native_batch_stream_rejects_ids_beyond_int32_and_handles_tiny_lists():
                                 lens.ctypes.data)
     assert rc == 0 and r.to_python_state() == before
     assert lens.tolist()[:3] == [2, 2, 2] and out.reshape(-1)[:6].tolist() == [7, 9, 7, 9, 7, 9] and one_t[0] == 7 and one_p[0] == 9
+
+
+def test_schedule_rows_are_recognised_as_one_flat_block():
+    """`BatchChunk.build` takes the batches `BatchSchedule.next_batches` hands out -- consecutive rows of one contiguous int64
+    matrix -- as ONE flat view (no concatenation on the critical path of a one-chunk run); anything else takes the copying path."""
+    from ggad_amd.minibatch import _rows_as_flat
+    m = np.empty((20, 200), dtype=np.int64)
+    m[:] = np.arange(4000).reshape(20, 200)
+    rows = list(m)
+    flat = _rows_as_flat(rows)
+    assert flat is not None and np.shares_memory(flat, m) and np.array_equal(flat, m.reshape(-1))
+    assert np.array_equal(_rows_as_flat(rows[3:9]), m[3:9].reshape(-1))
+    for other in ([m[0], m[2], m[4]], [m[0], m[5], m[2]], [m[0], m[2], m[2]], [np.arange(5), np.arange(5)],
+                  [m[0, :100], m[1, :100]], list(m[1::2][:5]), [list(range(5))], [m[0].astype(np.int32), m[1].astype(np.int32)]):
+        assert _rows_as_flat(other) is None
