@@ -6,6 +6,9 @@
 // goes to the device in ONE pinned block with ONE copy, followed by 8 kernel launches (3 for an inference plan) -- the
 // previous version of this path issued 28 launches and ~0.25 ms of Python per chunk, which bounded short runs.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -62,6 +65,8 @@ int ggad_mb_plan_build(const ggad_mb_plan *P, const int64_t *nodes_host, const i
   const bool train = P->train != 0;
   if (train) GGAD_REQUIRE(labels_host && P->x2 && (P->hop2 == 1 || P->hop2 == 2));
   std::memset(info, 0, sizeof(*info));
+  static const bool timing = getenv("GGAD_BUILD_TIMING") != nullptr;      // host phases of this call on stderr (us)
+  const auto tt0 = std::chrono::steady_clock::now();
   const int nb = n_batches;
   const int64_t rows = batch_ptr_host[nb];
   GGAD_REQUIRE(rows >= 1 && rows < (1 << 25));
@@ -141,10 +146,12 @@ int ggad_mb_plan_build(const ggad_mb_plan *P, const int64_t *nodes_host, const i
     return GGAD_E_CAPACITY;
   if (mode == 1) GGAD_REQUIRE(P->seg_t && P->pc && P->items && P->part2);        // sized by the capacities checked above
 
+  const auto tt1 = std::chrono::steady_clock::now();
   // ---- staging block
   hipStream_t st = as_stream(stream);
   hipError_t he = hipEventSynchronize(static_cast<hipEvent_t>(P->stage_event));      // the previous upload has left the block
   if (he != hipSuccess) { ggad_set_error(he, "mb_plan_build (stage event)"); return GGAD_E_LAUNCH; }
+  const auto tt2 = std::chrono::steady_clock::now();
   int32_t *S = P->stage_host;
   int32_t *bp = S + off_bp, *bep = S + off_bep, *nd = S + off_nodes, *lb = S + off_labels, *meta = S + off_meta,
           *rpos = S + off_rpos, *slot = S + off_slot, *eptr = S + off_eptr, *ckp = S + off_ckp, *ckrc = S + off_ckrc,
@@ -198,11 +205,13 @@ int ggad_mb_plan_build(const ggad_mb_plan *P, const int64_t *nodes_host, const i
   ckp[rows] = (int32_t)c;
   if (batch_ent_ptr_host_out) batch_ent_ptr_host_out[nb] = e;
   if (ent_ptr_host_out) ent_ptr_host_out[rows] = e;
+  const auto tt3 = std::chrono::steady_clock::now();
   he = hipMemcpyAsync(P->stage, S, (size_t)stage_need * sizeof(int32_t), hipMemcpyHostToDevice, st);
   if (he != hipSuccess) { ggad_set_error(he, "mb_plan_build (upload)"); return GGAD_E_LAUNCH; }
   he = hipEventRecord(static_cast<hipEvent_t>(P->stage_event), st);
   if (he != hipSuccess) { ggad_set_error(he, "mb_plan_build (stage event record)"); return GGAD_E_LAUNCH; }
 
+  const auto tt4 = std::chrono::steady_clock::now();
   // ---- device part
   ggad_plan_view V;
   const int32_t *D = P->stage;
@@ -215,6 +224,12 @@ int ggad_mb_plan_build(const ggad_mb_plan *P, const int64_t *nodes_host, const i
   hipEvent_t ev0 = static_cast<hipEvent_t>(P->ev_gather0), ev1 = static_cast<hipEvent_t>(P->ev_gather1);
   if (mode == 1) rc = ggad_int_ldsw_hop2(P, V, st, ev0, ev1);
   else if (mode == 2) rc = ggad_int_global_hop2(P, V, st, ev0, ev1);
+  if (timing) {
+    const auto tt5 = std::chrono::steady_clock::now();
+    auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    fprintf(stderr, "[ggad_mb_plan_build] %d batches: sizes %.1f  stage-event wait %.1f  fill %.1f  copy + event %.1f  launches %.1f us (%lld KB staged)\n", nb,
+            us(tt0, tt1), us(tt1, tt2), us(tt2, tt3), us(tt3, tt4), us(tt4, tt5), (long long)(stage_need * 4 / 1024));
+  }
   return rc;
 }
 
