@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <atomic>
 #include <climits>
+#include <mutex>
 
 #include "common.h"
 
@@ -841,8 +842,19 @@ int ggad_int_ldsw_hop2(const ggad_mb_plan *P, const ggad_plan_view &V, hipStream
   k_seg_transpose<<<dim3(ggad_skip_grid((unsigned)((V.n_ents + 63) / 64), skip)), dim3(256), 0, st>>>(
       P->tile_off, n_tiles, P->ent_own, P->ent_col, V.n_ents, V.seg_stride, P->seg_t, skip);
   const size_t lds = (size_t)(TW_TILE / 2) * 4 + (size_t)(3 * TW_MAXOWN + 1) * 4;
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void *)k_tile_counts, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  {  // the opt-in for 139 KB of dynamic LDS is a per-DEVICE attribute of the kernel: set (and checked) once per device of the process
+    static std::mutex mu;
+    static int state[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return GGAD_E_INVALID;
+    std::lock_guard<std::mutex> lock(mu);
+    if (state[dev] == 0) {
+      const bool ok = hipFuncSetAttribute((const void *)k_tile_counts, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+      (void)hipGetLastError();
+      state[dev] = ok ? 1 : -1;
+    }
+    if (state[dev] != 1) { ggad_set_error(hipErrorInvalidValue, "mb_plan_build: this device cannot give k_tile_counts its LDS"); return GGAD_E_LAUNCH; }
+  }
   k_tile_counts<<<dim3(ggad_skip_grid((unsigned)n_tiles * (unsigned)V.n_batches, skip)), dim3(TW_T), lds, st>>>(
       P->col, P->seg_t, V.seg_stride, P->own_rp, V.batch_ent_ptr, P->pw_base, P->pc, n_tiles, V.n_batches, P->counters, skip);
   if (ev0) (void)hipEventRecord(ev0, st);
