@@ -73,6 +73,7 @@ constexpr int TW_SHIFT = 15;
 constexpr int TW_TILE = 1 << TW_SHIFT;
 constexpr int TW_MAXOWN = 6144;          // owner slots (entries) per batch the LDS arrays hold; larger batches: slabs
 constexpr int TW_T = 1024;
+constexpr int TW_BRK = 1536;              // bracket entries: (tile, batch) pairs up to 64 * (TW_BRK - 1), beyond that the full descent
 
 // seg_t[t][e] = tile_off[ent_col[e]][t] for owner entries (0 for the others: empty segments), tile-major so that the
 // workgroup of (tile t, batch b) reads its owners' segment bounds as two contiguous runs.  (Reading tile_off directly
@@ -151,6 +152,7 @@ __global__ void __launch_bounds__(TW_T) k_tile_counts(const int32_t *__restrict_
   int *offs = reinterpret_cast<int *>(lds_u + TW_TILE / 2);  // TW_MAXOWN + 1
   int *segbeg = offs + TW_MAXOWN + 1;                      // TW_MAXOWN   (index into col[])
   int *dst = segbeg + TW_MAXOWN;                           // TW_MAXOWN   (index into pc[])
+  int *brk = dst + TW_MAXOWN;                              // TW_BRK: owner of every 64th pair (the search window of a wave's trip)
   __shared__ int wbuf[16];
   unsigned vbx, vgx;
   if (!ggad_vblock(skip, vbx, vgx)) return;
@@ -224,9 +226,34 @@ __global__ void __launch_bounds__(TW_T) k_tile_counts(const int32_t *__restrict_
           for (int st = s0; st > 0; st >>= 1) { const int m = lo + st; lo = (offs[min(m, n_own)] <= pp) ? m : lo; }
           own = lo; j = pp - offs[lo];
         };
+        // Bracket table: the owner of every 64th pair, one full descent per BLOCK of 64 pairs (not per pair).  The 64 consecutive
+        // pairs of a wave's trip lie between two neighbouring brackets -- ~16 owners apart on the bench graph --, so a pair's own
+        // descent starts there and takes log2 of that distance (4-5) LDS reads at random addresses instead of 12-13: the located
+        // pairs were bound by LDS bank conflicts (9.8 of 27 us per workgroup, scripts/g2_phase_clocks.py).
+        const int nblk = ((P - 1) >> 6) + 1;
+        const bool use_brk = nblk + 1 <= TW_BRK;                 // uniform
+        if (use_brk && (pass == 0 || n_slabs > 1)) {
+          for (int b = threadIdx.x; b <= nblk; b += TW_T) {
+            int own = n_own, j = 0;
+            if (b < nblk) locate(min(64 * b, P - 1), own, j);
+            brk[b] = own;
+          }
+          __syncthreads();
+        }
         auto locate4 = [&](const int (&pp)[4], int (&own)[4], int (&j)[4]) {
           int lo[4] = {0, 0, 0, 0};
-          for (int st = s0; st > 0; st >>= 1) {
+          int smax = s0;
+          if (use_brk) {
+            smax = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int b = pp[q] >> 6;
+              lo[q] = brk[b];
+              const int w = brk[b + 1] - lo[q];
+              smax = max(smax, w > 0 ? 1 << (31 - __clz(w)) : 0);
+            }
+          }
+          for (int st = smax; st > 0; st >>= 1) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) { const int m = lo[q] + st; lo[q] = (offs[min(m, n_own)] <= pp[q]) ? m : lo[q]; }
           }
@@ -289,7 +316,6 @@ __global__ void __launch_bounds__(TW_T) k_tile_counts(const int32_t *__restrict_
             }
           }
         }
-        (void)locate;
         TC_MARK(3 + 2 * pass);
       }
       __syncthreads();
@@ -841,7 +867,7 @@ int ggad_int_ldsw_hop2(const ggad_mb_plan *P, const ggad_plan_view &V, hipStream
   const int skip = P->xcd_skip >= 0 && P->xcd_skip < 8 ? P->xcd_skip : -1;      // leave one XCD to the resident chunk kernel
   k_seg_transpose<<<dim3(ggad_skip_grid((unsigned)((V.n_ents + 63) / 64), skip)), dim3(256), 0, st>>>(
       P->tile_off, n_tiles, P->ent_own, P->ent_col, V.n_ents, V.seg_stride, P->seg_t, skip);
-  const size_t lds = (size_t)(TW_TILE / 2) * 4 + (size_t)(3 * TW_MAXOWN + 1) * 4;
+  const size_t lds = (size_t)(TW_TILE / 2) * 4 + (size_t)(3 * TW_MAXOWN + 1) * 4 + (size_t)TW_BRK * 4;
   {  // the opt-in for 139 KB of dynamic LDS is a per-DEVICE attribute of the kernel: set (and checked) once per device of the process
     static std::mutex mu;
     static int state[64] = {};
