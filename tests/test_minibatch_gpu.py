@@ -307,6 +307,48 @@ def test_xcd_resident_chunk_equals_launch_chain(d, bsz, n_ano, hub):
     np.testing.assert_allclose(res["xcd"][1][0], [tot.item(), cls.item(), mar.item(), rec.item()], atol=1e-5, rtol=0)
 
 
+def test_xcd_records_prepared_on_another_stream_equal_in_launch_records():
+    """`MiniBatchEngine.xcd_prepare` (ggad_mb_xcd_prepare: the chunk kernel's records and x2 per entry, on the PLAN's stream, in a
+    block owned by the chunk) against the records the launch builds itself: bit-identical weights, losses and optimiser state
+    over two chunks, the second one re-using the record block; a prepare made for an earlier build is not used."""
+    g, batches, labels = _random_case(n=12000, n_entries=150000, f=17, d=64, seed=77, nb=6, bsz=150, n_ano=40)
+    torch.manual_seed(3)
+    w = torch.nn.init.xavier_uniform_(torch.empty(1, 64))
+    W = torch.nn.init.xavier_uniform_(torch.empty(64, 17))
+    fc = torch.nn.init.xavier_uniform_(torch.empty(64, 64))
+    side = torch.cuda.Stream()
+    res = {}
+    for key in ("in_launch", "prepared"):
+        graph, feat, ch = _setup(g, max_batches=len(batches), hop2="ldsw")
+        eng = MiniBatchEngine(17, 64, DEV, resident=True)
+        eng.load_params(w, W, fc)
+        for rep, (bs, ls) in enumerate(((batches, labels), (batches[::-1], labels[::-1]))):
+            if key == "prepared":
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    ch.build(bs, ls)
+                    eng.xcd_prepare(ch)             # (the very first call finds no workspace yet: that chunk's records are built in the launch)
+                torch.cuda.current_stream().wait_stream(side)
+                assert rep == 0 or ch.xcd_prepared[0] == ch.build_count
+            else:
+                ch.build(bs, ls)
+            eng.train_chunk(ch, log_base=rep * len(bs))
+            torch.cuda.synchronize()
+            assert eng.xcd_status()["error"] == 0
+        if key == "prepared":                        # a stale prepare (older build) must be ignored
+            stale = ch.xcd_prepared
+            ch.build(batches, labels)
+            assert ch.xcd_prepared == stale and stale[0] != ch.build_count
+            eng.train_chunk(ch, log_base=2 * len(batches))
+        else:
+            ch.build(batches, labels)
+            eng.train_chunk(ch, log_base=2 * len(batches))
+        torch.cuda.synchronize()
+        res[key] = (eng.params.cpu().numpy().copy(), eng.losses(3 * len(batches)).copy(), eng.exp_avg_sq.cpu().numpy().copy())
+    for a, b in zip(res["in_launch"], res["prepared"]):
+        np.testing.assert_array_equal(a, b)
+
+
 def test_rebuild_reuses_clean_slots():
     g, batches, labels = _random_case(n=5000, n_entries=30000, f=17, d=64, seed=4, nb=2, bsz=60, n_ano=10)
     graph, feat, ch = _setup(g, max_batches=2)
