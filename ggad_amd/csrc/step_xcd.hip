@@ -335,15 +335,38 @@ __global__ void __launch_bounds__(XT) k_train_chunk_xcd(XcdArgs A) {
     batch_info(b, row0, B, ck0, nck);
     float *log8 = A.loss_log + (int64_t)8 * (A.log_base + b);
     // ---------------------------------------------------------------- weights of this step: L2 -> LDS (written by phase E of the previous step)
+    // ALL the loads of this block first, then the LDS stores: as loops of (load, store) the compiler put an s_waitcnt vmcnt(0)
+    // behind every load -- nine dependent L2 round trips (W^T 2, fc^T 4, w, the batch's n0, its label-1 sources): 1.3 us per step
+    const int n0s = b < XBT ? bt_n0[b] : A.batch_n0[b];
+    const int n_ra = (A.dbg & 2) ? 0 : min(B - n0s, XRA);
+    const int ra_v = S.pos_meta[row0 + min(n0s + (int)threadIdx.x, B - 1)];      // sources of the generated columns (label-1 rows), for phase E
+                                                                                   // (unconditional, clamped: in flight with the weights)
+    const float w_v = (threadIdx.x >= XT - GGAD_WAVE && on) ? cld(params + lane) : 0.0f;
     if ((D & 1) == 0) {                                   // all three blocks start on even offsets: 8-byte loads
-      for (int i = 2 * threadIdx.x; i < XFT * D; i += 2 * XT) {
-        const f2 v = cld2(params + L.o_Wt() + i);
-        wt_lds[i] = v.x; wt_lds[i + 1] = v.y;
+      constexpr int NWT = (XFT * GGAD_MAX_D / 2 + XT - 1) / XT, NFC = (GGAD_MAX_D * GGAD_MAX_D / 2 + XT - 1) / XT;
+      f2 vwt[NWT], vfc[NFC];
+#pragma unroll
+      for (int k = 0; k < NWT; ++k) {
+        const int i = 2 * ((int)threadIdx.x + k * XT);
+        vwt[k] = cld2(params + L.o_Wt() + min(i, XFT * D - 2));
       }
-      for (int i = 2 * threadIdx.x; i < D * D; i += 2 * XT) {
-        const int r2 = i / D, c2 = i - r2 * D;
-        const f2 v = cld2(params + L.o_fcT() + i);
-        fct[r2 * FCS + c2] = v.x; fct[r2 * FCS + c2 + 1] = v.y;
+#pragma unroll
+      for (int k = 0; k < NFC; ++k) {
+        const int i = 2 * ((int)threadIdx.x + k * XT);
+        vfc[k] = cld2(params + L.o_fcT() + min(i, D * D - 2));
+      }
+#pragma unroll
+      for (int k = 0; k < NWT; ++k) {
+        const int i = 2 * ((int)threadIdx.x + k * XT);
+        if (i < XFT * D) { wt_lds[i] = vwt[k].x; wt_lds[i + 1] = vwt[k].y; }
+      }
+#pragma unroll
+      for (int k = 0; k < NFC; ++k) {
+        const int i = 2 * ((int)threadIdx.x + k * XT);
+        if (i < D * D) {
+          const int r2 = i / D, c2 = i - r2 * D;
+          fct[r2 * FCS + c2] = vfc[k].x; fct[r2 * FCS + c2 + 1] = vfc[k].y;
+        }
       }
     } else {
       for (int i = threadIdx.x; i < XFT * D; i += XT) wt_lds[i] = cld(params + L.o_Wt() + i);
@@ -352,12 +375,8 @@ __global__ void __launch_bounds__(XT) k_train_chunk_xcd(XcdArgs A) {
         fct[r2 * FCS + c2] = cld(params + L.o_fcT() + i);
       }
     }
-    if (threadIdx.x >= XT - GGAD_WAVE) w_lds[lane] = on ? cld(params + lane) : 0.0f;
-    {                                                       // sources of the generated columns (label-1 rows), for phase E
-      const int n0s = b < XBT ? bt_n0[b] : A.batch_n0[b];
-      if (!(A.dbg & 2))
-        for (int j = threadIdx.x; j < min(B - n0s, XRA); j += XT) ra_lds[j] = S.pos_meta[row0 + n0s + j] >> 2;
-    }
+    if (threadIdx.x >= XT - GGAD_WAVE) w_lds[lane] = w_v;
+    if ((int)threadIdx.x < n_ra) ra_lds[threadIdx.x] = ra_v >> 2;
     __syncthreads();
     float WB[XKS][XNT];                                   // W^T in the B-operand layout: W[16 t + a][4 j + g]
 #pragma unroll
