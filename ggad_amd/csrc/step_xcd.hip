@@ -904,10 +904,22 @@ __global__ void __launch_bounds__(256) k_xcd_prep(XcdPrepArgs P) {
   // x2 is stored at owner entries (the reference's deduplicated unique_nodes_list, graphsage.py:306); the other entries of a
   // (batch, column) get a copy of their owner's row, so that the rows of a piece are the consecutive entries [e0, e0 + cnt)
   // (half a wave per entry, lane = feature: one read of the owner per entry, not one per float)
-  const int f = threadIdx.x & 31;
-  for (int64_t e = tid >> 5; e < P.n_ents; e += ((int64_t)gridDim.x * 256) >> 5) {
-    const int o = P.ent_own[e];
-    if (o != (int)e && f < XFT) P.x2[e * XFT + f] = P.x2[(int64_t)o * XFT + f];
+  // four entries per trip, their owner ids first, then the four rows (every load unconditional: an owner re-reads its own row),
+  // then the stores: one entry per trip was a chain of two dependent round trips per entry, ten entries per thread
+  const int f = min((int)(threadIdx.x & 31), XFT - 1);
+  const bool fl = (threadIdx.x & 31) < XFT;
+  const int64_t stride = ((int64_t)gridDim.x * 256) >> 5;
+  for (int64_t e0 = tid >> 5; e0 < P.n_ents; e0 += 4 * stride) {
+    int64_t e[4];
+    int o[4];
+    float v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { e[q] = min(e0 + q * stride, (int64_t)P.n_ents - 1); o[q] = P.ent_own[e[q]]; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = P.x2[(int64_t)o[q] * XFT + f];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (fl && e0 + q * stride < P.n_ents && o[q] != (int)e[q]) P.x2[e[q] * XFT + f] = v[q];
   }
 }
 
