@@ -85,6 +85,7 @@ struct ggad_plan_view {      // device views into the staging block of ONE build
   const int32_t *batch_ptr, *batch_ent_ptr, *nodes, *row_slot, *ent_ptr, *row_ck_ptr, *ck_rc, *ck_e0;
   int32_t n_batches, n_rows, n_ents, n_chunks;
   int32_t seg_stride;        // entries per tile row of seg_t (n_ents rounded up to 64)
+  int64_t pair_bound;        // host bound on the (owner, neighbour) pairs of THIS build (the capacities may be far larger)
 };
 int ggad_int_hop1(const ggad_mb_plan *P, const ggad_plan_view &V, int ldsw, int reset_now, hipStream_t st);
 int ggad_int_global_hop2(const ggad_mb_plan *P, const ggad_plan_view &V, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);

@@ -895,7 +895,7 @@ int ggad_int_ldsw_hop2(const ggad_mb_plan *P, const ggad_plan_view &V, hipStream
         P->ent_own, P->ent_col, P->own_deg, V.n_ents, P->node_head, P->own_next, P->tile_off, n_tiles, P->grp, P->items, big, gbnd,
         P->counters, range_deg, skip);
     // waves take ITEM_GRAB work items at a time from a cursor: enough workgroups to fill the chip, no more than there can be items
-    const int64_t max_items = (int64_t)V.n_ents + P->pair_cap / SLICE;
+    const int64_t max_items = (int64_t)V.n_ents + (V.pair_bound > 0 ? V.pair_bound : P->pair_cap) / SLICE;      // (of this build, not of the buffers)
     // as many workgroups as are RESIDENT (4 per CU at 105 VGPRs), reservations of 12 items at most: with 2,048 workgroups the second
     // thousand only started when the first left -- at the very end -- and the reservation size followed the nominal wave count
     // (4 items at 20 batches, 32-64 at 150).  Measured (20 / 150 batches): 8 per CU, cap 64: 553 / 1,440 us; 4 per CU, cap 12: 410 / 1,390 us

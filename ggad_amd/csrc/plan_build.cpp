@@ -219,6 +219,7 @@ int ggad_mb_plan_build(const ggad_mb_plan *P, const int64_t *nodes_host, const i
   V.ent_ptr = D + off_eptr; V.row_ck_ptr = D + off_ckp; V.ck_rc = D + off_ckrc; V.ck_e0 = D + off_cke0;
   V.n_batches = nb; V.n_rows = (int32_t)rows; V.n_ents = (int32_t)n_ents; V.n_chunks = (int32_t)n_chunks;
   V.seg_stride = (int32_t)seg_stride;
+  V.pair_bound = bound;
   int rc = ggad_int_hop1(P, V, mode == 1 ? 1 : 0, mode != 2 ? 1 : 0, st);
   if (rc) return rc;
   hipEvent_t ev0 = static_cast<hipEvent_t>(P->ev_gather0), ev1 = static_cast<hipEvent_t>(P->ev_gather1);
