@@ -90,6 +90,7 @@ struct ggad_plan_view {      // device views into the staging block of ONE build
 int ggad_int_hop1(const ggad_mb_plan *P, const ggad_plan_view &V, int ldsw, int reset_now, hipStream_t st);
 int ggad_int_global_hop2(const ggad_mb_plan *P, const ggad_plan_view &V, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
 int ggad_int_ldsw_hop2(const ggad_mb_plan *P, const ggad_plan_view &V, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
+int ggad_int_range_deg();      // owners above this degree are gathered by id range (INT32_MAX: the partition is off)
 
 // ---- one-shot gradient exchange (exchange.cpp owns the handle, step.hip the kernel)
 constexpr int GGAD_XCHG_MAX_WORLD = 16;

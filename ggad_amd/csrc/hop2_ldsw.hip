@@ -861,6 +861,8 @@ std::atomic<int> g_range_deg{[] { const char *e = getenv("GGAD_RANGE_DEG"); retu
 
 }  // namespace
 
+int ggad_int_range_deg() { return g_range_deg.load() > 0 ? std::max(g_range_deg.load(), GGAD_RANGE_DEG) : INT32_MAX; }
+
 int ggad_int_ldsw_hop2(const ggad_mb_plan *P, const ggad_plan_view &V, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
   if (V.n_ents == 0 || V.n_batches == 0) return GGAD_OK;
   const int n_tiles = (int)((P->n_nodes + TW_TILE - 1) >> TW_SHIFT);
@@ -888,7 +890,7 @@ int ggad_int_ldsw_hop2(const ggad_mb_plan *P, const ggad_plan_view &V, hipStream
   if (P->node_major && F <= 64) {
     // ggad_mb_plan::items holds 12 * item_cap ints: [0, 2 cap) the common work items, [2 cap, 3 cap) the big list (group ids),
     // [3 cap, 12 cap) its range boundaries (GGAD_RANGES + 1 per big group; groups <= entries <= item_cap)
-    const int range_deg = g_range_deg.load() > 0 ? std::max(g_range_deg.load(), GGAD_RANGE_DEG) : INT32_MAX;
+    const int range_deg = ggad_int_range_deg();
     static const int affine = [] { const char *e = getenv("GGAD_RANGE_AFFINE"); return e ? atoi(e) : 1; }();
     int32_t *big = P->items + 2 * (int64_t)P->item_cap, *gbnd = P->items + 3 * (int64_t)P->item_cap;
     k_build_groups<<<dim3(ggad_skip_grid((unsigned)((V.n_ents + 255) / 256), skip)), dim3(256), 0, st>>>(

@@ -7,6 +7,7 @@
 // previous version of this path issued 28 launches and ~0.25 ms of Python per chunk, which bounded short runs.
 #include <algorithm>
 #include <chrono>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -136,7 +137,7 @@ int ggad_mb_plan_build(const ggad_mb_plan *P, const int64_t *nodes_host, const i
     info->need_items = n_ents + bound / SL;
     // slots of feat_dim floats: ceil(deg / SL) <= 2 deg / SL per occurrence of an owner with > SL neighbours, GGAD_RANGES per
     // occurrence of one with > GGAD_RANGE_DEG
-    info->need_part2 = (2 + (int64_t)GGAD_RANGES * SL / GGAD_RANGE_DEG) * (bound / SL) + 8;
+    info->need_part2 = (2 + (ggad_int_range_deg() == INT32_MAX ? 0 : (int64_t)GGAD_RANGES * SL / GGAD_RANGE_DEG)) * (bound / SL) + 8;
     info->need_seg = n_tiles1 * seg_stride;
   }
   info->need_cnt2 = (mode == 2 && P->cnt2 == nullptr) ? 1 : 0;
