@@ -10,7 +10,7 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int32, c_int64, c_uint32, c_uint64, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libggad_hip.so")
+LIB_PATH = os.environ.get("GGAD_LIB_PATH") or os.path.join(HERE, "libggad_hip.so")      # (GGAD_LIB_PATH: experiment builds)
 
 
 class GgadLibraryError(RuntimeError):
@@ -115,6 +115,15 @@ SIGNATURES = {
     "ggad_spmm_panel_fill": (c_int32, [_P, _P, _I, _P, _P, _I, _I, _I, _P, _P, _P, _L, _I, _I]),
     "ggad_spmm_panel_f32": (c_int32, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _L, _P, _P, _P, _P, _L, _P, _P]),
     "ggad_spmm_sliced_f32": (c_int32, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _L, _I, _L, _P, _P, _P, _P, _L, _P, _P, _P]),
+    "ggad_spmm_ring_available": (c_int32, []),
+    "ggad_spmm_ring_slot_rows": (c_int32, []),
+    "ggad_spmm_ring_slots": (c_int32, []),
+    "ggad_spmm_ring_window": (c_int32, []),
+    "ggad_spmm_ring_walkers": (c_int32, []),
+    "ggad_spmm_ring_rounds": (c_int32, []),
+    "ggad_spmm_ring_count": (c_int32, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _I]),
+    "ggad_spmm_ring_fill": (c_int32, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _L, _I]),
+    "ggad_spmm_ring_f32": (c_int32, [_P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _L, _P, _P, _P, _P, _L, _P, _P]),
     "ggad_prelu_bwd_splits": (c_int32, [_I]),
     "ggad_prelu_bwd_f32": (c_int32, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "ggad_relu_bwd_f32": (c_int32, [_P, _P, _L, _P, _P]),

@@ -501,6 +501,185 @@ __global__ void __launch_bounds__(1024) k_spmm_panel(const int32_t *__restrict__
   }
 }
 
+// ---- LDS-RING variant of the panel product (round 4): staging overlapped with the walk, flexible schedule ----------------------
+// k_spmm_panel above fills the whole LDS with one 1,270-row panel, so nothing can be staged while it is walked (two barriers per
+// panel, 35 % of the kernel), and pads every (round, panel) tile to its longest row (27 % of the step slots empty).  Here the
+// operand slice passes through a RING of RING_S slots of RING_RS rows: during phase j the walkers read the slots j .. j+V-1 while a
+// LOADER wave (wave 15: LDS-DMA, global_load_lds_dwordx4, no registers, its own vmcnt) fetches slot j+S-1 into the buffer phase
+// j-1 released; ONE barrier per phase hands the buffer over.  The schedule is built on the host (csrc/spmm_ring_build.cpp): a
+// lane group that has no open entry in the slot that is about to be overwritten walks its next entries anywhere in the window,
+// so the 8 rows of a round drift apart by up to a window instead of being padded per panel (0.73 -> 0.85 of the steps carry an
+// entry).  The price of small slots is tiny tiles (4 steps per (round, phase) on average), so the walk is FLAT: a per-wave list of
+// quads (4 steps x 8 lane groups), each tagged with its accumulator; the accumulator is selected with the VGPR index mode
+// (s_set_gpr_idx_on: M0-relative destination / second source of the v_pk_add_f32 -- VOP3P takes the index too, scripts/gpr_idx_probe.hip) instead of one unrolled loop nest per
+// accumulator -- no per-tile loop overhead, reads of quad q + 1 in flight while quad q is added.  The walk is one asm statement
+// with pinned registers (the 64 accumulators v[64:127] are its outputs); everything around it is plain HIP.
+constexpr int RING_S = 5;                           // ring slots
+constexpr int RING_RS = 248;                        // source rows per slot (31 LDS-DMA pieces of 8 rows)
+constexpr int RING_V = RING_S - 1;                  // slots readable during a phase
+constexpr int RING_WALK = 15;                       // walker waves (wave 15 loads)
+constexpr int RING_KR = 16;                         // rounds (of 8 lane rows) per walker: 64 accumulator registers
+constexpr int RING_LDS = (RING_S * RING_RS + 2) * SPMM_SL * 16;   // ring + two zero rows
+static_assert(RING_LDS <= 160 * 1024 && RING_RS % 8 == 0, "ring must fit the 160 KB of a CU; slots are whole 1 KB pieces");
+typedef float ring_v32f __attribute__((ext_vector_type(32)));
+
+#define RING_RD(X0_, X1_, X2_, X3_)                                                                                  \
+  "ds_read_b128 " X0_ ", v8\n ds_read_b128 " X1_ ", v9\n ds_read_b128 " X2_ ", v10\n ds_read_b128 " X3_ ", v11\n"
+#ifdef RING_NO_ADD
+#define RING_ADD4(AB_, CD_) ""
+#else
+#define RING_ADD4(AB_, CD_) "v_pk_add_f32 v[64:65], " AB_ ", v[64:65]\n v_pk_add_f32 v[66:67], " CD_ ", v[66:67]\n"
+#endif
+// (timing experiments only, scripts/ring_variants.sh: -DRING_NO_BARRIER / -DRING_NO_ADD / -DRING_NO_LOAD give wrong results)
+#ifdef RING_NO_BARRIER
+#define RING_BARRIER ""
+#define RING_LOADER_BARRIER()
+#else
+#define RING_BARRIER "s_barrier\n"
+#define RING_LOADER_BARRIER() __builtin_amdgcn_s_barrier()
+#endif
+#define RING_RD_A RING_RD("v[16:19]", "v[20:23]", "v[24:27]", "v[28:31]")
+#define RING_RD_B RING_RD("v[32:35]", "v[36:39]", "v[40:43]", "v[44:47]")
+#define RING_ADD_A RING_ADD4("v[16:17]", "v[18:19]") RING_ADD4("v[20:21]", "v[22:23]") RING_ADD4("v[24:25]", "v[26:27]") RING_ADD4("v[28:29]", "v[30:31]")
+#define RING_ADD_B RING_ADD4("v[32:33]", "v[34:35]") RING_ADD4("v[36:37]", "v[38:39]") RING_ADD4("v[40:41]", "v[42:43]") RING_ADD4("v[44:45]", "v[46:47]")
+// one quad: addresses of its 4 steps, its 4 reads, then -- while they fly -- the additions of the PREVIOUS quad into the
+// accumulator s42 selects; afterwards s42 = this quad's accumulator offset (control bits 0..5 of its byte), and a set bit 6 ends
+// the phase: all reads of this wave have returned, the barrier releases the slot
+#define RING_QUAD(W0_, W1_, RD_CUR_, ADD_PREV_, BFE_, BIT_, L_)                                                      \
+  "v_mad_u32_u16 v8, " W0_ ", s43, v14\n v_mad_u32_u16 v9, " W0_ ", s43, v14 op_sel:[1,0,0,0]\n"                      \
+  "v_mad_u32_u16 v10, " W1_ ", s43, v14\n v_mad_u32_u16 v11, " W1_ ", s43, v14 op_sel:[1,0,0,0]\n"                    \
+  RD_CUR_                                                                                                            \
+  "s_waitcnt lgkmcnt(4)\n s_set_gpr_idx_on s42, 0xa\n"                                                               \
+  ADD_PREV_                                                                                                          \
+  "s_set_gpr_idx_off\n s_bfe_u32 s42, s41, " BFE_ "\n s_bitcmp1_b32 s41, " BIT_ "\n s_cbranch_scc0 " L_ "f\n"        \
+  "s_waitcnt lgkmcnt(0)\n" RING_BARRIER L_ ":\n"
+#define RING_SB(I0_, I1_, I2_, I3_, I4_, I5_, I6_, I7_)                                                              \
+  RING_QUAD(I0_, I1_, RING_RD_A, RING_ADD_B, "0x60000", "6", "1")                                                    \
+  RING_QUAD(I2_, I3_, RING_RD_B, RING_ADD_A, "0x60008", "14", "2")                                                   \
+  RING_QUAD(I4_, I5_, RING_RD_A, RING_ADD_B, "0x60010", "22", "3")                                                   \
+  RING_QUAD(I6_, I7_, RING_RD_B, RING_ADD_A, "0x60018", "30", "4")
+#define RING_ZERO8(B_) "v_mov_b32 v" #B_ ", 0\n"
+#define RING_CLOB_V "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23",   \
+  "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42",      \
+  "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61",      \
+  "v62", "v63"
+
+__global__ void __launch_bounds__(1024) k_spmm_ring(const int32_t *__restrict__ wg_tab, const int32_t *__restrict__ wave_sb,
+                                                    const uint16_t *__restrict__ idx, const uint32_t *__restrict__ ctl,
+                                                    const int32_t *__restrict__ row_tab, int n_phases,
+                                                    const float4 *__restrict__ XS, int n_src, int W,
+                                                    const float *__restrict__ row_scale, const float *__restrict__ diag,
+                                                    const float *__restrict__ X, int64_t ldx, const float *__restrict__ bias,
+                                                    const float *__restrict__ prelu_a, float *__restrict__ out, int64_t ldo,
+                                                    float *__restrict__ out_pre) {
+  extern __shared__ __attribute__((aligned(16))) float4 panel[];
+  const int slice = wg_tab[2 * blockIdx.x], block = wg_tab[2 * blockIdx.x + 1];
+  if (slice < 0) return;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const float4 *__restrict__ xs = XS + (int64_t)slice * n_src * SPMM_SL;
+  if (wave == RING_WALK) {
+    // ---- loader: slot s = source rows [s * RS, (s + 1) * RS) -> buffer s % S, 1 KB (8 rows) per instruction, lanes past the operand off
+    auto issue = [&](int slot) {
+      const int r0 = slot * RING_RS;
+      const int nf4 = (n_src - r0 < RING_RS ? n_src - r0 : RING_RS) * SPMM_SL;
+      const float4 *__restrict__ src = xs + (int64_t)r0 * SPMM_SL;
+      float4 *dst = panel + (slot % RING_S) * RING_RS * SPMM_SL;
+#pragma unroll
+      for (int p = 0; p < RING_RS * SPMM_SL / 64; ++p) {
+        const int i = p * 64 + lane;
+        if (i < nf4)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i),
+                                           (__attribute__((address_space(3))) void *)(dst + p * 64), 16, 0, 0);
+      }
+    };
+#ifdef RING_NO_LOAD
+    __builtin_amdgcn_s_barrier();
+    for (int j = 0; j < n_phases; ++j) RING_LOADER_BARRIER();
+    return;
+#endif
+    for (int s = 0; s < RING_S - 1 && s < n_phases; ++s) issue(s);
+    __builtin_amdgcn_s_waitcnt(0x0f70);              // vmcnt(0) (lgkmcnt / expcnt untouched)
+    __builtin_amdgcn_s_barrier();                    // B0: the first window is resident
+    for (int j = 0; j < n_phases; ++j) {
+      if (j + RING_S - 1 < n_phases) issue(j + RING_S - 1);        // into the buffer phase j - 1 released
+      __builtin_amdgcn_s_waitcnt(0x0f70);
+      RING_LOADER_BARRIER();                         // end of phase j: slot j is free, slot j + V has landed
+    }
+    return;
+  }
+  const int g = lane >> 3, j = lane & 7;
+  if (tid < 2 * SPMM_SL) panel[RING_S * RING_RS * SPMM_SL + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int gw = block * RING_WALK + wave;
+  const int sb0 = __builtin_amdgcn_readfirstlane(wave_sb[2 * gw]), nsb = __builtin_amdgcn_readfirstlane(wave_sb[2 * gw + 1]);
+  const uint16_t *ip = idx + (int64_t)sb0 * 128;
+  const uint32_t *cp = ctl + sb0;
+  const uint32_t lane_off = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)panel + j * 16, grp_off = g * 16;
+  ring_v32f a0, a1;
+  asm volatile(
+      "s_mov_b64 s[36:37], %[ip]\n s_mov_b64 s[38:39], %[cp]\n s_mov_b32 s40, %[nsb]\n s_movk_i32 s43, 0x80\n s_mov_b32 s42, 0\n"
+      "v_mov_b32 v14, %[lane]\n v_mov_b32 v15, %[grp]\n v_mov_b32 v7, 0\n"
+      "global_load_dwordx4 v[48:51], v15, s[36:37]\n global_load_dwordx4 v[52:55], v15, s[36:37] offset:128\n"
+      "global_load_dword v12, v7, s[38:39]\n"
+      RING_ZERO8(32) RING_ZERO8(33) RING_ZERO8(34) RING_ZERO8(35) RING_ZERO8(36) RING_ZERO8(37) RING_ZERO8(38) RING_ZERO8(39)
+      RING_ZERO8(40) RING_ZERO8(41) RING_ZERO8(42) RING_ZERO8(43) RING_ZERO8(44) RING_ZERO8(45) RING_ZERO8(46) RING_ZERO8(47)
+      RING_ZERO8(64) RING_ZERO8(65) RING_ZERO8(66) RING_ZERO8(67) RING_ZERO8(68) RING_ZERO8(69) RING_ZERO8(70) RING_ZERO8(71)
+      RING_ZERO8(72) RING_ZERO8(73) RING_ZERO8(74) RING_ZERO8(75) RING_ZERO8(76) RING_ZERO8(77) RING_ZERO8(78) RING_ZERO8(79)
+      RING_ZERO8(80) RING_ZERO8(81) RING_ZERO8(82) RING_ZERO8(83) RING_ZERO8(84) RING_ZERO8(85) RING_ZERO8(86) RING_ZERO8(87)
+      RING_ZERO8(88) RING_ZERO8(89) RING_ZERO8(90) RING_ZERO8(91) RING_ZERO8(92) RING_ZERO8(93) RING_ZERO8(94) RING_ZERO8(95)
+      RING_ZERO8(96) RING_ZERO8(97) RING_ZERO8(98) RING_ZERO8(99) RING_ZERO8(100) RING_ZERO8(101) RING_ZERO8(102) RING_ZERO8(103)
+      RING_ZERO8(104) RING_ZERO8(105) RING_ZERO8(106) RING_ZERO8(107) RING_ZERO8(108) RING_ZERO8(109) RING_ZERO8(110) RING_ZERO8(111)
+      RING_ZERO8(112) RING_ZERO8(113) RING_ZERO8(114) RING_ZERO8(115) RING_ZERO8(116) RING_ZERO8(117) RING_ZERO8(118) RING_ZERO8(119)
+      RING_ZERO8(120) RING_ZERO8(121) RING_ZERO8(122) RING_ZERO8(123) RING_ZERO8(124) RING_ZERO8(125) RING_ZERO8(126) RING_ZERO8(127)
+      "s_waitcnt lgkmcnt(0)\n s_barrier\n"           // B0 (the zero rows were written before this statement)
+      "10:\n"                                        // ---- super-block in v[48:55] / v12; the next one goes to v[56:63] / v13
+      "s_add_u32 s36, s36, 0x100\n s_addc_u32 s37, s37, 0\n s_add_u32 s38, s38, 4\n s_addc_u32 s39, s39, 0\n"
+      "global_load_dwordx4 v[56:59], v15, s[36:37]\n global_load_dwordx4 v[60:63], v15, s[36:37] offset:128\n"
+      "global_load_dword v13, v7, s[38:39]\n"
+      "s_waitcnt vmcnt(3)\n v_readfirstlane_b32 s41, v12\n"
+      RING_SB("v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55")
+      "s_sub_u32 s40, s40, 1\n s_cmp_eq_u32 s40, 0\n s_cbranch_scc1 20f\n"
+      "s_add_u32 s36, s36, 0x100\n s_addc_u32 s37, s37, 0\n s_add_u32 s38, s38, 4\n s_addc_u32 s39, s39, 0\n"
+      "global_load_dwordx4 v[48:51], v15, s[36:37]\n global_load_dwordx4 v[52:55], v15, s[36:37] offset:128\n"
+      "global_load_dword v12, v7, s[38:39]\n"
+      "s_waitcnt vmcnt(3)\n v_readfirstlane_b32 s41, v13\n"
+      RING_SB("v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63")
+      "s_sub_u32 s40, s40, 1\n s_cmp_eq_u32 s40, 0\n s_cbranch_scc0 10b\n"
+      "20:\n"                                        // ---- the last quad's additions; no load may land after the statement
+      "s_waitcnt lgkmcnt(0)\n s_set_gpr_idx_on s42, 0xa\n" RING_ADD_B "s_set_gpr_idx_off\n s_waitcnt vmcnt(0)\n"
+      : "={v[64:95]}"(a0), "={v[96:127]}"(a1)
+      : [ip] "s"(ip), [cp] "s"(cp), [nsb] "s"(nsb), [lane] "v"(lane_off), [grp] "v"(grp_off)
+      : RING_CLOB_V, "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "scc", "memory");
+  const int vi = slice * SPMM_SL + j;
+  if (vi >= (W >> 2)) return;
+  const float a = prelu_a ? *prelu_a : 1.0f;
+  const int32_t *__restrict__ rt = row_tab + (int64_t)gw * RING_KR * 8 + g;
+#pragma unroll
+  for (int k = 0; k < RING_KR; ++k) {
+    const int rowv = rt[k * 8];
+    if (rowv < 0) continue;
+    float4 z = k < 8 ? make_float4(a0[4 * k], a0[4 * k + 1], a0[4 * k + 2], a0[4 * k + 3])
+                     : make_float4(a1[4 * (k & 7)], a1[4 * (k & 7) + 1], a1[4 * (k & 7) + 2], a1[4 * (k & 7) + 3]);
+    const int row = rowv & ~GGAD_SPMM_PANEL_WIDE;
+    if (rowv & GGAD_SPMM_PANEL_WIDE) {               // wide round: ONE row over the 8 lane groups (same flag in all 8 slots)
+#pragma unroll
+      for (int off = 8; off < GGAD_WAVE; off <<= 1) {                           // fixed butterfly over lane bits 3..5
+        z.x += __shfl_xor(z.x, off, GGAD_WAVE); z.y += __shfl_xor(z.y, off, GGAD_WAVE);
+        z.z += __shfl_xor(z.z, off, GGAD_WAVE); z.w += __shfl_xor(z.w, off, GGAD_WAVE);
+      }
+      if (g != 0) continue;
+    }
+    if (row_scale) { const float r = row_scale[row]; z.x *= r; z.y *= r; z.z *= r; z.w *= r; }
+    if (diag) {
+      const float dv = diag[row];
+      const float4 x = reinterpret_cast<const float4 *>(X + (int64_t)row * ldx)[vi];
+      z.x = fmaf(dv, x.x, z.x); z.y = fmaf(dv, x.y, z.y); z.z = fmaf(dv, x.z, z.z); z.w = fmaf(dv, x.w, z.w);
+    }
+    spmm_epilogue_store(z, vi, bias, prelu_a, a, out + (int64_t)row * ldo, out_pre ? out_pre + (int64_t)row * ldo : nullptr);
+  }
+}
+
 // rows split into several segments: out[row] = epilogue(sum of part[first .. first + count))   (fixed order)
 __global__ void __launch_bounds__(256) k_spmm_combine(const int32_t *__restrict__ multi_row, const int32_t *__restrict__ multi_first,
                                                       const int32_t *__restrict__ multi_count, int n_multi,
@@ -1127,6 +1306,49 @@ int ggad_spmm_panel_f32(const int32_t *wg_tab, int32_t n_wg, const uint32_t *dir
                                                                  reinterpret_cast<const float4 *>(xs_workspace), (int)n_src_rows, W,
                                                                  row_scale, diag, X, ldx, bias, prelu_a, out, ldo, out_pre);
   GGAD_CHECK_LAUNCH("spmm_panel_f32");
+  return GGAD_OK;
+}
+
+// k_spmm_ring: the same opt-in for its RING_LDS bytes (per device, under a mutex)
+static bool ring_lds_ready() {
+  static std::mutex mu;
+  static int state[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  std::lock_guard<std::mutex> lock(mu);
+  if (state[dev] == 0) {
+    const bool ok = hipFuncSetAttribute((const void *)k_spmm_ring, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS) == hipSuccess;
+    (void)hipGetLastError();
+    state[dev] = ok ? 1 : -1;
+  }
+  return state[dev] == 1;
+}
+int32_t ggad_spmm_ring_available(void) { return ring_lds_ready() ? 1 : 0; }
+int32_t ggad_spmm_ring_slot_rows(void) { return RING_RS; }
+int32_t ggad_spmm_ring_slots(void) { return RING_S; }
+int32_t ggad_spmm_ring_window(void) { return RING_V; }
+int32_t ggad_spmm_ring_walkers(void) { return RING_WALK; }
+int32_t ggad_spmm_ring_rounds(void) { return RING_KR; }
+
+int ggad_spmm_ring_f32(const int32_t *wg_tab, int32_t n_wg, const int32_t *wave_sb, const uint16_t *idx, const uint32_t *ctl,
+                       const int32_t *row_tab, int32_t n_phases, const float *col_scale, const float *row_scale, const float *diag,
+                       const float *X, int64_t ldx, int32_t W, int64_t n_src_rows, float *xs_workspace, const float *bias,
+                       const float *prelu_a, float *out, int64_t ldo, float *out_pre, ggad_stream_t stream_) {
+  GGAD_REQUIRE(wg_tab && wave_sb && idx && ctl && row_tab && X && out && xs_workspace && W >= 4 && (W & 3) == 0 && n_wg >= 0);
+  GGAD_REQUIRE((ldx & 3) == 0 && (ldo & 3) == 0 && ldx >= W && ldo >= W && n_src_rows >= 1);
+  const int S = spmm_n_slices(W);
+  GGAD_REQUIRE(n_src_rows * S * SPMM_SL < (1ll << 31));
+  GGAD_REQUIRE(n_phases == (int32_t)((n_src_rows + RING_RS - 1) / RING_RS));
+  if (n_wg == 0) return GGAD_OK;
+  hipStream_t st = as_stream(stream_);
+  if (!ring_lds_ready()) return GGAD_E_INVALID;
+  const int64_t nt = n_src_rows * S * SPMM_SL;
+  k_slice_major<<<dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st>>>(X, ldx, (int)n_src_rows, W, S, col_scale,
+                                                                        reinterpret_cast<float4 *>(xs_workspace));
+  k_spmm_ring<<<dim3((unsigned)n_wg), dim3(1024), RING_LDS, st>>>(wg_tab, wave_sb, idx, ctl, row_tab, n_phases,
+                                                                reinterpret_cast<const float4 *>(xs_workspace), (int)n_src_rows, W,
+                                                                row_scale, diag, X, ldx, bias, prelu_a, out, ldo, out_pre);
+  GGAD_CHECK_LAUNCH("spmm_ring_f32");
   return GGAD_OK;
 }
 

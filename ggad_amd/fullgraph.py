@@ -336,6 +336,172 @@ class Csr:
                     diag=None if diag is None else _dev_f32(diag, dev), fill=fill, blocks=int(nb), rounds=int(kr))
 
 
+    def ring_plan(self, n_slices: int, rows_sel: Optional[np.ndarray] = None, cache: Optional[dict] = None):
+        """Quad stream, control bytes, per-wave extents, row table and workgroup table of `ggad_spmm_ring_f32` (layout described at
+        k_spmm_ring in fullgraph.hip and in csrc/spmm_ring_build.cpp) for the whole matrix or the row subset `rows_sel`, or None
+        under the conditions of `panel_plan`.  Cached per slice count."""
+        key = ("ring", int(n_slices), os.environ.get("GGAD_RING_XCD", "slice"))
+        store = self._plans if cache is None else cache
+        if key in store:
+            return store[key]
+        fac = self.value_factors()
+        plan = None
+        if fac is not False and (rows_sel is None or fac[2] is None):
+            plan = self._build_ring(int(n_slices), fac, rows_sel)
+        store[key] = plan
+        return plan
+
+    def _build_ring(self, n_slices, fac, rows_sel=None):
+        import heapq
+        lib = _lib.load()
+        RS, S, V = int(lib.ggad_spmm_ring_slot_rows()), int(lib.ggad_spmm_ring_slots()), int(lib.ggad_spmm_ring_window())
+        NW, KR = int(lib.ggad_spmm_ring_walkers()), int(lib.ggad_spmm_ring_rounds())
+        m = self.host
+        n_rows, n_src = m.shape
+        rs, cs, diag = fac
+        skip_diag = 1 if diag is not None else 0                          # the diagonal is applied in the epilogue
+        rowptr = np.ascontiguousarray(m.indptr, dtype=np.int64)
+        colv = np.ascontiguousarray(m.indices, dtype=np.int32)
+        cnt = np.diff(rowptr)
+        if skip_diag:
+            cnt = cnt - (m.diagonal() != 0)
+        rows = None if rows_sel is None else np.asarray(rows_sel, dtype=np.int64)
+        if rows is not None:                                              # output row i = matrix row rows[i]
+            cnt = cnt[rows]
+            n_rows = len(rows)
+        nnz = int(cnt.sum())
+        if nnz == 0:
+            return None
+        order = np.argsort(-cnt, kind="stable")                           # rows of similar length share a round
+        NP = (n_src + RS - 1) // RS                                       # phases = slots of the operand
+        # hub rows get a WIDE round of their own (the row over all 8 lane groups), as in the panel plan: rows longer than half a
+        # wave's share, bounded by the accumulator slots that are free
+        nb0 = max(1, 256 // n_slices)
+        while -(-((n_rows + 7) // 8) // (nb0 * NW)) > KR:
+            nb0 += max(1, 256 // n_slices)
+        share = nnz / 8.0 / (nb0 * NW)
+        n_wide = int(np.searchsorted(-cnt[order], -max(256.0, share / 2.0), side="left"))
+        room = nb0 * NW * KR - (n_rows + 7) // 8
+        n_wide = max(0, min(n_wide, int(room * 8 // 7 * 0.9)))
+        n_norm_rounds = (n_rows - n_wide + 7) // 8
+        n_rounds = n_wide + n_norm_rounds
+        nb = kr = None
+        for mult in range(1, 65):                                         # workgroups ~ a multiple of the 256 CUs
+            nb = max(1, (256 * mult) // n_slices)
+            kr = -(-n_rounds // (nb * NW))
+            if kr <= KR:
+                break
+        if kr is None or kr > KR:
+            return None
+        src_rows = (order if rows is None else rows[order]).astype(np.int32)
+        round_rows = np.full((n_rounds, 8), -1, dtype=np.int32)
+        round_out = np.full((n_rounds, 8), -1, dtype=np.int32)
+        WIDE = 0x40000000
+        round_rows[:n_wide, :] = src_rows[:n_wide, None]
+        round_out[:n_wide, :] = (order[:n_wide, None] | WIDE).astype(np.int32)
+        rest = n_rows - n_wide
+        round_rows[n_wide:].reshape(-1)[:rest] = src_rows[n_wide:]
+        round_out[n_wide:].reshape(-1)[:rest] = order[n_wide:].astype(np.int32)
+        round_wide = np.zeros(n_rounds, dtype=np.int32)
+        round_wide[:n_wide] = 1
+        round_rows = np.ascontiguousarray(round_rows.reshape(-1))
+        quads = np.empty(n_rounds * NP, dtype=np.uint16)
+        hp = lambda a: a.ctypes.data
+        _lib.check(lib.ggad_spmm_ring_count(hp(rowptr), hp(colv), n_rounds, hp(round_rows), hp(round_wide), skip_diag, RS, S, V, NP,
+                                            hp(quads), 0), "ggad_spmm_ring_count")
+        quads = quads.reshape(n_rounds, NP)
+        work = quads.astype(np.int64).sum(1)
+        fill = nnz / float(max(1, int(work.sum())) * 32)
+        if fill < 0.4:
+            return None
+        # rounds to workgroups in a snake over their work, inside a workgroup longest first to the least loaded walker with a free slot
+        by_work = np.argsort(-work, kind="stable")
+        pos_w = np.arange(n_rounds, dtype=np.int64)
+        lap, ix = pos_w // nb, pos_w % nb
+        blk_of_round = np.empty(n_rounds, dtype=np.int64)
+        blk_of_round[by_work] = np.where(lap % 2 == 0, ix, nb - 1 - ix)
+        wave_of_round = np.empty(n_rounds, dtype=np.int64)
+        k_of_round = np.empty(n_rounds, dtype=np.int64)
+        members = [[] for _ in range(nb)]
+        for r_ in by_work.tolist():
+            members[blk_of_round[r_]].append(r_)
+        work_l = work.tolist()
+        for b in range(nb):
+            heap = [(0, w) for w in range(NW)]
+            used = [0] * NW
+            for r_ in members[b]:
+                load, w = heapq.heappop(heap)
+                wave_of_round[r_], k_of_round[r_] = w, used[w]
+                used[w] += 1
+                if used[w] < KR:
+                    heapq.heappush(heap, (load + work_l[r_], w))
+        gw_of_round = blk_of_round * NW + wave_of_round
+        n_gw = nb * NW
+        # stream of a walker: phase-major, inside a phase its rounds in accumulator order; a phase without work gets one dummy quad
+        # (zero rows) that carries the end-of-phase flag -- every walker meets every barrier
+        tab = np.zeros((n_gw, NP, KR + 1), dtype=np.int64)
+        tab[gw_of_round, :, k_of_round] = quads
+        tab[:, :, KR] = tab[:, :, :KR].sum(2) == 0
+        flat = tab.reshape(n_gw, NP * (KR + 1))
+        ends = np.cumsum(flat, axis=1)                                   # quads of the walker up to and including (phase, slot)
+        tq = ends[:, -1]
+        nsb = (tq + 3) // 4
+        sb_off = np.zeros(n_gw + 1, dtype=np.int64)
+        np.cumsum(nsb, out=sb_off[1:])
+        total_sb = int(sb_off[-1])
+        if total_sb * 128 >= 2 ** 31:
+            return None
+        starts = (ends - flat).reshape(n_gw, NP, KR + 1) + (sb_off[:-1] * 4)[:, None, None]
+        quad_off = np.ascontiguousarray(starts[gw_of_round, :, k_of_round])         # (n_rounds, NP): absolute quad of every tile
+        # control byte per quad: accumulator offset (4 * slot) in bits 0..5, bit 6 = last quad of its phase
+        ctl = np.zeros((total_sb + 1) * 4, dtype=np.uint8)
+        kbyte = np.tile(np.concatenate((np.arange(KR, dtype=np.int64) * 4, [0])), NP)
+        for g_ in range(n_gw):
+            base = int(sb_off[g_]) * 4
+            ctl[base:base + int(tq[g_])] = np.repeat(kbyte, flat[g_]).astype(np.uint8)
+            phase_end = ends[g_].reshape(NP, KR + 1)[:, -1] - 1 + base
+            ctl[phase_end] |= 0x40
+        idx = np.empty((total_sb + 1) * 128, dtype=np.uint16)            # one spare super-block: the walk prefetches one ahead
+        _lib.check(lib.ggad_spmm_ring_fill(hp(rowptr), hp(colv), n_rounds, hp(round_rows), hp(round_wide), skip_diag, RS, S, V, NP,
+                                           hp(np.ascontiguousarray(quads.reshape(-1))), hp(quad_off.reshape(-1)), hp(idx), total_sb + 1, 0),
+                   "ggad_spmm_ring_fill")
+        wave_sb = np.stack((sb_off[:-1], nsb), axis=1).astype(np.int32)
+        row_tab = np.full((n_gw * KR, 8), -1, dtype=np.int32)
+        row_tab[gw_of_round * KR + k_of_round] = round_out
+        # workgroup table (workgroup i runs on XCD i % 8).  "slice": the workgroups of a slice share an XCD and its L2 (slot loads hit);
+        # "block": the workgroups of a row block do (their common quad stream hits)
+        lists = [[] for _ in range(8)]
+        if os.environ.get("GGAD_RING_XCD", "slice") == "block":
+            allw = [(sl, b) for b in range(nb) for sl in range(n_slices)]
+            q, rem = divmod(len(allw), 8)
+            at = 0
+            for x in range(8):
+                take = q + (1 if x < rem else 0)
+                lists[x] = allw[at:at + take]
+                at += take
+        else:
+            full = (n_slices // 8) * 8
+            for sl in range(full):
+                lists[sl % 8].extend((sl, b) for b in range(nb))
+            for i, it in enumerate([(sl, b) for b in range(nb) for sl in range(full, n_slices)]):
+                lists[i % 8].append(it)
+        L = max(len(x) for x in lists)
+        wg = np.full((L * 8, 2), -1, dtype=np.int32)
+        for x in range(8):
+            if lists[x]:
+                wg[x + 8 * np.arange(len(lists[x]))] = np.asarray(lists[x], dtype=np.int32)
+        dev = self.dev
+        if rs is not None and rows is not None:
+            rs = rs[rows]
+        t16 = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int16)).to(dev)
+        per_phase = flat.reshape(n_gw, NP, KR + 1).sum(2)                 # quads per (walker, phase): the barrier waits for the longest
+        return dict(wg=_dev_i32(wg, dev), n_wg=int(L * 8), wave_sb=_dev_i32(wave_sb, dev), idx=t16(idx),
+                    ctl=torch.from_numpy(ctl.view(np.int32)).to(dev), row_tab=_dev_i32(row_tab, dev), n_phases=int(NP),
+                    rs=None if rs is None else _dev_f32(rs, dev), cs=None if cs is None else _dev_f32(cs, dev),
+                    diag=None if diag is None else _dev_f32(diag, dev), fill=fill, blocks=int(nb), rounds=int(kr),
+                    quads=int(tq.sum()), phase_skew=float(per_phase.reshape(nb, NW, NP).max(1).sum() / max(1.0, per_phase.sum() / NW)))
+
+
 class FullGraphAdj:
     """Everything the full-graph step needs from the two adjacency matrices, built once on the host.
 
@@ -493,9 +659,11 @@ def _use_panel(csr: Csr, p, X: torch.Tensor):
     nnz = p.get("nnz", csr.nnz)
     if force != "1" and not (w >= 64 and nnz >= 64 * p["n_out"] and nnz >= (1 << 20)):
         return None
+    ring = os.environ.get("GGAD_SPMM_RING", "1") != "0" and bool(_lib.load().ggad_spmm_ring_available())
+    build = Csr.ring_plan if ring else Csr.panel_plan                       # the LDS ring (k_spmm_ring) unless it is turned off
     if p.get("rows") is not None:                                         # row subset: the plan lives on the segment plan
-        return csr.panel_plan((w // 4 + 7) // 8, p["rows"], p.setdefault("panel_cache", {}))
-    return csr.panel_plan((w // 4 + 7) // 8)
+        return build(csr, (w // 4 + 7) // 8, p["rows"], p.setdefault("panel_cache", {}))
+    return build(csr, (w // 4 + 7) // 8)
 
 
 def _xs_workspace(X: torch.Tensor, n_ws: int) -> torch.Tensor:
@@ -529,8 +697,12 @@ def spmm(csr: Csr, X: torch.Tensor, plan=None, bias=None, prelu_a=None, want_pre
     if pp is not None:
         xs = _xs_workspace(X, int(_lib.load().ggad_spmm_sliced_workspace_elems(X.shape[0], W)))
         opt_p = lambda t: ptr(t) if t is not None else 0
-        call("ggad_spmm_panel_f32", ptr(pp["wg"]), pp["n_wg"], ptr(pp["dir"]), ptr(pp["stream"]), ptr(pp["row_tab"]), pp["n_chunks"],
-             opt_p(pp["cs"]), opt_p(pp["rs"]), opt_p(pp["diag"]), ptr(X), W, W, X.shape[0], ptr(xs), *opt)
+        if "wave_sb" in pp:
+            call("ggad_spmm_ring_f32", ptr(pp["wg"]), pp["n_wg"], ptr(pp["wave_sb"]), ptr(pp["idx"]), ptr(pp["ctl"]), ptr(pp["row_tab"]),
+                 pp["n_phases"], opt_p(pp["cs"]), opt_p(pp["rs"]), opt_p(pp["diag"]), ptr(X), W, W, X.shape[0], ptr(xs), *opt)
+        else:
+            call("ggad_spmm_panel_f32", ptr(pp["wg"]), pp["n_wg"], ptr(pp["dir"]), ptr(pp["stream"]), ptr(pp["row_tab"]), pp["n_chunks"],
+                 opt_p(pp["cs"]), opt_p(pp["rs"]), opt_p(pp["diag"]), ptr(X), W, W, X.shape[0], ptr(xs), *opt)
     elif _use_sliced(csr, p, X):
         if p["long"] is None:      # the sliced kernel walks long segments (8 index loads, one reduction and store per wave)
             # (GGAD_SPMM_COL_RANGES > 1 cuts them at column-range boundaries and launches range by range so that one phase's

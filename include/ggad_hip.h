@@ -485,6 +485,38 @@ int ggad_spmm_panel_f32(const int32_t *wg_tab, int32_t n_wg, const uint32_t *dir
                         int64_t ldx, int32_t W, int64_t n_src_rows, float *xs_workspace, const float *bias, const float *prelu_a,
                         float *out, int64_t ldo, float *out_pre, ggad_stream_t stream_);
 
+/* The same product (replaces torch.bmm(adj, .), model.py:31, under the conditions of ggad_spmm_panel_f32) with the operand slice
+ * passing through a RING of ggad_spmm_ring_slots() LDS slots of ggad_spmm_ring_slot_rows() source rows: during phase j the
+ * ggad_spmm_ring_walkers() walker waves of a workgroup read the slots j .. j + ggad_spmm_ring_window() - 1 while one more wave
+ * stages slot j + slots - 1 by LDS-DMA; one barrier per phase.  The entries are a host-built per-walker list of QUADS (4 steps x 8
+ * lane groups x 16-bit LDS row index; layout at k_spmm_ring in fullgraph.hip, built by ggad_amd/fullgraph.py::Csr.ring_plan):
+ * wg_tab[n_wg][2] = (slice, block) or (-1, -1); wave_sb[block * walkers + wave][2] = {first super-block (4 quads), count};
+ * idx = [super-block][2 halves][8 lane groups][2 quads][4 steps] uint16 (+ one spare super-block); ctl = one byte per quad:
+ * bits 0..5 = 4 * accumulator slot (< ggad_spmm_ring_rounds()), bit 6 = last quad of its phase (every walker flags every phase);
+ * row_tab[(block * walkers + wave) * rounds + slot][8] = output row (| GGAD_SPMM_PANEL_WIDE) or -1; n_phases = ceil(n_src_rows /
+ * slot_rows).  Deterministic; agrees with the other SpMM kernels to fp32 round-off.
+ * Host half (csrc/spmm_ring_build.cpp, host pointers, threads): ggad_spmm_ring_count -> quads_rp[round][phase] = quads the round
+ * walks in that phase under the flexible schedule (a lane group without open entry in the slot that is overwritten next walks
+ * its next entries anywhere in the window); ggad_spmm_ring_fill writes idx given the absolute first quad of every (round, phase)
+ * tile (quad_off), n_sb = super-blocks of idx including the spare one.  round_rows / round_wide / skip_diag as for the panel plan. */
+int ggad_spmm_ring_count(const int64_t *rowptr, const int32_t *col, int32_t n_rounds, const int32_t *round_rows,
+                         const int32_t *round_wide, int32_t skip_diag, int32_t slot_rows, int32_t n_ring_slots, int32_t window,
+                         int32_t n_phases, uint16_t *quads_rp, int32_t n_threads);
+int ggad_spmm_ring_fill(const int64_t *rowptr, const int32_t *col, int32_t n_rounds, const int32_t *round_rows,
+                        const int32_t *round_wide, int32_t skip_diag, int32_t slot_rows, int32_t n_ring_slots, int32_t window,
+                        int32_t n_phases, const uint16_t *quads_rp, const int64_t *quad_off, uint16_t *idx, int64_t n_sb,
+                        int32_t n_threads);
+int32_t ggad_spmm_ring_available(void);
+int32_t ggad_spmm_ring_slot_rows(void);
+int32_t ggad_spmm_ring_slots(void);
+int32_t ggad_spmm_ring_window(void);
+int32_t ggad_spmm_ring_walkers(void);
+int32_t ggad_spmm_ring_rounds(void);
+int ggad_spmm_ring_f32(const int32_t *wg_tab, int32_t n_wg, const int32_t *wave_sb, const uint16_t *idx, const uint32_t *ctl,
+                       const int32_t *row_tab, int32_t n_phases, const float *col_scale, const float *row_scale, const float *diag,
+                       const float *X, int64_t ldx, int32_t W, int64_t n_src_rows, float *xs_workspace, const float *bias,
+                       const float *prelu_a, float *out, int64_t ldo, float *out_pre, ggad_stream_t stream_);
+
 /* PReLU backward: dz = g * (z > 0 ? 1 : a); db[W] = column sums of dz; *da = sum g * z * [z <= 0].
  * workspace: float[2 * ggad_prelu_bwd_splits(M) * W].  db / da may be NULL. */
 int32_t ggad_prelu_bwd_splits(int32_t M);

@@ -327,9 +327,11 @@ def test_prelu_backward_kernel_against_autograd(shape):
         assert torch.equal(x.view(torch.int32), y.view(torch.int32))
 
 
+@pytest.mark.parametrize("ring", ["1", "0"])
 @pytest.mark.parametrize("w", [300, 64, 4])
-def test_spmm_lds_panel_equals_row_major(w, monkeypatch):
-    """The LDS-panel product (k_spmm_panel: operand staged in 1,270-row panels, values factored into row / column scales, the
+def test_spmm_lds_panel_equals_row_major(w, ring, monkeypatch):
+    """The LDS-ring product (k_spmm_ring, ring = "1": operand slice through a ring of LDS slots staged by a loader wave, flexible
+    schedule) and the LDS-panel product (k_spmm_panel: operand staged in 1,270-row panels, values factored into row / column scales, the
     diagonal applied in the epilogue) against the wave-per-segment kernel and scipy: normalised adjacency with `+ I`
     (3 panels, the last one partial) with bias + PReLU + pre-activation, and a 0/1 pattern matrix (diagonal inside the
     stream); deterministic; row subsets (panels for the pattern matrix, segments where the diagonal is separate); a matrix whose values do
@@ -342,13 +344,14 @@ def test_spmm_lds_panel_equals_row_major(w, monkeypatch):
     x = torch.from_numpy(rng.standard_normal((n, w)).astype(np.float32)).to(DEV)
     bias = torch.from_numpy(rng.standard_normal(w).astype(np.float32)).to(DEV)
     slope = torch.tensor([0.25], device=DEV)
+    monkeypatch.setenv("GGAD_SPMM_RING", ring)
     for mat in (U.normalize_adj(a) + sp.eye(n), U.normalize_adj(a + sp.eye(n)), (a + sp.eye(n)).tocsr()):
         csr = FG.Csr(mat, DEV)
         monkeypatch.setenv("GGAD_SPMM_PANEL", "0")
         monkeypatch.setenv("GGAD_SPMM_SLICED", "0")
         o0, pre0 = FG.spmm(csr, x, bias=bias, prelu_a=slope, want_pre=True)
         monkeypatch.setenv("GGAD_SPMM_PANEL", "1")
-        assert FG._use_panel(csr, csr.plan(), x) is not None
+        assert ("wave_sb" in FG._use_panel(csr, csr.plan(), x)) == (ring == "1")
         o1, pre1 = FG.spmm(csr, x, bias=bias, prelu_a=slope, want_pre=True)
         o2 = FG.spmm(csr, x, bias=bias, prelu_a=slope)
         ref = csr.host.astype(np.float64) @ x.cpu().numpy().astype(np.float64) + bias.cpu().numpy().astype(np.float64)
@@ -367,13 +370,15 @@ def test_spmm_lds_panel_equals_row_major(w, monkeypatch):
     assert FG._use_panel(csr, csr.plan(), x) is None
 
 
-def test_spmm_lds_panel_single_partial_panel_and_rectangular(monkeypatch):
-    """Operands shorter than one panel (one partial panel, the zero rows behind it) and a rectangular pattern matrix (the N x |J|
+@pytest.mark.parametrize("ring", ["1", "0"])
+def test_spmm_lds_panel_single_partial_panel_and_rectangular(ring, monkeypatch):
+    """Operands shorter than one panel / ring slot (one partial panel, the zero rows behind it) and a rectangular pattern matrix (the N x |J|
     column subset of the affinity backward, `run.py:182-188`): forced LDS-panel product against scipy."""
     import scipy.sparse as sp
     rng = np.random.default_rng(5)
     monkeypatch.setenv("GGAD_SPMM_PANEL", "1")
-    for n_rows, n_src, dens in ((900, 900, 0.2), (2000, 700, 0.15), (300, 2900, 0.1)):
+    monkeypatch.setenv("GGAD_SPMM_RING", ring)
+    for n_rows, n_src, dens in ((900, 900, 0.2), (2000, 700, 0.15), (300, 2900, 0.1), (150, 200, 0.5)):
         a = sp.random(n_rows, n_src, density=dens, random_state=7, format="csr", dtype=np.float32)
         a.data[:] = 1.0
         csr = FG.Csr(a, DEV)
