@@ -523,14 +523,24 @@ constexpr int RING_LDS = (RING_S * RING_RS + 2) * SPMM_SL * 16;   // ring + two 
 static_assert(RING_LDS <= 160 * 1024 && RING_RS % 8 == 0, "ring must fit the 160 KB of a CU; slots are whole 1 KB pieces");
 typedef float ring_v32f __attribute__((ext_vector_type(32)));
 
-#define RING_RD(X0_, X1_, X2_, X3_)                                                                                  \
-  "ds_read_b128 " X0_ ", v8\n ds_read_b128 " X1_ ", v9\n ds_read_b128 " X2_ ", v10\n ds_read_b128 " X3_ ", v11\n"
-#ifdef RING_NO_ADD
-#define RING_ADD4(AB_, CD_) ""
+// (timing experiments only, scripts/ring_variants.sh: -DRING_NO_BARRIER / -DRING_NO_ADD / -DRING_NO_LOAD / -DRING_NO_IDX give wrong results)
+#ifdef RING_NO_IDX
+#define RING_IDX_ON ""
+#define RING_IDX_OFF ""
 #else
-#define RING_ADD4(AB_, CD_) "v_pk_add_f32 v[64:65], " AB_ ", v[64:65]\n v_pk_add_f32 v[66:67], " CD_ ", v[66:67]\n"
+#define RING_IDX_ON "s_set_gpr_idx_on s42, 0xa\n"
+#define RING_IDX_OFF "s_set_gpr_idx_off\n"
 #endif
-// (timing experiments only, scripts/ring_variants.sh: -DRING_NO_BARRIER / -DRING_NO_ADD / -DRING_NO_LOAD give wrong results)
+#ifdef RING_NO_ADD
+#define RING_ADD2(AB_, CD_) ""
+#else
+#define RING_ADD2(AB_, CD_) "v_pk_add_f32 v[64:65], " AB_ ", v[64:65]\n v_pk_add_f32 v[66:67], " CD_ ", v[66:67]\n"
+#endif
+#ifdef RING_NO_STREAM_ADV
+#define RING_ADV "s_add_u32 s38, s38, 4\n s_addc_u32 s39, s39, 0\n"          /* every walker re-reads its first super-block of indices */
+#else
+#define RING_ADV "s_add_u32 s36, s36, 0x100\n s_addc_u32 s37, s37, 0\n s_add_u32 s38, s38, 4\n s_addc_u32 s39, s39, 0\n"
+#endif
 #ifdef RING_NO_BARRIER
 #define RING_BARRIER ""
 #define RING_LOADER_BARRIER()
@@ -538,26 +548,52 @@ typedef float ring_v32f __attribute__((ext_vector_type(32)));
 #define RING_BARRIER "s_barrier\n"
 #define RING_LOADER_BARRIER() __builtin_amdgcn_s_barrier()
 #endif
-#define RING_RD_A RING_RD("v[16:19]", "v[20:23]", "v[24:27]", "v[28:31]")
-#define RING_RD_B RING_RD("v[32:35]", "v[36:39]", "v[40:43]", "v[44:47]")
-#define RING_ADD_A RING_ADD4("v[16:17]", "v[18:19]") RING_ADD4("v[20:21]", "v[22:23]") RING_ADD4("v[24:25]", "v[26:27]") RING_ADD4("v[28:29]", "v[30:31]")
-#define RING_ADD_B RING_ADD4("v[32:33]", "v[34:35]") RING_ADD4("v[36:37]", "v[38:39]") RING_ADD4("v[40:41]", "v[42:43]") RING_ADD4("v[44:45]", "v[46:47]")
-// one quad: addresses of its 4 steps, its 4 reads, then -- while they fly -- the additions of the PREVIOUS quad into the
-// accumulator s42 selects; afterwards s42 = this quad's accumulator offset (control bits 0..5 of its byte), and a set bit 6 ends
-// the phase: all reads of this wave have returned, the barrier releases the slot
-#define RING_QUAD(W0_, W1_, RD_CUR_, ADD_PREV_, BFE_, BIT_, L_)                                                      \
-  "v_mad_u32_u16 v8, " W0_ ", s43, v14\n v_mad_u32_u16 v9, " W0_ ", s43, v14 op_sel:[1,0,0,0]\n"                      \
-  "v_mad_u32_u16 v10, " W1_ ", s43, v14\n v_mad_u32_u16 v11, " W1_ ", s43, v14 op_sel:[1,0,0,0]\n"                    \
-  RD_CUR_                                                                                                            \
-  "s_waitcnt lgkmcnt(4)\n s_set_gpr_idx_on s42, 0xa\n"                                                               \
-  ADD_PREV_                                                                                                          \
-  "s_set_gpr_idx_off\n s_bfe_u32 s42, s41, " BFE_ "\n s_bitcmp1_b32 s41, " BIT_ "\n s_cbranch_scc0 " L_ "f\n"        \
-  "s_waitcnt lgkmcnt(0)\n" RING_BARRIER L_ ":\n"
-#define RING_SB(I0_, I1_, I2_, I3_, I4_, I5_, I6_, I7_)                                                              \
-  RING_QUAD(I0_, I1_, RING_RD_A, RING_ADD_B, "0x60000", "6", "1")                                                    \
-  RING_QUAD(I2_, I3_, RING_RD_B, RING_ADD_A, "0x60008", "14", "2")                                                   \
-  RING_QUAD(I4_, I5_, RING_RD_A, RING_ADD_B, "0x60010", "22", "3")                                                   \
-  RING_QUAD(I6_, I7_, RING_RD_B, RING_ADD_A, "0x60018", "30", "4")
+// The walk is a software pipeline over PAIRS of steps, 4 pair slots of 8 registers (v[16:47]): at pair time t the two reads of pair t
+// have returned (at most the 6 of the pairs t+1 .. t+3 are outstanding), they are added into the accumulator s42 selects, and the reads
+// of pair t + 4 -- two quads ahead in the list -- go into the slot that just became free: 6 to 8 reads of every walker in flight at
+// all times.  A quad whose control byte has bit 6 set ends a phase on the READ side: after its last read is issued the walker waits
+// for all its reads and meets the barrier, then goes on reading (the additions of the two quads before run on behind it).
+#define RING_SLOT0(F_) F_("v[16:17]", "v[18:19]", "v[20:21]", "v[22:23]", "v[16:19]", "v[20:23]")
+#define RING_SLOT1(F_) F_("v[24:25]", "v[26:27]", "v[28:29]", "v[30:31]", "v[24:27]", "v[28:31]")
+#define RING_SLOT2(F_) F_("v[32:33]", "v[34:35]", "v[36:37]", "v[38:39]", "v[32:35]", "v[36:39]")
+#define RING_SLOT3(F_) F_("v[40:41]", "v[42:43]", "v[44:45]", "v[46:47]", "v[40:43]", "v[44:47]")
+#define RING_ADDS_(A_, B_, C_, D_, R0_, R1_) RING_IDX_ON RING_ADD2(A_, B_) RING_ADD2(C_, D_) RING_IDX_OFF
+#define RING_READS_(A_, B_, C_, D_, R0_, R1_) "ds_read_b128 " R0_ ", v8\n ds_read_b128 " R1_ ", v9\n"
+// A: the additions of the pair in SLOT_ (LGKM_ = reads that may still be outstanding), into the accumulator of control byte BFE_ of CTL_
+#define RING_A(SLOT_, LGKM_, CTL_, BFE_) "s_bfe_u32 s42, " CTL_ ", " BFE_ "\n s_waitcnt lgkmcnt(" LGKM_ ")\n" SLOT_(RING_ADDS_)
+// R: addresses (16-bit LDS row index * 128 + lane part, from either half of the stream word W_) and reads of a pair into SLOT_
+#define RING_R(SLOT_, W_) "v_mad_u32_u16 v8, " W_ ", s43, v14\n v_mad_u32_u16 v9, " W_ ", s43, v14 op_sel:[1,0,0,0]\n" SLOT_(RING_READS_)
+// F: end of a phase after the reads of a quad whose control byte (bit BIT_ of CTL_) says so
+#define RING_F(CTL_, BIT_) "s_bitcmp1_b32 " CTL_ ", " BIT_ "\n s_cbranch_scc0 9f\n s_waitcnt lgkmcnt(0)\n" RING_BARRIER "9:\n"
+// one super-block (4 quads = 8 pair times): words C4_ .. C7_ (quads 2, 3: still to be read) and control s41 of the current super-block,
+// N0_ .. N3_ (quads 0, 1) and control CTLV_ -> s44 of the next one.  The stream of the super-block after next is requested as early as
+// its registers are free: first half + control at the top (LOAD0_), second half after the current quads 2, 3 have been read (LOAD1_):
+// every stream load has 1.5 super-blocks (6 quads) of walk to arrive.  Loads return in order: vmcnt(3) leaves the 3 younger ones out.
+#define RING_BODY(C4_, C5_, C6_, C7_, N0_, N1_, N2_, N3_, CTLV_, LOAD0_, LOAD1_)                                     \
+  "s_waitcnt vmcnt(3)\n" RING_ADV LOAD0_                                                                             \
+  RING_A(RING_SLOT0, "6", "s41", "0x60000") RING_R(RING_SLOT0, C4_)                                                  \
+  RING_A(RING_SLOT1, "6", "s41", "0x60000") RING_R(RING_SLOT1, C5_) RING_F("s41", "22")                              \
+  RING_A(RING_SLOT2, "6", "s41", "0x60008") RING_R(RING_SLOT2, C6_)                                                  \
+  RING_A(RING_SLOT3, "6", "s41", "0x60008") RING_R(RING_SLOT3, C7_) RING_F("s41", "30")                              \
+  "s_waitcnt vmcnt(3)\n v_readfirstlane_b32 s44, " CTLV_ "\n" LOAD1_                                                 \
+  RING_A(RING_SLOT0, "6", "s41", "0x60010") RING_R(RING_SLOT0, N0_)                                                  \
+  RING_A(RING_SLOT1, "6", "s41", "0x60010") RING_R(RING_SLOT1, N1_) RING_F("s44", "6")                               \
+  RING_A(RING_SLOT2, "6", "s41", "0x60018") RING_R(RING_SLOT2, N2_)                                                  \
+  RING_A(RING_SLOT3, "6", "s41", "0x60018") RING_R(RING_SLOT3, N3_) RING_F("s44", "14")                              \
+  "s_mov_b32 s41, s44\n"
+// the last super-block of a walker: its quads 2, 3 are read, nothing after them
+#define RING_TAIL(C4_, C5_, C6_, C7_)                                                                                \
+  "s_waitcnt vmcnt(3)\n"                                                                                             \
+  RING_A(RING_SLOT0, "6", "s41", "0x60000") RING_R(RING_SLOT0, C4_)                                                  \
+  RING_A(RING_SLOT1, "6", "s41", "0x60000") RING_R(RING_SLOT1, C5_) RING_F("s41", "22")                              \
+  RING_A(RING_SLOT2, "6", "s41", "0x60008") RING_R(RING_SLOT2, C6_)                                                  \
+  RING_A(RING_SLOT3, "6", "s41", "0x60008") RING_R(RING_SLOT3, C7_) RING_F("s41", "30")                              \
+  RING_A(RING_SLOT0, "6", "s41", "0x60010") RING_A(RING_SLOT1, "4", "s41", "0x60010")                                \
+  RING_A(RING_SLOT2, "2", "s41", "0x60018") RING_A(RING_SLOT3, "0", "s41", "0x60018")
+#define RING_LOAD0_A "global_load_dwordx4 v[48:51], v15, s[36:37]\n global_load_dword v12, v7, s[38:39]\n"
+#define RING_LOAD1_A "global_load_dwordx4 v[52:55], v15, s[36:37] offset:128\n"
+#define RING_LOAD0_B "global_load_dwordx4 v[56:59], v15, s[36:37]\n global_load_dword v13, v7, s[38:39]\n"
+#define RING_LOAD1_B "global_load_dwordx4 v[60:63], v15, s[36:37] offset:128\n"
 #define RING_ZERO8(B_) "v_mov_b32 v" #B_ ", 0\n"
 #define RING_CLOB_V "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23",   \
   "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42",      \
@@ -618,12 +654,11 @@ __global__ void __launch_bounds__(1024) k_spmm_ring(const int32_t *__restrict__ 
   const uint32_t lane_off = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)panel + j * 16, grp_off = g * 16;
   ring_v32f a0, a1;
   asm volatile(
-      "s_mov_b64 s[36:37], %[ip]\n s_mov_b64 s[38:39], %[cp]\n s_mov_b32 s40, %[nsb]\n s_movk_i32 s43, 0x80\n s_mov_b32 s42, 0\n"
+      "s_mov_b64 s[36:37], %[ip]\n s_mov_b64 s[38:39], %[cp]\n s_mov_b32 s40, %[nsb]\n s_movk_i32 s43, 0x80\n"
       "v_mov_b32 v14, %[lane]\n v_mov_b32 v15, %[grp]\n v_mov_b32 v7, 0\n"
-      "global_load_dwordx4 v[48:51], v15, s[36:37]\n global_load_dwordx4 v[52:55], v15, s[36:37] offset:128\n"
-      "global_load_dword v12, v7, s[38:39]\n"
-      RING_ZERO8(32) RING_ZERO8(33) RING_ZERO8(34) RING_ZERO8(35) RING_ZERO8(36) RING_ZERO8(37) RING_ZERO8(38) RING_ZERO8(39)
-      RING_ZERO8(40) RING_ZERO8(41) RING_ZERO8(42) RING_ZERO8(43) RING_ZERO8(44) RING_ZERO8(45) RING_ZERO8(46) RING_ZERO8(47)
+      RING_LOAD0_A RING_LOAD1_A                      // super-block 0 -> v[48:55] / v12, super-block 1 -> v[56:63] / v13
+      RING_ADV
+      RING_LOAD0_B RING_LOAD1_B
       RING_ZERO8(64) RING_ZERO8(65) RING_ZERO8(66) RING_ZERO8(67) RING_ZERO8(68) RING_ZERO8(69) RING_ZERO8(70) RING_ZERO8(71)
       RING_ZERO8(72) RING_ZERO8(73) RING_ZERO8(74) RING_ZERO8(75) RING_ZERO8(76) RING_ZERO8(77) RING_ZERO8(78) RING_ZERO8(79)
       RING_ZERO8(80) RING_ZERO8(81) RING_ZERO8(82) RING_ZERO8(83) RING_ZERO8(84) RING_ZERO8(85) RING_ZERO8(86) RING_ZERO8(87)
@@ -632,25 +667,21 @@ __global__ void __launch_bounds__(1024) k_spmm_ring(const int32_t *__restrict__ 
       RING_ZERO8(104) RING_ZERO8(105) RING_ZERO8(106) RING_ZERO8(107) RING_ZERO8(108) RING_ZERO8(109) RING_ZERO8(110) RING_ZERO8(111)
       RING_ZERO8(112) RING_ZERO8(113) RING_ZERO8(114) RING_ZERO8(115) RING_ZERO8(116) RING_ZERO8(117) RING_ZERO8(118) RING_ZERO8(119)
       RING_ZERO8(120) RING_ZERO8(121) RING_ZERO8(122) RING_ZERO8(123) RING_ZERO8(124) RING_ZERO8(125) RING_ZERO8(126) RING_ZERO8(127)
-      "s_waitcnt lgkmcnt(0)\n s_barrier\n"           // B0 (the zero rows were written before this statement)
-      "10:\n"                                        // ---- super-block in v[48:55] / v12; the next one goes to v[56:63] / v13
-      "s_add_u32 s36, s36, 0x100\n s_addc_u32 s37, s37, 0\n s_add_u32 s38, s38, 4\n s_addc_u32 s39, s39, 0\n"
-      "global_load_dwordx4 v[56:59], v15, s[36:37]\n global_load_dwordx4 v[60:63], v15, s[36:37] offset:128\n"
-      "global_load_dword v13, v7, s[38:39]\n"
-      "s_waitcnt vmcnt(3)\n v_readfirstlane_b32 s41, v12\n"
-      RING_SB("v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55")
-      "s_sub_u32 s40, s40, 1\n s_cmp_eq_u32 s40, 0\n s_cbranch_scc1 20f\n"
-      "s_add_u32 s36, s36, 0x100\n s_addc_u32 s37, s37, 0\n s_add_u32 s38, s38, 4\n s_addc_u32 s39, s39, 0\n"
-      "global_load_dwordx4 v[48:51], v15, s[36:37]\n global_load_dwordx4 v[52:55], v15, s[36:37] offset:128\n"
-      "global_load_dword v12, v7, s[38:39]\n"
-      "s_waitcnt vmcnt(3)\n v_readfirstlane_b32 s41, v13\n"
-      RING_SB("v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63")
-      "s_sub_u32 s40, s40, 1\n s_cmp_eq_u32 s40, 0\n s_cbranch_scc0 10b\n"
-      "20:\n"                                        // ---- the last quad's additions; no load may land after the statement
-      "s_waitcnt lgkmcnt(0)\n s_set_gpr_idx_on s42, 0xa\n" RING_ADD_B "s_set_gpr_idx_off\n s_waitcnt vmcnt(0)\n"
+      "s_waitcnt vmcnt(4)\n v_readfirstlane_b32 s41, v12\n"
+      "s_waitcnt lgkmcnt(0)\n s_barrier\n"           // B0 (the zero rows were written before this statement): the first window is resident
+      RING_R(RING_SLOT0, "v48") RING_R(RING_SLOT1, "v49") RING_F("s41", "6")           // quads 0, 1 of the list: the pipeline fills
+      RING_R(RING_SLOT2, "v50") RING_R(RING_SLOT3, "v51") RING_F("s41", "14")
+      "10:\n s_cmp_eq_u32 s40, 1\n s_cbranch_scc1 12f\n"
+      RING_BODY("v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v13", RING_LOAD0_A, RING_LOAD1_A)
+      "s_sub_u32 s40, s40, 1\n s_cmp_eq_u32 s40, 1\n s_cbranch_scc1 13f\n"
+      RING_BODY("v60", "v61", "v62", "v63", "v48", "v49", "v50", "v51", "v12", RING_LOAD0_B, RING_LOAD1_B)
+      "s_sub_u32 s40, s40, 1\n s_branch 10b\n"
+      "12:\n" RING_TAIL("v52", "v53", "v54", "v55") "s_branch 14f\n"
+      "13:\n" RING_TAIL("v60", "v61", "v62", "v63")
+      "14:\n s_waitcnt vmcnt(0)\n"                   // no stream load may land after the statement
       : "={v[64:95]}"(a0), "={v[96:127]}"(a1)
       : [ip] "s"(ip), [cp] "s"(cp), [nsb] "s"(nsb), [lane] "v"(lane_off), [grp] "v"(grp_off)
-      : RING_CLOB_V, "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "scc", "memory");
+      : RING_CLOB_V, "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "scc", "memory");
   const int vi = slice * SPMM_SL + j;
   if (vi >= (W >> 2)) return;
   const float a = prelu_a ? *prelu_a : 1.0f;

@@ -177,42 +177,51 @@ int ggad_spmm_ring_fill(const int64_t *rowptr, const int32_t *col, int32_t n_rou
   int bad = 0;
   parallel_rounds(n_rounds, n_threads, [&](int32_t r0, int32_t r1) {
     LaneRows L;
-    std::vector<uint16_t> seq[GROUPS];
     for (int32_t r = r0; r < r1; ++r) {
       const bool wide = round_wide && round_wide[r];
       L.load(rowptr, col, round_rows + (int64_t)r * GROUPS, wide, skip_diag != 0, R);
       schedule_round(L, R, [&](int32_t j, int32_t T, const size_t (*pos)[2], const int32_t (*take)[2]) {
         const int64_t q0 = quad_off[(int64_t)r * n_phases + j];
         if (quads_rp[(int64_t)r * n_phases + j] != T / 4 || q0 < 0 || q0 + T / 4 > n_sb * 4) { __atomic_store_n(&bad, 1, __ATOMIC_RELAXED); return; }
-        // order inside a (tile, lane row): the first row of a bank-sharing pair takes its entries even, odd, even, ... (LDS row
-        // parity), the second odd, even, ...; what is left of the longer parity follows; a slot without entry reads the zero row of
-        // the parity its partner's entry does not have
-        int32_t tk[GROUPS];
-        for (int g = 0; g < GROUPS; ++g) {
-          auto &s = seq[g];
-          tk[g] = take[g][0] + take[g][1];
-          s.assign((size_t)tk[g], 0);
-          const int32_t mn = std::min(take[g][0], take[g][1]);
-          const int first = FIRST_ODD[g] ? 1 : 0;
-          for (int par = 0; par < 2; ++par)
-            for (int32_t k = 0; k < take[g][par]; ++k) {
-              const int32_t t = par == first ? k + std::min(k, mn) : k + std::min(k + 1, mn);
-              s[(size_t)t] = (uint16_t)R.lds_row(L.e[g][par][pos[g][par] + (size_t)k]);
-            }
-        }
+        // order inside a tile: the two lane rows of a bank-sharing pair (their 128-byte rows meet in two 16-lane service groups of the
+        // ds_read_b128) must read LDS rows of OPPOSITE parity in the same step.  Per pair and step, greedily: the parity assignment
+        // (even, odd) or (odd, even) under which more of the two rows have an entry left (ties: the one that takes from the longer
+        // lists); a row without entry of its parity reads the zero row of that parity if it can still afford a padded step, else it
+        // takes an entry of the other parity (a collision: + 2 LDS cycles for that half wave).
         for (int g = 0; g < GROUPS; ++g) {
           const int q = PARTNER[g];
+          if (g > q) continue;
+          int32_t left[2][2] = {{take[g][0], take[g][1]}, {take[q][0], take[q][1]}};     // [row of the pair][parity]
+          size_t at_e[2][2] = {{pos[g][0], pos[g][1]}, {pos[q][0], pos[q][1]}};
+          const int grp[2] = {g, q};
           for (int32_t t = 0; t < T; ++t) {
-            uint16_t v;
-            if (t < tk[g]) v = seq[g][(size_t)t];
-            else {
-              bool partner_odd = !FIRST_ODD[g];        // both padded: first rows read the even zero row, second rows the odd one
-              if (t < tk[q]) partner_odd = seq[q][(size_t)t] & 1;
-              if (wide) partner_odd = !FIRST_ODD[g];   // (a wide group only ever reads rows of its own parity class)
-              v = partner_odd ? zero_even : zero_odd;
+            const int32_t rem = T - t;
+            int best = 0, best_score = -1;
+            for (int asg = 0; asg < 2; ++asg) {                            // asg 0: row 0 reads even, row 1 odd; asg 1: the other way
+              int score = 0;
+              for (int r = 0; r < 2; ++r) {
+                const int par = asg ^ r;
+                const int32_t tot = left[r][0] + left[r][1];
+                if (left[r][par] > 0) score += 4 + (left[r][par] >= left[r][par ^ 1] ? 1 : 0);
+                else if (tot >= rem) score -= 8;                          // no slack: this row would have to collide
+              }
+              if (score > best_score) { best_score = score; best = asg; }
             }
-            idx[at(q0 + (t >> 2), g, t & 3)] = v;
+            for (int r = 0; r < 2; ++r) {
+              int par = best ^ r;
+              const int32_t tot = left[r][0] + left[r][1];
+              uint16_t v;
+              if (left[r][par] == 0 && tot >= rem && tot > 0) par ^= 1;     // forced: an entry of the other parity
+              if (left[r][par] > 0) {
+                v = (uint16_t)R.lds_row(L.e[grp[r]][par][at_e[r][par]++]);
+                --left[r][par];
+              } else {
+                v = par ? zero_odd : zero_even;
+              }
+              idx[at(q0 + (t >> 2), grp[r], t & 3)] = v;
+            }
           }
+          if (left[0][0] | left[0][1] | left[1][0] | left[1][1]) __atomic_store_n(&bad, 1, __ATOMIC_RELAXED);
         }
       });
     }

@@ -454,16 +454,16 @@ class Csr:
         starts = (ends - flat).reshape(n_gw, NP, KR + 1) + (sb_off[:-1] * 4)[:, None, None]
         quad_off = np.ascontiguousarray(starts[gw_of_round, :, k_of_round])         # (n_rounds, NP): absolute quad of every tile
         # control byte per quad: accumulator offset (4 * slot) in bits 0..5, bit 6 = last quad of its phase
-        ctl = np.zeros((total_sb + 1) * 4, dtype=np.uint8)
+        ctl = np.zeros((total_sb + 2) * 4, dtype=np.uint8)
         kbyte = np.tile(np.concatenate((np.arange(KR, dtype=np.int64) * 4, [0])), NP)
         for g_ in range(n_gw):
             base = int(sb_off[g_]) * 4
             ctl[base:base + int(tq[g_])] = np.repeat(kbyte, flat[g_]).astype(np.uint8)
             phase_end = ends[g_].reshape(NP, KR + 1)[:, -1] - 1 + base
             ctl[phase_end] |= 0x40
-        idx = np.empty((total_sb + 1) * 128, dtype=np.uint16)            # one spare super-block: the walk prefetches one ahead
+        idx = np.empty((total_sb + 2) * 128, dtype=np.uint16)            # two spare super-blocks: the walk requests its stream two ahead
         _lib.check(lib.ggad_spmm_ring_fill(hp(rowptr), hp(colv), n_rounds, hp(round_rows), hp(round_wide), skip_diag, RS, S, V, NP,
-                                           hp(np.ascontiguousarray(quads.reshape(-1))), hp(quad_off.reshape(-1)), hp(idx), total_sb + 1, 0),
+                                           hp(np.ascontiguousarray(quads.reshape(-1))), hp(quad_off.reshape(-1)), hp(idx), total_sb + 2, 0),
                    "ggad_spmm_ring_fill")
         wave_sb = np.stack((sb_off[:-1], nsb), axis=1).astype(np.int32)
         row_tab = np.full((n_gw * KR, 8), -1, dtype=np.int32)

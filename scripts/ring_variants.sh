@@ -3,7 +3,7 @@
 #   bash scripts/ring_variants.sh build      -> gpurun_variants/libggad_<variant>.so
 # and on the GPU box:  bash scripts/ring_variants.sh run [t_finance]
 cd "$(dirname "$0")/.."
-V="NO_BARRIER NO_ADD NO_LOAD NO_BARRIER_NO_LOAD NO_BARRIER_NO_ADD"
+V=${RING_VARIANTS:-"NO_BARRIER NO_ADD NO_IDX NO_BARRIER_NO_ADD"}
 if [ "$1" = build ]; then
   mkdir -p gpurun_variants
   python -m ggad_amd.build > /dev/null
