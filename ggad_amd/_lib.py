@@ -21,6 +21,7 @@ class GgadKernelError(RuntimeError):
     pass
 
 
+ABI_VERSION = 5    # what this binding was written against (include/ggad_hip.h, runtime.cpp); `load` refuses any other library
 _P = c_void_p      # device (or host) pointer
 EXCHANGE_CB = ctypes.CFUNCTYPE(c_int32, c_void_p)      # int exchange(void *user): the data-parallel all-reduce hook
 _I = c_int32
@@ -76,6 +77,7 @@ SIGNATURES = {
     "ggad_mb_xcd_record_elems": (c_int64, [_L, _L]),
     "ggad_mb_xcd_prepare": (c_int32, [_P, _I, _P, _I, _I, _I, _L, _L, _P, _P]),
     "ggad_mb_xcd_status": (c_int32, [_P, _P, _P]),
+    "ggad_mb_xcd_clear_error": (c_int32, [_P, _I, _P]),
     "ggad_mb_param_count": (c_int64, [_I, _I]),
     "ggad_mb_param_block_elems": (c_int64, [_I, _I]),
     "ggad_mb_params_sync": (c_int32, [_P, _I, _I, _P]),
@@ -219,6 +221,9 @@ def load(path: str = LIB_PATH) -> ctypes.CDLL:
             raise GgadLibraryError(f"{path} does not export {name}; rebuild it") from exc
         fn.restype = res
         fn.argtypes = args
+    if int(lib.ggad_abi_version()) != ABI_VERSION:
+        raise GgadLibraryError(f"{path} has ABI {int(lib.ggad_abi_version())}, this binding needs {ABI_VERSION}; rebuild it "
+                               "(`python -m ggad_amd.build --force`)")
     _lib = lib
     return lib
 

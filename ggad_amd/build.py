@@ -19,7 +19,7 @@ LIB = os.path.join(HERE, "libggad_hip.so")
 STAMP = os.path.join(HERE, ".libggad_hip.stamp")
 SOURCES = ["runtime.cpp", "plan_build.cpp", "exchange.cpp", "sampler.cpp", "sampler_x86.cpp", "spmm_panel_build.cpp", "spmm_ring_build.cpp", "plan.hip", "hop2_ldsw.hip", "step.hip", "step_xcd.hip", "fullgraph.hip", "gemm.hip", "baselines.hip"]
 HOST_ONLY = {"sampler.cpp", "sampler_x86.cpp", "spmm_panel_build.cpp", "spmm_ring_build.cpp"}      # plain C++ (x86 intrinsics behind a run-time CPU check), no device pass
-HEADERS = ["common.h", "step_common.h", os.path.join("..", "..", "include", "ggad_hip.h")]
+HEADERS = ["common.h", "step_common.h", "libggad_hip.map", os.path.join("..", "..", "include", "ggad_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-fno-fast-math",
          "-Wall", "-Wno-unused-function"] + os.environ.get("GGAD_EXTRA_HIPFLAGS", "").split()      # e.g. -DGGAD_G2_PROF (scripts/g2_phase_clocks.py)
 
@@ -63,7 +63,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for s, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {s}")
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + os.path.join(CSRC, "libggad_hip.map"), "-o", LIB] + objs
     if verbose:
         print("[ggad build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)

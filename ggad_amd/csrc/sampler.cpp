@@ -25,6 +25,7 @@
 
 #include "../../include/ggad_hip.h"
 
+#pragma GCC visibility push(hidden)
 extern "C" {          // sampler_x86.cpp
 int ggad_x86_has_avx2(void);
 int ggad_x86_accept8(const uint32_t *y, int sh, uint32_t bound, int32_t *out);
@@ -32,6 +33,7 @@ int ggad_x86_accept_run(const uint32_t *y, int avail, int64_t n, int64_t *c_io, 
 void ggad_x86_temper(const uint32_t *in, uint32_t *out, int n);
 void ggad_x86_mt_twist(uint32_t *mt624);
 }
+#pragma GCC visibility pop
 
 struct ggad_mt19937 {
   uint32_t mt[624];

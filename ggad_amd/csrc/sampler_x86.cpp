@@ -60,6 +60,7 @@ __attribute__((target("avx2,popcnt"))) static inline bool accept_window(const ui
 
 }  // namespace
 
+#pragma GCC visibility push(hidden)        // internal to the library: not part of the C ABI (tests/test_abi.py)
 extern "C" {
 
 int ggad_x86_has_avx2(void) { return __builtin_cpu_supports("avx2") ? 1 : 0; }
@@ -160,3 +161,4 @@ __attribute__((target("avx2"))) void ggad_x86_temper(const uint32_t *in, uint32_
 }
 
 }  // extern "C"
+#pragma GCC visibility pop

@@ -71,7 +71,15 @@ struct XcdCtrl {
   unsigned long long prof[16];        // wall clocks (100 MHz) of rank 0 per phase (0..7) and sub-phase (8..15), accumulated over the launch
   unsigned done, helpers, pad[2];     // done: the chunk kernel has left; helpers: registration counter of the helper kernel
 };
-static_assert(sizeof(XcdCtrl) <= 1024 && sizeof(XcdCtrl) % 16 == 0, "control block is 256 floats of the workspace");
+static_assert(sizeof(XcdCtrl) <= 1020 && sizeof(XcdCtrl) % 16 == 0, "control block is 256 floats of the workspace");
+// The control block is cleared at every launch; the LAST word of its 256-float region is not: it keeps the first error code of ANY
+// launch since the host last cleared it (ggad_mb_xcd_clear_error), so a time-out of chunk k is still visible after chunk k + 1 has
+// reset `err` (the host reads the status once per run, not once per chunk).
+constexpr int XCD_STICKY_WORD = 255;
+__device__ __forceinline__ void xcd_fail(XcdCtrl *C, unsigned code) {
+  C->err = code;
+  atomicCAS(reinterpret_cast<unsigned *>(C) + XCD_STICKY_WORD, 0u, code);
+}
 
 struct XcdArgs {
   ggad_mb_step s;
@@ -121,7 +129,7 @@ __device__ __forceinline__ bool xcd_barrier(XcdCtrl *C, int rank, int G, unsigne
       if (__all((int)(v - round) >= 0)) break;
       __builtin_amdgcn_s_sleep(1);
       if ((++spins & 1023) == 0 && (wall_clock64() - t0 > timeout || cldu(&C->err) != 0)) {
-        if (threadIdx.x == 0) { C->err = 1; C->done = 1; s_dead = 1; }
+        if (threadIdx.x == 0) { xcd_fail(C, 1); C->done = 1; s_dead = 1; }
         break;
       }
     }
@@ -248,9 +256,9 @@ __global__ void __launch_bounds__(XT) k_train_chunk_xcd(XcdArgs A) {
       const unsigned long long t0 = wall_clock64();
       while (r < A.nv && cldu(&C->reg[xcc][0]) < (unsigned)A.nv) {
         __builtin_amdgcn_s_sleep(2);
-        if (cldu(&C->err) != 0 || wall_clock64() - t0 > A.timeout_ticks) { C->err = 2; C->done = 1; r = -1; break; }
+        if (cldu(&C->err) != 0 || wall_clock64() - t0 > A.timeout_ticks) { xcd_fail(C, 2); C->done = 1; r = -1; break; }
       }
-      if (r >= A.nv) { C->err = 3; r = -1; }                // more than grid / 8 workgroups on one XCD: not the dealing we rely on
+      if (r >= A.nv) { xcd_fail(C, 3); r = -1; }                // more than grid / 8 workgroups on one XCD: not the dealing we rely on
       if (r == 0) {
         C->survivors = (unsigned)A.nv; C->xcc = xcc;
         __hip_atomic_store(&C->placed, A.launch_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -1190,17 +1198,29 @@ int ggad_mb_train_chunk_xcd(const ggad_mb_step *tmpl, int32_t n_batches, const i
 }
 
 /* Control words of the LAST launch that used `workspace` (device -> host copy on `stream`, synchronises it):
- * out[0] error (0 ok, 1 barrier time-out, 2 registration time-out), out[1] workgroups that stayed, out[2] their XCD,
+ * out[0] error (0 ok, 1 barrier time-out, 2 registration time-out, 3 placement) -- of the last launch, or, when that one was clean,
+ * the first error of any launch since ggad_mb_xcd_clear_error (sticky); out[1] workgroups that stayed, out[2] their XCD,
  * out[3..10] phase clocks of rank 0 in 10 ns ticks (A, barrier, R, barrier, C, barrier, E, barrier). */
 int ggad_mb_xcd_status(const float *workspace, int64_t *out19, ggad_stream_t stream) {
   GGAD_REQUIRE(workspace && out19);
   int64_t *out11 = out19;
-  XcdCtrl h;
+  union { XcdCtrl c; unsigned w[256]; } h;
   hipStream_t st = as_stream(stream);
-  if (hipMemcpyAsync(&h, workspace, sizeof(XcdCtrl), hipMemcpyDeviceToHost, st) != hipSuccess) return GGAD_E_LAUNCH;
+  if (hipMemcpyAsync(&h, workspace, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess) return GGAD_E_LAUNCH;
   if (hipStreamSynchronize(st) != hipSuccess) return GGAD_E_LAUNCH;
-  out11[0] = h.err; out11[1] = h.survivors; out11[2] = h.xcc;
-  for (int k = 0; k < 16; ++k) out11[3 + k] = (int64_t)h.prof[k];
+  out11[0] = h.c.err ? h.c.err : h.w[XCD_STICKY_WORD]; out11[1] = h.c.survivors; out11[2] = h.c.xcc;
+  for (int k = 0; k < 16; ++k) out11[3 + k] = (int64_t)h.c.prof[k];
+  return GGAD_OK;
+}
+
+/* Clears the sticky error word of `workspace` (after the host has dealt with it), or -- code != 0 -- sets it as a launch that timed
+ * out would (tests of the host's recovery path). */
+int ggad_mb_xcd_clear_error(float *workspace, int32_t code, ggad_stream_t stream) {
+  GGAD_REQUIRE(workspace && code >= 0);
+  const unsigned v = (unsigned)code;
+  hipStream_t st = as_stream(stream);
+  if (hipMemcpyAsync(reinterpret_cast<unsigned *>(workspace) + XCD_STICKY_WORD, &v, sizeof(v), hipMemcpyHostToDevice, st) != hipSuccess) return GGAD_E_LAUNCH;
+  if (hipStreamSynchronize(st) != hipSuccess) return GGAD_E_LAUNCH;
   return GGAD_OK;
 }
 

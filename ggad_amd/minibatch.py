@@ -49,8 +49,12 @@ def _rows_as_flat(rows):
         r0, nb = (pa - p0) // (8 * w), len(rows)
         if (pa - p0) % (8 * w) or pz - pa != 8 * w * (nb - 1) or r0 + nb > base.shape[0]:
             return None
-        if nb > 2 and rows[nb // 2].ctypes.data - pa != 8 * w * (nb // 2):     # (a list that merely starts and ends like one)
-            return None
+        if nb > 2:       # EVERY row where the matrix has it (a list that merely starts and ends like a slice -- rows permuted by a
+            #              hook, say -- must not be built in matrix order): one vectorised comparison of nb pointers
+            ptrs = np.fromiter((r.__array_interface__["data"][0] if (r.base is base and r.ndim == 1 and len(r) == w) else -1
+                                for r in rows), dtype=np.int64, count=nb)
+            if not np.array_equal(ptrs, pa + 8 * w * np.arange(nb, dtype=np.int64)):
+                return None
         return base[r0:r0 + nb].reshape(-1)
     except (AttributeError, IndexError, TypeError):
         return None
@@ -285,6 +289,13 @@ class BatchChunk:
             # and a run that ramps 5 -> 20 -> 150 batches per build paid it inside every one of its first windows
             f = 1.1 * min(64.0, self.max_batches / max(1, nb)) if nb < self.max_batches else 1.0
             lim = 1_600_000_000                                   # (int32 offsets into pc[] / items[] / part2[])
+            if self.dev.type == "cuda":
+                # ... but never beyond a quarter of the memory that is free now: a small first build that happens to hold hub rows
+                # extrapolates to tens of gigabytes (pair counts 2 B, items 8-48 B, partial sums 4 F B per unit); what this build
+                # needs is always granted
+                free = torch.cuda.mem_get_info(self.dev)[0]
+                per_f = 2.0 * int(I.need_pairs) + 48.0 * int(I.need_items) + 4.0 * self.stride * int(I.need_part2) + 1.0
+                f = max(1.0, min(f, 0.25 * free / per_f))
             self._alloc(I.need_rows, I.need_ents, I.need_chunks, I.need_stage, max(int(I.need_pairs), min(lim, int(I.need_pairs * f))),
                         max(int(I.need_items), min(lim // 16, int(I.need_items * f))),
                         max(int(I.need_part2), min(lim // 32, int(I.need_part2 * f))), max(int(I.need_seg), int(I.need_seg * min(f, self.ent_cap / max(1, int(I.need_ents))))))
@@ -552,6 +563,11 @@ class MiniBatchEngine:
         return dict(error=int(out[0]), workgroups=int(out[1]), xcc=int(out[2]),
                     phase_us={n: out[3 + k] / 100.0 for k, n in enumerate(names)},
                     sub_us=[out[11 + k] / 100.0 for k in range(8)])
+
+    def set_resident_error(self, code: int = 0) -> None:
+        """Clear the sticky error word of the resident kernel's workspace (code 0), or set it as a timed-out launch would (tests)."""
+        if self.xcd_ws is not None:
+            _lib.check(self.lib.ggad_mb_xcd_clear_error(ptr(self.xcd_ws), int(code), _lib.current_stream()), "ggad_mb_xcd_clear_error")
 
     def check_resident(self) -> None:
         """Raise if the last XCD-resident launch timed out at a barrier (it leaves instead of hanging the GPU)."""

@@ -166,6 +166,11 @@ class DGraphTrainer:
         self.prefetch = bool(prefetch)
         self._stream = None
         self._pending = ([], [])        # batches taken from the sampler stream but not consumed yet
+        # recovery from a time-out of the XCD-resident chunk kernel (single process): optimiser state at the last check point and
+        # the batches of every run since -- `check_exchange` replays them on the launch chain when the kernel reported an error
+        self._snap = None
+        self._window = None             # list of (n_steps, nodes, labels) since the snapshot, or None: nothing recorded
+        self.resident_fallbacks = 0
 
     def plan_stream_first_xcd(self) -> int:
         """XCD on which block 0 of a launch on the plan stream runs right now (diagnostics: the index-skipping plan launches were
@@ -185,7 +190,12 @@ class DGraphTrainer:
         if self.exchange is not None:
             err = int(self.exchange.error() != 0)
         if self.engine.xcd_ws is not None and self.engine.xcd_status()["error"]:
-            err |= 2
+            if self.world == 1 and self._window:
+                self._replay_on_chain()                      # recoverable here: state of the last check point + the batches since
+            else:
+                err |= 2
+        elif self._window is not None:
+            self._window = None                              # a clean check point: the next run takes a fresh snapshot
         if dist is not None and self.world > 1 and dist.is_available() and dist.is_initialized():
             t = torch.tensor([err], dtype=torch.int32, device=self.feat.device if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -353,6 +363,7 @@ class DGraphTrainer:
         """Run n optimiser steps; returns nodes processed by THIS rank."""
         sizes = self.default_ramp(n_steps)
         pos = [0]
+        record = self._replay_begin()                 # (None unless the resident kernel runs and a replay could be needed)
 
         producer = None
         stream = getattr(self, "_stream", None) if prepared is None else None
@@ -372,7 +383,7 @@ class DGraphTrainer:
             producer = threading.Thread(target=produce, daemon=True)
             producer.start()
 
-        def take(k):
+        def take_raw(k):
             if prepared is not None:
                 bn, bl = prepared[0][pos[0]:pos[0] + k], prepared[1][pos[0]:pos[0] + k]
                 pos[0] += k
@@ -385,6 +396,13 @@ class DGraphTrainer:
                     raise item
                 return item
             return self.schedule.next_batches(k, self.sched_rank, self.sched_world)
+
+        def take(k):
+            bn, bl = take_raw(k)
+            if record is not None:
+                record[1].extend(bn)
+                record[2].extend(bl)
+            return bn, bl
 
         def build(ch, bn, bl):
             ch.build(bn, bl) if gather_hook is None else gather_hook(ch, bn, bl)
@@ -437,4 +455,49 @@ class DGraphTrainer:
         if producer is not None:
             producer.join()
         self.steps_done += n_steps
+        if record is not None and self._window is not None:
+            self._window.append((int(n_steps), record[1], record[2]))
         return nodes_seen
+
+    # ---- recovery from a time-out of the resident chunk kernel
+    _REPLAY_MAX_STEPS = 2048             # (a caller that never checks does not accumulate batches for ever)
+
+    def _replay_begin(self):
+        """Called at the top of `run_steps`.  While the resident kernel is in use (one process: with peers a replay would have to be
+        collective) the first run after a check point copies the optimiser state aside -- one fused multi-tensor copy on the current
+        stream -- and every run records its batches (references to the host arrays the sampler delivered)."""
+        e = self.engine
+        if not (e.resident and self.world == 1 and e.dev.type == "cuda"):
+            self._window = None
+            return None
+        live = [e.params, e.exp_avg, e.exp_avg_sq, e.step_counter]
+        if self._window is None or sum(w[0] for w in self._window) > self._REPLAY_MAX_STEPS:
+            if self._snap is None:
+                self._snap = [torch.empty_like(t) for t in live]
+            torch._foreach_copy_(self._snap, live)
+            self._window = []
+            self._window_steps0 = self.steps_done
+        return (None, [], [])
+
+    def _replay_on_chain(self) -> None:
+        """The resident kernel reported a time-out since the last check point: some optimiser steps are missing or half applied.
+        Restore the state of the check point, turn the resident kernel off for the rest of this trainer's life and run the
+        recorded batches again through the launch chain (the same kernels `resident=False` uses: bit-identical to a run that
+        never used the resident kernel)."""
+        import warnings
+        e = self.engine
+        window, self._window = self._window, None
+        warnings.warn("ggad_amd: the XCD-resident chunk kernel timed out (code %d); replaying %d optimiser steps on the launch "
+                      "chain and continuing without it" % (e.xcd_status()["error"], sum(w[0] for w in window)))
+        torch.cuda.synchronize(e.dev)
+        e.set_resident_error(0)
+        e.resident = False
+        self.resident_split = False
+        for ch in self.chunks:
+            ch.xcd_skip = -1
+        torch._foreach_copy_([e.params, e.exp_avg, e.exp_avg_sq, e.step_counter], self._snap)
+        self.steps_done = self._window_steps0
+        self.resident_fallbacks += 1
+        for n, bn, bl in window:
+            self.run_steps(n, prepared=(bn, bl))
+        torch.cuda.synchronize(e.dev)

@@ -374,6 +374,11 @@ int64_t ggad_mb_xcd_record_elems(int64_t rows_cap, int64_t pieces_cap);
 int ggad_mb_xcd_prepare(const ggad_mb_step *tmpl, int32_t n_batches, const int32_t *batch_ptr_dev, int32_t n_rows, int32_t n_pieces,
                         int32_t n_ents, int64_t rows_cap, int64_t pieces_cap, int32_t *records, ggad_stream_t stream);
 int ggad_mb_xcd_status(const float *workspace, int64_t *out19, ggad_stream_t stream);
+/* out19[0] of ggad_mb_xcd_status is STICKY: the control block is cleared at every launch, the first error code of any launch since the
+ * last ggad_mb_xcd_clear_error(workspace, 0, stream) is not (the caller allocates the workspace zeroed).  code != 0 sets the word as a
+ * launch that timed out would: the host's recovery path (ggad_amd/trainer.py: restore the entry snapshot, replay on the launch chain)
+ * is tested with it.  Synchronises `stream`. */
+int ggad_mb_xcd_clear_error(float *workspace, int32_t code, ggad_stream_t stream);
 
 /* Inference embeddings: h[i] = relu(W x1[i])  (GCNEncoder.forward, train_flag False).   graphsage.py:412 */
 int ggad_mb_encode(const float *params, int32_t D, int32_t F, const float *x1, int32_t n_rows, float *h,

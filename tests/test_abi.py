@@ -22,7 +22,32 @@ def test_library_builds_and_loads():
     path = build(verbose=False)
     assert os.path.exists(path)
     lib = _lib.load()
-    assert lib.ggad_abi_version() >= 1
+    assert lib.ggad_abi_version() == _lib.ABI_VERSION == 5
+
+
+def test_only_the_c_abi_is_exported():
+    """The dynamic symbol table holds the ggad_* entry points of include/ggad_hip.h and nothing else: no C++-mangled internal
+    (csrc/libggad_hip.map)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    names = [ln.split()[-1] for ln in out.splitlines() if ln.strip()]
+    assert len(names) > 100
+    assert [n for n in names if not n.startswith("ggad_")] == []
+    assert set(names) == set(_declared_symbols())
+
+
+def test_integration_doc_stub_runs_against_this_library():
+    """The ctypes stub INTEGRATION.md shows a maintainer (section 2): its first lines are executed as written -- the library
+    loads, the ABI version it asserts is the one the library reports, the structures it imports exist."""
+    import re
+    text = open(os.path.join(os.path.dirname(__file__), "..", "INTEGRATION.md")).read()
+    block = re.search(r"```python\n(import ctypes, numpy as np, torch.*?)\n```", text, re.S).group(1)
+    head = "\n".join(block.splitlines()[:6])
+    assert "ggad_abi_version() ==" in head and "argtypes" in head
+    ns = {}
+    exec(compile(head, "INTEGRATION.md", "exec"), ns)
+    assert ns["lib"].ggad_abi_version() == _lib.ABI_VERSION
+    assert f"ABI version {_lib.ABI_VERSION}" in text
 
 
 def test_every_declared_symbol_is_exported_and_bound():

@@ -202,6 +202,9 @@ def test_model_handler_end_to_end_vs_reference_run(tmp_path, monkeypatch):
     assert np.array_equal(np.array(ds["idx_anomaly"]), g["idx_anomaly"])
     assert synth.crc_of(np.asarray(ds["feat_data"], dtype=np.float32)) == int(g["feat_crc"])
     res = h.train()
+    # the path under test is the DEFAULT one: the XCD-resident chunk kernel, which must not have fallen back to the launch chain
+    assert h.trainer.engine.resident and h.trainer.resident_fallbacks == 0
+    assert h.trainer.engine.xcd_status()["error"] == 0
     ref = g["batch_losses"]
     got = h.last_epoch_losses
     assert got.shape == (150, 4)

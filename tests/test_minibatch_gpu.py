@@ -156,6 +156,33 @@ def test_loss_grads_adam_trajectory_vs_golden(name):
 
 
 @pytest.mark.parametrize("name", ["minibatch_small.npz", "minibatch_dense.npz"])
+def test_resident_chunk_kernel_trajectory_vs_golden(name):
+    """The DEFAULT hot path -- all optimiser steps of the chunk in the ONE launch resident on one XCD (`ggad_mb_train_chunk_xcd`,
+    reference loop `src/model_handler.py:330-364`) -- directly against the reference's golden trajectory: per-step losses and the
+    weights after the last Adam step (`final.*`), with the launch's own status word clean."""
+    g = load_golden(name)
+    if int(g["f"]) != 17:
+        pytest.skip("the resident kernel is built for the 17 DGraph-Fin features")
+    graph, feat, ch = _setup(g)
+    eng = MiniBatchEngine(int(g["f"]), int(g["d"]), DEV, lr=1e-3, weight_decay=0.007, resident=True)
+    eng.load_params(g["init.weight"], g["init.enc.weight"], g["init.enc.fc.weight"])
+    batches = [b for b in g["batches"]]
+    labels = [l for l in g["labels"]]
+    ch.build(batches, labels)
+    assert eng.resident
+    eng.train_chunk(ch)
+    torch.cuda.synchronize()
+    st = eng.xcd_status()
+    assert st["error"] == 0 and st["workgroups"] == 32, st
+    k = len(batches)
+    assert int(eng.step_counter.item()) == k
+    np.testing.assert_allclose(eng.losses(k), g["losses"], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(eng.weight.cpu().numpy(), g["final.weight"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(eng.enc_weight.cpu().numpy(), g["final.enc.weight"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(eng.enc_fc_weight.cpu().numpy(), g["final.enc.fc.weight"], atol=2e-5, rtol=0)
+
+
+@pytest.mark.parametrize("name", ["minibatch_small.npz", "minibatch_dense.npz"])
 def test_to_prob_vs_golden(name):
     g = load_golden(name)
     graph, feat, ch = _setup(g, train=False, max_batches=4)
@@ -572,6 +599,93 @@ def test_overlapped_chunks_equal_serial_execution():
     np.testing.assert_array_equal(chain[0][1], chain[1][1])
     np.testing.assert_allclose(chain[0][0], outs[0][0], atol=2e-6, rtol=0)
     np.testing.assert_allclose(chain[0][1], outs[0][1], atol=2e-6, rtol=0)
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_resident_kernel_error_is_sticky_and_recovered_on_the_launch_chain(overlap):
+    """A time-out of the XCD-resident chunk kernel (VERDICT r3 / ADVICE: its error word was reset by the next launch and aborted
+    training): the error is STICKY across launches, and at the next check point the trainer restores the optimiser state of the
+    previous check point, replays the recorded batches on the launch chain -- bit-identical to a trainer that never used the
+    resident kernel -- and goes on without it."""
+    import warnings
+    from ggad_amd.sampler import PyCompatRandom
+    from ggad_amd.trainer import BatchSchedule, DGraphTrainer
+    n = 30000
+    rowptr, col = synth.make_graph(n, 300000, 2, kind="powerlaw", max_degree=400)
+    feat_np = O.normalize_rows(synth.make_features(n, 17, 2)).astype(np.float32)
+    labels = np.zeros(n, dtype=np.int64)
+    pool = np.arange(1000, 1600)
+    labels[pool] = 1
+    train = np.arange(2000, 20000)
+    torch.manual_seed(4)
+    w = torch.nn.init.xavier_uniform_(torch.empty(1, 64))
+    W = torch.nn.init.xavier_uniform_(torch.empty(64, 17))
+    fc = torch.nn.init.xavier_uniform_(torch.empty(64, 64))
+
+    def make(resident):
+        graph = DeviceGraph(rowptr, col, DEV)
+        feat = torch.from_numpy(feat_np).to(DEV)
+        sched = BatchSchedule(train.copy(), pool.copy(), labels, 60, PyCompatRandom(72), n_pseudo=20, batches_per_epoch=5)
+        tr = DGraphTrainer(graph, feat, 64, sched, chunk_batches=3, overlap=overlap, prefetch=False,
+                           dense_cus=None if resident else 32)
+        assert bool(tr.engine.resident) == resident
+        tr.engine.load_params(w, W, fc)
+        return tr
+
+    def state(tr):
+        e = tr.engine
+        return [t.cpu().numpy().copy() for t in (e.params, e.exp_avg, e.exp_avg_sq, e.step_counter)]
+
+    chain = make(False)
+    chain.run_steps(4)
+    torch.cuda.synchronize()
+    chain.check_exchange()
+    mid = state(chain)
+    chain.run_steps(7)
+    chain.run_steps(5)
+    torch.cuda.synchronize()
+    want, want_losses = state(chain), chain.engine.losses(5).copy()
+
+    tr = make(True)
+    tr.run_steps(4)
+    torch.cuda.synchronize()
+    tr.check_exchange()                                      # a clean check point: the window starts again behind it
+    assert tr.resident_fallbacks == 0 and tr.engine.xcd_status()["error"] == 0
+    for a, b in zip(state(tr), mid):
+        np.testing.assert_allclose(a, b, atol=2e-6, rtol=1e-4)
+    tr.run_steps(7)
+    torch.cuda.synchronize()
+    tr.engine.set_resident_error(2)                          # as a chunk of this run whose registration wait timed out
+    tr.engine.params.mul_(1.5)                               # ... and left the weights in some half-updated state
+    tr.run_steps(5)                                          # the next launches clear their control block: the error must survive
+    torch.cuda.synchronize()
+    assert tr.engine.xcd_status()["error"] == 2
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        tr.check_exchange()
+    assert any("replaying 12 optimiser steps" in str(c.message) for c in caught)
+    assert tr.resident_fallbacks == 1 and not tr.engine.resident and tr.steps_done == 16
+    assert tr.engine.xcd_status()["error"] == 0
+    # the 4 resident steps before the check point stay (round-off away from the chain's); the 12 replayed ones ran on the chain
+    for a, b in zip(state(tr), want):
+        np.testing.assert_allclose(a, b, atol=4e-6, rtol=1e-4)
+    np.testing.assert_allclose(tr.engine.losses(5), want_losses, atol=4e-6, rtol=0)
+    # bit-exactness of the replay itself: a chain trainer started from the resident trainer's check-point state
+    ref = make(False)
+    ref.run_steps(4)                                         # (advances the sampler stream exactly as `tr` did)
+    torch.cuda.synchronize()
+    snap = tr._snap
+    for dst, src in zip((ref.engine.params, ref.engine.exp_avg, ref.engine.exp_avg_sq, ref.engine.step_counter), snap):
+        dst.copy_(src)
+    ref.run_steps(7)
+    ref.run_steps(5)
+    torch.cuda.synchronize()
+    for a, b in zip(state(tr), state(ref)):
+        np.testing.assert_array_equal(a, b)
+    tr.run_steps(3)                                          # and training goes on (launch chain)
+    torch.cuda.synchronize()
+    tr.check_exchange()
+    assert int(tr.engine.step_counter.item()) == 19
 
 
 def test_chunk_parallel_forward_on_hub_batches_equals_six_launch_chain():

@@ -127,5 +127,7 @@ def test_schedule_rows_are_recognised_as_one_flat_block():
     assert flat is not None and np.shares_memory(flat, m) and np.array_equal(flat, m.reshape(-1))
     assert np.array_equal(_rows_as_flat(rows[3:9]), m[3:9].reshape(-1))
     for other in ([m[0], m[2], m[4]], [m[0], m[5], m[2]], [m[0], m[2], m[2]], [np.arange(5), np.arange(5)],
+                  [m[0], m[3], m[2], m[1], m[4]], [m[0], m[1], m[3], m[2], m[4], m[5], m[6]],      # first / middle / last in place, others permuted
+                  [m[0], m[1].copy(), m[2]],
                   [m[0, :100], m[1, :100]], list(m[1::2][:5]), [list(range(5))], [m[0].astype(np.int32), m[1].astype(np.int32)]):
         assert _rows_as_flat(other) is None
