@@ -182,7 +182,8 @@ class MbPlan(ctypes.Structure):
                                           "seg_cap")]
                 + [(n, c_int32) for n in ("feat_dim", "feat_stride", "max_batches", "rows_cap", "ck_part_stride", "train", "hop2",
                                           "node_major")]
-                + [("mean_nbr_deg", c_float), ("xcd_skip", c_int32)])
+                + [("mean_nbr_deg", c_float), ("xcd_skip", c_int32)]
+                + [(n, c_void_p) for n in ("ev_tile0", "ev_tile1")])
 
 
 class MbPlanInfo(ctypes.Structure):

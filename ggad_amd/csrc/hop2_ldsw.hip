@@ -883,8 +883,10 @@ int ggad_int_ldsw_hop2(const ggad_mb_plan *P, const ggad_plan_view &V, hipStream
     }
     if (state[dev] != 1) { ggad_set_error(hipErrorInvalidValue, "mb_plan_build: this device cannot give k_tile_counts its LDS"); return GGAD_E_LAUNCH; }
   }
+  if (P->ev_tile0) (void)hipEventRecord(static_cast<hipEvent_t>(P->ev_tile0), st);
   k_tile_counts<<<dim3(ggad_skip_grid((unsigned)n_tiles * (unsigned)V.n_batches, skip)), dim3(TW_T), lds, st>>>(
       P->col, P->seg_t, V.seg_stride, P->own_rp, V.batch_ent_ptr, P->pw_base, P->pc, n_tiles, V.n_batches, P->counters, skip);
+  if (P->ev_tile1) (void)hipEventRecord(static_cast<hipEvent_t>(P->ev_tile1), st);
   if (ev0) (void)hipEventRecord(ev0, st);
   const int F = P->feat_dim;
   if (P->node_major && F <= 64) {

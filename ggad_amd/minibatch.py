@@ -112,6 +112,7 @@ class BatchChunk:
         self.info = _lib.MbPlanInfo()
         self.plan = _lib.MbPlan()
         self.gather2_events = None      # optional (start, stop) handles of ggad_event_create recorded around the 2-hop gather
+        self.tile_events = None         # ... and around k_tile_counts (the pair counting before it)
         self.n_batches = self.n_rows = self.n_ents = self.n_chunks = 0
         self.last_hop2 = "none"
         self.build_count = 0
@@ -273,6 +274,7 @@ class BatchChunk:
             P.ev_gather0, P.ev_gather1 = self.gather2_events
         else:
             P.ev_gather0 = P.ev_gather1 = None
+        P.ev_tile0, P.ev_tile1 = self.tile_events if self.tile_events is not None else (None, None)
         stream = _lib.current_stream()
         for attempt in range(3):
             rc = self.lib.ggad_mb_plan_build(ctypes.byref(P), nodes.ctypes.data, bp.ctypes.data, nb,

@@ -112,10 +112,13 @@ class ModelHandler(object):
 
         num_batches = int(getattr(args, "num_batches", 150))                            # :317
         rng = PyCompatRandom.from_python_state(random.getstate())
-        # data parallel: `dp_sampler: shared` (default) deals the reference's ONE stream to the ranks (rank r takes batches
-        # r, r + W, ...: every rank generates all of them); `dp_sampler: independent` gives every rank a stream of its own
-        # (seed * 1000003 + rank + 1), which is what lets an end-to-end run scale past the serial sampler (trainer.py)
-        own_stream = world > 1 and str(getattr(args, "dp_sampler", "shared")) == "independent"
+        # data parallel: `dp_sampler: independent` (the default when world > 1) gives every rank a batch stream of its own
+        # (seed * 1000003 + rank + 1).  The bit-exact sampler is ONE serial Mersenne-Twister stream (~31 us per batch on the host):
+        # dealt to W ranks (`dp_sampler: shared`, rank r takes batches r, r + W, ...) every rank must generate all W batches of a
+        # step, which caps an end-to-end run at ~6.4 M nodes/s for ANY W -- below one GPU's steady state.  The trajectory is not the
+        # reference's at W > 1 in either mode (global batch W x 150), so nothing is lost; `shared` stays as the opt-in for checks
+        # against the W-batch gradient-averaging oracle (tests/test_distributed_cpu.py).  W = 1: the reference's own stream.
+        own_stream = world > 1 and str(getattr(args, "dp_sampler", "independent")) != "shared"
         if own_stream:
             rng = PyCompatRandom(int(getattr(args, "seed", 0)) * 1000003 + rank + 1)
         sched = BatchSchedule(idx_train, self.dataset["idx_anomaly"], self.dataset["labels"], args.batch_size, rng,

@@ -121,6 +121,7 @@ typedef struct ggad_mb_plan {
   int32_t xcd_skip;          /* -1: plain launches.  0..7: the plan kernels leave one XCD to the XCD-resident chunk kernel: the
                                 workgroups with blockIdx % 8 == xcd_skip return at once (ggad_xcd_first_of_stream tells which
                                 residue the stream's dispatcher puts on which XCD); results do not depend on it */
+  void *ev_tile0, *ev_tile1;  /* optional events recorded around k_tile_counts (the pair counting of the LDS 2-hop stage) */
 } ggad_mb_plan;
 
 typedef struct ggad_mb_plan_info {

@@ -109,6 +109,65 @@ def test_two_rank_data_parallel_matches_gradient_averaging():
     np.testing.assert_allclose(w0, ref, atol=1e-6, rtol=0)
 
 
+def _worker_independent(rank, world, port, steps, seed, out):
+    """`dp_sampler: independent` (the default at W > 1, ggad_amd/model_handler.py): rank r draws from a stream of its own, seeded
+    seed * 1000003 + r + 1, and takes EVERY batch of it (`DGraphTrainer(own_stream=True)` -> next_batches(k, 0, 1))."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    rowptr, col, feat, labels, train, pool, init = _inputs()
+    sched = BatchSchedule(train.copy(), pool.copy(), labels, batch_size=30, rng=PyCompatRandom(seed * 1000003 + rank + 1),
+                          n_pseudo=10, batches_per_epoch=5)
+    p = O.MiniParams(*[t.clone().requires_grad_() for t in init])
+    opt = O.make_adam(p.tensors(), 1e-3, 0.007)
+    seen = []
+    for s in range(steps):
+        bn, bl = sched.next_batches(1, 0, 1)
+        seen.append(bn[0].copy())
+        g = _flat_grads(p, rowptr, col, feat, bn[0], bl[0])
+        scale = reduce_gradients(g, world, lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM))
+        _apply(p, opt, g, scale)
+    out[rank] = (torch.cat([t.detach().reshape(-1) for t in p.tensors()]).numpy(), np.stack(seen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_independent_streams_equal_single_rank_streams_with_those_seeds():
+    """The default multi-GPU sampler mode: the batches rank r sees at W = 2 are exactly the batches of a ONE-rank run seeded like rank r
+    (so a rank never generates a peer's batches: the host cost per step is one batch, not W), and the weights equal the
+    gradient-averaging restatement over the two streams."""
+    world, steps, seed = 2, 7, 72                              # 7 steps: crosses an epoch boundary (5 batches per epoch)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_independent, args=(world, _free_port(), steps, seed, out), nprocs=world, join=True)
+    (w0, seen0), (w1, seen1) = out[0], out[1]
+    np.testing.assert_array_equal(w0, w1)
+    rowptr, col, feat, labels, train, pool, init = _inputs()
+    solo = [BatchSchedule(train.copy(), pool.copy(), labels, batch_size=30, rng=PyCompatRandom(seed * 1000003 + r + 1), n_pseudo=10,
+                          batches_per_epoch=5) for r in range(world)]
+    p = O.MiniParams(*[t.clone().requires_grad_() for t in init])
+    opt = O.make_adam(p.tensors(), 1e-3, 0.007)
+    for s in range(steps):
+        gs = []
+        for r in range(world):
+            nodes, lab = solo[r].next_batch()                  # the single-rank stream with that seed
+            assert np.array_equal(nodes, (seen0, seen1)[r][s])
+            gs.append(_flat_grads(p, rowptr, col, feat, nodes, lab))
+        _apply(p, opt, gs[0] + gs[1], 1.0 / world)
+    ref = torch.cat([t.detach().reshape(-1) for t in p.tensors()]).numpy()
+    np.testing.assert_allclose(w0, ref, atol=1e-6, rtol=0)
+    assert not np.array_equal(seen0, seen1)                    # two different streams
+
+
+def test_model_handler_defaults_to_independent_streams_at_world_gt_1():
+    import types
+    src = open(os.path.join(os.path.dirname(__file__), "..", "ggad_amd", "model_handler.py")).read()
+    assert 'getattr(args, "dp_sampler", "independent")) != "shared"' in src
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(os.path.dirname(__file__), "..", "src", "dgraph.yml")))
+    assert cfg["dp_sampler"] == "independent"
+
+
 def test_world_one_is_the_reference_schedule():
     """W = 1: batch b of epoch e = train[b*bs:(b+1)*bs] + first n_pseudo of the freshly shuffled pool,
     driven by the python `random` stream (model_handler.py:314,333-347)."""

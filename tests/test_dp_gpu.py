@@ -258,7 +258,8 @@ def test_bench_launch_line_two_ranks_one_gpu():
     env = dict(os.environ, GGAD_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "60", "--warmup", "30",
-           "--nodes", "200000", "--entries", "4000000", "--chunk", "30"]
+           "--nodes", "200000", "--entries", "4000000", "--chunk", "30",
+           "--e2e-steps", "60", "--e2e-reps", "2"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -266,3 +267,10 @@ def test_bench_launch_line_two_ranks_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 60 and d["scaling"] == "weak" and d["cpu_baseline"] is None
     assert d["value"] > 0 and np.isfinite(d["last_loss"]) and d["config"]["parallelism"] == "dp2"
+    # one batch stream per rank by default; the end-to-end legs (sampler inside the window) are reported for BOTH sampler modes, so a
+    # scaling run cannot hide the serial stream's ~6.4 M nodes/s ceiling of the shared mode
+    assert "one per rank" in d["config"]["batch_streams"]
+    e2e = d["e2e_with_sampler"]
+    assert e2e["default_mode"] == "independent"
+    for mode in ("independent", "shared"):
+        assert e2e[mode]["value"] > 0 and e2e[mode]["sampler_us_per_batch"] > 0 and e2e[mode]["reps"] >= 1, e2e[mode]
