@@ -820,6 +820,58 @@ class LinearFn(torch.autograd.Function):
         return dx, dw, None
 
 
+def mlp_score_supported(w1: torch.Tensor, w2: torch.Tensor, w3: torch.Tensor) -> bool:
+    """The fused scorer-MLP kernels (csrc/mlp.hip) take these weights?  GGAD_MLP_FUSED=0 turns them off (A/B: the three GEMMs)."""
+    if os.environ.get("GGAD_MLP_FUSED", "1") == "0" or w3.shape[0] != 1 or w1.shape[0] != w2.shape[1] or w2.shape[0] != w3.shape[1]:
+        return False
+    return bool(_lib.load().ggad_mlp_score_supported(int(w1.shape[1]), int(w1.shape[0]), int(w2.shape[0])))
+
+
+def mlp_score_fwd(x: torch.Tensor, w1, w2, w3):
+    """(f1, f2, f3) = relu(x W1^T), relu(f1 W2^T), f2 w3^T in ONE launch (model.py:176-180)."""
+    x, w1, w2, w3 = x.contiguous(), w1.contiguous(), w2.contiguous(), w3.contiguous()
+    r, h = x.shape
+    h1, h2 = w1.shape[0], w2.shape[0]
+    f1 = torch.empty(r, h1, dtype=torch.float32, device=x.device)
+    f2 = torch.empty(r, h2, dtype=torch.float32, device=x.device)
+    f3 = torch.empty(r, 1, dtype=torch.float32, device=x.device)
+    call("ggad_mlp_score_fwd_f32", ptr(x), h, r, h, h1, h2, ptr(w1), ptr(w2), ptr(w3), ptr(f1), ptr(f2), ptr(f3))
+    return f1, f2, f3
+
+
+def mlp_score_dgrad(g3: torch.Tensor, f1, f2, w1, w2, w3, dx_add: Optional[torch.Tensor] = None):
+    """(dz2, dz1, dx): the data gradients of the scorer MLP in ONE launch; dx = dz1 W1 (+ dx_add)."""
+    g3 = g3.contiguous().reshape(-1)
+    r, h1 = f1.shape
+    h2, h = f2.shape[1], w1.shape[1]
+    dz2, dz1 = torch.empty_like(f2), torch.empty_like(f1)
+    dx = torch.empty(r, h, dtype=torch.float32, device=f1.device)
+    if dx_add is not None:
+        dx_add = dx_add.contiguous()
+    call("ggad_mlp_score_dgrad_f32", ptr(g3), r, h, h1, h2, ptr(f1), ptr(f2), ptr(w1.contiguous()), ptr(w2.contiguous()), ptr(w3.contiguous()),
+         ptr(dz2), ptr(dz1), ptr(dx), h, ptr(dx_add) if dx_add is not None else 0, h)
+    return dz2, dz1, dx
+
+
+class MlpScoreFn(torch.autograd.Function):
+    """f_3 = fc3(relu(fc2(relu(fc1(x))))) (`model.py:176-180`) on the fused kernels: one launch forward, one for the data gradients,
+    three split-K GEMMs for the weight gradients."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2, w3):
+        f1, f2, f3 = mlp_score_fwd(x, w1, w2, w3)
+        ctx.save_for_backward(x, f1, f2, w1, w2, w3)
+        return f3
+
+    @staticmethod
+    def backward(ctx, g):
+        x, f1, f2, w1, w2, w3 = ctx.saved_tensors
+        g = g.contiguous()
+        dz2, dz1, dx = mlp_score_dgrad(g, f1, f2, w1, w2, w3)
+        return (dx if ctx.needs_input_grad[0] else None, gemm(dz1, x, True, False), gemm(dz2, f1, True, False),
+                gemm(g.reshape(-1, 1), f2, True, False))
+
+
 class SpmmRowsFn(torch.autograd.Function):
     """A_hat[rows, :] @ emb  (`model.py:151-155`)."""
 
@@ -861,9 +913,12 @@ class GgadHeadFn(torch.autograd.Function):
         emb_con = gemm(con_pre, w4, False, True, relu=True)
         comb = torch.empty(nn_ + na, h, dtype=torch.float32, device=dev)
         call("ggad_head_combine_f32", ptr(emb), ptr(hs["nrm"]), nn_, ptr(emb_con), na, h, ptr(comb))
-        f1 = gemm(comb, w1, False, True, relu=True)
-        f2 = gemm(f1, w2, False, True, relu=True)
-        f3 = gemm(f2, w3, False, True)
+        if mlp_score_supported(w1, w2, w3):
+            f1, f2, f3 = mlp_score_fwd(comb, w1, w2, w3)                   # one launch (csrc/mlp.hip)
+        else:
+            f1 = gemm(comb, w1, False, True, relu=True)
+            f2 = gemm(f1, w2, False, True, relu=True)
+            f3 = gemm(f2, w3, False, True)
         emb_out = torch.empty_like(emb)
         call("ggad_head_emb_out_f32", ptr(emb), ptr(hs["abn_pos"]), ptr(emb_con), n, h, ptr(emb_out))
         ctx.save_for_backward(con_pre, emb_con, comb, f1, f2, w4, w1, w2, w3)
@@ -882,7 +937,12 @@ class GgadHeadFn(torch.autograd.Function):
         g_out, g_comb, g_f3, g_con, g_abn = c(g_out), c(g_comb), c(g_f3), c(g_con), c(g_abn)
         dw1 = dw2 = dw3 = None
         d_comb = g_comb
-        if g_f3 is not None:                                               # scorer MLP, as LinearFn.backward three times
+        if g_f3 is not None and mlp_score_supported(w1, w2, w3):           # scorer MLP: data gradients in one launch (+ g_comb)
+            dz2, dz1, d_comb = mlp_score_dgrad(g_f3, f1, f2, w1, w2, w3, g_comb)
+            dw3 = gemm(g_f3.reshape(-1, 1), f2, True, False)
+            dw2 = gemm(dz2, f1, True, False)
+            dw1 = gemm(dz1, comb, True, False)
+        elif g_f3 is not None:                                             # ... or as LinearFn.backward three times
             dw3 = gemm(g_f3, f2, True, False)
             df2 = gemm(g_f3, w3, False, False)
             dz2 = torch.empty_like(df2)

@@ -150,7 +150,8 @@ def bench_one(name: str, dev, epochs: int = 30, seed: int = 0, h: int = 300) -> 
     w = torch.randn(h, h, device=dev)
     t_spmm = _time_call(lambda: FG.spmm(full.A, x))
     plan0 = full.A.plan()
-    kernel = ("k_spmm_panel" if FG._use_panel(full.A, plan0, x) is not None
+    pp0 = FG._use_panel(full.A, plan0, x)
+    kernel = (("k_spmm_ring" if "wave_sb" in pp0 else "k_spmm_panel") if pp0 is not None
               else "k_spmm_sliced" if FG._use_sliced(full.A, plan0, x)
               else "k_spmm_rowslice" if FG._use_rowslice(full.A, plan0, x) else "k_spmm_seg")
     t_gemm = _time_call(lambda: FG.gemm(x, w, False, True))

@@ -17,7 +17,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .fullgraph import FullGraphAdj, GcnLayerFn, GgadHeadFn, LinearFn, SpmmRowsFn
+from .fullgraph import FullGraphAdj, GcnLayerFn, GgadHeadFn, LinearFn, MlpScoreFn, SpmmRowsFn, mlp_score_supported
 
 _ADJ_CACHE = {}
 
@@ -134,6 +134,8 @@ class Model(nn.Module):
         return hit[1]
 
     def _score(self, x):
+        if mlp_score_supported(self.fc1.weight, self.fc2.weight, self.fc3.weight):
+            return MlpScoreFn.apply(x, self.fc1.weight, self.fc2.weight, self.fc3.weight)      # model.py:176-180 in one launch
         f = LinearFn.apply(x, self.fc1.weight, True)                       # fc1 + relu     model.py:176-177
         f = LinearFn.apply(f, self.fc2.weight, True)                       # fc2 + relu     :178-179
         return LinearFn.apply(f, self.fc3.weight, False)                   # fc3            :180

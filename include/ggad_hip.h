@@ -523,6 +523,21 @@ int ggad_spmm_ring_f32(const int32_t *wg_tab, int32_t n_wg, const int32_t *wave_
                        const float *X, int64_t ldx, int32_t W, int64_t n_src_rows, float *xs_workspace, const float *bias,
                        const float *prelu_a, float *out, int64_t ldo, float *out_pre, ggad_stream_t stream_);
 
+/* Fused scorer MLP (model.py:176-180: f_1 = relu(fc1 x), f_2 = relu(fc2 f_1), f_3 = fc3 f_2; Linear weights [out][in], no bias) on
+ * the exact-f32 matrix cores, one launch each way instead of three GEMMs forward and five launches for the data gradients backward
+ * (SURVEY.md 2.1 F8 / 8b `mlp_score_f32`).  X: R x H (row stride ldx, multiple of 4, 16-byte aligned); W1: H1 x H, W2: H2 x H1,
+ * w3: H2.  fwd writes f1 (R x H1), f2 (R x H2) -- the backward's operands -- and f3 (R).  dgrad: dz2 = (g3 w3^T) [f2 > 0] (R x H2),
+ * dz1 = (dz2 W2) [f1 > 0] (R x H1), dx = dz1 W1 (+ dx_add, e.g. another gradient of x; NULL = none), row strides ld_dx / ld_add; the
+ * weight gradients dz1^T x, dz2^T f1, g3^T f2 stay ggad_gemm_f32 calls (split over the R rows).  ggad_mlp_score_supported: H <= 512
+ * and a multiple of 4, H1 <= 256 and even, H2 <= 128 (else callers take the three GEMMs).  Sums run over k in blocks of 16 with
+ * a fixed lane-to-k map: deterministic, equal to a k-ordered product to fp32 round-off. */
+int32_t ggad_mlp_score_supported(int32_t H, int32_t H1, int32_t H2);
+int ggad_mlp_score_fwd_f32(const float *X, int64_t ldx, int32_t R, int32_t H, int32_t H1, int32_t H2, const float *W1, const float *W2,
+                           const float *w3, float *f1, float *f2, float *f3, ggad_stream_t stream);
+int ggad_mlp_score_dgrad_f32(const float *g3, int32_t R, int32_t H, int32_t H1, int32_t H2, const float *f1, const float *f2,
+                             const float *W1, const float *W2, const float *w3, float *dz2, float *dz1, float *dx, int64_t ld_dx,
+                             const float *dx_add, int64_t ld_add, ggad_stream_t stream);
+
 /* PReLU backward: dz = g * (z > 0 ? 1 : a); db[W] = column sums of dz; *da = sum g * z * [z <= 0].
  * workspace: float[2 * ggad_prelu_bwd_splits(M) * W].  db / da may be NULL. */
 int32_t ggad_prelu_bwd_splits(int32_t M);

@@ -327,6 +327,59 @@ def test_prelu_backward_kernel_against_autograd(shape):
         assert torch.equal(x.view(torch.int32), y.view(torch.int32))
 
 
+@pytest.mark.parametrize("r,h", [(1830, 300), (6476, 300), (37, 64), (16, 12), (5, 512), (100, 20)])
+def test_fused_scorer_mlp_forward_and_data_gradients(r, h, monkeypatch):
+    """The scorer MLP of `model.py:176-180` (fc1 + relu, fc2 + relu, fc3, Linear weights without bias) as ONE launch forward and
+    ONE launch for the data gradients (csrc/mlp.hip, v_mfma_f32_16x16x4_f32) against torch in float64: f_1, f_2, f_3, the masked
+    gradients dz_2, dz_1, d_x (+ an incoming gradient of x), the three weight gradients through `MlpScoreFn`; deterministic; equal to
+    the three-GEMM path to fp32 round-off."""
+    h1, h2 = h // 2, h // 4
+    rng = np.random.default_rng(r + h)
+    x = torch.from_numpy(rng.standard_normal((r, h)).astype(np.float32)).to(DEV)
+    w1 = torch.from_numpy((rng.standard_normal((h1, h)) / np.sqrt(h)).astype(np.float32)).to(DEV)
+    w2 = torch.from_numpy((rng.standard_normal((h2, h1)) / np.sqrt(h1)).astype(np.float32)).to(DEV)
+    w3 = torch.from_numpy((rng.standard_normal((1, h2)) / np.sqrt(h2)).astype(np.float32)).to(DEV)
+    g3 = torch.from_numpy(rng.standard_normal((r, 1)).astype(np.float32)).to(DEV)
+    gx = torch.from_numpy(rng.standard_normal((r, h)).astype(np.float32)).to(DEV)
+    assert FG.mlp_score_supported(w1, w2, w3)
+    f1, f2, f3 = FG.mlp_score_fwd(x, w1, w2, w3)
+    xd, w1d, w2d, w3d = (t.double().cpu().requires_grad_() for t in (x, w1, w2, w3))
+    r1 = torch.relu(xd @ w1d.T)
+    r2 = torch.relu(r1 @ w2d.T)
+    r3 = r2 @ w3d.T
+    tol = lambda ref: 3e-6 * (1.0 + float(ref.abs().max()))            # noqa: E731
+    assert (f1.double().cpu() - r1).abs().max().item() < tol(r1)
+    assert (f2.double().cpu() - r2).abs().max().item() < tol(r2)
+    assert (f3.double().cpu() - r3).abs().max().item() < tol(r3)
+    again = FG.mlp_score_fwd(x, w1, w2, w3)
+    assert all(torch.equal(a.view(torch.int32), b.view(torch.int32)) for a, b in zip((f1, f2, f3), again))
+    # data gradients: masks taken from the kernel's own f_1 / f_2 (an activation within round-off of 0 may flip in float64)
+    dz2, dz1, dx = FG.mlp_score_dgrad(g3, f1, f2, w1, w2, w3, gx)
+    m2, m1 = (f2 > 0).double().cpu(), (f1 > 0).double().cpu()
+    e2 = (g3.double().cpu() @ w3d.detach()) * m2
+    e1 = (e2 @ w2d.detach()) * m1
+    ex = e1 @ w1d.detach() + gx.double().cpu()
+    assert (dz2.double().cpu() - e2).abs().max().item() < tol(e2)
+    assert (dz1.double().cpu() - e1).abs().max().item() < tol(e1)
+    assert (dx.double().cpu() - ex).abs().max().item() < tol(ex)
+    _, _, dx0 = FG.mlp_score_dgrad(g3, f1, f2, w1, w2, w3)
+    assert (dx0.double().cpu() + gx.double().cpu() - ex).abs().max().item() < tol(ex)
+    # autograd node against the three LinearFn nodes (GEMM path)
+    outs = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("GGAD_MLP_FUSED", fused)
+        xs, a, b, c = (t.clone().requires_grad_() for t in (x, w1, w2, w3))
+        if fused == "1":
+            y = FG.MlpScoreFn.apply(xs, a, b, c)
+        else:
+            assert not FG.mlp_score_supported(a, b, c)
+            y = FG.LinearFn.apply(FG.LinearFn.apply(FG.LinearFn.apply(xs, a, True), b, True), c, False)
+        (y * g3).sum().backward()
+        outs.append([y.detach()] + [t.grad for t in (xs, a, b, c)])
+    for u, v in zip(*outs):
+        assert (u - v).abs().max().item() < 2e-5 * (1.0 + v.abs().max().item())
+
+
 @pytest.mark.parametrize("ring", ["1", "0"])
 @pytest.mark.parametrize("w", [300, 64, 4])
 def test_spmm_lds_panel_equals_row_major(w, ring, monkeypatch):
