@@ -237,6 +237,124 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))
   }
 }
 
+// ---- round 4: the same 64 x 64 x 32 tiling with the operands staged by LDS-DMA ---------------------------------------------------
+// k_gemm_f32 above brings every K-tile through registers (global -> VGPR -> masked ds_write): 156 VGPRs = 3 workgroups per CU, two
+// barriers and 16 LDS stores per thread per K-tile; on the K = 300 products of the path (10 K-tiles) the matrix pipe is busy a third
+// of the time.  Here (shapes whose 16-byte chunks are aligned: every N x 300 x 300 product and weight gradient of the path)
+//  - both operand tiles are written by `global_load_lds_dwordx4` (no staging registers, no LDS stores, no masks: rows / columns
+//    outside the matrix read a clamped row -- their outputs are never stored --, k outside the split reads a zero line), double
+//    buffered, ONE barrier per K-tile; 60 VGPRs and 32 KB of LDS: 5 workgroups per CU, so a wave's barrier waits and the prologue /
+//    epilogue of one workgroup hide behind the MFMAs of four others;
+//  - an operand whose k index is the fast one (x and W of x W^T) keeps that layout in LDS: [row][32 k], its 16-byte chunks
+//    XOR-swizzled by (row >> 1) & 7, and is read with ONE ds_read_b128 per 4 MFMA k-steps, conflict-free for the 16-lane service
+//    groups of that instruction (cdna_hip_programming.md T2).  The MFMA sums over the 2 k its lane halves hold; which k only has to
+//    agree between the two fragments: half h of step (j, c) takes k = 8 j + 4 h + c for both;
+//  - an operand whose m / n index is the fast one keeps [32 k][64] rows and ds_read_b32 as before.
+__device__ __attribute__((aligned(16))) float g_gemm_zero_line[4] = {0.f, 0.f, 0.f, 0.f};
+
+__device__ __forceinline__ void gemm_dma16(const float *src, uint32_t lds_off) {
+  // (inline asm: hipcc then does not know of an LDS-DMA in flight and puts no vmcnt(0) in front of the LDS reads of the OTHER buffer)
+  asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(lds_off), "v"(src) : "memory");
+}
+
+template <bool A_KFAST, bool B_NFAST, int NBUF>
+__global__ void __launch_bounds__(256) k_gemm_dma(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C, int M,
+                                                  int N, int K, int sam, int sak, int sbk, int sbn, int64_t ldc,
+                                                  const float *__restrict__ bias, int relu, int k_per_split, int64_t c_split_stride) {
+  __shared__ __attribute__((aligned(16))) float lds[NBUF][2][2048];    // [buffer][A / B][64 x 32 floats]; NBUF - 1 K-tiles in flight
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 1, wc = wid & 1;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int k_begin = blockIdx.z * k_per_split;
+  const int k_end = min(K, k_begin + k_per_split);
+  floatx16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // this lane's two 16-byte pieces of each operand tile (piece p = 2 wid + u lands at LDS bytes p * 1024 + lane * 16)
+  const float *srcA[2], *srcB[2];
+  int kA[2], kB[2];                                                   // k offset of the piece inside the K-tile
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int p = 2 * wid + u;
+    if (A_KFAST) {
+      const int r = 8 * p + (lane >> 3), lc = (lane & 7) ^ ((r >> 1) & 7);
+      kA[u] = 4 * lc;
+      srcA[u] = A + (int64_t)min(m0 + r, M - 1) * sam + kA[u];
+    } else {                                                          // [k][m], m fast
+      const int kk = 4 * p + (lane >> 4), mm = m0 + 4 * (lane & 15);
+      kA[u] = kk;
+      srcA[u] = A + (int64_t)kk * sak + (mm < M ? mm : 0);
+    }
+    if (!B_NFAST) {                                                   // [n][k], k fast
+      const int r = 8 * p + (lane >> 3), lc = (lane & 7) ^ ((r >> 1) & 7);
+      kB[u] = 4 * lc;
+      srcB[u] = B + (int64_t)min(n0 + r, N - 1) * sbn + kB[u];
+    } else {
+      const int kk = 4 * p + (lane >> 4), nn = n0 + 4 * (lane & 15);
+      kB[u] = kk;
+      srcB[u] = B + (int64_t)kk * sbk + (nn < N ? nn : 0);
+    }
+  }
+  const int64_t stepA = A_KFAST ? 32 : (int64_t)32 * sak, stepB = B_NFAST ? (int64_t)32 * sbk : 32;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)&lds[0][0][0];
+  auto issue = [&](int k0, int buf) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const uint32_t off = lds0 + (uint32_t)buf * 16384u + (uint32_t)(2 * wid + u) * 1024u;
+      gemm_dma16(k0 + kA[u] < k_end ? srcA[u] + (int64_t)((k0 - k_begin) / 32) * stepA + (A_KFAST ? k_begin : (int64_t)k_begin * sak) : g_gemm_zero_line, off);
+      gemm_dma16(k0 + kB[u] < k_end ? srcB[u] + (int64_t)((k0 - k_begin) / 32) * stepB + (B_NFAST ? (int64_t)k_begin * sbk : k_begin) : g_gemm_zero_line,
+                 off + 8192u);
+    }
+  };
+  const int i = lane & 31, h = lane >> 5;
+  const int rowA = wr * 32 + i, rowB = wc * 32 + i;
+  // K-tiles t .. t + NBUF - 2 are in flight while tile t is multiplied; a wave issues 4 loads per tile and loads return in order,
+  // so vmcnt(4 (NBUF - 2)) at the end of tile t means ITS pieces of tile t + 1 have landed (tiles past the end are issued as
+  // zero lines into buffers nobody reads: the count stays uniform)
+  if (k_begin < k_end) {
+#pragma unroll
+    for (int t = 0; t < NBUF - 1; ++t) issue(k_begin + 32 * t, t);
+    if (NBUF == 2) __builtin_amdgcn_s_waitcnt(0x0f70); else __builtin_amdgcn_s_waitcnt(0x0f74);      // vmcnt(0) / vmcnt(4)
+    __syncthreads();
+  }
+  int buf = 0, nxt = NBUF - 1;
+  for (int k0 = k_begin; k0 < k_end; k0 += 32) {
+    issue(k0 + 32 * (NBUF - 1), nxt);                                 // (the barrier that ended the previous tile freed that buffer)
+    const float *At = &lds[buf][0][0], *Bt = &lds[buf][1][0];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f4 a, b;
+      if (A_KFAST) a = *reinterpret_cast<const f4 *>(At + rowA * 32 + 4 * ((2 * j + h) ^ ((rowA >> 1) & 7)));
+      else { a.x = At[(8 * j + 4 * h) * 64 + rowA]; a.y = At[(8 * j + 4 * h + 1) * 64 + rowA]; a.z = At[(8 * j + 4 * h + 2) * 64 + rowA]; a.w = At[(8 * j + 4 * h + 3) * 64 + rowA]; }
+      if (!B_NFAST) b = *reinterpret_cast<const f4 *>(Bt + rowB * 32 + 4 * ((2 * j + h) ^ ((rowB >> 1) & 7)));
+      else { b.x = Bt[(8 * j + 4 * h) * 64 + rowB]; b.y = Bt[(8 * j + 4 * h + 1) * 64 + rowB]; b.z = Bt[(8 * j + 4 * h + 2) * 64 + rowB]; b.w = Bt[(8 * j + 4 * h + 3) * 64 + rowB]; }
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+    }
+    if (NBUF == 2) __builtin_amdgcn_s_waitcnt(0x0f70); else __builtin_amdgcn_s_waitcnt(0x0f74);      // the next tile has landed (this wave's pieces) ...
+    __syncthreads();                                                  // ... everybody's; and everybody is done reading this one
+    buf = buf + 1 == NBUF ? 0 : buf + 1;
+    nxt = nxt + 1 == NBUF ? 0 : nxt + 1;
+  }
+  // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  float *Cout = C + (int64_t)blockIdx.z * c_split_stride;
+  const int col = n0 + wc * 32 + (lane & 31);
+  if (col < N) {
+    const float bv = (bias != nullptr) ? bias[col] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (row < M) {
+        float v = acc[r] + bv;
+        if (relu) v = fmaxf(v, 0.0f);
+        Cout[(int64_t)row * ldc + col] = v;
+      }
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) k_splitk_reduce(const float *__restrict__ ws, int splits, int64_t split_stride,
                                                        float *__restrict__ C, int M, int N, int64_t ldc,
                                                        const float *__restrict__ bias, int relu) {
@@ -319,6 +437,38 @@ int ggad_gemm_f32(const float *A, const float *B, float *C, int32_t M, int32_t N
   const bool aligned = ((a_kfast ? K : M) % 4 == 0) && ((b_nfast ? N : K) % 4 == 0);
   const int vec = force_scalar ? 0 : (aligned ? 1 : 2);
   const int64_t ws_elems = workspace ? ggad_gemm_workspace_elems(M, N, K) : 0;
+  // LDS-DMA kernel: every 16-byte chunk an operand tile is made of must be 16-byte aligned in memory and lie inside one row
+  static const bool no_dma = [] { const char *e = getenv("GGAD_GEMM_DMA"); return e && e[0] == '0'; }();
+  const bool a_ok = (((uintptr_t)A & 15) == 0) && (a_kfast ? (sam % 4 == 0 && K % 4 == 0) : (sak % 4 == 0 && M % 4 == 0));
+  const bool b_ok = (((uintptr_t)B & 15) == 0) && (b_nfast ? (sbk % 4 == 0 && N % 4 == 0) : (sbn % 4 == 0 && K % 4 == 0));
+  if (!no_dma && tm == 64 && a_ok && b_ok && K >= 32) {
+    const int splits = ws_elems ? (int)(ws_elems / ((int64_t)M * N)) : 1;
+    int kps = K;
+    if (splits > 1) { kps = (K + splits - 1) / splits; kps = (kps + BK - 1) / BK * BK; }
+    float *out = splits > 1 ? workspace : C;
+    const dim3 grid(gx, gy, splits);
+#define GGAD_DMA_ARGS A, B, out, (int)M, (int)N, (int)K, (int)sam, (int)sak, (int)sbk, (int)sbn, splits > 1 ? (int64_t)N : ldc, \
+                      splits > 1 ? (const float *)nullptr : bias, splits > 1 ? 0 : (int)relu, kps, (int64_t)M * N
+    static const int nbuf = [] { const char *e = getenv("GGAD_GEMM_DMA_BUFS"); return e ? atoi(e) : 2; }();
+    if (nbuf == 2) {
+      if (a_kfast && b_nfast) k_gemm_dma<true, true, 2><<<grid, dim3(256), 0, st>>>(GGAD_DMA_ARGS);
+      else if (a_kfast) k_gemm_dma<true, false, 2><<<grid, dim3(256), 0, st>>>(GGAD_DMA_ARGS);
+      else if (b_nfast) k_gemm_dma<false, true, 2><<<grid, dim3(256), 0, st>>>(GGAD_DMA_ARGS);
+      else k_gemm_dma<false, false, 2><<<grid, dim3(256), 0, st>>>(GGAD_DMA_ARGS);
+    } else {
+      if (a_kfast && b_nfast) k_gemm_dma<true, true, 3><<<grid, dim3(256), 0, st>>>(GGAD_DMA_ARGS);
+      else if (a_kfast) k_gemm_dma<true, false, 3><<<grid, dim3(256), 0, st>>>(GGAD_DMA_ARGS);
+      else if (b_nfast) k_gemm_dma<false, true, 3><<<grid, dim3(256), 0, st>>>(GGAD_DMA_ARGS);
+      else k_gemm_dma<false, false, 3><<<grid, dim3(256), 0, st>>>(GGAD_DMA_ARGS);
+    }
+#undef GGAD_DMA_ARGS
+    if (splits > 1) {
+      const int64_t tot = (int64_t)M * N;
+      k_splitk_reduce<<<dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st>>>(workspace, splits, (int64_t)M * N, C, M, N, ldc, bias, relu);
+    }
+    GGAD_CHECK_LAUNCH("gemm_f32 (dma)");
+    return GGAD_OK;
+  }
   if (ws_elems == 0) {
     if (tm == 128)
       launch_gemm<128>(vec, a_kfast, b_nfast, dim3(gx, gy, 1), st, A, B, C, (int)M, (int)N, (int)K, (int)sam, (int)sak, (int)sbk, (int)sbn,

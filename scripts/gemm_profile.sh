@@ -3,7 +3,7 @@
 # PMC passes run with --kernel-trace only (never with hip/hsa/sys traces), one counter group per run.
 set -u
 cd /tmp && export TMPDIR=/tmp
-R=/root/repo
+R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/gemm_prof
 mkdir -p $OUT
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python $R/scripts/gemm_pmc.py > $OUT/trace.log 2>&1
