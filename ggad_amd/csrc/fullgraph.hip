@@ -514,8 +514,12 @@ __global__ void __launch_bounds__(1024) k_spmm_panel(const int32_t *__restrict__
 // (s_set_gpr_idx_on: M0-relative destination / second source of the v_pk_add_f32 -- VOP3P takes the index too, scripts/gpr_idx_probe.hip) instead of one unrolled loop nest per
 // accumulator -- no per-tile loop overhead, reads of quad q + 1 in flight while quad q is added.  The walk is one asm statement
 // with pinned registers (the 64 accumulators v[64:127] are its outputs); everything around it is plain HIP.
-constexpr int RING_S = 5;                           // ring slots
-constexpr int RING_RS = 248;                        // source rows per slot (31 LDS-DMA pieces of 8 rows)
+#ifndef GGAD_RING_S
+#define GGAD_RING_S 5
+#define GGAD_RING_RS 248
+#endif
+constexpr int RING_S = GGAD_RING_S;                 // ring slots
+constexpr int RING_RS = GGAD_RING_RS;               // source rows per slot (a multiple of 8: whole 1 KB LDS-DMA pieces)
 constexpr int RING_V = RING_S - 1;                  // slots readable during a phase
 constexpr int RING_WALK = 15;                       // walker waves (wave 15 loads)
 constexpr int RING_KR = 16;                         // rounds (of 8 lane rows) per walker: 64 accumulator registers
