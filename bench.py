@@ -412,6 +412,7 @@ def main():
             tile_ms.append(float(ms.value))
     dense_ms = [c0.elapsed_time(c1) for c0, c1, _ in chunk_ev]
     dense_steps = [nb for _, _, nb in chunk_ev]
+    del chunk_ev[:], chunk_ev_pool[:]          # (HIP events must not outlive the runtime: destroyed here, not at interpreter exit)
     for h in ev_pool:
         lib.ggad_event_destroy(h)
     mode = trainer.chunk.last_hop2
@@ -655,6 +656,7 @@ def main():
         flush_c()
     if out is not None:
         print(json.dumps(out), flush=True)
+    trainer.close()
     if pg:
         torch.distributed.destroy_process_group()
         os._exit(0) if rank != 0 else None       # non-zero ranks leave without running exit-time stdio flushes

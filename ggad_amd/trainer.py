@@ -314,6 +314,12 @@ class DGraphTrainer:
                     raw.append(h.value)
                     out.append(torch.cuda.ExternalStream(h.value, device=device))
             self._raw_streams = raw
+            self._own_streams = list(raw)              # created here (hipExtStreamCreateWithCUMask): destroyed by `close`
+            import atexit
+            import weakref
+            ref = weakref.ref(self)
+            atexit.register(lambda: ref() is not None and ref().close())     # before the HIP runtime goes away (a profiler's exit
+            #                                                                  hook crashed on streams that were still alive)
             if getattr(self, "resident_split", False):
                 first = ctypes.c_int32(-1)
                 _lib.check(lib.ggad_xcd_first_of_stream(ctypes.byref(first), raw[0]), "ggad_xcd_first_of_stream")
@@ -326,6 +332,19 @@ class DGraphTrainer:
         except Exception as exc:      # no CU masking on this stack: plain streams still give a correct (slower) overlap
             warnings.warn(f"CU-masked streams unavailable ({exc}); overlapping with plain streams")
             return torch.cuda.Stream(device=device, priority=0), torch.cuda.Stream(device=device, priority=-1)
+
+    def close(self) -> None:
+        """Destroy the CU-masked HIP streams this trainer created (idempotent; the trainer must not run afterwards)."""
+        own, self._own_streams = getattr(self, "_own_streams", None), None
+        if own:
+            try:
+                torch.cuda.synchronize(self.feat.device)
+                from . import _lib
+                lib = _lib.load()
+                for h in own:
+                    lib.ggad_stream_destroy(h)
+            except Exception:
+                pass
 
     def start_stream(self, total_steps: int) -> None:
         """Persistent sampler thread for the next `total_steps` optimiser steps: it keeps up to 3 chunks of batches ready
