@@ -29,7 +29,7 @@ from .sampler import PyCompatRandom
 
 def _other_llc_cpus():
     """CPUs (allowed to this process) of an L3 domain OTHER than the one the calling thread runs on -- the home of the sampler
-    pipeline -- or None (one L3 only, no sysfs, GGAD_SAMPLER_LLC=same): the least busy such domain (10 ms of /proc/stat)."""
+    pipeline -- or None (one L3 only, no sysfs, GGAD_SAMPLER_LLC=same).  Deterministic: the next domain in CPU order."""
     import ctypes
     if os.environ.get("GGAD_SAMPLER_LLC", "other") == "same":
         return None
@@ -44,29 +44,11 @@ def _other_llc_cpus():
         if len(doms) < 2:
             return None
         mine = next((i for i, d in enumerate(doms) if here in d), 0)
-        cand = [d for i, d in enumerate(doms) if i != mine and len(d) >= 6]      # (the sampler wants six CPUs for its stages)
-        if not cand:
-            return None
-        # the host is shared (load average 30-45 on the bench boxes): take the candidate whose CPUs were least busy over 10 ms
-        def busy():
-            out = {}
-            with open("/proc/stat") as fh:
-                for ln in fh:
-                    if ln.startswith("cpu") and ln[3].isdigit():
-                        f = ln.split()
-                        v = [int(x) for x in f[1:9]]
-                        out[int(f[0][3:])] = (sum(v) - v[3] - v[4], sum(v))      # (busy, total) jiffies
-            return out
-        try:
-            import time as _t
-            a = busy()
-            _t.sleep(0.01)
-            b = busy()
-            load = lambda d: sum(b[c][0] - a[c][0] for c in d if c in a and c in b)      # noqa: E731
-            cand.sort(key=lambda d: (load(d), min(d)))
-        except (OSError, ValueError, KeyError):
-            pass
-        return cand[0]
+        for step in range(1, len(doms)):
+            d = doms[(mine + step) % len(doms)]
+            if len(d) >= 6:                  # (the sampler wants six CPUs for its stages)
+                return d
+        return None
     except (OSError, AttributeError, ValueError):
         return None
 
