@@ -60,7 +60,7 @@ def parse():
     ap.add_argument("--cpu-batches", type=int, default=3, help="batches timed on the dense-faithful CPU port (0 = skip the CPU legs)")
     ap.add_argument("--cpu-epochs", type=int, default=4, help="epochs of 150 batches of the sparse CPU variant: 1 warm-up + the rest timed "
                     "(BASELINE.md section 3 protocol; 0 = the same few batches as the dense port)")
-    ap.add_argument("--cpu-epoch-budget", type=float, default=150.0, help="seconds after which the sparse CPU variant stops adding epochs")
+    ap.add_argument("--cpu-epoch-budget", type=float, default=120.0, help="seconds after which the sparse CPU variant stops adding epochs")
     ap.add_argument("--e2e-reps", type=int, default=5, help="repetitions of the end-to-end leg (median reported)")
     ap.add_argument("--dp-sampler", default="independent", choices=["independent", "shared"],
                     help="multi-GPU batch streams: one per rank (default, scales end to end) or the reference's one stream dealt to the ranks")
