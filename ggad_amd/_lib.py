@@ -106,6 +106,9 @@ SIGNATURES = {
     "ggad_spmm_rowslice_short": (c_int32, []),
     "ggad_spmm_rowslice_long": (c_int32, []),
     "ggad_spmm_rowslice_f32": (c_int32, [_P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _I, _P, _L, _I, _P, _P, _P, _L, _P, _P]),
+    "ggad_spmm_rowline_supported": (c_int32, [_P, _L, _I, _L]),
+    "ggad_spmm_rowline_f32": (c_int32, [_P, _P, _I, _P, _I, _P, _I, _P, _L, _I, _L, _P, _P, _P, _L, _P, _P]),
+    "ggad_prelu_bwd_ld_f32": (c_int32, [_P, _P, _P, _I, _I, _P, _L, _P, _P, _P, _P]),
     "ggad_spmm_sliced_workspace_elems": (c_int64, [_L, _I]),
     "ggad_spmm_sliced_seg_len": (c_int32, []),
     "ggad_spmm_panel_available": (c_int32, []),
@@ -244,6 +247,13 @@ def ptr(t) -> int:
         return 0
     if not t.is_contiguous():
         raise ValueError("tensor handed to the C-ABI must be contiguous")
+    return t.data_ptr()
+
+
+def ptr_rows(t) -> int:
+    """Device pointer of a 2-D tensor whose rows are contiguous (unit column stride; the row stride is passed beside it)."""
+    if t.dim() != 2 or t.stride(1) != 1 or t.stride(0) < t.shape[1]:
+        raise ValueError("tensor handed to the C-ABI must have contiguous rows")
     return t.data_ptr()
 
 

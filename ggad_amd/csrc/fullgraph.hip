@@ -21,18 +21,28 @@ namespace {
 constexpr int SPMM_MAXCH = 4;   // float4 chunks of 64 lanes: W <= 1024
 constexpr int SPMM_SEG = 64;    // neighbours per segment (= one wave-wide index load)
 
+typedef float spmm_f4 __attribute__((ext_vector_type(4)));
+typedef int spmm_i2 __attribute__((ext_vector_type(2)));
+typedef int spmm_i4 __attribute__((ext_vector_type(4)));
+
+// NT: streaming stores (the rows leave the XCD's L2 early: the L2 of a gathering kernel is for the operand it gathers from)
+template <bool NT = false>
 __device__ __forceinline__ void spmm_epilogue_store(float4 z, int vi, const float *__restrict__ bias, const float *prelu_a,
                                                     float a, float *__restrict__ out_row, float *__restrict__ pre_row) {
   if (bias) {
     const float4 b = reinterpret_cast<const float4 *>(bias)[vi];
     z.x += b.x; z.y += b.y; z.z += b.z; z.w += b.w;                          // out += bias              model.py:32-33
   }
-  if (pre_row) reinterpret_cast<float4 *>(pre_row)[vi] = z;
+  if (pre_row) {
+    if (NT) __builtin_nontemporal_store((spmm_f4){z.x, z.y, z.z, z.w}, reinterpret_cast<spmm_f4 *>(pre_row) + vi);
+    else reinterpret_cast<float4 *>(pre_row)[vi] = z;
+  }
   if (prelu_a) {                                                               // PReLU                    model.py:35
     z.x = z.x > 0.f ? z.x : a * z.x; z.y = z.y > 0.f ? z.y : a * z.y;
     z.z = z.z > 0.f ? z.z : a * z.z; z.w = z.w > 0.f ? z.w : a * z.w;
   }
-  reinterpret_cast<float4 *>(out_row)[vi] = z;
+  if (NT) __builtin_nontemporal_store((spmm_f4){z.x, z.y, z.z, z.w}, reinterpret_cast<spmm_f4 *>(out_row) + vi);
+  else reinterpret_cast<float4 *>(out_row)[vi] = z;
 }
 
 // One wave per SEGMENT (<= 64 consecutive neighbours of one row): rows are split so that a hub row does not
@@ -121,7 +131,7 @@ __global__ void __launch_bounds__(256) k_spmm_seg(const int32_t *__restrict__ co
 // place, no partial sums, no combine launch).  Rows of more than RS_LONG entries (hubs) take a whole wave: six entries per load,
 // the six partial sums added by shuffles.  Summation order: CSR order inside a row (short rows), six interleaved running sums
 // combined in group order (long rows): deterministic.
-constexpr int RS_W = 40, RS_Q = RS_W / 4, RS_G = 6;
+constexpr int RS_W = 40, RS_Q40 = RS_W / 4, RS_G40 = 6;        // the 40-column slices; the line variant: 8 float4, 8 rows per wave
 constexpr int RS_U = 8;                  // loads in flight per lane: the walk of a row is a chain of memory round trips
 constexpr int RS_SHORT = 32;             // rows of <= 32 entries: one lane group each (<= 4 round trips)
 constexpr int RS_LONG = 192;             // rows of <= 192 entries: one wave each, 48 entries per round trip; longer (hubs): a workgroup
@@ -129,10 +139,11 @@ constexpr int RS_LONG = 192;             // rows of <= 192 entries: one wave eac
 // entries e0, e0 + step, ... < t of one row, RS_U per round trip, accumulated into acc (this lane's float4 of the slice).  The ten
 // lanes of a group fetch the next ten (column, value) pairs with ONE load each and hand them round by shuffles: per 8 entries the
 // vector-memory path sees 8 + 2 instructions instead of 24 (it accepts one wave-wide load per ~17 clocks per CU whatever it carries)
+template <int Q>
 __device__ __forceinline__ void rs_walk(const int32_t *__restrict__ col, const float *__restrict__ val, const float *__restrict__ X,
                                         int64_t ldx, int vic, int e0, int step, int t, bool lane_on, int g, int q, float4 &acc) {
-  static_assert(RS_U <= RS_Q, "a group's lanes hold one round of (column, value) pairs");
-  const int gbase = g * RS_Q;
+  static_assert(RS_U <= Q, "a group's lanes hold one round of (column, value) pairs");
+  const int gbase = g * Q;
   int eq = min(e0 + q * step, max(t - 1, 0));
   int ce = col[eq];                                                 // (column, value) pairs of the first round
   float ve = (lane_on && e0 + q * step < t) ? (val ? val[eq] : 1.0f) : 0.0f;
@@ -158,6 +169,7 @@ __device__ __forceinline__ void rs_walk(const int32_t *__restrict__ col, const f
 }
 
 // blocks [0, n_slices * ublocks): 4 units each (a unit = 6 short rows, or one medium row); then n_slices blocks per hub row
+template <int RS_Q, int RS_G>
 __global__ void __launch_bounds__(256) k_spmm_rowslice(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
                                                        const float *__restrict__ val, const int32_t *__restrict__ unit_rows,
                                                        const int32_t *__restrict__ unit_out, int n_units,
@@ -168,9 +180,9 @@ __global__ void __launch_bounds__(256) k_spmm_rowslice(const int32_t *__restrict
                                                        const float *__restrict__ bias, const float *__restrict__ prelu_a,
                                                        float *__restrict__ out, int64_t ldo, float *__restrict__ out_pre) {
   __shared__ float4 hub_part[4][RS_Q];
-  const int slice = blockIdx.x % n_slices;
-  const int ub = blockIdx.x / n_slices, wid = threadIdx.x >> 6;
+  const int wid = threadIdx.x >> 6;
   const int ublocks = (n_units + n_long + 3) / 4;
+  const int slice = blockIdx.x % n_slices, ub = blockIdx.x / n_slices;
   const int lane = lane_id();
   const int g = lane / RS_Q, q = lane - g * RS_Q;
   const int vi = slice * RS_Q + q;                                 // float4 index inside a row of X / out
@@ -186,7 +198,7 @@ __global__ void __launch_bounds__(256) k_spmm_rowslice(const int32_t *__restrict
       const int row = lane_on ? unit_rows[u * RS_G + g] : -1;
       int e = 0, t = 0;
       if (row >= 0) { e = rowptr[row]; t = rowptr[row + 1]; }
-      rs_walk(col, val, X, ldx, vic, e, 1, t, lane_on, gc, q, acc);
+      rs_walk<RS_Q>(col, val, X, ldx, vic, e, 1, t, lane_on, gc, q, acc);
       if (row >= 0 && vi < (W >> 2)) {
         const int orow = unit_out[u * RS_G + g];
         spmm_epilogue_store(acc, vi, bias, prelu_a, a, out + (int64_t)orow * ldo, out_pre ? out_pre + (int64_t)orow * ldo : nullptr);
@@ -195,7 +207,7 @@ __global__ void __launch_bounds__(256) k_spmm_rowslice(const int32_t *__restrict
     }
     const int lr = u - n_units;                                    // a medium row: the six lane groups take every sixth entry
     const int row = long_rows[lr];
-    rs_walk(col, val, X, ldx, vic, rowptr[row] + gc, RS_G, rowptr[row + 1], lane_on, gc, q, acc);
+    rs_walk<RS_Q>(col, val, X, ldx, vic, rowptr[row] + gc, RS_G, rowptr[row + 1], lane_on, gc, q, acc);
     if (!lane_on) acc = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 tot = acc;                                              // group 0 + 1 + ... + 5, in that order
 #pragma unroll
@@ -214,7 +226,7 @@ __global__ void __launch_bounds__(256) k_spmm_rowslice(const int32_t *__restrict
   const int hr = ub - ublocks;
   if (hr >= n_hub) return;
   const int row = hub_rows[hr];
-  rs_walk(col, val, X, ldx, vic, rowptr[row] + wid * RS_G + gc, 4 * RS_G, rowptr[row + 1], lane_on, gc, q, acc);
+  rs_walk<RS_Q>(col, val, X, ldx, vic, rowptr[row] + wid * RS_G + gc, 4 * RS_G, rowptr[row + 1], lane_on, gc, q, acc);
   if (!lane_on) acc = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 tot = acc;
 #pragma unroll
@@ -232,6 +244,205 @@ __global__ void __launch_bounds__(256) k_spmm_rowslice(const int32_t *__restrict
     const int orow = hub_out[hr];
     spmm_epilogue_store(r, vi, bias, prelu_a, a, out + (int64_t)orow * ldo, out_pre ? out_pre + (int64_t)orow * ldo : nullptr);
   }
+}
+
+// ---- the same product, LINE-granular and persistent, for operands whose rows are 128-byte aligned ---------------------------------
+// (row stride a multiple of 32 floats: the producers of the path pad their 300-float rows to 320, fullgraph.py::padded_rows).
+// Two things the counters of k_spmm_rowslice showed (profiles/r03_spmm_reddit_pmc.csv): a 160-byte slice of a 1,200-byte row
+// straddles 2-3 lines, so every XCD fetched 2.3 x the bytes it used; and 21,000 waves of 2,800 cycles each kept less than ONE wave
+// per SIMD resident -- the launch was bound by the rate workgroups are dispatched at, not by memory.  Here a slice is one 128-byte
+// line (8 float4: a wave holds 8 rows, all 64 lanes of a load carry data, nothing is fetched that is not used) and the grid is a
+// fixed number of workgroups per XCD whose waves loop over the work items of that XCD: line x of every unit (W = 300 is 10 lines for
+// 8 XCDs: the lines 8 and 9 are split by rows over the XCDs x % 2 == 0 / == 1, a quarter of the rows each, so an L2 keeps two lines
+// of every row -- 2.8 MB at Reddit size -- and every XCD has 1.25 lines of work).  The host hands (first entry, end, output row) per
+// row slot in one table, so a wave's chain of dependent round trips is table -> columns -> rows of X instead of unit -> rowptr ->
+// columns -> rows.  Items: the medium rows (one wave each, longest first), then the units of 8 short rows (longest first); hub rows
+// (a workgroup each) before them.  workgroup b runs on XCD b % 8 (dispatcher rotation).  Summation order as in k_spmm_rowslice with
+// 8 groups: CSR order inside a short row; 8 (medium) or 8 x waves (hub) interleaved running sums combined in a fixed order.
+constexpr int RL_G = 8;                  // rows per wave = float4 per line
+
+__device__ __forceinline__ float4 rl_group_sum(float4 acc, int q) {          // group 0 + 1 + ... + 7, in that order
+  float4 tot = acc;
+#pragma unroll
+  for (int k = 1; k < RL_G; ++k) {
+    const int src = q + k * RL_G;
+    tot.x += __shfl(acc.x, src, GGAD_WAVE); tot.y += __shfl(acc.y, src, GGAD_WAVE);
+    tot.z += __shfl(acc.z, src, GGAD_WAVE); tot.w += __shfl(acc.w, src, GGAD_WAVE);
+  }
+  return tot;
+}
+
+typedef float rl_f2 __attribute__((ext_vector_type(2)));
+
+// the (column, value) pair of entry e0 + q * step of this lane's row (the last entry again, with value 0, past the end t): lane q
+// of a group fetches pair q of a round of 8
+__device__ __forceinline__ int2 rl_pair(const int2 *__restrict__ ent, int e0, int step, int t, int q) {
+  const int at = e0 + q * step;
+  int2 p = ent[min(at, max(t - 1, 0))];
+  if (at >= t) p.y = 0;
+  return p;
+}
+
+constexpr int RL_R = 4;                  // rounds of 8 entries a wave item has at most: short rows <= 32 entries, medium rows <= 192 over 8 groups
+
+// A wave item: entries e0, e0 + step, ... < t of this lane group's row (<= RL_R rounds of 8), accumulated into acc (this lane's
+// float4 of the line).  Its pairs are ALL in registers (lane q holds pairs q, q + 8, ..., fetched while the previous item was
+// walked) and go to the wave's 2 KB of LDS in one go -- (byte offset of the row of X, value) per ds_write_b64 -- so the rounds depend
+// on nothing but their own loads: four ds_read_b128 give a lane the 8 pairs of its row (the 8 lanes of a group read the same
+// addresses: broadcasts, no bank conflict), then 8 loads of X rows with 32-bit offsets from a uniform base, 8 adds and 16
+// v_pk_fma_f32.  (The first version handed the pairs round by ds_bpermute and walked 64-bit addresses: 360 vector instructions per
+// item.  Per-workgroup clocks -- scripts/rowline_clocks.py -- then showed what actually bounds the launch: the hub rows and the
+// number of load instructions of the vector-memory path, 16 clocks each per CU.)
+__device__ __forceinline__ void rl_walk_item(const char *__restrict__ Xb, uint32_t ldx4, uint32_t voff, int e0, int step, int t,
+                                             int lane, int g, const int2 (&pe)[RL_R], int2 *__restrict__ lds_w, float4 &acc) {
+  rl_f2 a01 = {acc.x, acc.y}, a23 = {acc.z, acc.w};
+#pragma unroll
+  for (int r = 0; r < RL_R; ++r) lds_w[r * 64 + lane] = make_int2((int)__umul24((uint32_t)pe[r].x, ldx4), pe[r].y);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+  for (int r = 0; r < RL_R; ++r) {
+    if (e0 + r * RL_G * step < t) {
+      const int4 *rd = reinterpret_cast<const int4 *>(lds_w + r * 64 + g * RL_G);
+      int4 p[RL_G / 2];
+#pragma unroll
+      for (int k = 0; k < RL_G / 2; ++k) p[k] = rd[k];
+      float4 x[RL_G];
+#pragma unroll
+      for (int k = 0; k < RL_G / 2; ++k) {
+        x[2 * k] = *reinterpret_cast<const float4 *>(Xb + ((uint32_t)p[k].x + voff));
+        x[2 * k + 1] = *reinterpret_cast<const float4 *>(Xb + ((uint32_t)p[k].z + voff));
+      }
+#pragma unroll
+      for (int k = 0; k < RL_G / 2; ++k) {
+        const float v0 = __int_as_float(p[k].y), v1 = __int_as_float(p[k].w);
+        const rl_f2 s0 = {v0, v0}, s1 = {v1, v1};
+        a01 = __builtin_elementwise_fma(s0, (rl_f2){x[2 * k].x, x[2 * k].y}, a01);
+        a23 = __builtin_elementwise_fma(s0, (rl_f2){x[2 * k].z, x[2 * k].w}, a23);
+        a01 = __builtin_elementwise_fma(s1, (rl_f2){x[2 * k + 1].x, x[2 * k + 1].y}, a01);
+        a23 = __builtin_elementwise_fma(s1, (rl_f2){x[2 * k + 1].z, x[2 * k + 1].w}, a23);
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();                                 // (the next item's ds_writes stay behind these reads)
+  acc = make_float4(a01.x, a01.y, a23.x, a23.y);
+}
+
+#ifdef GGAD_RL_PROF
+__device__ unsigned long long g_rl_prof[4 * 8192];          // per workgroup: start, hub rows done, end (wall_clock64, 100 MHz), items walked
+#endif
+
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) k_spmm_rowline(const int2 *__restrict__ ent, const int4 *__restrict__ unit_tab, int n_units,
+                                                          const int4 *__restrict__ long_tab, int n_long,
+                                                          const int4 *__restrict__ hub_tab, int n_hub, int n_lines,
+                                                          const float *__restrict__ X, int64_t ldx, int W,
+                                                          const float *__restrict__ bias, const float *__restrict__ prelu_a,
+                                                          float *__restrict__ out, int64_t ldo, float *__restrict__ out_pre) {
+  __shared__ float4 hub_part[NW][RL_G];
+  __shared__ int2 pair_lds[NW][RL_R * 64];
+#ifdef GGAD_RL_PROF
+  if (threadIdx.x == 0 && blockIdx.x < 8192) g_rl_prof[4 * blockIdx.x] = wall_clock64();
+#endif
+  const int wid = threadIdx.x >> 6, lane = lane_id(), g = lane >> 3, q = lane & 7;
+  const int x = blockIdx.x & 7, b = blockIdx.x >> 3, B = gridDim.x >> 3;
+  const int extra = n_lines - 8;                                   // lines beyond one per XCD (0 <= extra <= 8)
+  const int k = extra > 0 ? x % extra : 0, r = extra > 0 ? x / extra : 0;      // this XCD is the r-th of the XCDs k, k + extra, ... serving line 8 + k
+  const int servers = extra > 0 ? (8 - k + extra - 1) / extra : 1;
+  const int nv = W >> 2;
+  const float a = prelu_a ? *prelu_a : 1.0f;
+  const char *Xb = reinterpret_cast<const char *>(X);
+  const uint32_t ldx4 = (uint32_t)ldx * 4u;
+  int2 *lds_w = pair_lds[wid];
+  // wave items, software-pipelined: while item i is walked, the pair of the first round of item i + stride and the table entry of
+  // item i + 2 stride are in flight -- the chain of dependent round trips per item is the rounds of X rows alone
+  const int NU = n_long + n_units;
+  const int share = extra > 0 ? (NU + servers - 1) / servers : 0;
+  const int n_items = NU + share, stride = B * NW;
+  auto unit_of = [&](int i, int &slice) -> int {                   // -1: nothing (past the end, or past this XCD's share of an extra line)
+    slice = x;
+    if (i >= n_items) return -1;
+    if (i < NU) return i;
+    slice = 8 + k;
+    const int u = r * share + (i - NU);
+    return u < NU ? u : -1;
+  };
+  auto fetch_tab = [&](int i) -> int4 {                            // (first entry of this lane group, end, output row, step)
+    int slice;
+    const int u = unit_of(i, slice);
+    if (u < 0) return make_int4(0, 0, -1, 1);
+    if (u < n_long) { int4 m = long_tab[u]; m.x += g; m.w = RL_G; return m; }
+    int4 m = unit_tab[(int64_t)(u - n_long) * RL_G + g];
+    m.w = 1;
+    return m;
+  };
+  const int i0 = b * NW + wid;
+  int4 m0 = fetch_tab(i0), m1 = fetch_tab(i0 + stride);
+  int2 pe[RL_R];
+#pragma unroll
+  for (int rr = 0; rr < RL_R; ++rr) pe[rr] = rl_pair(ent, m0.x + rr * RL_G * m0.w, m0.w, m0.y, q);
+  {                                                                // hub rows (behind the first prefetches): the 8 x NW lane groups of the
+    const int hshare = extra > 0 ? (n_hub + servers - 1) / servers : 0;      // workgroup take every (8 NW)-th entry, 8 NW x 8 RL_R entries per pass
+    for (int i = b; i < n_hub + hshare; i += B) {
+      int slice = x, h = i;
+      if (i >= n_hub) { slice = 8 + k; h = r * hshare + (i - n_hub); if (h >= n_hub) break; }
+      const int4 m = hub_tab[h];
+      const int vi = slice * RL_G + q, vic = vi < nv ? vi : 0;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int step = NW * RL_G;
+      for (int e0 = m.x + wid * RL_G + g; e0 < m.y; e0 += step * RL_G * RL_R) {      // (the whole wave leaves together: e0 differs by < step)
+        int2 ph[RL_R];
+#pragma unroll
+        for (int rr = 0; rr < RL_R; ++rr) ph[rr] = rl_pair(ent, e0 + rr * RL_G * step, step, m.y, q);
+        rl_walk_item(Xb, ldx4, (uint32_t)vic * 16u, e0, step, m.y, lane, g, ph, lds_w, acc);
+      }
+      const float4 tot = rl_group_sum(acc, q);
+      if (g == 0) hub_part[wid][q] = tot;
+      __syncthreads();
+      if (wid == 0 && g == 0 && vi < nv) {
+        float4 t = hub_part[0][q];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) { const float4 p2 = hub_part[w][q]; t.x += p2.x; t.y += p2.y; t.z += p2.z; t.w += p2.w; }
+        spmm_epilogue_store(t, vi, bias, prelu_a, a, out + (int64_t)m.z * ldo, out_pre ? out_pre + (int64_t)m.z * ldo : nullptr);
+      }
+      __syncthreads();
+    }
+  }
+#ifdef GGAD_RL_PROF
+  if (threadIdx.x == 0 && blockIdx.x < 8192) g_rl_prof[4 * blockIdx.x + 1] = wall_clock64();
+  int n_walked = 0;
+#endif
+  for (int i = i0; i < n_items; i += stride) {
+#ifdef GGAD_RL_PROF
+    ++n_walked;
+#endif
+    int slice;
+    const int u = unit_of(i, slice);
+    const int vi = slice * RL_G + q, vic = vi < nv ? vi : 0;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    // (inside: this item's pairs go to LDS, then the loads below -- next item's pairs, the table entry after it -- are in flight
+    // behind the rounds' loads of X rows)
+    const int4 m2 = fetch_tab(i + 2 * stride);
+    int2 pn[RL_R];
+#pragma unroll
+    for (int rr = 0; rr < RL_R; ++rr) pn[rr] = rl_pair(ent, m1.x + rr * RL_G * m1.w, m1.w, m1.y, q);
+    rl_walk_item(Xb, ldx4, (uint32_t)vic * 16u, m0.x, m0.w, m0.y, lane, g, pe, lds_w, acc);
+    if (u >= 0 && u < n_long) {                                    // a medium row: the 8 lane groups took every 8th entry
+      const float4 tot = rl_group_sum(acc, q);
+      if (g == 0 && vi < nv)
+        spmm_epilogue_store(tot, vi, bias, prelu_a, a, out + (int64_t)m0.z * ldo, out_pre ? out_pre + (int64_t)m0.z * ldo : nullptr);
+    } else if (m0.z >= 0 && vi < nv) {                             // 8 short rows, one per lane group (an empty slot: m.z < 0, no entries)
+      spmm_epilogue_store(acc, vi, bias, prelu_a, a, out + (int64_t)m0.z * ldo, out_pre ? out_pre + (int64_t)m0.z * ldo : nullptr);
+    }
+    m0 = m1; m1 = m2;
+#pragma unroll
+    for (int rr = 0; rr < RL_R; ++rr) pe[rr] = pn[rr];
+  }
+#ifdef GGAD_RL_PROF
+  __syncthreads();
+  if (threadIdx.x == 0 && blockIdx.x < 8192) { g_rl_prof[4 * blockIdx.x + 2] = wall_clock64(); g_rl_prof[4 * blockIdx.x + 3] = n_walked; }
+#endif
 }
 
 // ---- XCD-sliced variant for dense neighbourhoods (T-Finance: 470 neighbours per row, X = 47 MB) -----------------------
@@ -785,7 +996,8 @@ __global__ void __launch_bounds__(256) k_prelu_bwd(const float *__restrict__ g, 
 // 39,357 x 300: one 256-byte row piece per wave and trip, 5 waves per CU).
 __global__ void __launch_bounds__(256) k_prelu_bwd_v4(const float4 *__restrict__ g, const float4 *__restrict__ z,
                                                       const float *__restrict__ prelu_a, int M, int nvec, float4 *__restrict__ dz,
-                                                      float4 *__restrict__ part_db, float4 *__restrict__ part_da) {
+                                                      int64_t ldz, float4 *__restrict__ part_db, float4 *__restrict__ part_da) {
+  // ldz: row stride of dz in float4 (nvec when dense; more when the next product wants 128-byte aligned rows)
   __shared__ float4 sb[256], sa[256];
   const int t = threadIdx.x;
   const int RP = 256 / nvec;                        // rows per pass of the workgroup (nvec <= 256)
@@ -797,7 +1009,7 @@ __global__ void __launch_bounds__(256) k_prelu_bwd_v4(const float4 *__restrict__
     float4 d;                                                                                                     \
     d.x = Z_.x > 0.f ? G_.x : a * G_.x; d.y = Z_.y > 0.f ? G_.y : a * G_.y;                                       \
     d.z = Z_.z > 0.f ? G_.z : a * G_.z; d.w = Z_.w > 0.f ? G_.w : a * G_.w;                                       \
-    dz[O_] = d;                                                                                                   \
+    dz[(O_) / nvec * ldz + (O_) % nvec] = d;                                                                     \
     adb.x += d.x; adb.y += d.y; adb.z += d.z; adb.w += d.w;                                                       \
     ada.x += Z_.x > 0.f ? 0.f : G_.x * Z_.x; ada.y += Z_.y > 0.f ? 0.f : G_.y * Z_.y;                             \
     ada.z += Z_.z > 0.f ? 0.f : G_.z * Z_.z; ada.w += Z_.w > 0.f ? 0.f : G_.w * Z_.w;                             \
@@ -1244,7 +1456,7 @@ int ggad_spmm_csr_f32(const int32_t *col, const float *val, const int32_t *seg_b
   return GGAD_OK;
 }
 
-int32_t ggad_spmm_rowslice_group(void) { return RS_G; }
+int32_t ggad_spmm_rowslice_group(void) { return RS_G40; }
 int32_t ggad_spmm_rowslice_short(void) { return RS_SHORT; }
 int32_t ggad_spmm_rowslice_long(void) { return RS_LONG; }
 
@@ -1259,12 +1471,45 @@ int ggad_spmm_rowslice_f32(const int32_t *rowptr, const int32_t *col, const floa
   const int n_slices = (W + RS_W - 1) / RS_W;
   const int64_t blocks = (int64_t)n_slices * ((n_units + n_long + 3) / 4 + n_hub);
   GGAD_REQUIRE(blocks < (1ll << 31));
-  k_spmm_rowslice<<<dim3((unsigned)blocks), dim3(256), 0, as_stream(stream)>>>(rowptr, col, val, unit_rows, unit_out, n_units, long_rows,
-                                                                            long_out, n_long, hub_rows, hub_out, n_hub, n_slices, X,
-                                                                            ldx, W, bias, prelu_a, out, ldo, out_pre);
+  k_spmm_rowslice<RS_Q40, RS_G40><<<dim3((unsigned)blocks), dim3(256), 0, as_stream(stream)>>>(
+      rowptr, col, val, unit_rows, unit_out, n_units, long_rows, long_out, n_long, hub_rows, hub_out, n_hub, n_slices, X, ldx, W, bias,
+      prelu_a, out, ldo, out_pre);
   GGAD_CHECK_LAUNCH("spmm_rowslice_f32");
   return GGAD_OK;
 }
+
+/* The line-granular persistent variant (k_spmm_rowline): X rows 128-byte aligned (pointer and ldx * 4), 256 <= W <= 512, the whole
+ * operand addressable with 32 bits.  ent: (column, value bits) per entry, CSR order.  Tables of (first entry, end, output row, 0):
+ * unit_tab 8 slots per unit of short rows (empty slot: 0, 0, -1), long_tab / hub_tab one per row. */
+int32_t ggad_spmm_rowline_supported(const float *X, int64_t ldx, int32_t W, int64_t n_src_rows) {
+  return (X && (((uintptr_t)X) & 127) == 0 && (ldx & 31) == 0 && ldx >= W && ldx <= 4096 && W >= 256 && W <= 512 && (W & 3) == 0 &&
+          n_src_rows >= 1 && n_src_rows < (1 << 24) && n_src_rows * ldx * 4 < (1ll << 32)) ? 1 : 0;
+}
+
+int ggad_spmm_rowline_f32(const int32_t *ent, const int32_t *unit_tab, int32_t n_units, const int32_t *long_tab, int32_t n_long,
+                          const int32_t *hub_tab, int32_t n_hub, const float *X, int64_t ldx, int32_t W, int64_t n_src_rows,
+                          const float *bias, const float *prelu_a, float *out, int64_t ldo, float *out_pre, ggad_stream_t stream) {
+  GGAD_REQUIRE(ent && X && out && n_units >= 0 && n_long >= 0 && n_hub >= 0 && ggad_spmm_rowline_supported(X, ldx, W, n_src_rows));
+  GGAD_REQUIRE((n_units == 0 || unit_tab) && (n_long == 0 || long_tab) && (n_hub == 0 || hub_tab));
+  GGAD_REQUIRE((ldo & 3) == 0 && ldo >= W && ((((uintptr_t)unit_tab) | ((uintptr_t)long_tab) | ((uintptr_t)hub_tab)) & 15) == 0 && (((uintptr_t)ent) & 7) == 0);
+  if (n_units + n_long + n_hub == 0) return GGAD_OK;
+  static const int env_bpx = [] { const char *e = getenv("GGAD_ROWLINE_BPX"); return e ? atoi(e) : 0; }();
+  const int n_lines = (W + 31) / 32, nw = 4;
+  const int64_t items = (int64_t)(n_units + n_long) * 5 / 4 + 1;           // per XCD at 10 lines
+  int bpx = env_bpx > 0 ? env_bpx : 256;                                   // 8 workgroups of 4 waves per CU: 8 waves per SIMD
+  bpx = (int)std::max<int64_t>(1, std::min<int64_t>(bpx, std::max<int64_t>((items + nw - 1) / nw, n_hub)));
+  k_spmm_rowline<4><<<dim3(8u * bpx), dim3(256), 0, as_stream(stream)>>>(
+      reinterpret_cast<const int2 *>(ent), reinterpret_cast<const int4 *>(unit_tab), n_units, reinterpret_cast<const int4 *>(long_tab), n_long,
+      reinterpret_cast<const int4 *>(hub_tab), n_hub, n_lines, X, ldx, W, bias, prelu_a, out, ldo, out_pre);
+  GGAD_CHECK_LAUNCH("spmm_rowline_f32");
+  return GGAD_OK;
+}
+
+#ifdef GGAD_RL_PROF
+int ggad_debug_rowline_prof(unsigned long long *dst, int32_t n_words) {      // scripts/rowline_clocks.py (GGAD_EXTRA_HIPFLAGS=-DGGAD_RL_PROF builds only)
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_rl_prof), sizeof(unsigned long long) * n_words) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int64_t ggad_spmm_sliced_workspace_elems(int64_t n_src_rows, int32_t W) {
   return n_src_rows * spmm_n_slices(W) * SPMM_SL * 4;
@@ -1389,23 +1634,30 @@ int ggad_spmm_ring_f32(const int32_t *wg_tab, int32_t n_wg, const int32_t *wave_
 
 int32_t ggad_prelu_bwd_splits(int32_t M) { int s = (M + 63) / 64; return s < 1 ? 1 : (s > 256 ? 256 : s); }
 
-int ggad_prelu_bwd_f32(const float *g, const float *z, const float *prelu_a, int32_t M, int32_t W, float *dz, float *db,
-                       float *da, float *workspace, ggad_stream_t stream) {
-  GGAD_REQUIRE(g && z && prelu_a && dz && workspace && M >= 1 && W >= 1);
+int ggad_prelu_bwd_ld_f32(const float *g, const float *z, const float *prelu_a, int32_t M, int32_t W, float *dz, int64_t ld_dz, float *db,
+                          float *da, float *workspace, ggad_stream_t stream) {
+  GGAD_REQUIRE(g && z && prelu_a && dz && workspace && M >= 1 && W >= 1 && ld_dz >= W);
   const int S = ggad_prelu_bwd_splits(M);
   float *pdb = workspace, *pda = workspace + (int64_t)S * W;
   hipStream_t st = as_stream(stream);
-  if ((W & 3) == 0 && W <= 1024 && (((uintptr_t)g | (uintptr_t)z | (uintptr_t)dz | (uintptr_t)workspace) & 15) == 0 && (((int64_t)S * W) & 3) == 0)
+  if ((W & 3) == 0 && (ld_dz & 3) == 0 && W <= 1024 && (((uintptr_t)g | (uintptr_t)z | (uintptr_t)dz | (uintptr_t)workspace) & 15) == 0 && (((int64_t)S * W) & 3) == 0)
     k_prelu_bwd_v4<<<dim3(S), dim3(256), 0, st>>>(reinterpret_cast<const float4 *>(g), reinterpret_cast<const float4 *>(z), prelu_a, M, W >> 2,
-                                                  reinterpret_cast<float4 *>(dz), reinterpret_cast<float4 *>(pdb), reinterpret_cast<float4 *>(pda));
-  else
+                                                  reinterpret_cast<float4 *>(dz), ld_dz >> 2, reinterpret_cast<float4 *>(pdb), reinterpret_cast<float4 *>(pda));
+  else {
+    GGAD_REQUIRE(ld_dz == W);                                    // (the scalar kernel writes dense rows)
     k_prelu_bwd<<<dim3((W + 63) / 64, S), dim3(256), 0, st>>>(g, z, prelu_a, M, W, dz, pdb, pda);
+  }
   if (W <= 1024)
     k_prelu_bwd_final<<<dim3(1), dim3(1024), 0, st>>>(pdb, pda, S, W, db, da);
   else
     k_prelu_bwd_final_wide<<<dim3(1), dim3(1024), 0, st>>>(pdb, pda, S, W, db, da);      // layers wider than 1,024 (tam.py --embedding_dim > 512)
   GGAD_CHECK_LAUNCH("prelu_bwd_f32");
   return GGAD_OK;
+}
+
+int ggad_prelu_bwd_f32(const float *g, const float *z, const float *prelu_a, int32_t M, int32_t W, float *dz, float *db,
+                       float *da, float *workspace, ggad_stream_t stream) {
+  return ggad_prelu_bwd_ld_f32(g, z, prelu_a, M, W, dz, W, db, da, workspace, stream);
 }
 
 int ggad_relu_bwd_f32(const float *g, const float *y, int64_t n, float *dz, ggad_stream_t stream) {

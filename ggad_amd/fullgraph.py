@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import call, ptr
+from ._lib import call, ptr, ptr_rows
 
 
 def _dev_i32(a, dev):
@@ -48,6 +48,13 @@ class Csr:
         self.host = m
         self.dev = dev
         self._plans = {}
+
+    def entries(self) -> torch.Tensor:
+        """(column, bits of the value) per stored entry, interleaved int32 (what k_spmm_rowline fetches with one 8-byte load)."""
+        e = self._plans.get("entries")
+        if e is None:
+            e = self._plans["entries"] = torch.stack((self.col, self.val.view(torch.int32)), 1).contiguous()
+        return e
 
     def plan(self, rows_sel: Optional[np.ndarray] = None, key=None, seg: Optional[int] = None, col_ranges: int = 1):
         """Segment tables for ggad_spmm_csr_f32 / ggad_spmm_sliced_f32 (whole matrix, or the row subset `rows_sel`); cached.
@@ -117,15 +124,18 @@ class Csr:
             self._plans[key] = p
         return p
 
-    def rowslice_plan(self, p):
+    def rowslice_plan(self, p, lines: bool = False):
         """Units of the column-sliced kernel for sparse neighbourhoods (k_spmm_rowslice) for the rows of segment plan `p` (whole
-        matrix or a row subset): rows sorted by length into groups of 6, rows of more than `ggad_spmm_rowslice_long()` entries apart.
-        Cached on the plan."""
-        rs = p.get("rowslice")
+        matrix or a row subset): rows sorted by length into groups of 6 (8 for the line-granular variant, `lines`), rows of more
+        than `ggad_spmm_rowslice_long()` entries apart.  Cached on the plan."""
+        slot = "rowline" if lines else "rowslice"
+        rs = p.get(slot)
         if rs is not None:
             return rs
         lib = _lib.load()
         G, SHORT, LONG = int(lib.ggad_spmm_rowslice_group()), int(lib.ggad_spmm_rowslice_short()), int(lib.ggad_spmm_rowslice_long())
+        if lines:
+            G = 8
         rp = self.host.indptr.astype(np.int64)
         rows = np.arange(self.shape[0], dtype=np.int64) if p.get("rows") is None else np.asarray(p["rows"], dtype=np.int64)
         outr = np.arange(len(rows), dtype=np.int64)
@@ -139,11 +149,22 @@ class Csr:
         uo = np.zeros(n_units * G, dtype=np.int64)
         ur[:len(sr)], uo[:len(so)] = sr, so
         mo = np.argsort(-deg[is_med], kind="stable")                    # longest first: they start first
+        ho = np.argsort(-deg[is_hub], kind="stable")
         dev = self.dev
-        rs = dict(unit_rows=_dev_i32(ur, dev), unit_out=_dev_i32(uo, dev), n_units=int(n_units),
-                  long_rows=_dev_i32(rows[is_med][mo], dev), long_out=_dev_i32(outr[is_med][mo], dev), n_long=int(is_med.sum()),
-                  hub_rows=_dev_i32(rows[is_hub], dev), hub_out=_dev_i32(outr[is_hub], dev), n_hub=int(is_hub.sum()))
-        p["rowslice"] = rs
+        if lines:                                                       # (first entry, end, output row, 0) per slot: k_spmm_rowline
+            def tab(r, o):
+                t = np.zeros((len(r), 4), dtype=np.int32)
+                ok = r >= 0
+                t[ok, 0], t[ok, 1] = rp[r[ok]], rp[r[ok] + 1]
+                t[:, 2] = np.where(ok, o, -1)
+                return torch.from_numpy(t.reshape(-1)).to(dev)
+            rs = dict(unit_tab=tab(ur, uo), n_units=int(n_units), long_tab=tab(rows[is_med][mo], outr[is_med][mo]), n_long=int(is_med.sum()),
+                      hub_tab=tab(rows[is_hub][ho], outr[is_hub][ho]), n_hub=int(is_hub.sum()))
+        else:
+            rs = dict(unit_rows=_dev_i32(ur, dev), unit_out=_dev_i32(uo, dev), n_units=int(n_units),
+                      long_rows=_dev_i32(rows[is_med][mo], dev), long_out=_dev_i32(outr[is_med][mo], dev), n_long=int(is_med.sum()),
+                      hub_rows=_dev_i32(rows[is_hub], dev), hub_out=_dev_i32(outr[is_hub], dev), n_hub=int(is_hub.sum()))
+        p[slot] = rs
         return rs
 
     def value_factors(self):
@@ -605,8 +626,9 @@ class FullGraphAdj:
 
 
 # ------------------------------------------------------------------------------------------------ kernels
-def gemm(A: torch.Tensor, B: torch.Tensor, trans_a: bool, trans_b: bool, bias=None, relu: bool = False) -> torch.Tensor:
-    """C = op(A) op(B) on the matrix cores; A, B row-major 2-D fp32."""
+def gemm(A: torch.Tensor, B: torch.Tensor, trans_a: bool, trans_b: bool, bias=None, relu: bool = False, out=None) -> torch.Tensor:
+    """C = op(A) op(B) on the matrix cores; A, B row-major 2-D fp32.  `out`: an (M, N) destination with unit column stride (its
+    row stride may exceed N: `padded_rows`)."""
     A, B = A.contiguous(), B.contiguous()
     M, K = (A.shape[1], A.shape[0]) if trans_a else (A.shape[0], A.shape[1])
     K2, N = (B.shape[1], B.shape[0]) if trans_b else (B.shape[0], B.shape[1])
@@ -614,11 +636,13 @@ def gemm(A: torch.Tensor, B: torch.Tensor, trans_a: bool, trans_b: bool, bias=No
         raise ValueError("gemm shape mismatch")
     sam, sak = (1, A.shape[1]) if trans_a else (A.shape[1], 1)
     sbk, sbn = (1, B.shape[1]) if trans_b else (B.shape[1], 1)
-    C = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    C = out if out is not None else torch.empty(M, N, dtype=torch.float32, device=A.device)
+    if tuple(C.shape) != (M, N) or C.stride(1) != 1 or C.stride(0) < N or C.dtype != torch.float32:
+        raise ValueError("gemm: out must be (M, N) fp32 with unit column stride")
     lib = _lib.load()
     ws_n = int(lib.ggad_gemm_workspace_elems(M, N, K))
     ws = torch.empty(ws_n, dtype=torch.float32, device=A.device) if ws_n else None
-    call("ggad_gemm_f32", ptr(A), ptr(B), ptr(C), M, N, K, sam, sak, sbk, sbn, N, ptr(bias) if bias is not None else 0,
+    call("ggad_gemm_f32", ptr(A), ptr(B), ptr_rows(C), M, N, K, sam, sak, sbk, sbn, C.stride(0), ptr(bias) if bias is not None else 0,
          1 if relu else 0, ptr(ws) if ws is not None else 0)
     return C
 
@@ -644,6 +668,26 @@ def _use_rowslice(csr: Csr, p, X: torch.Tensor) -> bool:
         return force == "1"
     w = X.shape[1]
     return w >= 160 and X.shape[0] * w * 4 >= (4 << 20)
+
+
+def _use_rowline(X: torch.Tensor) -> bool:
+    """A row-strided operand the line-granular kernel (k_spmm_rowslice<8, 8, true>) takes as it is: 128-byte aligned rows."""
+    return bool(_lib.load().ggad_spmm_rowline_supported(ptr_rows(X), X.stride(0), X.shape[1], X.shape[0]))
+
+
+def padded_rows(n_rows: int, W: int, dev, consumer=None):
+    """An (n_rows, W) fp32 matrix for a producer kernel to fill.  When the product that will read it -- `consumer` = (csr, plan) --
+    is one of the sparse-neighbourhood products (what `_use_rowslice` selects: Reddit, Photo), its rows start on 128-byte lines
+    (a view of a matrix with the row stride rounded up to 32 floats; the padding columns are never read) and `spmm` then runs the
+    line-granular kernel; a plain contiguous matrix otherwise.  GGAD_SPMM_ROWLINE=0: always contiguous."""
+    ld = (W + 31) // 32 * 32
+    if consumer is not None and ld != W and os.environ.get("GGAD_SPMM_ROWLINE", "1") != "0":
+        csr, p = consumer
+        p = p if p is not None else csr.plan()
+        X = torch.empty(n_rows, ld, dtype=torch.float32, device=dev)[:, :W]
+        if csr.nnz > 0 and _use_rowline(X) and _use_panel(csr, p, X) is None and not _use_sliced(csr, p, X) and _use_rowslice(csr, p, X):
+            return X
+    return torch.empty(n_rows, W, dtype=torch.float32, device=dev)
 
 
 def _use_panel(csr: Csr, p, X: torch.Tensor):
@@ -684,17 +728,27 @@ def _part_buffer(p, W: int, dev):
     return part
 
 
-def spmm(csr: Csr, X: torch.Tensor, plan=None, bias=None, prelu_a=None, want_pre=False):
-    """out = act(csr[rows] @ X + bias); `plan` = csr.plan(...) selects the rows (default: all)."""
-    X = X.contiguous()
+def spmm(csr: Csr, X: torch.Tensor, plan=None, bias=None, prelu_a=None, want_pre=False, out=None):
+    """out = act(csr[rows] @ X + bias); `plan` = csr.plan(...) selects the rows (default: all).  `out`: destination (and shape of
+    the pre-activation copy) with unit column stride; its row stride may exceed W."""
+    strided = X.dim() == 2 and X.stride(1) == 1 and X.stride(0) > X.shape[1] and csr.nnz > 0 and _use_rowline(X)     # padded rows: see padded_rows()
+    if not strided:
+        X = X.contiguous()
     W = X.shape[1]
     p = plan if plan is not None else csr.plan()
-    out = torch.empty(p["n_out"], W, dtype=torch.float32, device=X.device)
-    pre = torch.empty_like(out) if want_pre else None
-    opt = (ptr(bias) if bias is not None else 0, ptr(prelu_a) if prelu_a is not None else 0, ptr(out), W,
-           ptr(pre) if pre is not None else 0)
-    pp = _use_panel(csr, p, X)
-    if pp is not None:
+    if out is None:
+        out = torch.empty(p["n_out"], W, dtype=torch.float32, device=X.device)
+    elif tuple(out.shape) != (p["n_out"], W) or out.dtype != torch.float32:
+        raise ValueError("spmm: out must be (rows, W) fp32")
+    pre = torch.empty_strided(out.shape, out.stride(), dtype=torch.float32, device=X.device) if want_pre else None
+    opt = (ptr(bias) if bias is not None else 0, ptr(prelu_a) if prelu_a is not None else 0, ptr_rows(out), out.stride(0),
+           ptr_rows(pre) if pre is not None else 0)
+    pp = None if strided else _use_panel(csr, p, X)
+    if strided:
+        rs = csr.rowslice_plan(p, lines=True)
+        call("ggad_spmm_rowline_f32", ptr(csr.entries()), ptr(rs["unit_tab"]), rs["n_units"], ptr(rs["long_tab"]), rs["n_long"],
+             ptr(rs["hub_tab"]), rs["n_hub"], ptr_rows(X), X.stride(0), W, X.shape[0], *opt)
+    elif pp is not None:
         xs = _xs_workspace(X, int(_lib.load().ggad_spmm_sliced_workspace_elems(X.shape[0], W)))
         opt_p = lambda t: ptr(t) if t is not None else 0
         if "wave_sb" in pp:
@@ -767,7 +821,7 @@ class GcnLayerFn(torch.autograd.Function):
             call("ggad_prelu_fwd_f32", ptr(z), ptr(prelu_a), z.numel(), ptr(out))
             ctx.save_for_backward(ax, weight, z, prelu_a)
         else:
-            t = gemm(x, weight, False, True)                                     # seq_fts = fc(seq)        model.py:27
+            t = gemm(x, weight, False, True, out=padded_rows(x.shape[0], weight.shape[0], x.device, (adj.A, None)))      # seq_fts = fc(seq)   model.py:27
             out, z = spmm(adj.A, t, bias=bias, prelu_a=prelu_a, want_pre=True)   # bmm(adj, .) + bias, act  model.py:31-35
             ctx.save_for_backward(x, weight, z, prelu_a)
         ctx.adj = adj
@@ -783,10 +837,10 @@ class GcnLayerFn(torch.autograd.Function):
         lib = _lib.load()
         S = int(lib.ggad_prelu_bwd_splits(M))
         ws = torch.empty(2 * S * W, dtype=torch.float32, device=z.device)
-        dz = torch.empty_like(z)
+        dz = torch.empty_like(z) if ctx.reordered else padded_rows(M, W, z.device, (adj.At, None))      # read by A_hat^T dZ below
         db = torch.empty(W, dtype=torch.float32, device=z.device)
         da = torch.empty(1, dtype=torch.float32, device=z.device)
-        call("ggad_prelu_bwd_f32", ptr(g), ptr(z), ptr(prelu_a), M, W, ptr(dz), ptr(db), ptr(da), ptr(ws))
+        call("ggad_prelu_bwd_ld_f32", ptr(g), ptr(z), ptr(prelu_a), M, W, ptr_rows(dz), dz.stride(0), ptr(db), ptr(da), ptr(ws))
         if ctx.reordered:                                                    # x holds A_hat X here
             dw = gemm(dz, x, True, False)                                    # (H x N)(N x F), no transposed product needed
             return None, dw, (db if ctx.has_bias else None), da.view_as(prelu_a), None

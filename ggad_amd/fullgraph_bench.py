@@ -11,6 +11,7 @@ bound it, with their roofline fractions (CSR SpMM bytes = 
 """
 from __future__ import annotations
 
+import os
 import random
 import time
 import types
@@ -61,10 +62,33 @@ def build_model(ds, dev, h: int = 300, seed: int = 0):
     return full, model, opt, feats
 
 
-def _time_call(fn, reps: int = 20) -> float:
+def _time_call(fn, reps: int = 20, graph: bool = None) -> float:
+    """Seconds per call on the device.  `graph` (default: GGAD_TIME_GRAPH != 0): the calls are captured into one hipGraph and the
+    replay is timed, so the figure is the kernel's, not the Python launch path's (20-30 us per eager call -- more than the sparse
+    products themselves take)."""
     import torch
     fn()
     torch.cuda.synchronize()
+    if graph is None:
+        graph = os.environ.get("GGAD_TIME_GRAPH", "1") != "0"
+    if graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                for _ in range(reps):
+                    fn()
+        torch.cuda.current_stream().wait_stream(side)
+        g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
@@ -148,11 +172,14 @@ def bench_one(name: str, dev, epochs: int = 30, seed: int = 0, h: int = 300) -> 
     n, nnz = ds["n"], int(full.A.nnz)
     x = torch.randn(n, h, device=dev)
     w = torch.randn(h, h, device=dev)
-    t_spmm = _time_call(lambda: FG.spmm(full.A, x))
+    xa = FG.padded_rows(n, h, dev, (full.A, None))                     # the rows the layer's projection writes (128-byte aligned
+    xa.copy_(x)                                                        # on the sparse configs: the line-granular product)
+    t_spmm = _time_call(lambda: FG.spmm(full.A, xa))
     plan0 = full.A.plan()
     pp0 = FG._use_panel(full.A, plan0, x)
     kernel = (("k_spmm_ring" if "wave_sb" in pp0 else "k_spmm_panel") if pp0 is not None
               else "k_spmm_sliced" if FG._use_sliced(full.A, plan0, x)
+              else "k_spmm_rowline" if not xa.is_contiguous()
               else "k_spmm_rowslice" if FG._use_rowslice(full.A, plan0, x) else "k_spmm_seg")
     t_gemm = _time_call(lambda: FG.gemm(x, w, False, True))
     spmm_bytes = 8.0 * nnz + 4.0 * (n + 1) + 8.0 * n * h

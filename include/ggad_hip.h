@@ -438,6 +438,20 @@ int ggad_spmm_rowslice_f32(const int32_t *rowptr, const int32_t *col, const floa
                            const int32_t *unit_out, int32_t n_units, const int32_t *long_rows, const int32_t *long_out, int32_t n_long,
                            const int32_t *hub_rows, const int32_t *hub_out, int32_t n_hub, const float *X, int64_t ldx, int32_t W,
                            const float *bias, const float *prelu_a, float *out, int64_t ldo, float *out_pre, ggad_stream_t stream);
+/* The same product, LINE-granular and persistent, for operands whose rows are 128-byte aligned (X and ldx * 4 multiples of 128: the
+ * producers of the path pad their 300-float rows to 320): a slice = one 128-byte line of a row, a wave = 8 rows, line x of all rows on
+ * XCD x, the lines beyond the eighth split by rows over the XCDs, a fixed grid whose waves loop over the XCD's items (k_spmm_rowline
+ * in fullgraph.hip; model.py:31 on the sparse configs).  ent: int32 x 2 = (column, bits of the fp32 value) per stored entry in CSR
+ * order; n_src_rows * ldx * 4 < 2^32.  Tables of int32 x 4 = (first entry, end, output row, 0):
+ * unit_tab 8 consecutive slots per unit of short rows (empty slot: 0, 0, -1; rows of <= ggad_spmm_rowslice_short() entries, longest
+ * first), long_tab one per medium row (<= ggad_spmm_rowslice_long() entries), hub_tab one per longer row.  256 <= W <= 512. */
+int32_t ggad_spmm_rowline_supported(const float *X, int64_t ldx, int32_t W, int64_t n_src_rows);
+int ggad_spmm_rowline_f32(const int32_t *ent, const int32_t *unit_tab, int32_t n_units, const int32_t *long_tab, int32_t n_long,
+                          const int32_t *hub_tab, int32_t n_hub, const float *X, int64_t ldx, int32_t W, int64_t n_src_rows,
+                          const float *bias, const float *prelu_a, float *out, int64_t ldo, float *out_pre, ggad_stream_t stream);
+/* ggad_prelu_bwd_f32 with a row stride for dz (ld_dz >= W, multiple of 4): the gradient a following line-granular product reads. */
+int ggad_prelu_bwd_ld_f32(const float *g, const float *z, const float *prelu_a, int32_t M, int32_t W, float *dz, int64_t ld_dz, float *db,
+                          float *da, float *workspace, ggad_stream_t stream);
 
 /* Same product for dense neighbourhoods (hundreds of neighbours per row, X larger than an XCD's 4 MB L2): X is first
  * re-laid slice-major into xs_workspace (ggad_spmm_sliced_workspace_elems(n_src_rows, W) floats; column slices of 32 floats =

@@ -1,10 +1,10 @@
 #!/bin/bash
 # PMC passes over the N x N x 300 product on a SPARSE-neighbourhood config (Reddit / Photo): k_spmm_seg (+ k_spmm_combine) and the
-# column-sliced k_spmm_rowslice.  Each counter group in its own run (--kernel-trace only).  Usage: bash scripts/r03_pmc_spmm_sparse.sh [reddit]
+# column-sliced k_spmm_rowslice.  Each counter group in its own run (--kernel-trace only).  Usage: bash scripts/pmc_spmm_sparse.sh [reddit]
 DS=${1:-reddit}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/r03_spmm_${DS}_pmc.csv
+OUT=$R/gpurun_out/${ROUND:-r04}_spmm_${DS}_pmc.csv
 echo "kernel,counter,dispatches,sum,avg_per_dispatch" > $OUT
 i=0
 for G in \
@@ -17,6 +17,6 @@ for G in \
   rm -rf /tmp/pms$i
   rocprofv3 --kernel-trace --pmc $G -d /tmp/pms$i -o p -- python $R/scripts/spmm_sparse_variants.py $DS > /tmp/pms$i.log 2>&1
   DB=$(find /tmp/pms$i -name "*.db" | head -1)
-  if [ -n "$DB" ]; then python $R/scripts/rocpd_pmc.py $DB | grep -v "^kernel,counter" | grep "spmm_seg\|spmm_rowslice\|spmm_combine" >> $OUT; else echo "pass $i failed: $G" >> $OUT; fi
+  if [ -n "$DB" ]; then python $R/scripts/rocpd_pmc.py $DB | grep -v "^kernel,counter" | grep "spmm_seg\|spmm_rowslice\|spmm_rowline\|spmm_combine" >> $OUT; else echo "pass $i failed: $G" >> $OUT; fi
 done
 cat $OUT

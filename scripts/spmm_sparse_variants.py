@@ -1,5 +1,5 @@
 """N x N x 300 product on the SPARSE-neighbourhood configs (Reddit, Photo): wave-per-segment kernel against the XCD-sliced kernel and the
-column-sliced six-rows-per-wave kernel (k_spmm_rowslice).  Usage (GPU box): python scripts/spmm_sparse_variants.py [reddit photo]"""
+column-sliced six-rows-per-wave kernel (k_spmm_rowslice) and its line-granular form on 128-byte aligned rows (rowline).  Usage (GPU box): python scripts/spmm_sparse_variants.py [reddit photo]"""
 import os
 import random
 import sys
@@ -33,5 +33,17 @@ for name in (sys.argv[1:] or ["reddit", "photo"]):
         res[tag] = out.clone()
         t = _time_call(lambda: FG.spmm(full.A, x), 50)
         print(f"{name:8s} {tag:7s}: {t * 1e6:7.1f} us  ({floor_us / (t * 1e6):.3f} of the 8 TB/s floor {floor_us:.2f} us)", flush=True)
-    for tag in ("sliced", "rowslice"):
+    xp = torch.empty(n, 320, device=dev)[:, :300]
+    xp.copy_(x)
+    assert FG._use_rowline(xp)
+    rsp = full.A.rowslice_plan(full.A.plan(), lines=True)
+    print(name, "rowline plan: units", rsp["n_units"], "medium", rsp["n_long"], "hub", rsp["n_hub"], flush=True)
+    res["rowline"] = FG.spmm(full.A, xp).clone()
+    t = _time_call(lambda: FG.spmm(full.A, xp), 50)
+    print(f"{name:8s} rowline: {t * 1e6:7.1f} us  ({floor_us / (t * 1e6):.3f} of the 8 TB/s floor {floor_us:.2f} us)", flush=True)
+    op = torch.empty(n, 320, device=dev)[:, :300]
+    res["rowline_po"] = FG.spmm(full.A, xp, out=op).clone()
+    t = _time_call(lambda: FG.spmm(full.A, xp, out=op), 50)
+    print(f"{name:8s} rowline, padded out: {t * 1e6:7.1f} us", flush=True)
+    for tag in ("sliced", "rowslice", "rowline", "rowline_po"):
         print(f"{name:8s} max rel diff {tag} vs seg: {((res[tag] - res['seg']).abs().max() / res['seg'].abs().max()).item():.2e}", flush=True)

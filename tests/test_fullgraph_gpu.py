@@ -518,3 +518,102 @@ def test_gcn_layer_cached_aggregate_equals_reference_order(monkeypatch):
         o3 = layer(x[None], fa)[0]
     assert not torch.allclose(o1, o2) and torch.allclose(o2, o3, rtol=1e-5, atol=1e-5)
 
+
+
+def _padded(t, ld):
+    """`t` copied into a view of an (rows, ld) matrix whose padding holds NaN (nothing may read it)."""
+    buf = torch.full((t.shape[0], ld), float("nan"), device=t.device)
+    v = buf[:, :t.shape[1]]
+    v.copy_(t)
+    return v
+
+
+@pytest.mark.parametrize("w", [300, 256, 260, 512, 384])
+def test_spmm_rowline_on_padded_rows_against_scipy(w):
+    """The line-granular persistent product (k_spmm_rowline: operand rows on 128-byte lines, one line per XCD, the lines beyond the
+    eighth split by rows) against scipy in float64: short rows, empty rows, medium rows (one wave), hub rows of one and of several
+    passes (> 1,024 entries), bias + PReLU + pre-activation copy, a row subset with repeats, a padded destination.  The padding
+    columns hold NaN: a kernel that reads them fails."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(w)
+    n, m = 2600, 3100
+    a = sp.random(n, m, density=0.006, random_state=5, format="lil", dtype=np.float32)
+    a[7, :] = 0
+    a[n - 1, :] = 0
+    for r, k in ((100, 2500), (101, 1025), (640, 193), (641, 192), (900, 33), (901, 64), (1200, 1024)):
+        a[r, :] = 0
+        cols = rng.permutation(m)[:k]
+        a[r, cols] = rng.standard_normal(k).astype(np.float32)
+    csr = FG.Csr(a.tocsr(), DEV)
+    xh = rng.standard_normal((m, w)).astype(np.float32)
+    ld = (w + 31) // 32 * 32 + (32 if w % 32 == 0 else 0)           # (an aligned width gets a whole line of padding: still strided)
+    x = _padded(torch.from_numpy(xh).to(DEV), ld)
+    assert x.stride(0) == ld and FG._use_rowline(x)
+    ref = csr.host.astype(np.float64) @ xh.astype(np.float64)
+    scale = np.abs(ref).max() + 1.0
+    got = FG.spmm(csr, x)
+    assert got.is_contiguous()
+    assert np.abs(got.cpu().numpy() - ref).max() / scale < 2e-6
+    assert (got[[7, n - 1]] == 0).all()
+    rs = csr.plan()["rowline"]
+    assert rs["n_hub"] == 4 and rs["n_long"] >= 4 and rs["n_units"] * 8 >= n - rs["n_hub"] - rs["n_long"]
+    bias = torch.from_numpy(rng.standard_normal(w).astype(np.float32)).to(DEV)
+    slope = torch.tensor([0.25], device=DEV)
+    dst = torch.full((n, ld), float("nan"), device=DEV)[:, :w]
+    o, pre = FG.spmm(csr, x, bias=bias, prelu_a=slope, want_pre=True, out=dst)
+    assert o.data_ptr() == dst.data_ptr() and pre.stride(0) == ld
+    z = ref + bias.cpu().numpy()
+    assert np.abs(pre.cpu().numpy() - z).max() / scale < 2e-6
+    assert np.abs(o.cpu().numpy() - np.where(z > 0, z, 0.25 * z)).max() / scale < 2e-6
+    assert torch.isnan(dst.as_strided((n, ld - w), (ld, 1), dst.storage_offset() + w)).all()          # the padding is not written
+    rows = np.array([100, 7, 3, n - 1, 99, 100, 640, 641, 901] + list(range(1190, 1230)))
+    sub = FG.spmm(csr, x, plan=csr.plan(rows, key=("rl", w)))
+    assert np.abs(sub.cpu().numpy() - ref[rows]).max() / scale < 2e-6
+    again = FG.spmm(csr, x)
+    assert torch.equal(again.view(torch.int32), got.view(torch.int32))                                  # fixed summation order
+
+
+def test_gcn_layer_with_padded_rows_equals_dense_rows(monkeypatch):
+    """GcnLayerFn with the projection and the PReLU gradient written into 128-byte aligned rows (padded_rows -> k_spmm_rowline)
+    against the same layer on contiguous rows (GGAD_SPMM_ROWLINE=0): output and every gradient; plus ggad_prelu_bwd_ld_f32 and a
+    gemm with a padded destination on their own."""
+    import scipy.sparse as sp
+    from ggad_amd import _lib
+    from ggad_amd._lib import call, ptr, ptr_rows
+    n, f, h = 4000, 300, 300
+    rowptr, col = synth.make_graph(n, 70000, 4, kind="powerlaw", max_degree=n // 8)
+    a = synth.csr_to_scipy(rowptr, col, n)
+    fa = FG.FullGraphAdj(U.normalize_adj(a) + sp.eye(n), a + sp.eye(n), DEV)
+    rng = np.random.default_rng(2)
+    xh = torch.from_numpy(rng.standard_normal((n, f)).astype(np.float32)).to(DEV)
+    gout = torch.from_numpy(rng.standard_normal((n, h)).astype(np.float32)).to(DEV)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("GGAD_SPMM_ROWLINE", mode)
+        t = FG.padded_rows(n, h, DEV, (fa.A, None))
+        assert (t.stride(0) == 320) == (mode == "1")
+        torch.manual_seed(0)
+        layer = GCN(f, h, "prelu").to(DEV)
+        x = xh.clone().requires_grad_(True)
+        out = layer(x[None], fa)
+        (out[0] * gout).sum().backward()
+        res[mode] = (out[0].detach().cpu().numpy(), x.grad.cpu().numpy(), layer.fc.weight.grad.cpu().numpy(), layer.bias.grad.cpu().numpy(),
+                     layer.act.weight.grad.cpu().numpy())
+    for k in range(5):
+        scale = np.abs(res["0"][k]).max() + 1e-6
+        assert np.abs(res["0"][k] - res["1"][k]).max() / scale < 5e-6, k
+    # the strided PReLU gradient equals the dense one bit for bit; so does a gemm into a padded destination
+    z, g = torch.randn(n, h, device=DEV), torch.randn(n, h, device=DEV)
+    slope = torch.tensor([0.25], device=DEV)
+    S = int(_lib.load().ggad_prelu_bwd_splits(n))
+    ws = torch.empty(2 * S * h, device=DEV)
+    dz0, db0, da0 = torch.empty_like(z), torch.empty(h, device=DEV), torch.empty(1, device=DEV)
+    call("ggad_prelu_bwd_f32", ptr(g), ptr(z), ptr(slope), n, h, ptr(dz0), ptr(db0), ptr(da0), ptr(ws))
+    dz1 = torch.full((n, 320), float("nan"), device=DEV)[:, :h]
+    db1, da1 = torch.empty(h, device=DEV), torch.empty(1, device=DEV)
+    call("ggad_prelu_bwd_ld_f32", ptr(g), ptr(z), ptr(slope), n, h, ptr_rows(dz1), 320, ptr(db1), ptr(da1), ptr(ws))
+    assert torch.equal(dz0, dz1) and torch.equal(db0, db1) and torch.equal(da0, da1)
+    w = torch.randn(h, f, device=DEV)
+    c0 = FG.gemm(xh, w, False, True)
+    c1 = FG.gemm(xh, w, False, True, out=torch.full((n, 320), float("nan"), device=DEV)[:, :h])
+    assert c1.stride(0) == 320 and torch.equal(c0, c1)
