@@ -17,6 +17,8 @@ kernel.  W = 1 is exactly the reference schedule.
 from __future__ import annotations
 
 import os
+import sys
+import time
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -476,10 +478,20 @@ class DGraphTrainer:
         if not self.overlap or len(sizes) == 1:
             if split:                                  # nothing runs beside the chunk kernel: the plan takes the whole chip
                 self.chunk.xcd_skip = -1
+            timing = os.environ.get("GGAD_RUN_TIMING")               # host phases of a chunk on stderr (us)
             for k in sizes:
+                t0 = time.perf_counter()
                 bn, bl = take(k)
+                t1 = time.perf_counter()
                 build(self.chunk, bn, bl)
+                t2 = time.perf_counter()
                 self.engine.train_chunk(self.chunk, self.allreduce, self.world, log_base=done, exchange=self.exchange)   # loss log slot = step index
+                if timing:
+                    t3 = time.perf_counter()
+                    torch.cuda.synchronize()
+                    t4 = time.perf_counter()
+                    print("[run_steps] %d batches: take %.1f  build + xcd_prepare %.1f  train_chunk call %.1f  device drain %.1f us"
+                          % (k, (t1 - t0) * 1e6, (t2 - t1) * 1e6, (t3 - t2) * 1e6, (t4 - t3) * 1e6), file=sys.stderr, flush=True)
                 nodes_seen += sum(len(b) for b in bn)
                 done += k
         else:
