@@ -344,7 +344,7 @@ def main():
             return
         e0, e1, t0_, t1_ = ev_pool[4 * len(ev_pairs):4 * len(ev_pairs) + 4]
         chunk.gather2_events = (e0, e1)
-        chunk.tile_events = (t0_, t1_)
+        chunk.tile_events = (t0_, t1_) if not os.environ.get("GGAD_BENCH_NO_TILE_EV") else None
         chunk.build(bn, bl)
         chunk.gather2_events = None
         chunk.tile_events = None
@@ -354,7 +354,7 @@ def main():
 
     def timed_train_chunk(ch, *args, **kw):
         # events on the stream the dense steps are launched on (torch's current stream inside `with torch.cuda.stream(main)`)
-        if 2 * len(chunk_ev) + 2 > len(chunk_ev_pool):
+        if 2 * len(chunk_ev) + 2 > len(chunk_ev_pool) or os.environ.get("GGAD_BENCH_NO_CHUNK_EV"):
             return orig_train_chunk(ch, *args, **kw)
         c0, c1 = chunk_ev_pool[2 * len(chunk_ev)], chunk_ev_pool[2 * len(chunk_ev) + 1]
         c0.record()
@@ -387,6 +387,8 @@ def main():
     nodes_local = trainer.run_steps(a.steps, prepared=timed, gather_hook=timed_build)
     barrier()
     elapsed = time.perf_counter() - t1
+    if os.environ.get("GGAD_BENCH_SYNC_PROBE"):
+        t2 = time.perf_counter(); barrier(); print("idle synchronize: %.1f us" % ((time.perf_counter() - t2) * 1e6), file=sys.stderr)
     trainer.engine.train_chunk = orig_train_chunk
     trainer.check_exchange(dist if world > 1 else None)
     if world > 1:

@@ -859,9 +859,12 @@ struct XcdPrepArgs {
   const int32_t *step_counter;
   float lr;
   int n_batches, n_rows, n_pieces, n_ents;
+  unsigned *ctrl_clear;                 // the control block of the launch that follows, or null: zeroed here (no memset launch)
+  int ctrl_words;
 };
 __global__ void __launch_bounds__(256) k_xcd_prep(XcdPrepArgs P) {
   const int tid = blockIdx.x * 256 + threadIdx.x;
+  if (P.ctrl_clear && tid < P.ctrl_words) P.ctrl_clear[tid] = 0u;
   auto batch_row0 = [&](int row) {                       // first row of the batch that holds `row`
     int lo = 0, hi = P.n_batches;
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (P.batch_ptr[mid] <= row) lo = mid; else hi = mid; }
@@ -1047,15 +1050,18 @@ inline void record_views(int32_t *recs, int64_t rows_cap, int64_t pieces_cap, in
   batch_n0 = recs + (rows_cap + pieces_cap + 2) * REC;
 }
 int launch_records(const ggad_mb_step &s, int32_t n_batches, const int32_t *batch_ptr_dev, int32_t n_rows, int32_t n_pieces, int32_t n_ents,
-                   int32_t *pos_rec, int32_t *ck_rec, int32_t *batch_n0, float *adam_sc, hipStream_t st) {
+                   int32_t *pos_rec, int32_t *ck_rec, int32_t *batch_n0, float *adam_sc, hipStream_t st, void *ctrl_clear = nullptr) {
   XcdPrepArgs Q;
+  Q.ctrl_clear = static_cast<unsigned *>(ctrl_clear);
+  Q.ctrl_words = (int)(sizeof(XcdCtrl) / sizeof(unsigned));
   Q.batch_ptr = batch_ptr_dev; Q.ent_ptr = s.ent_ptr; Q.row_ck_ptr = s.row_ck_ptr; Q.ck_rc = s.ck_rc; Q.ck_e0 = s.ck_e0;
   Q.ent_own = s.ent_own; Q.labels = s.labels; Q.pos_meta = s.pos_meta; Q.row_pos = s.row_pos;
   Q.x2 = const_cast<float *>(s.x2);
   Q.ck_rec = ck_rec; Q.pos_rec = pos_rec; Q.batch_n0 = batch_n0;
   Q.adam_sc = adam_sc; Q.step_counter = s.step_counter; Q.lr = s.lr;
   Q.n_batches = n_batches; Q.n_rows = n_rows; Q.n_pieces = n_pieces; Q.n_ents = n_ents;
-  const int64_t work = std::max<int64_t>(std::max<int64_t>(std::max<int64_t>(n_rows, n_pieces), (int64_t)n_ents * 8), n_batches);
+  const int64_t work = std::max<int64_t>(std::max<int64_t>(std::max<int64_t>(std::max<int64_t>(n_rows, n_pieces), (int64_t)n_ents * 8), n_batches),
+                                         ctrl_clear ? Q.ctrl_words : 0);
   const unsigned blocks = (unsigned)std::min<int64_t>((work + 255) / 256, 8192);
   k_xcd_prep<<<dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st>>>(Q);
   GGAD_CHECK_LAUNCH("mb_train_chunk_xcd (records)");
@@ -1136,14 +1142,14 @@ int ggad_mb_train_chunk_xcd(const ggad_mb_step *tmpl, int32_t n_batches, const i
   static unsigned launch_seq = 0;
   A.launch_id = ++launch_seq ? launch_seq : ++launch_seq;      // never 0 (the cleared control block)
   hipStream_t st = as_stream(stream);
-  // registration counters, barrier slots and the error word start from zero on every launch (profile clocks too)
-  if (hipMemsetAsync(workspace, 0, sizeof(XcdCtrl), st) != hipSuccess) return GGAD_E_LAUNCH;
+  // registration counters, barrier slots and the error word start from zero on every launch (profile clocks too): cleared by the
+  // prep launch below (a memset is a launch of its own: 4 us + a gap in front of every chunk)
   {  // records + entry-complete x2: one whole-chip launch per chunk (the plan's tables are read-only for everybody else) -- or,
      // when the caller prepared them, only the Adam scalars of the chunk's steps (they need the step counter as it is NOW)
-    const int rc = records ? launch_records(s, n_batches, batch_ptr_dev, 0, 0, 0, nullptr, nullptr, nullptr, const_cast<float *>(A.adam_sc), st)
+    const int rc = records ? launch_records(s, n_batches, batch_ptr_dev, 0, 0, 0, nullptr, nullptr, nullptr, const_cast<float *>(A.adam_sc), st, workspace)
                            : launch_records(s, n_batches, batch_ptr_dev, n_rows, n_pieces, n_ents, const_cast<int32_t *>(A.pos_rec),
                                             const_cast<int32_t *>(A.ck_rec), const_cast<int32_t *>(A.batch_n0),
-                                            const_cast<float *>(A.adam_sc), st);
+                                            const_cast<float *>(A.adam_sc), st, workspace);
     if (rc) return rc;
   }
   // the L2 warmer runs BESIDE the chunk kernel on a stream of its own: it starts once the control block is cleared (ev0) and the

@@ -17,6 +17,8 @@ from __future__ import annotations
 
 import ctypes
 import os
+import sys
+import time
 from typing import Callable, Optional, Sequence
 
 import numpy as np
@@ -35,8 +37,52 @@ def _f32(n, device):
     return torch.empty(int(max(n, 1)), dtype=torch.float32, device=device)
 
 
+_BUILD_TIMING = bool(os.environ.get("GGAD_BUILD_TIMING"))
+
+
+def _addr(a: np.ndarray) -> int:
+    return a.__array_interface__["data"][0]
+
+
+class RowList(list):
+    """The rows of a C-contiguous 2-D int64 matrix as a list that remembers the matrix: what `BatchSchedule.next_batches` hands out.
+    `BatchChunk.build` then takes the matrix as it is -- no per-row work (checking the 40 row pointers of a 20-batch build in
+    Python cost 70-90 us on the critical path of a one-chunk run).  A slice is again a RowList; anything that changes the list in
+    place forgets the matrix, and the list is then treated like any other list of arrays."""
+
+    __slots__ = ("matrix",)
+
+    def __init__(self, matrix: np.ndarray):
+        super().__init__(matrix)
+        self.matrix = matrix if (matrix.ndim == 2 and matrix.dtype == np.int64 and matrix.flags.c_contiguous) else None
+
+    def __getitem__(self, i):
+        if isinstance(i, slice) and self.matrix is not None:
+            n = list.__len__(self)
+            start, stop, step = i.indices(n)
+            if step == 1 and n == self.matrix.shape[0]:
+                if start == 0 and stop == n:
+                    return self                                   # (the whole list: no new row views)
+                return RowList(self.matrix[start:max(start, stop)])
+        return super().__getitem__(i)
+
+    def _forget(name):                                    # noqa: N805
+        def method(self, *a, **kw):
+            self.matrix = None
+            return getattr(list, name)(self, *a, **kw)
+        method.__name__ = name
+        return method
+
+    for _n in ("__setitem__", "__delitem__", "__iadd__", "__imul__", "append", "extend", "insert", "pop", "remove", "reverse", "sort", "clear"):
+        locals()[_n] = _forget(_n)
+    del _n, _forget
+
+
 def _rows_as_flat(rows):
     """The rows of a list as ONE flat int64 view when they are consecutive rows of a C-contiguous 2-D int64 matrix (else None)."""
+    if type(rows) is RowList:
+        m = rows.matrix
+        return m.reshape(-1) if (m is not None and m.shape[0] == len(rows) and m.shape[0] > 0) else _rows_as_flat(list(rows))
     try:
         a, z = rows[0], rows[-1]
         base = a.base
@@ -232,6 +278,7 @@ class BatchChunk:
         nb = len(batches)
         if nb > self.max_batches or nb == 0:
             raise ValueError(f"chunk holds 1..{self.max_batches} batches, got {nb}")
+        self._t_build0 = time.perf_counter()
         bp = self._bp_host
         # what `BatchSchedule.next_batches` hands out: consecutive rows of ONE contiguous int64 matrix (ids) and of another (labels)
         # -- no copy, no per-batch Python work (24 us per 20-batch build otherwise, on the critical path of a one-chunk run)
@@ -277,10 +324,12 @@ class BatchChunk:
         P.ev_tile0, P.ev_tile1 = self.tile_events if self.tile_events is not None else (None, None)
         stream = _lib.current_stream()
         for attempt in range(3):
-            rc = self.lib.ggad_mb_plan_build(ctypes.byref(P), nodes.ctypes.data, bp.ctypes.data, nb,
-                                             lab.ctypes.data if lab is not None else None, ctypes.byref(I),
-                                             self._ep_host.ctypes.data, self._bep_host.ctypes.data,
-                                             self._bmr_host.ctypes.data, stream)
+            if _BUILD_TIMING:
+                print("[BatchChunk.build] python before the native call %.1f us" % ((time.perf_counter() - self._t_build0) * 1e6), file=sys.stderr)
+            # (`.ctypes.data` builds a ctypes object per call: ~1 us each on the host of a GPU box, six of them on the critical path of a
+            # one-chunk run; the array interface is a third of that)
+            rc = self.lib.ggad_mb_plan_build(ctypes.byref(P), _addr(nodes), _addr(bp), nb, _addr(lab) if lab is not None else None,
+                                             ctypes.byref(I), _addr(self._ep_host), _addr(self._bep_host), _addr(self._bmr_host), stream)
             if rc != -3:
                 break
             _check_i32(int(I.need_ents))

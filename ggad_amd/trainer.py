@@ -25,7 +25,7 @@ import numpy as np
 import torch
 
 from .graph import DeviceGraph
-from .minibatch import BatchChunk, MiniBatchEngine, reduce_gradients  # noqa: F401 (re-exported)
+from .minibatch import BatchChunk, MiniBatchEngine, RowList, reduce_gradients  # noqa: F401 (re-exported)
 from .sampler import PyCompatRandom
 
 
@@ -104,7 +104,9 @@ class BatchSchedule:
         mlen = lens[rank::world][:count]
         if int(mlen.min()) == stride:
             lab2d = self.labels[mine].astype(np.int64)      # one vectorised lookup for the whole call
-            return list(mine), list(lab2d)
+            if world > 1:
+                mine = np.ascontiguousarray(mine)           # (this rank's rows as their own matrix)
+            return RowList(mine), RowList(lab2d)
         nodes = [mine[s, :mlen[s]] for s in range(count)]
         labs = [self.labels[n].astype(np.int64) for n in nodes]
         return nodes, labs
@@ -419,6 +421,7 @@ class DGraphTrainer:
     def run_steps(self, n_steps: int, prepared: Optional[Tuple[List[np.ndarray], List[np.ndarray]]] = None,
                   gather_hook=None) -> int:
         """Run n optimiser steps; returns nodes processed by THIS rank."""
+        t_entry = time.perf_counter()
         sizes = self.default_ramp(n_steps)
         pos = [0]
         record = self._replay_begin()                 # (None unless the resident kernel runs and a replay could be needed)
@@ -471,6 +474,7 @@ class DGraphTrainer:
 
         def build(ch, bn, bl):
             ch.build(bn, bl) if gather_hook is None else gather_hook(ch, bn, bl)
+            self._t_built = time.perf_counter()
             self.engine.xcd_prepare(ch)        # records of the resident chunk kernel: on the plan's stream, not on its 28 CUs
 
         nodes_seen, done = 0, 0
@@ -480,6 +484,9 @@ class DGraphTrainer:
                 self.chunk.xcd_skip = -1
             timing = os.environ.get("GGAD_RUN_TIMING")               # host phases of a chunk on stderr (us)
             for k in sizes:
+                if timing:
+                    ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    ev_a.record()
                 t0 = time.perf_counter()
                 bn, bl = take(k)
                 t1 = time.perf_counter()
@@ -487,11 +494,13 @@ class DGraphTrainer:
                 t2 = time.perf_counter()
                 self.engine.train_chunk(self.chunk, self.allreduce, self.world, log_base=done, exchange=self.exchange)   # loss log slot = step index
                 if timing:
+                    ev_b.record()
                     t3 = time.perf_counter()
                     torch.cuda.synchronize()
                     t4 = time.perf_counter()
-                    print("[run_steps] %d batches: take %.1f  build + xcd_prepare %.1f  train_chunk call %.1f  device drain %.1f us"
-                          % (k, (t1 - t0) * 1e6, (t2 - t1) * 1e6, (t3 - t2) * 1e6, (t4 - t3) * 1e6), file=sys.stderr, flush=True)
+                    print("[run_steps] device: first event -> last event %.1f us" % (ev_a.elapsed_time(ev_b) * 1e3), file=sys.stderr)
+                    print("[run_steps] %d batches: entry -> loop %.1f  take %.1f  build + xcd_prepare %.1f (build %.1f)  train_chunk call %.1f  device drain %.1f us"
+                          % (k, (t0 - t_entry) * 1e6, (t1 - t0) * 1e6, (t2 - t1) * 1e6, (self._t_built - t1) * 1e6, (t3 - t2) * 1e6, (t4 - t3) * 1e6), file=sys.stderr, flush=True)
                 nodes_seen += sum(len(b) for b in bn)
                 done += k
         else:
