@@ -21,7 +21,7 @@ class GgadKernelError(RuntimeError):
     pass
 
 
-ABI_VERSION = 5    # what this binding was written against (include/ggad_hip.h, runtime.cpp); `load` refuses any other library
+ABI_VERSION = 6    # what this binding was written against (include/ggad_hip.h, runtime.cpp); `load` refuses any other library
 _P = c_void_p      # device (or host) pointer
 EXCHANGE_CB = ctypes.CFUNCTYPE(c_int32, c_void_p)      # int exchange(void *user): the data-parallel all-reduce hook
 _I = c_int32
@@ -189,7 +189,7 @@ class MbPlan(ctypes.Structure):
                 + [(n, c_int32) for n in ("feat_dim", "feat_stride", "max_batches", "rows_cap", "ck_part_stride", "train", "hop2",
                                           "node_major")]
                 + [("mean_nbr_deg", c_float), ("xcd_skip", c_int32)]
-                + [(n, c_void_p) for n in ("ev_tile0", "ev_tile1")])
+                + [(n, c_void_p) for n in ("ev_tile0", "ev_tile1", "node_pack_host")])
 
 
 class MbPlanInfo(ctypes.Structure):

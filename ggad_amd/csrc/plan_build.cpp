@@ -86,9 +86,12 @@ int ggad_mb_plan_build(const ggad_mb_plan *P, const int64_t *nodes_host, const i
   static thread_local std::vector<int32_t> row_deg;
   if ((int64_t)row_deg.size() < rows) row_deg.resize((size_t)rows);
   constexpr int PF = 24;
+  const int64_t *pack = P->node_pack_host;                 // (degree << 40) | pair bound: one miss per node instead of two
+  constexpr int64_t PACK_MASK = (1LL << 40) - 1;
   for (int64_t i = 0; i < rows && i < PF; ++i) {
     const int64_t v = nodes_host[i];
     GGAD_REQUIRE(v >= 0 && v < P->n_nodes);
+    if (pack) { __builtin_prefetch(&pack[v]); continue; }
     __builtin_prefetch(&P->closed_deg_host[v]);
     if (want_ldsw) __builtin_prefetch(&P->pair_bound_host[v]);
   }
@@ -98,15 +101,19 @@ int ggad_mb_plan_build(const ggad_mb_plan *P, const int64_t *nodes_host, const i
       if (i + PF < rows) {
         const int64_t vn = nodes_host[i + PF];
         GGAD_REQUIRE(vn >= 0 && vn < P->n_nodes);
-        __builtin_prefetch(&P->closed_deg_host[vn]);
-        if (want_ldsw) __builtin_prefetch(&P->pair_bound_host[vn]);
+        if (pack) __builtin_prefetch(&pack[vn]);
+        else {
+          __builtin_prefetch(&P->closed_deg_host[vn]);
+          if (want_ldsw) __builtin_prefetch(&P->pair_bound_host[vn]);
+        }
       }
       const int64_t v = nodes_host[i];
-      const int64_t r = P->closed_deg_host[v];
+      const int64_t pk = pack ? pack[v] : 0;
+      const int64_t r = pack ? (pk >> 40) : P->closed_deg_host[v];
       row_deg[(size_t)i] = (int32_t)r;
       be += r;
       n_chunks += (r + CL - 1) / CL;
-      if (want_ldsw) bound += P->pair_bound_host[v];
+      if (want_ldsw) bound += pack ? (pk & PACK_MASK) : P->pair_bound_host[v];
     }
     n_ents += be;
     max_batch_ents = std::max(max_batch_ents, be);

@@ -177,6 +177,19 @@ class DeviceGraph:
             self.__dict__["_pair_bound"] = t
         return t
 
+    @property
+    def node_pack_host(self) -> np.ndarray:
+        """int64[n]: (closed degree << 40) | pair bound -- `ggad_mb_plan.node_pack_host`, one cache miss per batch node in the
+        sizing pass of the plan builder instead of two."""
+        t = self.__dict__.get("_node_pack")
+        if t is None:
+            pb = self.pair_bound_host
+            if int(pb.max(initial=0)) >= (1 << 40):
+                raise ValueError("pair bound of a node does not fit 40 bits")
+            t = np.ascontiguousarray((self.closed_deg_i32.astype(np.int64) << 40) | pb)
+            self.__dict__["_node_pack"] = t
+        return t
+
     def tile_offsets(self, shift: int = 16) -> torch.Tensor:
         """Static per-node table of CSR-row offsets at the (1 << shift)-id tile boundaries (tiled 2-hop kernels)."""
         cache = self.__dict__.setdefault("_tile_off", {})

@@ -255,6 +255,7 @@ class BatchChunk:
         P.tile_off = ptr(g.tile_offsets(self.lib.ggad_mb_ldsw_tile_shift())) if ldsw else None
         P.closed_deg_host = g.closed_deg_i32.ctypes.data
         P.pair_bound_host = g.pair_bound_host.ctypes.data if ldsw else None
+        P.node_pack_host = g.node_pack_host.ctypes.data if ldsw else None
         P.stage_host, P.stage, P.stage_event = self.stage_host.data_ptr(), ptr(self.stage), self._stage_event
         P.cnt1, P.own1, P.cnt2 = ptr(self.cnt1), ptr(self.own1), ptr(self.cnt2)
         P.ent_col, P.ent_slot, P.ent_row = ptr(self.ent_col), ptr(self.ent_slot), ptr(self.ent_row)

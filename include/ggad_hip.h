@@ -122,6 +122,9 @@ typedef struct ggad_mb_plan {
                                 workgroups with blockIdx % 8 == xcd_skip return at once (ggad_xcd_first_of_stream tells which
                                 residue the stream's dispatcher puts on which XCD); results do not depend on it */
   void *ev_tile0, *ev_tile1;  /* optional events recorded around k_tile_counts (the pair counting of the LDS 2-hop stage) */
+  const int64_t *node_pack_host; /* optional (ABI 6): (closed_deg_host[i] << 40) | pair_bound_host[i] per node -- the sizing pass of
+                                    ggad_mb_plan_build then takes ONE cache miss per batch node instead of two (it is on the critical
+                                    path of a one-chunk run).  Null: the two tables above are read. */
 } ggad_mb_plan;
 
 typedef struct ggad_mb_plan_info {

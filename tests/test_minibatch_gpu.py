@@ -475,9 +475,9 @@ def test_ldsw_falls_back_to_global_counters():
     the device-atomic 2-hop kernels; same results, counters reset, and the next chunk goes back to "ldsw"."""
     g, batches, labels = _random_case(n=9000, n_entries=70000, f=17, d=64, seed=77, nb=3, bsz=120, n_ano=30)
     graph, feat, ch = _setup(g, max_batches=3, hop2="ldsw")
-    bound = graph.pair_bound_host                 # the table the native plan builder reads: overwritten in place
+    bound = graph.node_pack_host                  # the table the native plan builder reads ((degree << 40) | pair bound): overwritten in place
     real = bound.copy()
-    bound[:] = 1 << 27
+    bound[:] = (real >> 40 << 40) | (1 << 27)
     ch.build(batches, labels)
     torch.cuda.synchronize()
     assert ch.last_hop2 == "global"
