@@ -393,6 +393,151 @@ static void launch_gemm(int mode, bool a_kfast, bool b_nfast, dim3 grid, hipStre
   else launch_gemm2<TM, false, false>(a_kfast, b_nfast, grid, st, args...);
 }
 
+// ---- tall products with a SMALL second operand: op(B) resident in LDS (k_gemm_bres) -------------------------------------------------
+// The projections of the full-graph path are (N nodes x 300) (300 x 300): the second operand is 360 KB, the first is streamed once.
+// The 64 x 64 x 32 tiles above re-stage a 64 x 32 piece of B per K-tile and workgroup behind a barrier and run 860 workgroups of ten
+// K-tiles each at Reddit size: prologue, epilogue and the per-tile hand-off are never hidden (MFMA pipe busy 0.39-0.51,
+// profiles/r04_gemm_mfma_pmc.csv).  Here a workgroup keeps a SLAB of op(B) -- 32 columns x all of K, K-fast rows of KP floats, 40 KB
+// -- in LDS for its whole life (3-4 workgroups per CU, a persistent grid) and its four waves walk 16-row blocks of A on their own: no
+// barrier after the fill.  v_mfma_f32_16x16x4_f32 (exact f32): lane (i = lane % 16, ks = lane / 16) loads ONE float4 of A per 16 k --
+// A[row i][16 s + 4 ks ..+3], straight from memory into the operand registers -- and one ds_read_b128 of the slab per column tile --
+// Bt[col j][16 s + 4 ks ..+3] --: component m of both feeds MFMA m, i.e. lane group ks supplies k = 16 s + 4 ks + m (any assignment
+// of k to the lane-group slots is a valid one as long as A and B agree).  8 MFMA per 16-byte load of A; the row block's K range is
+// fetched in two halves, each in flight while the other is multiplied (the second half of a block with the first half of the next).
+// KP = 8 or 56 mod 64: the 16 lanes of a ds_read_b128 service group then touch 64 different banks.
+// Summation order per output: k ascending inside a lane group's chain is NOT the order of the tiles above (one accumulator, k-slots
+// interleaved 16 apart) -- fixed, deterministic, and exact-f32 products / adds like theirs; results agree to round-off.
+constexpr int BR_COLS = 32;                  // columns of a slab (two MFMA column tiles)
+typedef float br_f4 __attribute__((ext_vector_type(4)));
+
+// the row blocks rb0, rb0 + stride, ... < rb_end of one wave against the slab in LDS; TC = column tiles of the slab (2, or 1 for the
+// last one).  A block's K range is fetched in two halves, each in flight while the other is multiplied (the second half of a block
+// with the first half of the next).
+template <int KS, int TC>
+__device__ __forceinline__ void bres_rows(const float *__restrict__ A, float *__restrict__ C, const float *__restrict__ bt, int M, int N,
+                                          int K, int64_t lda, int64_t ldc, const float *__restrict__ bias, int relu, int KP, int col0,
+                                          int rb0, int rb_end, int stride, int lane) {
+  const int li = lane & 15, ks = lane >> 4;
+  const int koff = 4 * ks;
+  if (rb0 >= rb_end) return;
+  // the float4 of step s: k = 16 s + 4 ks; beyond K: the last valid one again (it meets the slab's zeros)
+  auto load_part = [&](int rb, int s0, int cnt, float4 *dst) {
+    const int row = min(rb * 16 + li, M - 1);
+    const float *ar = A + (int64_t)row * lda;
+#pragma unroll
+    for (int q = 0; q < cnt; ++q) dst[q] = *reinterpret_cast<const float4 *>(ar + min(16 * (s0 + q) + koff, K - 4));
+  };
+  const float *bl = bt + li * KP + koff;
+  float bv[TC];
+#pragma unroll
+  for (int t = 0; t < TC; ++t) bv[t] = bias ? bias[min(col0 + 16 * t + li, N - 1)] : 0.0f;
+  // (the slab reads of step q + 1 are requested before the MFMAs of step q and nothing moves across a step: left to itself the
+  // compiler hoists every ds_read of a half in front of its MFMAs -- 250 VGPRs and spills)
+  auto mul_part = [&](int s0, int cnt, const float4 *a, br_f4 (&acc)[TC]) {
+    float4 bq[TC], bn[TC];
+#pragma unroll
+    for (int t = 0; t < TC; ++t) bq[t] = *reinterpret_cast<const float4 *>(bl + 16 * t * KP + 16 * s0);
+#pragma unroll
+    for (int q = 0; q < cnt; ++q) {
+      const float4 av = a[q];
+      const int qn = q + 1 < cnt ? q + 1 : q;
+#pragma unroll
+      for (int t = 0; t < TC; ++t) bn[t] = *reinterpret_cast<const float4 *>(bl + 16 * t * KP + 16 * (s0 + qn));
+      __builtin_amdgcn_sched_barrier(0);                               // (the reads stay in front of the step's MFMAs: scheduled freely
+#pragma unroll                                                         //  they sat behind the seventh, their latency exposed every step)
+      for (int t = 0; t < TC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bq[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < TC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bq[t].y, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < TC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bq[t].z, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < TC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bq[t].w, acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < TC; ++t) bq[t] = bn[t];
+    }
+  };
+  auto store_block = [&](int rb, const br_f4 (&acc)[TC]) {
+#pragma unroll
+    for (int t = 0; t < TC; ++t) {
+      const int col = col0 + 16 * t + li;
+      if (col < N) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int row = rb * 16 + 4 * ks + v;
+          float o = acc[t][v] + bv[t];
+          if (relu) o = fmaxf(o, 0.0f);
+          if (row < M) C[(int64_t)row * ldc + col] = o;
+        }
+      }
+    }
+  };
+  constexpr int H0 = (KS + 1) / 2, H1 = KS - H0;
+  float4 a0[H0], a1[H1 > 0 ? H1 : 1];
+  int rb = rb0;
+  load_part(rb, 0, H0, a0);
+  for (; rb < rb_end; rb += stride) {
+    load_part(rb, H0, H1, a1);
+    br_f4 acc[TC];
+#pragma unroll
+    for (int t = 0; t < TC; ++t) acc[t] = br_f4{0.f, 0.f, 0.f, 0.f};
+    mul_part(0, H0, a0, acc);
+    load_part(min(rb + stride, rb_end - 1), 0, H0, a0);       // the next block's first half (the last block: itself again, unused)
+    mul_part(H0, H1, a1, acc);
+    store_block(rb, acc);
+  }
+}
+
+template <int KS>                            // K-steps of 16 (K <= 16 KS)
+__global__ void __launch_bounds__(256, 3) k_gemm_bres(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C,
+                                                   int M, int N, int K, int64_t lda, int64_t sbk, int64_t sbn, int64_t ldc,
+                                                   const float *__restrict__ bias, int relu, int KP) {
+  extern __shared__ __attribute__((aligned(16))) float bt[];      // [BR_COLS][KP]
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n_tiles = (N + 15) >> 4, n_slabs = (n_tiles + 1) >> 1;
+  // workgroup b runs on XCD b % 8 (dispatcher rotation).  An XCD owns an eighth of the row blocks and has workgroups on EVERY slab,
+  // dealt in proportion to the slabs' column tiles (the last slab may hold one), all walking the XCD's row blocks in the same order:
+  // the ten slabs read a row block of A at about the same time, so its second to tenth reads are served by that XCD's L2 (slabs
+  // dealt chip-wide re-read A from the fabric once per slab: 470 MB for T-Finance's 47 MB, 30 of 115 us).
+  const int GX = gridDim.x >> 3, x = blockIdx.x & 7, bi = blockIdx.x >> 3;
+  int slab = 0, beg = 0, end = 0;
+  for (int s2 = 0; s2 < n_slabs; ++s2) {
+    const int e2 = (int)((int64_t)GX * min(2 * s2 + 2, n_tiles) / n_tiles);
+    if (bi >= e2) { slab = s2 + 1; beg = e2; }
+    else { end = e2; break; }
+  }
+  const int col0 = slab * BR_COLS, tcount = min(2, n_tiles - 2 * slab);
+  const int gs = end - beg, g = bi - beg;
+  const int RB = (M + 15) >> 4;
+  const int rb_lo = (int)((int64_t)RB * x >> 3), rb_hi = (int)((int64_t)RB * (x + 1) >> 3);
+  // ---- fill: Bt[n][k] = op(B)[k][col0 + n], zero beyond N / K
+  const int kpad = KS * 16;
+  if (sbk == 1) {                                                  // K-fast in memory: rows copied (float4)
+    for (int i = threadIdx.x; i < BR_COLS * (kpad >> 2); i += 256) {
+      const int n = i / (kpad >> 2), k4 = (i - n * (kpad >> 2)) << 2;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (col0 + n < N && k4 < K) v = *reinterpret_cast<const float4 *>(B + (int64_t)(col0 + n) * sbn + k4);      // (K % 4 == 0)
+      *reinterpret_cast<float4 *>(bt + n * KP + k4) = v;
+    }
+  } else {                                                         // N-fast in memory: transposed on the way in
+    for (int i = threadIdx.x; i < (BR_COLS >> 2) * kpad; i += 256) {
+      const int k = i >> 3, n4 = (i & 7) << 2;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k < K && col0 + n4 < N) v = *reinterpret_cast<const float4 *>(B + (int64_t)k * sbk + col0 + n4);         // (N % 4 == 0)
+      bt[(n4 + 0) * KP + k] = v.x; bt[(n4 + 1) * KP + k] = v.y; bt[(n4 + 2) * KP + k] = v.z; bt[(n4 + 3) * KP + k] = v.w;
+    }
+  }
+  __syncthreads();
+  if (tcount == 2) bres_rows<KS, 2>(A, C, bt, M, N, K, lda, ldc, bias, relu, KP, col0, rb_lo + g * 4 + wid, rb_hi, gs * 4, lane);
+  else bres_rows<KS, 1>(A, C, bt, M, N, K, lda, ldc, bias, relu, KP, col0, rb_lo + g * 4 + wid, rb_hi, gs * 4, lane);
+}
+
+static int bres_kp(int kpad) {               // smallest row stride >= kpad that is 8 or 56 mod 64
+  int kp = kpad;
+  while ((kp & 63) != 8 && (kp & 63) != 56) kp += 4;
+  return kp;
+}
+
 // Row tile: 64 x 64 workgroup tiles everywhere.  The 128-row tile (two accumulators per wave) was the default for grids of
 // >= 3 workgroups per CU; measured again in round 2 it loses on every shape of the path (39357 x 300 x 300: 105-107 vs 98 us,
 // 4096^3: 1269 vs 1239 us, Photo's K = 745: 79 vs 60 us).  GGAD_GEMM_TM=128 still selects it for experiments.
@@ -437,6 +582,29 @@ int ggad_gemm_f32(const float *A, const float *B, float *C, int32_t M, int32_t N
   const bool aligned = ((a_kfast ? K : M) % 4 == 0) && ((b_nfast ? N : K) % 4 == 0);
   const int vec = force_scalar ? 0 : (aligned ? 1 : 2);
   const int64_t ws_elems = workspace ? ggad_gemm_workspace_elems(M, N, K) : 0;
+  // tall product, small second operand: op(B) resident in LDS
+  static const int bres = [] { const char *e = getenv("GGAD_GEMM_BRES"); return e ? atoi(e) : 1; }();
+  // (measured, scripts/gemm_bres_ab.py: 39,357 rows 105-108 -> 92-97 us; at 7,500-12,000 rows -7 ... +5 %, inside the box-to-box noise --
+  //  three waves per SIMD walking 2.1-2.3 row blocks each leave a third round that is 15 % full -- so those keep the tiled kernel)
+  static const int bres_min_m = [] { const char *e = getenv("GGAD_GEMM_BRES_MIN_M"); return e ? atoi(e) : 16384; }();
+  static const int bres_wgs = [] { const char *e = getenv("GGAD_GEMM_BRES_WGS"); return e ? atoi(e) : 3; }();       // workgroups per CU (146 VGPRs, 40 KB of LDS)
+  if (bres && a_kfast && ws_elems == 0 && M >= bres_min_m && K >= 128 && K <= 320 && K % 4 == 0 && N > 64 && N <= 1024 &&
+      (((uintptr_t)A & 15) == 0) && sam % 4 == 0 && (((uintptr_t)B & 15) == 0) &&
+      ((sbk == 1 && sbn % 4 == 0) || (sbn == 1 && sbk % 4 == 0 && N % 4 == 0))) {
+    const int KSn = (K + 15) / 16, KP = bres_kp(KSn * 16);
+    const size_t lds = (size_t)BR_COLS * KP * sizeof(float);
+    const int G = 256 * std::max(1, std::min(bres_wgs, (int)(160 * 1024 / (lds + 512))));      // (a multiple of 8; per XCD >= 32 >= slabs)
+#define GGAD_BRES(KSV) k_gemm_bres<KSV><<<dim3(G), dim3(256), lds, st>>>(A, B, C, (int)M, (int)N, (int)K, sam, sbk, sbn, ldc, bias, (int)relu, KP)
+    switch (KSn) {
+      case 8: GGAD_BRES(8); break;   case 9: GGAD_BRES(9); break;   case 10: GGAD_BRES(10); break; case 11: GGAD_BRES(11); break;
+      case 12: GGAD_BRES(12); break; case 13: GGAD_BRES(13); break; case 14: GGAD_BRES(14); break; case 15: GGAD_BRES(15); break;
+      case 16: GGAD_BRES(16); break; case 17: GGAD_BRES(17); break; case 18: GGAD_BRES(18); break; case 19: GGAD_BRES(19); break;
+      default: GGAD_BRES(20); break;
+    }
+#undef GGAD_BRES
+    GGAD_CHECK_LAUNCH("gemm_f32 (resident operand)");
+    return GGAD_OK;
+  }
   // LDS-DMA kernel: every 16-byte chunk an operand tile is made of must be 16-byte aligned in memory and lie inside one row
   static const bool no_dma = [] { const char *e = getenv("GGAD_GEMM_DMA"); return e && e[0] == '0'; }();
   const bool a_ok = (((uintptr_t)A & 15) == 0) && (a_kfast ? (sam % 4 == 0 && K % 4 == 0) : (sak % 4 == 0 && M % 4 == 0));

@@ -32,11 +32,13 @@ def _adj(g):
 @pytest.mark.parametrize("shape", [(70, 50, 33), (300, 300, 7535), (1, 75, 1000), (130, 1, 40), (64, 64, 16), (257, 129, 3000),
                                    (132, 68, 36), (131, 67, 745), (7535, 300, 745), (66, 302, 130), (500, 300, 10), (257, 64, 3),
                                    (300, 10, 5000), (10984, 300, 300), (300, 300, 10984), (1830, 300, 300), (300, 64, 10984),
-                                   (260, 132, 64), (64, 64, 32), (68, 300, 36), (4096, 512, 1024)])
+                                   (260, 132, 64), (64, 64, 32), (68, 300, 36), (4096, 512, 1024),
+                                   (5000, 260, 320), (2048, 68, 128), (3000, 1024, 256), (2500, 300, 132), (4100, 96, 300), (39357, 300, 300)])
 @pytest.mark.parametrize("dma", ["1", "0"])
 def test_gemm_f32_all_layouts(shape, dma, monkeypatch):
     """C = op(A) op(B) (+ bias, ReLU) on the exact-f32 matrix cores for every layout and for shapes with ragged edges, split-K
-    (weight gradients: K = number of nodes) and the aligned K = 300 products of the path, which take the LDS-DMA kernel (k_gemm_dma;
+    (weight gradients: K = number of nodes), the tall products with a small second operand (M >= 2048, 128 <= K <= 320: k_gemm_bres,
+    op(B) resident in LDS, for both memory layouts of B) and the aligned K = 300 products of the path, which take the LDS-DMA kernel (k_gemm_dma;
     dma = "0" is decided when the library first reads GGAD_GEMM_DMA, so that run only re-checks the register-staged kernel when it is
     the first in the process), against numpy in float64."""
     monkeypatch.setenv("GGAD_GEMM_DMA", dma)
