@@ -519,12 +519,18 @@ __global__ void __launch_bounds__(256, 3) k_gemm_bres(const float *__restrict__ 
       if (col0 + n < N && k4 < K) v = *reinterpret_cast<const float4 *>(B + (int64_t)(col0 + n) * sbn + k4);      // (K % 4 == 0)
       *reinterpret_cast<float4 *>(bt + n * KP + k4) = v;
     }
-  } else {                                                         // N-fast in memory: transposed on the way in
-    for (int i = threadIdx.x; i < (BR_COLS >> 2) * kpad; i += 256) {
-      const int k = i >> 3, n4 = (i & 7) << 2;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (k < K && col0 + n4 < N) v = *reinterpret_cast<const float4 *>(B + (int64_t)k * sbk + col0 + n4);         // (N % 4 == 0)
-      bt[(n4 + 0) * KP + k] = v.x; bt[(n4 + 1) * KP + k] = v.y; bt[(n4 + 2) * KP + k] = v.z; bt[(n4 + 3) * KP + k] = v.w;
+  } else {                                                         // N-fast in memory: transposed on the way in.  A wave takes 64
+    // consecutive k (lane = k) and walks the eight float4 of their 128-byte lines: the scalar stores of a lane group then fall on
+    // consecutive banks (lanes over the columns instead -- coalesced reads -- put eight lanes on every bank: 4 KP = 0 mod 32; the
+    // conflict counter showed a third of the LDS cycles of the launch there); the lines stay in the L1 between the eight passes
+    for (int kb = 64 * wid; kb < kpad; kb += 256) {
+      const int k = kb + lane;
+#pragma unroll
+      for (int n4 = 0; n4 < BR_COLS; n4 += 4) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < K && col0 + n4 < N) v = *reinterpret_cast<const float4 *>(B + (int64_t)k * sbk + col0 + n4);      // (N % 4 == 0)
+        if (k < kpad) { bt[(n4 + 0) * KP + k] = v.x; bt[(n4 + 1) * KP + k] = v.y; bt[(n4 + 2) * KP + k] = v.z; bt[(n4 + 3) * KP + k] = v.w; }
+      }
     }
   }
   __syncthreads();
