@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Launch-order timeline of the LAST `n` kernels of a traced run: start offset, duration, gap to the previous kernel's end.
-Usage: rocpd_timeline.py results.db [n=60] [anchor kernel substring: start at its last occurrence instead]"""
+"""Timeline of the LAST chunk of a traced `bench.py --steps 20` run: every plan kernel and the first / last dense kernels with start
+and end relative to the chunk's first kernel, plus the idle gaps between consecutive kernels.  Usage: rocpd_timeline.py results.db"""
 import sqlite3
 import sys
 
@@ -10,16 +10,23 @@ from rocpd_stats import short  # noqa: E402
 db = sqlite3.connect(sys.argv[1])
 cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
 name_col = "name" if "name" in cols else "kernel_name"
-rows = [(short(n).split("<")[0][:56], s, e) for n, s, e in db.execute(f"select {name_col}, start, end from kernels order by start")]
-n = int(sys.argv[2]) if len(sys.argv) > 2 else 60
-if len(sys.argv) > 3:
-    idx = [i for i, r in enumerate(rows) if sys.argv[3] in r[0]]
-    rows = rows[idx[-1]:idx[-1] + n]
-else:
-    rows = rows[-n:]
-t0, prev_end, busy = rows[0][1], rows[0][1], 0.0
-for name, s, e in rows:
-    print(f"{(s - t0) / 1e3:9.1f} us  {name:58s} {(e - s) / 1e3:8.1f} us   gap {(s - prev_end) / 1e3:7.1f}")
-    busy += (e - s) / 1e3
+rows = [(short(n).split("<")[0], s, e) for n, s, e in db.execute(f"select {name_col}, start, end from kernels order by start")]
+idx = [i for i, r in enumerate(rows) if r[0] == "k_expand"]
+a = idx[-1]
+seg = rows[a:]
+# stop at the last dense kernel of the chunk (the XCD-resident chunk kernel, or the last k_grad_reduce of the launch chain)
+last = max(i for i, r in enumerate(seg) if r[0] in ("k_grad_reduce", "k_train_chunk_xcd"))
+seg = seg[:last + 1]
+t0 = seg[0][1]
+prev_end = t0
+gaps = 0.0
+for i, (n, s, e) in enumerate(seg):
+    gap = (s - prev_end) / 1e3
+    if gap > 0:
+        gaps += gap
+    if i < 14 or i >= len(seg) - 6:
+        print(f"{n:22s} start {(s - t0) / 1e3:9.1f} us  dur {(e - s) / 1e3:8.1f} us  gap before {gap:6.1f}")
+    elif i == 14:
+        print("   ...")
     prev_end = max(prev_end, e)
-print(f"kernels {len(rows)}, sum {busy:.1f} us, span {(prev_end - t0) / 1e3:.1f} us")
+print(f"chunk span {(seg[-1][2] - t0) / 1e3:.1f} us, kernels {len(seg)}, sum of gaps {gaps:.1f} us")
