@@ -327,6 +327,11 @@ def main():
     from ggad_amd import _lib
     lib = _lib.load()
     ev_pairs = []
+    # A HIP event between two kernels of a stream is a barrier packet: ~6 us of idle device per event (profiles/r04_k20_timeline.txt).
+    # A run of ONE chunk (the driver's --steps 20) therefore carries only the two events around the gather inside the timed region;
+    # the pair-counting kernel and the resident chunk kernel are event-timed in an instrumented REPEAT of the same window right
+    # after it (same batches, same sizes; not part of `value`).  Long runs (many chunks) are instrumented in place: 12 launches.
+    instrument = {"all": len(trainer.default_ramp(a.steps)) > 1}
 
     def new_event():
         h = ctypes.c_void_p()
@@ -344,7 +349,7 @@ def main():
             return
         e0, e1, t0_, t1_ = ev_pool[4 * len(ev_pairs):4 * len(ev_pairs) + 4]
         chunk.gather2_events = (e0, e1)
-        chunk.tile_events = (t0_, t1_) if not os.environ.get("GGAD_BENCH_NO_TILE_EV") else None
+        chunk.tile_events = (t0_, t1_) if instrument["all"] else None
         chunk.build(bn, bl)
         chunk.gather2_events = None
         chunk.tile_events = None
@@ -354,7 +359,7 @@ def main():
 
     def timed_train_chunk(ch, *args, **kw):
         # events on the stream the dense steps are launched on (torch's current stream inside `with torch.cuda.stream(main)`)
-        if 2 * len(chunk_ev) + 2 > len(chunk_ev_pool) or os.environ.get("GGAD_BENCH_NO_CHUNK_EV"):
+        if 2 * len(chunk_ev) + 2 > len(chunk_ev_pool) or not instrument["all"]:
             return orig_train_chunk(ch, *args, **kw)
         c0, c1 = chunk_ev_pool[2 * len(chunk_ev)], chunk_ev_pool[2 * len(chunk_ev) + 1]
         c0.record()
@@ -387,8 +392,14 @@ def main():
     nodes_local = trainer.run_steps(a.steps, prepared=timed, gather_hook=timed_build)
     barrier()
     elapsed = time.perf_counter() - t1
-    if os.environ.get("GGAD_BENCH_SYNC_PROBE"):
-        t2 = time.perf_counter(); barrier(); print("idle synchronize: %.1f us" % ((time.perf_counter() - t2) * 1e6), file=sys.stderr)
+    n_timed_pairs = len(ev_pairs)
+    by_kernel_from = "the timed region"
+    losses = trainer.engine.losses(a.steps)                # (before the repeat below overwrites the log slots)
+    if not instrument["all"] and world == 1:
+        instrument["all"] = True
+        trainer.run_steps(a.steps, prepared=timed, gather_hook=timed_build)
+        barrier()
+        by_kernel_from = "an instrumented repeat of the timed window (same batches) right after it"
     trainer.engine.train_chunk = orig_train_chunk
     trainer.check_exchange(dist if world > 1 else None)
     if world > 1:
@@ -400,18 +411,23 @@ def main():
         nodes_total = float(nn.item())
     else:
         nodes_total = float(nodes_local)
-    losses = trainer.engine.losses(a.steps)
 
     # ---------------- roofline of the dominant kernel
     gather_ms, gather_nbrs, gather_batches, tile_ms = [], [], [], []
-    for e0, e1, bn, t0_, t1_ in ev_pairs:
+    tile_nbrs, nbr_cache = [], {}
+    for i, (e0, e1, bn, t0_, t1_) in enumerate(ev_pairs):
         ms = ctypes.c_float()
         _lib.check(lib.ggad_event_elapsed_ms(e0, e1, ctypes.byref(ms)), "ggad_event_elapsed_ms")
-        gather_ms.append(float(ms.value))
-        gather_nbrs.append(hop2_neighbours(bn))
-        gather_batches.append(len(bn))
-        if lib.ggad_event_elapsed_ms(t0_, t1_, ctypes.byref(ms)) == 0:      # (not recorded by the device-atomic fallback path)
-            tile_ms.append(float(ms.value))
+        key = (len(bn), bn[0].__array_interface__["data"][0])              # (the repeat builds the same batches again)
+        if key not in nbr_cache:
+            nbr_cache[key] = hop2_neighbours(bn)
+        if i < n_timed_pairs:                                                # (the roofline's launches: the timed region's own)
+            gather_ms.append(float(ms.value))
+            gather_nbrs.append(nbr_cache[key])
+            gather_batches.append(len(bn))
+        if lib.ggad_event_elapsed_ms(t0_, t1_, ctypes.byref(ms)) == 0:      # (not recorded by the device-atomic fallback path, nor
+            tile_ms.append(float(ms.value))                                  #  inside a one-chunk timed region)
+            tile_nbrs.append(nbr_cache[key])
     dense_ms = [c0.elapsed_time(c1) for c0, c1, _ in chunk_ev]
     dense_steps = [nb for _, _, nb in chunk_ev]
     del chunk_ev[:], chunk_ev_pool[:]          # (HIP events must not outlive the runtime: destroyed here, not at interpreter exit)
@@ -469,7 +485,7 @@ def main():
                   "avg_launch_ms": avg_ms, "share_of_timed_region": roofline["gather_share_of_timed_region"]}]
     if tile_ms:
         # pair counting: reads the 4-byte column id of every (batch, owner) neighbour and writes its 2-byte pair count
-        t_alg = [6.0 * nb for nb in gather_nbrs[:len(tile_ms)]]
+        t_alg = [6.0 * nb for nb in tile_nbrs]
         t_ach = (sum(t_alg) / 1e9) / (sum(tile_ms) / 1e3)
         t_traffic = (float(tile_hbm_per_nbr) * float(np.mean(gather_nbrs))) if tile_hbm_per_nbr else None
         by_kernel.append({"kernel": "k_tile_counts (LDS pair counting per (tile of 32,768 ids, batch))", "replaces": "src/graphsage.py:335-348 (the U x U2 mask)",
@@ -492,6 +508,7 @@ def main():
                           "frac_of_fp32_peak": 3.0e7 / (us_step * 1e-6) / 157.3e12, "frac_of_hbm_peak": 2.0e6 / (us_step * 1e-6) / 8.0e12,
                           "share_of_timed_region": (sum(dense_ms) / 1e3) / elapsed})
     roofline["by_kernel"] = by_kernel
+    roofline["by_kernel_measured_in"] = by_kernel_from
     roofline["timed_region_accounted"] = float(sum(k["share_of_timed_region"] or 0.0 for k in by_kernel))
 
     # ---------------- extra legs (single GPU): steady state, end to end with the sampler, the full-graph programs

@@ -1078,6 +1078,13 @@ __global__ void __launch_bounds__(1024) k_prelu_bwd_final(const float *__restric
     const int s_lo = (int)((int64_t)S * g / G), s_hi = (int)((int64_t)S * (g + 1) / G);
     float b4[4] = {0.f, 0.f, 0.f, 0.f}, a4[4] = {0.f, 0.f, 0.f, 0.f};
     int s0 = s_lo;
+    for (; s0 + 16 <= s_hi; s0 += 16) {                    // (16 partials of each array in flight: S = 172 at Reddit size is 57 per group --
+      float vb[16], va[16];                                //  four round trips instead of seven; the same additions in the same order)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { vb[k] = part_db[(int64_t)(s0 + k) * W + c]; va[k] = part_da[(int64_t)(s0 + k) * W + c]; }
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { b4[k & 3] += vb[k]; a4[k & 3] += va[k]; }
+    }
     for (; s0 + 8 <= s_hi; s0 += 8) {
       float vb[8], va[8];
 #pragma unroll
@@ -1119,6 +1126,15 @@ __global__ void __launch_bounds__(256) k_prelu_fwd(const float *__restrict__ z, 
                                                    float *__restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) { const float v = z[i]; out[i] = v > 0.f ? v : *prelu_a * v; }
+}
+__global__ void __launch_bounds__(256) k_prelu_fwd_v4(const float4 *__restrict__ z, const float *__restrict__ prelu_a, int64_t n4,
+                                                      float4 *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float a = *prelu_a;
+  float4 v = z[i];
+  v.x = v.x > 0.f ? v.x : a * v.x; v.y = v.y > 0.f ? v.y : a * v.y; v.z = v.z > 0.f ? v.z : a * v.z; v.w = v.w > 0.f ? v.w : a * v.w;
+  out[i] = v;
 }
 
 // inv[r] = 1/|x_r| (inf -> 0), xn = x * inv                                     run.py:177-180
@@ -1711,7 +1727,11 @@ int ggad_head_emb_grad_f32(const float *g_out, const int32_t *abn_pos, const int
 int ggad_prelu_fwd_f32(const float *z, const float *prelu_a, int64_t n, float *out, ggad_stream_t stream) {
   GGAD_REQUIRE(z && prelu_a && out && n >= 0);
   if (n == 0) return GGAD_OK;
-  k_prelu_fwd<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream)>>>(z, prelu_a, n, out);
+  if ((n & 3) == 0 && ((((uintptr_t)z) | ((uintptr_t)out)) & 15) == 0)
+    k_prelu_fwd_v4<<<dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, as_stream(stream)>>>(reinterpret_cast<const float4 *>(z), prelu_a, n / 4,
+                                                                                              reinterpret_cast<float4 *>(out));
+  else
+    k_prelu_fwd<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream)>>>(z, prelu_a, n, out);
   GGAD_CHECK_LAUNCH("prelu_fwd_f32");
   return GGAD_OK;
 }
