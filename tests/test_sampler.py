@@ -131,3 +131,45 @@ def test_schedule_rows_are_recognised_as_one_flat_block():
                   [m[0], m[1].copy(), m[2]],
                   [m[0, :100], m[1, :100]], list(m[1::2][:5]), [list(range(5))], [m[0].astype(np.int32), m[1].astype(np.int32)]):
         assert _rows_as_flat(other) is None
+
+
+def test_row_list_remembers_its_matrix_until_it_is_changed():
+    """`BatchSchedule.next_batches` hands its batches out as `RowList`s: `BatchChunk.build` takes their matrix as it is (no per-row
+    work on the critical path of a one-chunk run).  Slices stay RowLists over the sliced matrix; every in-place change makes the list
+    an ordinary list again -- rows permuted by a hook must not be built in matrix order."""
+    from ggad_amd.minibatch import RowList, _rows_as_flat
+    m = np.arange(60, dtype=np.int64).reshape(6, 10)
+    r = RowList(m)
+    assert isinstance(r, list) and len(r) == 6 and np.array_equal(r[4], m[4])
+    assert np.shares_memory(_rows_as_flat(r), m) and np.array_equal(_rows_as_flat(r), m.reshape(-1))
+    s = r[2:5]
+    assert type(s) is RowList and np.array_equal(_rows_as_flat(s), m[2:5].reshape(-1)) and r[0:6] is r and type(r[::2]) is list
+    assert len(r[3:3]) == 0 and _rows_as_flat(r[3:3]) is None
+    for change in (lambda t: t.reverse(), lambda t: t.__setitem__(0, t[1]), lambda t: t.append(m[0]), lambda t: t.pop(), lambda t: t.sort(key=lambda a: -a[0]),
+                   lambda t: t.extend([m[1]]), lambda t: t.insert(0, m[5]), lambda t: t.__delitem__(0)):
+        t = r[1:6]
+        assert t.matrix is not None
+        change(t)
+        assert t.matrix is None
+        flat = _rows_as_flat(t)                          # (now checked row by row like any list: in matrix order or not at all)
+        assert flat is None or np.array_equal(flat, np.concatenate(t))
+    swapped = r[0:5]
+    swapped[1], swapped[2] = swapped[2], swapped[1]
+    assert _rows_as_flat(swapped) is None
+    assert RowList(m.astype(np.int32)).matrix is None and RowList(m[:, ::2]).matrix is None
+
+
+def test_schedule_hands_out_row_lists():
+    import random as pyrandom
+    from ggad_amd.minibatch import RowList
+    from ggad_amd.sampler import PyCompatRandom
+    from ggad_amd.trainer import BatchSchedule
+    labels = np.zeros(5000, dtype=np.int64)
+    labels[4000:] = 1
+    pyrandom.seed(3)
+    sched = BatchSchedule(np.arange(4000), np.arange(4000, 5000), labels, 150, PyCompatRandom.from_python_state(pyrandom.getstate()))
+    bn, bl = sched.next_batches(7)
+    assert type(bn) is RowList and type(bl) is RowList and bn.matrix.shape == (7, 200) and bl.matrix.shape == (7, 200)
+    assert all(np.array_equal(labels[a], b) for a, b in zip(bn, bl))
+    b2, l2 = sched.next_batches(3, rank=1, world=2)      # (a rank's rows of a shared stream: their own contiguous matrix)
+    assert type(b2) is RowList and b2.matrix is not None and b2.matrix.flags.c_contiguous and len(b2) == 3
