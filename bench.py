@@ -351,9 +351,10 @@ def main():
         chunk.gather2_events = (e0, e1)
         chunk.tile_events = (t0_, t1_) if instrument["all"] else None
         chunk.build(bn, bl)
-        chunk.gather2_events = None
-        chunk.tile_events = None
-        ev_pairs.append((e0, e1, bn, t0_, t1_))
+        with_tile = chunk.tile_events is not None and chunk.last_hop2 == "ldsw"      # (the device-atomic fallback records none; an event
+        chunk.gather2_events = None                                                   #  that was never recorded must not be queried: the
+        chunk.tile_events = None                                                      #  error stays in the runtime's last-error slot)
+        ev_pairs.append((e0, e1, bn, t0_ if with_tile else None, t1_))
 
     orig_train_chunk = trainer.engine.train_chunk
 
@@ -425,8 +426,8 @@ def main():
             gather_ms.append(float(ms.value))
             gather_nbrs.append(nbr_cache[key])
             gather_batches.append(len(bn))
-        if lib.ggad_event_elapsed_ms(t0_, t1_, ctypes.byref(ms)) == 0:      # (not recorded by the device-atomic fallback path, nor
-            tile_ms.append(float(ms.value))                                  #  inside a one-chunk timed region)
+        if t0_ is not None and lib.ggad_event_elapsed_ms(t0_, t1_, ctypes.byref(ms)) == 0:      # (none inside a one-chunk timed region)
+            tile_ms.append(float(ms.value))
             tile_nbrs.append(nbr_cache[key])
     dense_ms = [c0.elapsed_time(c1) for c0, c1, _ in chunk_ev]
     dense_steps = [nb for _, _, nb in chunk_ev]
