@@ -508,6 +508,10 @@ def main():
                           "flop_per_step": 3.0e7, "bytes_per_step": 2.0e6,
                           "frac_of_fp32_peak": 3.0e7 / (us_step * 1e-6) / 157.3e12, "frac_of_hbm_peak": 2.0e6 / (us_step * 1e-6) / 8.0e12,
                           "share_of_timed_region": (sum(dense_ms) / 1e3) / elapsed})
+    if roofline["frac"] and roofline["frac"] > 1.0:
+        roofline["frac_note"] = ("above 1 because `achieved` charges every (batch, owner) occurrence its neighbours' rows (the reference gathers "
+                                 "batch by batch) while a launch of many batches fetches the rows of a node that occurs in several of them "
+                                 "once: `hbm_frac` is the fraction of the HBM peak the launch actually moves")
     roofline["by_kernel"] = by_kernel
     roofline["by_kernel_measured_in"] = by_kernel_from
     roofline["timed_region_accounted"] = float(sum(k["share_of_timed_region"] or 0.0 for k in by_kernel))
