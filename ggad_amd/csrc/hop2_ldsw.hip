@@ -904,8 +904,14 @@ int ggad_int_ldsw_hop2(const ggad_mb_plan *P, const ggad_plan_view &V, hipStream
     // thousand only started when the first left -- at the very end -- and the reservation size followed the nominal wave count
     // (4 items at 20 batches, 32-64 at 150).  Measured (20 / 150 batches): 8 per CU, cap 64: 553 / 1,440 us; 4 per CU, cap 12: 410 / 1,390 us
     // (3 per CU 418 / 1,660; cap 32: 408 / 1,490-1,540).
-    static const int wg_per_cu = [] { const char *e = getenv("GGAD_G2_WG_PER_CU"); return e ? atoi(e) : 4; }();
-    static const int take_cap = [] { const char *e = getenv("GGAD_G2_TAKE_CAP"); return e ? atoi(e) : 12; }();
+    // Launches of <= 32 batches (round 4, scripts/k20_knob_sweep.sh, same box, three runs each at 20 batches): 3 per CU with cap 8
+    // 428-434 us against 439-442 (4, 12); 5 / 6 per CU 482 / 520; 2 per CU 486-502; cap 4 490: the small launch wants fewer waves on
+    // the memory system and smaller reservations, the 150-batch launch does not (3 per CU 1,660 us above).
+    static const int env_wg = [] { const char *e = getenv("GGAD_G2_WG_PER_CU"); return e ? atoi(e) : 0; }();
+    static const int env_cap = [] { const char *e = getenv("GGAD_G2_TAKE_CAP"); return e ? atoi(e) : 0; }();
+    const bool small_launch = V.n_batches <= 32;
+    const int wg_per_cu = env_wg > 0 ? env_wg : (small_launch ? 3 : 4);
+    const int take_cap = env_cap > 0 ? env_cap : (small_launch ? 8 : 12);
     const unsigned wgs = (unsigned)std::min<int64_t>((max_items + 4 * ITEM_GRAB - 1) / (4 * ITEM_GRAB), 256 * wg_per_cu);
     // the trainer's table (rows padded to one 128-byte line): the matrix-core slice, at every launch size by default.  Measured on
     // the bench graph (plan alone, MFMA / VALU slice): 20 batches 562-571 / 559-562 us, 32: 617-645 / 639-672, 48: 750 / 814-840,
