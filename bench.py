@@ -231,14 +231,33 @@ def e2e_leg(a, trainer, sched, barrier, dist=None, world=1, rank=0):
                     "sampler_us_per_batch = the sampler alone per batch THIS RANK consumes (host-bound ceiling of the leg)"}
 
 
+def respawn_command(n_gpus, argv, port=None):
+    """The launch line a bare `python bench.py --gpus N ...` turns itself into (the driver's own form):
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <argv>`."""
+    if port is None:
+        port = os.environ.get("MASTER_PORT")
+    if port is None:
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n_gpus)}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py")] + list(argv)
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as typed: become the launcher (one rank per GPU); rank 0's JSON line is this process's output
+        cmd = respawn_command(a.gpus, sys.argv[1:])
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.execv(cmd[0], cmd)
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+        sys.exit(f"bench.py --gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                 f"(python -m torch.distributed.run --nproc-per-node {a.gpus} ... bench.py --gpus {a.gpus}), or run it bare")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     # one rank per GPU; GGAD_BENCH_BACKEND=gloo lets several ranks share one GPU (tests of the multi-rank path on a 1-GPU box)

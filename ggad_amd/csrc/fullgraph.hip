@@ -896,7 +896,7 @@ __global__ void __launch_bounds__(1024) k_spmm_ring(const int32_t *__restrict__ 
       "14:\n s_waitcnt vmcnt(0)\n"                   // no stream load may land after the statement
       : "={v[64:95]}"(a0), "={v[96:127]}"(a1)
       : [ip] "s"(ip), [cp] "s"(cp), [nsb] "s"(nsb), [lane] "v"(lane_off), [grp] "v"(grp_off)
-      : RING_CLOB_V, "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "scc", "memory");
+      : RING_CLOB_V, "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "m0", "scc", "memory");
   const int vi = slice * SPMM_SL + j;
   if (vi >= (W >> 2)) return;
   const float a = prelu_a ? *prelu_a : 1.0f;

@@ -254,7 +254,7 @@ __device__ __attribute__((aligned(16))) float g_gemm_zero_line[4] = {0.f, 0.f, 0
 
 __device__ __forceinline__ void gemm_dma16(const float *src, uint32_t lds_off) {
   // (inline asm: hipcc then does not know of an LDS-DMA in flight and puts no vmcnt(0) in front of the LDS reads of the OTHER buffer)
-  asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(lds_off), "v"(src) : "memory");
+  asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(lds_off), "v"(src) : "m0", "memory");
 }
 
 template <bool A_KFAST, bool B_NFAST, int NBUF>

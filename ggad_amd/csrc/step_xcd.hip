@@ -47,6 +47,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include <cstddef>
 #include "step_common.h"
 
 namespace {
@@ -1219,13 +1220,17 @@ int ggad_mb_xcd_status(const float *workspace, int64_t *out19, ggad_stream_t str
   return GGAD_OK;
 }
 
-/* Clears the sticky error word of `workspace` (after the host has dealt with it), or -- code != 0 -- sets it as a launch that timed
- * out would (tests of the host's recovery path). */
+/* Clears the error words of `workspace` (the sticky one and the last launch's; after the host has dealt with the error), or --
+ * code != 0 -- sets both as a launch that timed out would (tests of the host's recovery path). */
 int ggad_mb_xcd_clear_error(float *workspace, int32_t code, ggad_stream_t stream) {
   GGAD_REQUIRE(workspace && code >= 0);
   const unsigned v = (unsigned)code;
   hipStream_t st = as_stream(stream);
   if (hipMemcpyAsync(reinterpret_cast<unsigned *>(workspace) + XCD_STICKY_WORD, &v, sizeof(v), hipMemcpyHostToDevice, st) != hipSuccess) return GGAD_E_LAUNCH;
+  // ... and the error word of the LAST launch with it (a launch that times out writes both): when the failed launch was the last
+  // resident one (the host fell back to the launch chain) nothing else would ever reset it and ggad_mb_xcd_status would keep reporting it
+  if (hipMemcpyAsync(reinterpret_cast<char *>(workspace) + offsetof(XcdCtrl, err), &v, sizeof(v), hipMemcpyHostToDevice, st) != hipSuccess)
+    return GGAD_E_LAUNCH;
   if (hipStreamSynchronize(st) != hipSuccess) return GGAD_E_LAUNCH;
   return GGAD_OK;
 }

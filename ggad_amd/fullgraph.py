@@ -460,6 +460,8 @@ class Csr:
         n_gw = nb * NW
         # stream of a walker: phase-major, inside a phase its rounds in accumulator order; a phase without work gets one dummy quad
         # (zero rows) that carries the end-of-phase flag -- every walker meets every barrier
+        if n_gw * NP * (KR + 1) * 32 > (4 << 30):                         # the dense (walker, phase, slot) host tables below: ~32 B per cell
+            return None                                                  # (a very large operand: the panel / sliced kernels take it)
         tab = np.zeros((n_gw, NP, KR + 1), dtype=np.int64)
         tab[gw_of_round, :, k_of_round] = quads
         tab[:, :, KR] = tab[:, :, :KR].sum(2) == 0
@@ -704,10 +706,15 @@ def _use_panel(csr: Csr, p, X: torch.Tensor):
     if force != "1" and not (w >= 64 and nnz >= 64 * p["n_out"] and nnz >= (1 << 20)):
         return None
     ring = os.environ.get("GGAD_SPMM_RING", "1") != "0" and bool(_lib.load().ggad_spmm_ring_available())
-    build = Csr.ring_plan if ring else Csr.panel_plan                       # the LDS ring (k_spmm_ring) unless it is turned off
-    if p.get("rows") is not None:                                         # row subset: the plan lives on the segment plan
-        return build(csr, (w // 4 + 7) // 8, p["rows"], p.setdefault("panel_cache", {}))
-    return build(csr, (w // 4 + 7) // 8)
+    # the LDS ring (k_spmm_ring) unless it is turned off or its plan does not qualify (fill, rounds, stream size): then the panels
+    for build in ((Csr.ring_plan, Csr.panel_plan) if ring else (Csr.panel_plan,)):
+        if p.get("rows") is not None:                                     # row subset: the plan lives on the segment plan
+            plan = build(csr, (w // 4 + 7) // 8, p["rows"], p.setdefault("panel_cache", {}))
+        else:
+            plan = build(csr, (w // 4 + 7) // 8)
+        if plan is not None:
+            return plan
+    return None
 
 
 def _xs_workspace(X: torch.Tensor, n_ws: int) -> torch.Tensor:
@@ -886,6 +893,8 @@ def mlp_score_fwd(x: torch.Tensor, w1, w2, w3):
     x, w1, w2, w3 = x.contiguous(), w1.contiguous(), w2.contiguous(), w3.contiguous()
     r, h = x.shape
     h1, h2 = w1.shape[0], w2.shape[0]
+    if w1.shape[1] != h or w2.shape[1] != h1 or tuple(w3.shape) != (1, h2):
+        raise ValueError(f"mlp_score shape mismatch: x {tuple(x.shape)}, w1 {tuple(w1.shape)}, w2 {tuple(w2.shape)}, w3 {tuple(w3.shape)}")
     f1 = torch.empty(r, h1, dtype=torch.float32, device=x.device)
     f2 = torch.empty(r, h2, dtype=torch.float32, device=x.device)
     f3 = torch.empty(r, 1, dtype=torch.float32, device=x.device)
@@ -898,6 +907,11 @@ def mlp_score_dgrad(g3: torch.Tensor, f1, f2, w1, w2, w3, dx_add: Optional[torch
     g3 = g3.contiguous().reshape(-1)
     r, h1 = f1.shape
     h2, h = f2.shape[1], w1.shape[1]
+    if (f2.shape[0] != r or g3.numel() != r or tuple(w1.shape) != (h1, h) or tuple(w2.shape) != (h2, h1) or tuple(w3.shape) != (1, h2)
+            or (dx_add is not None and tuple(dx_add.shape) != (r, h))):
+        raise ValueError(f"mlp_score_dgrad shape mismatch: g3 {g3.numel()}, f1 {tuple(f1.shape)}, f2 {tuple(f2.shape)}, "
+                         f"w1 {tuple(w1.shape)}, w2 {tuple(w2.shape)}, w3 {tuple(w3.shape)}")
+    f1, f2 = f1.contiguous(), f2.contiguous()
     dz2, dz1 = torch.empty_like(f2), torch.empty_like(f1)
     dx = torch.empty(r, h, dtype=torch.float32, device=f1.device)
     if dx_add is not None:

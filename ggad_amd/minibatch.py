@@ -483,8 +483,13 @@ class MiniBatchEngine:
             # (the chunk's own capacities: a 5-batch warm-up followed by a 20-batch window otherwise re-allocated inside the window)
             self._xcd_caps = (max(int(ch.n_rows * 1.25) + 64, int(ch.rows_cap), self._xcd_caps[0]),
                               max(int(ch.n_chunks * 1.25) + 64, int(ch.ck_cap), self._xcd_caps[1]))
+            old_ws = self.xcd_ws
             self.xcd_ws = torch.zeros(int(self.lib.ggad_mb_xcd_workspace_elems(self._xcd_rows, self.D, self.F, *self._xcd_caps)),
                                       dtype=torch.float32, device=self.dev)
+            if old_ws is not None:
+                # an error recorded by a launch on the old workspace (sticky word 255, `err` of its last launch: the first 256 floats
+                # are the control block) must survive the growth -- the host reads the status once per run, not once per chunk
+                self.xcd_ws[:256].copy_(old_ws[:256])
         if self.loss_log.numel() < 8 * log_slots:
             new = torch.zeros(8 * max(log_slots, 2 * (self.loss_log.numel() // 8)), dtype=torch.float32, device=self.dev)
             new[:self.loss_log.numel()].copy_(self.loss_log)

@@ -555,6 +555,11 @@ class DGraphTrainer:
             self._window = None
             return None
         live = [e.params, e.exp_avg, e.exp_avg_sq, e.step_counter]
+        if self._window is not None and sum(w[0] for w in self._window) > self._REPLAY_MAX_STEPS:
+            # the window is about to be rolled: a time-out inside it must not be swallowed by the fresh snapshot
+            if e.xcd_ws is not None and e.xcd_status()["error"]:
+                self._replay_on_chain()
+                return self._replay_begin()
         if self._window is None or sum(w[0] for w in self._window) > self._REPLAY_MAX_STEPS:
             if self._snap is None:
                 self._snap = [torch.empty_like(t) for t in live]

@@ -6,6 +6,7 @@ dealing (`BatchSchedule.next_batches`), the single all-reduce(SUM) + 1/W contrac
 and that every rank ends with the same weights as a one-process run that averages the W gradients."""
 import os
 import socket
+import subprocess
 import sys
 
 import numpy as np
@@ -13,6 +14,8 @@ import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from ggad_amd import synth
 from ggad_amd.sampler import PyCompatRandom
@@ -188,3 +191,34 @@ def test_world_one_is_the_reference_schedule():
     assert reduce_gradients(torch.zeros(3), 1, None) == 1.0
     with pytest.raises(ValueError):
         reduce_gradients(torch.zeros(3), 2, None)
+
+
+def test_bench_bare_gpus_n_respawn_command_is_well_formed():
+    """`python bench.py --gpus N` without WORLD_SIZE re-executes itself through torch.distributed.run: the command is the
+    driver's own launch line (one rank per GPU, rendezvous on 127.0.0.1) with the user's argv passed through untouched."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ggad_bench_cli", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    argv = ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    cmd = bench.respawn_command(8, argv, port=29511)
+    assert cmd[0] == sys.executable and cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == argv
+    # torch.distributed.run accepts that line (argument parsing only, nothing is launched)
+    from torch.distributed.run import get_args_parser
+    ns = get_args_parser().parse_args(cmd[3:])
+    assert ns.nproc_per_node == "8" and ns.master_addr == "127.0.0.1" and ns.training_script.endswith("bench.py")
+    assert ns.training_script_args == argv
+    # a free port is picked when none is given
+    p = int(bench.respawn_command(2, [])[bench.respawn_command(2, []).index("--master-port") + 1])
+    assert 1024 < p < 65536
+    # without a GPU the bare line still gets as far as the launcher and every rank reports the missing GPU (no "must be launched with")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    import torch
+    if not torch.cuda.is_available():
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-extras"], env=env,
+                             capture_output=True, text=True, timeout=300)
+        assert "needs a GPU" in out.stderr and "must be launched" not in out.stderr

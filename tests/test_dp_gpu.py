@@ -274,3 +274,18 @@ def test_bench_launch_line_two_ranks_one_gpu():
     assert e2e["default_mode"] == "independent"
     for mode in ("independent", "shared"):
         assert e2e[mode]["value"] > 0 and e2e[mode]["sampler_us_per_batch"] > 0 and e2e[mode]["reps"] >= 1, e2e[mode]
+
+
+def test_bench_bare_line_spawns_two_ranks_one_gpu():
+    """`python bench.py --gpus 2 ...` as typed (no torchrun, WORLD_SIZE unset): the process re-executes itself through
+    torch.distributed.run, rank 0 prints the one JSON line with n_gpus 2, rc 0."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(GGAD_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "40", "--warmup", "20",
+           "--nodes", "200000", "--entries", "4000000", "--chunk", "20", "--no-extras"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 40 and d["value"] > 0 and d["config"]["parallelism"] == "dp2"

@@ -688,6 +688,104 @@ def test_resident_kernel_error_is_sticky_and_recovered_on_the_launch_chain(overl
     assert int(tr.engine.step_counter.item()) == 19
 
 
+def test_resident_error_of_the_last_launch_is_cleared_by_the_recovery_and_survives_workspace_growth():
+    """(a) when the launch that failed is the LAST resident launch (one-chunk run, persistent placement error) the
+    recovery must leave no error behind -- the next check point after the replay is clean, not a second raise; (b) an error
+    recorded before the workspace is re-allocated (a larger chunk) is carried over; (c) a time-out in a window that is about
+    to be rolled (more than _REPLAY_MAX_STEPS un-checked steps) is replayed, not swallowed by the fresh snapshot."""
+    import warnings
+    from ggad_amd.sampler import PyCompatRandom
+    from ggad_amd.trainer import BatchSchedule, DGraphTrainer
+    n = 30000
+    rowptr, col = synth.make_graph(n, 300000, 2, kind="powerlaw", max_degree=400)
+    feat_np = O.normalize_rows(synth.make_features(n, 17, 2)).astype(np.float32)
+    labels = np.zeros(n, dtype=np.int64)
+    pool = np.arange(1000, 1600)
+    labels[pool] = 1
+    train = np.arange(2000, 20000)
+    torch.manual_seed(4)
+    w = torch.nn.init.xavier_uniform_(torch.empty(1, 64))
+    W = torch.nn.init.xavier_uniform_(torch.empty(64, 17))
+    fc = torch.nn.init.xavier_uniform_(torch.empty(64, 64))
+
+    def make(resident, chunk=3):
+        graph = DeviceGraph(rowptr, col, DEV)
+        feat = torch.from_numpy(feat_np).to(DEV)
+        sched = BatchSchedule(train.copy(), pool.copy(), labels, 60, PyCompatRandom(72), n_pseudo=20, batches_per_epoch=5)
+        tr = DGraphTrainer(graph, feat, 64, sched, chunk_batches=chunk, overlap=False, prefetch=False,
+                           dense_cus=None if resident else 32)
+        tr.engine.load_params(w, W, fc)
+        return tr
+
+    def state(tr):
+        e = tr.engine
+        return [t.cpu().numpy().copy() for t in (e.params, e.exp_avg, e.exp_avg_sq, e.step_counter)]
+
+    chain = make(False)
+    chain.run_steps(6)
+    torch.cuda.synchronize()
+    want = state(chain)
+
+    # (a) the failed launch is the last resident one
+    tr = make(True)
+    tr.run_steps(6)
+    torch.cuda.synchronize()
+    tr.engine.set_resident_error(1)                          # both words, as a launch that timed out leaves them
+    assert tr.engine.xcd_status()["error"] == 1
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        tr.check_exchange()
+    assert any("replaying 6 optimiser steps" in str(c.message) for c in caught)
+    assert tr.resident_fallbacks == 1 and not tr.engine.resident
+    assert tr.engine.xcd_status()["error"] == 0
+    for a, b in zip(state(tr), want):
+        np.testing.assert_array_equal(a, b)                  # the whole run was replayed on the chain from the initial state
+    tr.check_exchange()                                      # used to raise: `err` of the last launch was never cleared
+    tr.run_steps(2)
+    torch.cuda.synchronize()
+    tr.check_exchange()
+    assert int(tr.engine.step_counter.item()) == 8
+
+    # (b) growth of the workspace keeps a recorded error
+    tr = make(True, chunk=2)
+    tr.run_steps(2)
+    torch.cuda.synchronize()
+    tr.engine.set_resident_error(2)
+    old = tr.engine.xcd_ws
+    tr.engine._xcd_rows = 0                                  # force the re-allocation path on the next chunk
+    tr.engine._xcd_caps = (0, 0)
+    tr.run_steps(2)
+    torch.cuda.synchronize()
+    assert tr.engine.xcd_ws is not old and tr.engine.xcd_status()["error"] == 2
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tr.check_exchange()
+    assert tr.resident_fallbacks == 1 and tr.engine.xcd_status()["error"] == 0
+
+    # (c) a window that rolls over looks at the error word first
+    tr = make(True)
+    tr._REPLAY_MAX_STEPS = 4
+    tr.run_steps(3)
+    tr.run_steps(3)                                          # 6 > 4 un-checked steps: the next run would roll the window
+    torch.cuda.synchronize()
+    tr.engine.set_resident_error(1)
+    tr.engine.params.mul_(1.5)
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        tr.run_steps(2)
+    assert any("replaying 6 optimiser steps" in str(c.message) for c in caught)
+    torch.cuda.synchronize()
+    tr.check_exchange()
+    assert tr.resident_fallbacks == 1 and int(tr.engine.step_counter.item()) == 8
+    ref = make(False)
+    ref.run_steps(3)
+    ref.run_steps(3)
+    ref.run_steps(2)
+    torch.cuda.synchronize()
+    for a, b in zip(state(tr), state(ref)):
+        np.testing.assert_array_equal(a, b)
+
+
 def test_chunk_parallel_forward_on_hub_batches_equals_six_launch_chain():
     """Batches with hub rows (> 256 entries) take the chunk-parallel forward of chain 0 (k_fwd_chunks + k_loss_pos_ck, relu
     mask recomputed in bwd_flat); chain 2 keeps project -> fwd_rows -> loss_pos.  Same losses / gradients / weights up to the
