@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libggad_hip.so")
 STAMP = os.path.join(HERE, ".libggad_hip.stamp")
-SOURCES = ["runtime.cpp", "plan_build.cpp", "exchange.cpp", "sampler.cpp", "sampler_x86.cpp", "spmm_panel_build.cpp", "spmm_ring_build.cpp", "plan.hip", "hop2_ldsw.hip", "step.hip", "step_xcd.hip", "fullgraph.hip", "gemm.hip", "mlp.hip", "baselines.hip"]
+SOURCES = ["runtime.cpp", "plan_build.cpp", "exchange.cpp", "sampler.cpp", "sampler_x86.cpp", "spmm_panel_build.cpp", "spmm_ring_build.cpp", "plan.hip", "hop2_ldsw.hip", "step.hip", "step_xcd.hip", "fullgraph.hip", "gemm.hip", "gemm_slab.hip", "mlp.hip", "baselines.hip"]
 HOST_ONLY = {"sampler.cpp", "sampler_x86.cpp", "spmm_panel_build.cpp", "spmm_ring_build.cpp"}      # plain C++ (x86 intrinsics behind a run-time CPU check), no device pass
 HEADERS = ["common.h", "step_common.h", "libggad_hip.map", os.path.join("..", "..", "include", "ggad_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-fno-fast-math",

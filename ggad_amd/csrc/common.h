@@ -92,6 +92,10 @@ int ggad_int_global_hop2(const ggad_mb_plan *P, const ggad_plan_view &V, hipStre
 int ggad_int_ldsw_hop2(const ggad_mb_plan *P, const ggad_plan_view &V, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
 int ggad_int_range_deg();      // owners above this degree are gathered by id range (INT32_MAX: the partition is off)
 
+// ---- gemm_slab.hip: the slab-resident tall product; 1 = launched, 0 = not this kernel's shape, < 0 = launch error
+int ggad_int_gemm_slab(const float *A, const float *B, float *C, int M, int N, int K, int64_t lda, int64_t sbk, int64_t sbn, int64_t ldc,
+                       const float *bias, int relu, hipStream_t st);
+
 // ---- one-shot gradient exchange (exchange.cpp owns the handle, step.hip the kernel)
 constexpr int GGAD_XCHG_MAX_WORLD = 16;
 struct ggad_xchg_view {                          // what the kernel needs, passed by value

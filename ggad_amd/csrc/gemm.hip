@@ -589,6 +589,12 @@ int ggad_gemm_f32(const float *A, const float *B, float *C, int32_t M, int32_t N
   const int vec = force_scalar ? 0 : (aligned ? 1 : 2);
   const int64_t ws_elems = workspace ? ggad_gemm_workspace_elems(M, N, K) : 0;
   // tall product, small second operand: op(B) resident in LDS
+  // round 5: 80-column slabs, one persistent workgroup per CU, row blocks dealt to SIMDs (gemm_slab.hip); what it declines goes on below
+  if (a_kfast && ws_elems == 0) {
+    const int r = ggad_int_gemm_slab(A, B, C, (int)M, (int)N, (int)K, sam, sbk, sbn, ldc, bias, (int)relu, st);
+    if (r < 0) { ggad_set_error(hipErrorLaunchFailure, "gemm_f32 (slab)"); return GGAD_E_LAUNCH; }
+    if (r > 0) return GGAD_OK;
+  }
   static const int bres = [] { const char *e = getenv("GGAD_GEMM_BRES"); return e ? atoi(e) : 1; }();
   // (measured, scripts/gemm_bres_ab.py: 39,357 rows 105-108 -> 92-97 us; at 7,500-12,000 rows -7 ... +5 %, inside the box-to-box noise --
   //  three waves per SIMD walking 2.1-2.3 row blocks each leave a third round that is 15 % full -- so those keep the tiled kernel)

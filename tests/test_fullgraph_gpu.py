@@ -33,12 +33,14 @@ def _adj(g):
                                    (132, 68, 36), (131, 67, 745), (7535, 300, 745), (66, 302, 130), (500, 300, 10), (257, 64, 3),
                                    (300, 10, 5000), (10984, 300, 300), (300, 300, 10984), (1830, 300, 300), (300, 64, 10984),
                                    (260, 132, 64), (64, 64, 32), (68, 300, 36), (4096, 512, 1024),
-                                   (5000, 260, 320), (2048, 68, 128), (3000, 1024, 256), (2500, 300, 132), (4100, 96, 300), (39357, 300, 300)])
+                                   (5000, 260, 320), (2048, 68, 128), (3000, 1024, 256), (2500, 300, 132), (4100, 96, 300), (39357, 300, 300),
+                                   (4111, 196, 252), (4500, 198, 300), (10984, 512, 256), (4200, 128, 244), (6000, 320, 320), (4097, 176, 316)])
 @pytest.mark.parametrize("dma", ["1", "0"])
 def test_gemm_f32_all_layouts(shape, dma, monkeypatch):
     """C = op(A) op(B) (+ bias, ReLU) on the exact-f32 matrix cores for every layout and for shapes with ragged edges, split-K
-    (weight gradients: K = number of nodes), the tall products with a small second operand (M >= 2048, 128 <= K <= 320: k_gemm_bres,
-    op(B) resident in LDS, for both memory layouts of B) and the aligned K = 300 products of the path, which take the LDS-DMA kernel (k_gemm_dma;
+    (weight gradients: K = number of nodes), the tall products with a small second operand (M >= 4096, 244 <= K <= 320, N a sum of
+    5- and 4-tile slabs: k_gemm_slab, round 5 -- 80-column slabs of op(B) resident in LDS, both memory layouts of B, 16-byte and scalar
+    stores; M >= 2048, 128 <= K <= 320 otherwise: k_gemm_bres) and the aligned K = 300 products of the path, which take the LDS-DMA kernel (k_gemm_dma;
     dma = "0" is decided when the library first reads GGAD_GEMM_DMA, so that run only re-checks the register-staged kernel when it is
     the first in the process), against numpy in float64."""
     monkeypatch.setenv("GGAD_GEMM_DMA", dma)
@@ -56,6 +58,26 @@ def test_gemm_f32_all_layouts(shape, dma, monkeypatch):
             got2 = FG.gemm(torch.from_numpy(a).to(DEV), torch.from_numpy(b).to(DEV), ta, tb, bias=torch.from_numpy(bias).to(DEV),
                            relu=True).cpu().numpy()
             assert np.abs(got2 - np.maximum(ref + bias, 0)).max() / scale < 2e-6
+
+
+@pytest.mark.parametrize("ldc", [300, 304, 320, 301])
+def test_gemm_slab_strided_output_and_switch(ldc, monkeypatch):
+    """k_gemm_slab writes into a row-strided destination (`padded_rows`: what GcnLayerFn hands it) with 16-byte stores when the stride
+    allows and scalar ones otherwise, never outside the N columns of a row; and the product equals the round-4 kernels' to round-off."""
+    rng = np.random.default_rng(ldc)
+    m, n, k = 9000, 300, 300
+    a = torch.from_numpy(rng.standard_normal((m, k)).astype(np.float32)).to(DEV)
+    for tb in (True, False):
+        b = torch.from_numpy(rng.standard_normal((n, k) if tb else (k, n)).astype(np.float32)).to(DEV)
+        bias = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).to(DEV)
+        buf = torch.full((m, ldc), -7.0, dtype=torch.float32, device=DEV)
+        out = buf[:, :n]
+        got = FG.gemm(a, b, False, tb, bias=bias, relu=True, out=out)
+        assert got.data_ptr() == buf.data_ptr()
+        ref = torch.relu(a.double() @ (b.double().T if tb else b.double()) + bias.double())
+        assert ((got.double() - ref).abs().max() / (ref.abs().max() + 1.0)).item() < 2e-6
+        if ldc > n:
+            assert bool((buf[:, n:] == -7.0).all())                     # the padding of every row is untouched
 
 
 @pytest.mark.parametrize("name", ["fullgraph_reddit_like.npz", "fullgraph_amazon_like.npz"])
