@@ -150,6 +150,7 @@ class ModelHandler(object):
         trainer = DGraphTrainer(graph, features.weight.data, args.emb_size, sched, chunk_batches=steps_per_epoch, rank=rank,
                                 world_size=world, allreduce=allreduce, engine=engine, exchange=exchange, own_stream=own_stream)
         self.trainer, self.model = trainer, gnn_model
+        self.epoch_losses, self.valid_history = [], []          # {total, cls, margin, rec} of every batch; (epoch, five metrics) of every sweep
         trainer.start_stream(steps_per_epoch * args.num_epochs)        # sampler thread alive across the validation pauses
         total_time = 0.0
         epoch = 0
@@ -169,6 +170,7 @@ class ModelHandler(object):
             for j in range(n_ep):
                 l = lall[j * steps_per_epoch:(j + 1) * steps_per_epoch]
                 self.last_epoch_losses = l
+                self.epoch_losses.append(l)
                 if rank == 0:
                     print(f"Epoch: {epoch + j}, loss: {l[:, 0].mean()}, marigin_loss: {l[:, 2].mean()}, time: {block_time / n_ep}s")
                     print("loss_cls", l[:, 1].mean())
@@ -182,6 +184,7 @@ class ModelHandler(object):
                     print("Valid at epoch {}".format(epoch))
                 f1_mac_val, f1_1_val, f1_0_val, auc_val, gmean_val = test_sage(idx_valid, y_valid, gnn_model, args.batch_size,
                                                                                args.thres, dist=dist, verbose=rank == 0)
+                self.valid_history.append((epoch, (f1_mac_val, f1_1_val, f1_0_val, auc_val, gmean_val)))
                 if auc_val > auc_best:
                     f1_mac_best, auc_best, ep_best = f1_mac_val, auc_val, epoch
                     if rank == 0:
@@ -194,6 +197,7 @@ class ModelHandler(object):
             total_time += time.time() - t0
             epoch += 1
         random.setstate(rng.to_python_state())       # hand the stream back to python `random`
+        self.end_state = {k: v.detach().clone() for k, v in gnn_model.state_dict().items() if "features" not in k}   # before the restore
         if ep_best >= 0:
             if rank == 0:
                 print("Restore model from epoch {}".format(ep_best))

@@ -99,6 +99,15 @@ def main():
     full = FullGraphAdj(normalize_adj(adj) + sp.eye(nb_nodes), adj + sp.eye(nb_nodes), dev)     # run.py:98-101, CSR in HBM
     feats = torch.FloatTensor(np.asarray(features, dtype=np.float32)[np.newaxis]).to(dev)
     model = Model(ft_size, args.embedding_dim, "prelu", args.negsamp_ratio, args.readout).to(dev)
+    fit(args, dev, full, feats, model, normal_label_idx, abnormal_label_idx, idx_test, ano_label)
+
+
+def fit(args, dev, full, feats, model, normal_label_idx, abnormal_label_idx, idx_test, ano_label, history=None):
+    """The training loop of the reference's script (`run.py:137-240`): Adam, `num_epoch` epochs, an evaluation forward (which draws
+    noise too, quirk 5) every 10th epoch.  `history` (a dict, tests / the end-of-training parity report): filled with the four loss
+    terms of every epoch, the AUROC / AP of every evaluation, and -- one extra evaluation after the last epoch, which the reference
+    does not run -- the final scores of all nodes."""
+    nb_nodes = feats.shape[1]
     optimiser = FlatAdam(model.parameters(), lr=args.lr, weight_decay=args.weight_decay)
     ls = full.loss_structs(normal_label_idx, abnormal_label_idx)
     idx_test_dev = torch.as_tensor(np.asarray(idx_test, dtype=np.int64), device=dev)
@@ -155,6 +164,8 @@ def main():
         torch.cuda.synchronize()
         epoch_times.append(time.time() - start_time)
         total_time += epoch_times[-1]
+        if history is not None:
+            history.setdefault("losses", []).append([loss.item(), loss_margin.item(), loss_bce.item(), loss_rec.item()])
         if not args.quiet:
             print("Total time is", total_time)
         if epoch % 2 == 0 and not args.quiet:
@@ -172,6 +183,16 @@ def main():
             print("Testing {} AUC:{:.4f}".format(args.dataset, auc))
             ap = average_precision(scores, y_test_dev)                        # = average_precision_score    run.py:238
             print("Testing AP:", ap)
+            if history is not None:
+                history.setdefault("eval", []).append([epoch, auc, ap])
+    if history is not None:
+        model.eval()
+        with torch.no_grad():
+            _, _, logits_eval, _, _ = model(feats, full, abnormal_label_idx, normal_label_idx, False, args)
+        scores = logits_eval[0, idx_test_dev, 0]
+        history["final_logits"] = logits_eval[0, :, 0].cpu().numpy()
+        history["final_auc"], history["final_ap"] = roc_auc(scores, y_test_dev), average_precision(scores, y_test_dev)
+        history["captured"] = graph is not None
     print("nodes/s (training window, run.py:146->214): {:.1f}".format(nb_nodes * args.num_epoch / total_time))
     med = float(np.median(epoch_times))
     print("median epoch {:.3f} ms -> {:.1f} nodes/s (first epoch {:.1f} ms incl. one-off plan building / module load)".format(

@@ -368,6 +368,97 @@ def ingest_case():
     print("wrote", path, {k: len(v) for k, v in out.items() if hasattr(v, "__len__") and "idx" in k})
 
 
+
+def full_graph_long_case(tag="long_photo_schedule", n=4200, n_entries=60000, f=64, n_h=300, seed=0, mean=0.02, var=0.01,
+                         num_epoch=100, outlier_rate=0.15):
+    """End-of-training parity (BASELINE north_star: "AUROC/AUPRC within 1e-4"): the WHOLE training schedule of the reference's
+    script for `--dataset photo` (run.py:46-48: 100 epochs; README: --mean 0.02 --var 0.01; Adam lr 1e-3) on a graph the dense
+    reference still runs here, restated around the imported `Model` exactly as run.py:137-240 drives it: ONE seeding at the
+    start, the noise of every training forward AND of every evaluation forward (every 10th epoch, quirk 5) drawn from the same
+    global CPU generator in program order.  Stored: the four loss terms of every epoch, AUROC / AP of every evaluation, and one
+    extra evaluation after the last epoch with the scores of all nodes.  Inputs are regenerated from the seed (CRC stored);
+    the initial weights are those of `torch.manual_seed(seed); Model(...)` (CRC stored).  N = 4200 rows and H = 300 send the
+    projections of every epoch through the round-5 slab GEMM."""
+    import scipy.sparse as sp
+    from sklearn.metrics import average_precision_score, roc_auc_score
+    from model import Model
+    import utils as rutils
+
+    rowptr, col = synth.make_graph(n, n_entries, seed, kind="powerlaw", max_degree=n // 8)
+    feat = synth.make_features(n, f, seed)
+    ano = synth.make_labels(n, 0.06, seed)
+    adj_sp = synth.csr_to_scipy(rowptr, col)
+    random.seed(seed)
+    all_idx = list(range(n))
+    random.shuffle(all_idx)
+    num_train, num_val = int(n * 0.3), int(n * 0.1)
+    idx_train = all_idx[:num_train]
+    idx_test = all_idx[num_train + num_val:]
+    all_normal = [i for i in idx_train if ano[i] == 0]
+    normal_idx = all_normal[: int(len(all_normal) * 0.5)]
+    random.shuffle(normal_idx)
+    abn_idx = normal_idx[: int(len(normal_idx) * outlier_rate)]
+
+    feats_dense, _ = rutils.preprocess_features(sp.lil_matrix(feat))
+    adj_norm = rutils.normalize_adj(adj_sp)
+    raw_adj = torch.FloatTensor(np.asarray((adj_sp + sp.eye(n)).todense()))
+    adj = torch.FloatTensor(np.asarray((adj_norm + sp.eye(n)).todense())[np.newaxis])
+    features = torch.FloatTensor(np.asarray(feats_dense)[np.newaxis])
+    args = types.SimpleNamespace(mean=mean, var=var)
+    bce = torch.nn.BCEWithLogitsLoss(reduction="none", pos_weight=torch.tensor([1]))
+
+    torch.manual_seed(seed)                                             # run.py:62 (the one seeding of the run)
+    model = Model(f, n_h, "prelu", 1, "avg")
+    init_crc = synth.crc_of(*[_np(v) for _, v in sorted(model.state_dict().items())])
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=0.0)
+    r_inv = torch.pow(torch.sum(raw_adj, 0), -1)
+    r_inv[torch.isinf(r_inv)] = 0.0
+    yt = ano[np.array(idx_test)]
+    losses, evals = [], []
+
+    def evaluate():
+        model.eval()
+        with torch.no_grad():
+            _, _, lg, _, _ = model(features, adj, abn_idx, normal_idx, False, args)
+        le = _np(lg[0, :, 0])
+        return le, roc_auc_score(yt, le[np.array(idx_test)]), average_precision_score(yt, le[np.array(idx_test)], average="macro", pos_label=1)
+
+    import time as _t
+    t0 = _t.time()
+    for epoch in range(num_epoch):
+        model.train()
+        opt.zero_grad()
+        emb, emb_combine, logits, emb_con, emb_abnormal = model(features, adj, abn_idx, normal_idx, True, args)
+        lbl = torch.cat((torch.zeros(len(normal_idx)), torch.ones(len(emb_con)))).unsqueeze(1).unsqueeze(0)
+        l_bce = torch.mean(bce(logits, lbl))
+        e = torch.squeeze(emb)
+        inv = torch.pow(torch.norm(e, dim=-1, keepdim=True), -1)
+        inv[torch.isinf(inv)] = 0.0
+        en = e * inv
+        aff = torch.sum(torch.mm(en, en.T) * raw_adj, 0) * r_inv
+        l_margin = (0.7 - (torch.mean(aff[normal_idx]) - torch.mean(aff[abn_idx]))).clamp_min(min=0)
+        l_rec = torch.mean(torch.sqrt(torch.sum(torch.pow(emb_con - emb_abnormal, 2), 1)))
+        total = l_margin + l_bce + l_rec
+        total.backward()
+        opt.step()
+        losses.append([total.item(), l_margin.item(), l_bce.item(), l_rec.item()])
+        if epoch % 10 == 0:
+            _, auc, ap = evaluate()
+            evals.append([epoch, auc, ap])
+            print(f"epoch {epoch}: loss {losses[-1][0]:.6f} auc {auc:.6f} ap {ap:.6f}  ({_t.time() - t0:.0f} s)", flush=True)
+    le, auc, ap = evaluate()
+    out = dict(n=n, n_entries=n_entries, f=f, n_h=n_h, seed=seed, mean=mean, var=var, num_epoch=num_epoch,
+               inputs_crc=synth.crc_of(rowptr, col, feat, ano), init_crc=init_crc,
+               idx_test=np.array(idx_test), normal_idx=np.array(normal_idx), abn_idx=np.array(abn_idx),
+               losses=np.array(losses, dtype=np.float64), evals=np.array(evals, dtype=np.float64),
+               final_logits=le, final_auc=auc, final_ap=ap)
+    for k, v in model.state_dict().items():
+        out["final_norm." + k] = np.float64(np.linalg.norm(_np(v).astype(np.float64)))
+    path = os.path.join(HERE, f"fullgraph_{tag}.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "final auc", auc, "ap", ap)
+
+
 def part_full():
     _stub_third_party()
     sys.path.insert(0, REF)
@@ -583,6 +674,73 @@ def handler_case():
     print("wrote", path, "metrics", out["metrics"])
 
 
+
+def handler_long_case(num_epochs=5, valid_epochs=2):
+    """`handler_case` over FIVE epochs of 150 batches with a validation sweep at epochs 0, 2 and 4 (model_handler.py:379-392), the
+    best checkpoint restored and the test sweep at the end (:405-414) -- the end-of-training parity case of the mini-batch path.
+    Stored: the loss terms of all 750 batches, the five metrics of every validation sweep, the weights each sweep saw (the last one:
+    the weights at the END of training), and the final test metrics."""
+    import pickle
+    import tempfile
+    n, n_entries, f, seed = 90000, 300000, 17, 11
+    rowptr, col = synth.make_graph(n, n_entries, seed, kind="powerlaw", max_degree=200)
+    feat_raw = synth.make_features(n, f, seed)
+    y = synth.make_labels(n, 0.02, seed)
+    adj_lists = synth.csr_to_adj_lists(rowptr, col)
+    tmp = tempfile.mkdtemp(prefix="ggad_golden_")
+    os.makedirs(os.path.join(tmp, "data"))
+    os.makedirs(os.path.join(tmp, "work", "data"))
+    np.savez(os.path.join(tmp, "data", "dgraphfin.npz"), x=feat_raw, y=y)
+    with open(os.path.join(tmp, "work", "data", "dgraphfin_adj_list"), "wb") as fh:
+        pickle.dump(adj_lists, fh)
+    cwd = os.getcwd()
+    os.chdir(os.path.join(tmp, "work"))
+    try:
+        import model_handler as mh
+        cfg = dict(data_name="dgraphfin", data_dir="./data/", train_ratio=0.4, test_ratio=0.67,
+                   save_dir="./pytorch_models/", model="GCN", multi_relation="GNN", emb_size=64, thres=0.4,
+                   rho=0.5, seed=72, optimizer="adam", lr=0.001, weight_decay=0.007, batch_size=150,
+                   num_epochs=num_epochs, valid_epochs=valid_epochs, alpha=2, no_cuda=True, cuda_id="0")
+        torch.manual_seed(72)
+        np.random.seed(72)
+        handler = mh.ModelHandler(cfg)
+        out = dict(n=n, n_entries=n_entries, f=f, graph_seed=seed, inputs_crc=synth.crc_of(rowptr, col, feat_raw, y),
+                   num_epochs=num_epochs, valid_epochs=valid_epochs)
+        import graphsage as gs
+        rec = []
+        orig_loss = gs.GCN.loss
+
+        def spy(self, nodes, labels):
+            r = orig_loss(self, nodes, labels)
+            rec.append([float(x) for x in r])
+            return r
+        gs.GCN.loss = spy
+        sweeps, seen = [], []
+        orig_test = mh.test_sage
+
+        def test_spy(cases, labels, model, batch_size, thres=0.5):
+            r = orig_test(cases, labels, model, batch_size, thres)
+            sweeps.append([float(x) for x in r])
+            seen.append({k: _np(v).copy() for k, v in model.state_dict().items() if "features" not in k})
+            return r
+        mh.test_sage = test_spy
+        res = handler.train()
+        mh.test_sage = orig_test
+        gs.GCN.loss = orig_loss
+        out["batch_losses"] = np.array(rec, dtype=np.float64)                 # (750, 4): total, cls, margin, rec
+        out["sweeps"] = np.array(sweeps, dtype=np.float64)                    # validations at epochs 0, 2, 4, then the test sweep
+        out["metrics"] = np.array(res, dtype=np.float64)
+        for k, v in seen[-2].items():                                         # the last validation: weights at the end of training
+            out["end." + k] = v
+        for k, v in seen[-1].items():                                         # the test sweep: the restored best checkpoint
+            out["best." + k] = v
+    finally:
+        os.chdir(cwd)
+    path = os.path.join(HERE, "handler_dgraph_like_5ep.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "sweeps", out["sweeps"], "metrics", out["metrics"])
+
+
 def baseline_case():
     """Mini-batch comparison models that share GGAD's 1-hop aggregate (src/graphsage_dominant.py, src/graphsage_anomalydae.py):
     module outputs, k training steps of the loop in src/model_handler_dominate.py:133-163, scores of src/utils.py:140-172."""
@@ -769,7 +927,7 @@ def part_mini(with_handler: bool):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--part", choices=["all", "full", "mini", "baselines", "ocgnn", "ingest", "sage", "pcgnn", "tam"], default="all")
+    ap.add_argument("--part", choices=["all", "full", "mini", "baselines", "ocgnn", "ingest", "sage", "pcgnn", "tam", "long_full", "long_mini"], default="all")
     ap.add_argument("--no-handler", action="store_true", help="skip the slow end-to-end ModelHandler case")
     a = ap.parse_args()
     if not os.path.isdir(REF):
@@ -777,11 +935,19 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     if a.part == "all":
         env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
-        for p in ("full", "mini", "baselines", "ocgnn", "ingest", "sage", "pcgnn", "tam"):
+        for p in ("full", "mini", "baselines", "ocgnn", "ingest", "sage", "pcgnn", "tam", "long_full", "long_mini"):
             cmd = [sys.executable, os.path.abspath(__file__), "--part", p] + (["--no-handler"] if a.no_handler else [])
             subprocess.check_call(cmd, env=env)
     elif a.part == "full":
         part_full()
+    elif a.part == "long_full":                    # end-of-training parity, full-graph script (~2 min of dense CPU epochs)
+        _stub_third_party()
+        sys.path.insert(0, REF)
+        full_graph_long_case()
+    elif a.part == "long_mini":                    # end-of-training parity, ModelHandler over 5 epochs
+        _stub_third_party()
+        sys.path.insert(0, os.path.join(REF, "src"))
+        handler_long_case()
     elif a.part == "ingest":
         _stub_third_party()
         sys.path.insert(0, REF)

@@ -1,5 +1,6 @@
 """GPU tests of the drop-in class surface (reference names / signatures / return arities / state_dict keys)
 against the golden vectors captured from the imported reference."""
+import os
 import random
 
 import numpy as np
@@ -362,3 +363,21 @@ def test_pcgnn_inter_aggregator_and_pca_layer_vs_reference_golden():
         pg, pl = model.to_prob(nodes, labels, False)
     np.testing.assert_allclose(pg.cpu().numpy(), g["prob_gnn"], atol=3e-6, rtol=0)
     np.testing.assert_allclose(pl.cpu().numpy(), g["prob_label"], atol=3e-6, rtol=0)
+
+
+def test_model_handler_five_epochs_end_of_training_parity(tmp_path, capsys):
+    """BASELINE north_star, "AUROC/AUPRC within 1e-4", mini-batch path: `ModelHandler.train()` over FIVE epochs of 150 batches with the
+    validation sweeps of epochs 0, 2 and 4, the best checkpoint restored and the test sweep (src/model_handler.py:310-414) against
+    the imported reference's run on the same seeds (tests/golden/make_golden.py --part long_mini): all 750 batch losses, the five
+    metrics of every sweep, the weights at the END of training and the restored ones.  The deltas are printed (README quotes them)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import parity_long
+    r = parity_long.handler_long(str(tmp_path))
+    with capsys.disabled():
+        print("\n[end-of-training parity, ModelHandler x 5 epochs]", r)
+    assert r["batches"] == 750 and r["valid_epochs"] == [0, 2, 4]
+    assert r["resident"] and r["fallbacks"] == 0                   # the default path: the XCD-resident chunk kernel
+    assert r["loss_delta_max"] < 5e-4                              # 750 sequential Adam steps
+    assert all(v <= 1e-4 for v in r["sweep_delta_max"].values()), r["sweep_delta_max"]
+    assert r["end_weight_delta_max"] < 1e-3 and r["best_weight_delta_max"] < 1e-3
