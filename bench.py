@@ -517,13 +517,26 @@ def main():
     if dense_ms:
         us_step = 1e3 * sum(dense_ms) / max(1, sum(dense_steps))
         resident = bool(trainer.engine.resident)
+        # issue time of the chunk kernel's instructions from the hardware counters of THIS command (scripts/pmc_chunk_xcd.sh ->
+        # profiles/r05_pmc_chunk_xcd.json, stamped with the commit of its sources, tests/test_profiles.py): SQ_ACTIVE_INST_ANY x 4
+        # clocks over the 112 SIMDs of the XCD's 28 compute units at 2.4 GHz
+        cx = None
+        cx_path = os.path.join(ROOT, "profiles", "r05_pmc_chunk_xcd.json")
+        if resident and os.path.exists(cx_path):
+            with open(cx_path) as fh:
+                cx = json.load(fh)
+        issue_us = float(cx["issue_us_per_step"]) if cx and cx.get("issue_us_per_step") else None
         by_kernel.append({"kernel": ("k_train_chunk_xcd (all optimiser steps of a chunk in one launch resident on one XCD, with its memset and "
                                      "Adam-scalar launch)" if resident else "launch chain of the dense steps (5 launches per step)"),
                           "replaces": "src/graphsage.py:395-454,171-258 + src/model_handler.py:356-364 (encoder, loss, backward, Adam)",
                           "bound": "issue", "us_per_step": us_step, "avg_launch_ms": float(np.mean(dense_ms)),
-                          # ~4,500 instructions per wave per step, two waves per SIMD on the 112-128 SIMDs of one XCD -> ~13 us
-                          # of pure issue; < 30 MFLOP and < 2 MB per step: ~1 % of the FP32 and HBM rooflines of the whole chip
-                          "issue_floor_us_per_step": 13.0 if resident else None, "frac": (13.0 / us_step) if resident else None,
+                          # < 30 MFLOP and < 2 MB per step: ~1 % of the FP32 and HBM rooflines of the whole chip; what the launch is made of
+                          # is instruction issue on one XCD and waiting (69 % of its wave cycles are parked at a barrier or a load)
+                          "issue_floor_us_per_step": issue_us, "frac": (issue_us / us_step) if issue_us else None,
+                          "issue_floor_source": (f"profiles/r05_pmc_chunk_xcd.json (SQ_ACTIVE_INST_ANY x 4 clocks / 112 SIMDs / 2.4 GHz; PMC passes of the "
+                                                 f"build whose chunk-kernel sources last changed in {cx.get('commit', 'unknown')})") if cx else None,
+                          "wave_instructions_per_wave_per_step": cx.get("wave_instructions_per_wave_per_step") if cx else None,
+                          "waves_parked_frac": (cx["counters"]["SQ_WAIT_ANY"] / cx["counters"]["SQ_WAVE_CYCLES"]) if cx else None,
                           "flop_per_step": 3.0e7, "bytes_per_step": 2.0e6,
                           "frac_of_fp32_peak": 3.0e7 / (us_step * 1e-6) / 157.3e12, "frac_of_hbm_peak": 2.0e6 / (us_step * 1e-6) / 8.0e12,
                           "share_of_timed_region": (sum(dense_ms) / 1e3) / elapsed})

@@ -31,3 +31,26 @@ def test_gather_pmc_file_is_stamped_with_the_last_change_of_the_gather_sources()
     assert not dirty.stdout.strip(), "uncommitted changes in the gather sources: commit them, then regenerate the PMC file"
     assert head and (doc["commit"].startswith(head) or head.startswith(doc["commit"])), \
         f"profiles/r04_pmc_gather2_items.json was measured on {doc['commit']}, the gather sources last changed in {head}: regenerate it"
+
+
+def test_chunk_kernel_pmc_file_is_stamped_with_the_last_change_of_its_sources():
+    """bench.py's `by_kernel` entry of k_train_chunk_xcd takes its issue floor from profiles/r05_pmc_chunk_xcd.json (the entry
+    rested on a literal): the file carries the commit in which the chunk kernel's sources last changed when its PMC passes ran
+    (scripts/pmc_chunk_xcd.sh)."""
+    path = os.path.join(ROOT, "profiles", "r05_pmc_chunk_xcd.json")
+    assert os.path.exists(path), "run scripts/pmc_chunk_xcd.sh on a GPU box and commit its JSON under profiles/"
+    doc = json.load(open(path))
+    assert 1.0 < doc["issue_us_per_step"] < doc["kernel_us_per_step"] < 200.0
+    c = doc["counters"]
+    for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_BUSY_CU_CYCLES", "SQ_WAVE_CYCLES"):
+        assert c.get(k, 0) > 0, k
+    if not os.path.isdir(os.path.join(ROOT, ".git")):
+        pytest.skip("no git history here (a snapshot on the GPU box): the stamp is checked where the repository is")
+    src = ["ggad_amd/csrc/step_xcd.hip", "ggad_amd/csrc/step_common.h"]
+    try:
+        out = subprocess.run(["git", "log", "-1", "--format=%h", "--"] + src, cwd=ROOT, check=True, capture_output=True, text=True)
+    except (OSError, subprocess.CalledProcessError):
+        pytest.skip("git not usable here")
+    head = out.stdout.strip()
+    assert head and (doc["commit"].startswith(head) or head.startswith(doc["commit"])), \
+        f"profiles/r05_pmc_chunk_xcd.json was measured on {doc['commit']}, the chunk kernel's sources last changed in {head}: regenerate it"
