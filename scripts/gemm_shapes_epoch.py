@@ -23,10 +23,10 @@ for name in (sys.argv[1:] or ["reddit"]):
     log = []
     real = FG.gemm
 
-    def timed(A, B, trans_a, trans_b, bias=None, relu=False):
+    def timed(A, B, trans_a, trans_b, bias=None, relu=False, out=None):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        C = real(A, B, trans_a, trans_b, bias, relu)
+        C = real(A, B, trans_a, trans_b, bias, relu, out)
         e1.record()
         log.append((tuple(A.shape), tuple(B.shape), trans_a, trans_b, e0, e1))
         return C
