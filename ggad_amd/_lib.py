@@ -21,7 +21,7 @@ class GgadKernelError(RuntimeError):
     pass
 
 
-ABI_VERSION = 6    # what this binding was written against (include/ggad_hip.h, runtime.cpp); `load` refuses any other library
+ABI_VERSION = 7    # what this binding was written against (include/ggad_hip.h, runtime.cpp); `load` refuses any other library
 _P = c_void_p      # device (or host) pointer
 EXCHANGE_CB = ctypes.CFUNCTYPE(c_int32, c_void_p)      # int exchange(void *user): the data-parallel all-reduce hook
 _I = c_int32
@@ -131,6 +131,8 @@ SIGNATURES = {
     "ggad_spmm_ring_f32": (c_int32, [_P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _L, _P, _P, _P, _P, _L, _P, _P]),
     "ggad_mlp_score_supported": (c_int32, [_I, _I, _I]),
     "ggad_mlp_score_fwd_f32": (c_int32, [_P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "ggad_mlp_score_wgrad_workspace_elems": (c_int64, [_I, _I, _I, _I]),
+    "ggad_mlp_score_wgrad_f32": (c_int32, [_P, _L, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "ggad_mlp_score_dgrad_f32": (c_int32, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _L, _P]),
     "ggad_prelu_bwd_splits": (c_int32, [_I]),
     "ggad_prelu_bwd_f32": (c_int32, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),

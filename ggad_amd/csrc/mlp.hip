@@ -12,6 +12,8 @@
 // A 16 x 16 x 4 MFMA sums over the 4 k its lane groups hold; WHICH k that is only has to agree between the A and the B fragment,
 // so lane group q of step s of the j-th 16-k block takes k = 16 j + 4 q + s: every lane fetches its 4 values with ONE 16-byte
 // load (A from LDS, B from the weight row in L2).  Results differ from a k-ordered chain by fp32 round-off only.
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -287,6 +289,182 @@ __global__ void __launch_bounds__(256) k_mlp_dgrad(const float *__restrict__ g3,
   mlp_layer_nfast<5>(z1, ld1, H1, W1, H, nullptr, nullptr, 0, dx, ld_dx, dx_add, ld_add, row0, n_rows, wave, lane);   // d_x = dz_1 W1
 }
 
+
+// ---- the three weight gradients of the scorer in ONE launch (+ one reduction): dW1 = dz_1^T x, dW2 = dz_2^T f_1, dW3 = g_3^T f_2
+// (model.py:176-180 backwards).  They were three split-K GEMM launches + three reductions of 9-13 + 4 us each for 0.2 GFLOP -- 47 us
+// of a 0.54-ms Reddit epoch, launch- and latency-bound (profiles/r04_reddit_last_epoch.txt).  All three are P^T Q over the SAME R rows:
+// a wave takes a tile of the output and a range of rows, and per step of 4 rows loads ONE vector of P's columns and ONE of Q's per
+// lane -- lane (a, g) of v_mfma_f32_16x16x4_f32 holds A[a][g] = P[row g][.] and B[g][a] = Q[row g][.]; with VP / VQ consecutive
+// columns per lane, component t of the vector belongs to the INTERLEAVED tile t (columns m0 + VP a + t), so one 16-byte load of x
+// feeds four column tiles and a 16 VP x 16 VQ wave tile costs two loads per VP VQ MFMAs.  Partials per row range go to the workspace,
+// k_mlp_wgrad_reduce adds them in range order (fixed: bit-reproducible).
+struct WgProd {                       // one product D (m x n) = P^T (m x R) Q (R x n)
+  const float *P, *Q;
+  int64_t ldp, ldq;
+  int m, n, vp, vq;                   // columns per lane of P / Q (4, 2 or 1: what their alignment allows)
+  int splits, tiles_m, tiles_n;       // row ranges; wave tiles of 16 vp x 16 vq
+  int task0;                          // first wave task of this product
+  int64_t part0;                      // its partials in the workspace: [splits][m][n]
+};
+struct WgArgs {
+  WgProd p[3];
+  int R, n_tasks;
+  float *ws;
+};
+
+template <int V> struct wg_vec;
+template <> struct wg_vec<4> { typedef mlp_f4 T; };
+template <> struct wg_vec<2> { typedef float T __attribute__((ext_vector_type(2))); };
+template <> struct wg_vec<1> { typedef float T; };
+template <int V> __device__ __forceinline__ float wg_get(const typename wg_vec<V>::T &v, int t) { if constexpr (V == 1) return v; else return v[t]; }
+
+template <int VP, int VQ>
+__device__ __forceinline__ void wg_task(const WgProd &W, int R, float *__restrict__ ws, int tile, int split, int lane) {
+  typedef typename wg_vec<VP>::T TP;
+  typedef typename wg_vec<VQ>::T TQ;
+  const int a = lane & 15, g = lane >> 4;
+  const int tm = tile / W.tiles_n, tn = tile - tm * W.tiles_n;
+  const int m0 = tm * 16 * VP, n0 = tn * 16 * VQ;
+  // rows [r0, r1) of this range: multiples of 4 (the last range takes the tail; rows beyond R contribute zero through P)
+  const int steps_all = (R + 3) >> 2;
+  const int s0 = (int)((int64_t)steps_all * split / W.splits), s1 = (int)((int64_t)steps_all * (split + 1) / W.splits);
+  const int pc = min(m0 + VP * a, W.m - VP), qc = min(n0 + VQ * a, W.n - VQ);      // clamped: a lane beyond the edge re-reads valid columns,
+  const float *pp = W.P + pc, *qq = W.Q + qc;                                      // its outputs are not stored
+  mlp_f4 acc[VP][VQ];
+#pragma unroll
+  for (int t = 0; t < VP; ++t)
+#pragma unroll
+    for (int u = 0; u < VQ; ++u) acc[t][u] = mlp_f4{0.f, 0.f, 0.f, 0.f};
+  constexpr int UN = 6;                                      // steps per batch: the loads of batch b + 1 are in flight under the MFMAs of batch b
+  TP pv[2][UN];
+  TQ qv[2][UN];
+  auto load_batch = [&](int sb, TP (&pd)[UN], TQ (&qd)[UN]) {
+#pragma unroll
+    for (int i = 0; i < UN; ++i) {
+      const int row = min(4 * min(sb + i, s1 - 1) + g, R - 1);
+      pd[i] = *reinterpret_cast<const TP *>(pp + (int64_t)row * W.ldp);
+      qd[i] = *reinterpret_cast<const TQ *>(qq + (int64_t)row * W.ldq);
+    }
+  };
+  auto mul_batch = [&](int sb, const TP (&pd)[UN], const TQ (&qd)[UN]) {
+#pragma unroll
+    for (int i = 0; i < UN; ++i) {
+      const bool on = sb + i < s1 && 4 * (sb + i) + g < R;
+#pragma unroll
+      for (int t = 0; t < VP; ++t) {
+        const float av = on ? wg_get<VP>(pd[i], t) : 0.0f;
+#pragma unroll
+        for (int u = 0; u < VQ; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wg_get<VQ>(qd[i], u), acc[t][u], 0, 0, 0);
+      }
+    }
+  };
+  if (s0 < s1) load_batch(s0, pv[0], qv[0]);
+  for (int sb = s0; sb < s1; sb += 2 * UN) {
+    if (sb + UN < s1) load_batch(sb + UN, pv[1], qv[1]);
+    mul_batch(sb, pv[0], qv[0]);
+    if (sb + UN < s1) {
+      if (sb + 2 * UN < s1) load_batch(sb + 2 * UN, pv[0], qv[0]);
+      mul_batch(sb + UN, pv[1], qv[1]);
+    }
+  }
+  // D[4 g + v][a] of tile (t, u) = output (m0 + VP (4 g + v) + t, n0 + VQ a + u): VQ consecutive columns per lane and row
+  float *part = ws + W.part0 + (int64_t)split * W.m * W.n;
+  if (n0 + VQ * a + VQ <= W.n) {
+#pragma unroll
+    for (int t = 0; t < VP; ++t)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int mi = m0 + VP * (4 * g + v) + t;
+        if (mi < W.m) {
+          TQ o;
+          if constexpr (VQ == 1) o = acc[t][0][v];
+          else {
+#pragma unroll
+            for (int u = 0; u < VQ; ++u) o[u] = acc[t][u][v];
+          }
+          *reinterpret_cast<TQ *>(part + (int64_t)mi * W.n + n0 + VQ * a) = o;
+        }
+      }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_mlp_wgrad(WgArgs A) {
+  const int lane = threadIdx.x & 63;
+  const int task = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (task >= A.n_tasks) return;
+  const int q = task >= A.p[2].task0 ? 2 : (task >= A.p[1].task0 ? 1 : 0);        // wave-uniform
+  const WgProd &W = A.p[q];
+  const int local = task - W.task0;
+  const int tiles = W.tiles_m * W.tiles_n;
+  const int split = local / tiles, tile = local - split * tiles;
+  if (W.vp == 2 && W.vq == 4) wg_task<2, 4>(W, A.R, A.ws, tile, split, lane);
+  else if (W.vp == 1 && W.vq == 2) wg_task<1, 2>(W, A.R, A.ws, tile, split, lane);
+  else if (W.vp == 1 && W.vq == 4) wg_task<1, 4>(W, A.R, A.ws, tile, split, lane);
+  else if (W.vp == 2 && W.vq == 2) wg_task<2, 2>(W, A.R, A.ws, tile, split, lane);
+  else wg_task<1, 1>(W, A.R, A.ws, tile, split, lane);
+}
+
+struct WgRed { float *out[3]; int64_t part0[3]; int len[3], splits[3]; };
+__global__ void __launch_bounds__(256) k_mlp_wgrad_reduce(WgRed Q, const float *__restrict__ ws) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    if (i < Q.len[q]) {
+      const float *p = ws + Q.part0[q] + i;
+      float s = 0.0f;
+      const int64_t st = Q.len[q];
+      int k = 0;
+      for (; k + 8 <= Q.splits[q]; k += 8) {                                   // range order: fixed; eight loads in flight
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = p[(k + j) * st];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[j];
+      }
+      for (; k < Q.splits[q]; ++k) s += p[k * st];
+      Q.out[q][i] = s;
+      return;
+    }
+    i -= Q.len[q];
+  }
+}
+
+static int wg_pick_vec(const float *p, int64_t ld, int n, int want) {
+  for (int v = want; v > 1; v >>= 1)
+    if (ld % v == 0 && n % v == 0 && n >= v && ((uintptr_t)p & (size_t)(4 * v - 1)) == 0) return v;
+  return 1;
+}
+// splits of a product: enough wave tasks to cover the chip a few times, >= 32 rows per range
+static int wg_splits(int R, int tiles, int weight) {
+  (void)tiles; (void)weight;
+  return std::min(std::max(1, R / 64), 64);                  // ranges of 64-100 rows: a wave's task is two or three batches of loads
+}
+static void wg_setup(WgArgs &A, int R, int H, int H1, int H2, const float *x, int64_t ldx, const float *dz1, const float *f1, const float *dz2,
+                     const float *f2, const float *g3) {
+  const float *P[3] = {dz1, dz2, g3}, *Q[3] = {x, f1, f2};
+  const int64_t ldp[3] = {H1, H2, 1}, ldq[3] = {ldx, H1, H2};
+  const int m[3] = {H1, H2, 1}, n[3] = {H, H1, H2};
+  const int weight[3] = {512, 192, 32};                      // wave tasks aimed at per product (the first one holds 9 / 10 of the arithmetic)
+  int task = 0;
+  int64_t part = 0;
+  for (int q = 0; q < 3; ++q) {
+    WgProd &W = A.p[q];
+    W.P = P[q]; W.Q = Q[q]; W.ldp = ldp[q]; W.ldq = ldq[q]; W.m = m[q]; W.n = n[q];
+    W.vp = std::min(2, wg_pick_vec(P[q], ldp[q], m[q], 2));
+    W.vq = wg_pick_vec(Q[q], ldq[q], n[q], 4);
+    if (!((W.vp == 2 && W.vq == 4) || (W.vp == 1 && W.vq == 2) || (W.vp == 1 && W.vq == 4) || (W.vp == 2 && W.vq == 2))) { W.vp = 1; W.vq = 1; }
+    W.tiles_m = (m[q] + 16 * W.vp - 1) / (16 * W.vp);
+    W.tiles_n = (n[q] + 16 * W.vq - 1) / (16 * W.vq);
+    W.splits = wg_splits(R, W.tiles_m * W.tiles_n, weight[q]);
+    W.task0 = task;
+    W.part0 = part;
+    task += W.tiles_m * W.tiles_n * W.splits;
+    part += (int64_t)W.splits * m[q] * n[q];
+  }
+  A.R = R;
+  A.n_tasks = task;
+}
+
 }  // namespace
 
 extern "C" {
@@ -317,6 +495,32 @@ int ggad_mlp_score_dgrad_f32(const float *g3, int32_t R, int32_t H, int32_t H1, 
   k_mlp_dgrad<<<dim3((unsigned)((R + MLP_R - 1) / MLP_R)), dim3(256), lds, as_stream(stream)>>>(g3, R, H, H1, H2, f1, f2, W1, W2, w3, dz2, dz1,
                                                                                              dx, ld_dx, dx_add, ld_add);
   GGAD_CHECK_LAUNCH("mlp_score_dgrad_f32");
+  return GGAD_OK;
+}
+
+int64_t ggad_mlp_score_wgrad_workspace_elems(int32_t R, int32_t H, int32_t H1, int32_t H2) {
+  if (R <= 0 || !ggad_mlp_score_supported(H, H1, H2)) return 0;
+  // an upper bound that does not depend on the operands' alignment (which decides the wave tiles and with them the ranges per product)
+  const int64_t max_splits = std::min(std::max(1, R / 64), 64);
+  return max_splits * ((int64_t)H1 * H + (int64_t)H2 * H1 + H2) + 16;
+}
+
+int ggad_mlp_score_wgrad_f32(const float *x, int64_t ldx, const float *dz1, const float *f1, const float *dz2, const float *f2, const float *g3,
+                             int32_t R, int32_t H, int32_t H1, int32_t H2, float *dW1, float *dW2, float *dW3, float *workspace,
+                             ggad_stream_t stream) {
+  GGAD_REQUIRE(x && dz1 && f1 && dz2 && f2 && g3 && dW1 && dW2 && dW3 && workspace && R >= 1 && ldx >= H);
+  GGAD_REQUIRE(ggad_mlp_score_supported(H, H1, H2) && ((uintptr_t)workspace & 15) == 0);
+  WgArgs A;
+  wg_setup(A, R, H, H1, H2, x, ldx, dz1, f1, dz2, f2, g3);
+  A.ws = workspace;
+  hipStream_t st = as_stream(stream);
+  k_mlp_wgrad<<<dim3((unsigned)((A.n_tasks + 3) / 4)), dim3(256), 0, st>>>(A);
+  WgRed Q;
+  Q.out[0] = dW1; Q.out[1] = dW2; Q.out[2] = dW3;
+  int total = 0;
+  for (int q = 0; q < 3; ++q) { Q.part0[q] = A.p[q].part0; Q.len[q] = A.p[q].m * A.p[q].n; Q.splits[q] = A.p[q].splits; total += Q.len[q]; }
+  k_mlp_wgrad_reduce<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st>>>(Q, workspace);
+  GGAD_CHECK_LAUNCH("mlp_score_wgrad_f32");
   return GGAD_OK;
 }
 

@@ -551,6 +551,14 @@ int ggad_spmm_ring_f32(const int32_t *wg_tab, int32_t n_wg, const int32_t *wave_
 int32_t ggad_mlp_score_supported(int32_t H, int32_t H1, int32_t H2);
 int ggad_mlp_score_fwd_f32(const float *X, int64_t ldx, int32_t R, int32_t H, int32_t H1, int32_t H2, const float *W1, const float *W2,
                            const float *w3, float *f1, float *f2, float *f3, ggad_stream_t stream);
+/* The three WEIGHT gradients of the scorer in one launch + one reduction (ABI 7; they were three split-K ggad_gemm_f32 calls):
+ *   dW1 (H1 x H) = dz1^T x,  dW2 (H2 x H1) = dz2^T f1,  dW3 (1 x H2) = g3^T f2      over the same R rows.
+ * x: R x H with row stride ldx; dz1, f1: R x H1; dz2, f2: R x H2; g3: R -- all contiguous but x.  Outputs contiguous.  workspace:
+ * float[ggad_mlp_score_wgrad_workspace_elems(R, H, H1, H2)], 16-byte aligned (partials per row range, added in range order). */
+int64_t ggad_mlp_score_wgrad_workspace_elems(int32_t R, int32_t H, int32_t H1, int32_t H2);
+int ggad_mlp_score_wgrad_f32(const float *x, int64_t ldx, const float *dz1, const float *f1, const float *dz2, const float *f2, const float *g3,
+                             int32_t R, int32_t H, int32_t H1, int32_t H2, float *dW1, float *dW2, float *dW3, float *workspace,
+                             ggad_stream_t stream);
 int ggad_mlp_score_dgrad_f32(const float *g3, int32_t R, int32_t H, int32_t H1, int32_t H2, const float *f1, const float *f2,
                              const float *W1, const float *W2, const float *w3, float *dz2, float *dz1, float *dx, int64_t ld_dx,
                              const float *dx_add, int64_t ld_add, ggad_stream_t stream);

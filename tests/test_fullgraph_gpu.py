@@ -358,6 +358,42 @@ def test_prelu_backward_kernel_against_autograd(shape):
         assert torch.equal(x.view(torch.int32), y.view(torch.int32))
 
 
+@pytest.mark.parametrize("r,h,ldx", [(1830, 300, 300), (6476, 300, 320), (1203, 300, 300), (37, 64, 64), (16, 12, 12), (5, 512, 512), (100, 20, 24),
+                                     (3001, 128, 128)])
+def test_fused_scorer_mlp_weight_gradients(r, h, ldx, monkeypatch):
+    """The three weight gradients of the scorer (`model.py:176-180` backwards: dW1 = dz1^T x, dW2 = dz2^T f1, dW3 = g3^T f2) in ONE
+    launch + one reduction (`ggad_mlp_score_wgrad_f32`, round 5: interleaved 16 VP x 16 VQ wave tiles, row ranges summed in order)
+    against float64 and against the three split-K GEMMs they replace; row-strided x; deterministic; through `MlpScoreFn`."""
+    h1, h2 = h // 2, h // 4
+    rng = np.random.default_rng(7 * r + h)
+    buf = torch.from_numpy(rng.standard_normal((r, ldx)).astype(np.float32)).to(DEV)
+    x = buf[:, :h]
+    dz1, f1 = (torch.from_numpy(rng.standard_normal((r, h1)).astype(np.float32)).to(DEV) for _ in range(2))
+    dz2, f2 = (torch.from_numpy(rng.standard_normal((r, h2)).astype(np.float32)).to(DEV) for _ in range(2))
+    g3 = torch.from_numpy(rng.standard_normal((r, 1)).astype(np.float32)).to(DEV)
+    d1, d2, d3 = FG.mlp_score_wgrad(x, dz1, f1, dz2, f2, g3)
+    assert tuple(d1.shape) == (h1, h) and tuple(d2.shape) == (h2, h1) and tuple(d3.shape) == (1, h2)
+    for got, p, q in ((d1, dz1, x), (d2, dz2, f1), (d3, g3, f2)):
+        ref = p.double().T @ q.double()
+        assert ((got.double() - ref).abs().max() / (ref.abs().max() + 1.0)).item() < 2e-6
+        via_gemm = FG.gemm(p.contiguous(), q.contiguous(), True, False)
+        assert ((got - via_gemm).abs().max() / (ref.abs().max() + 1.0)).item() < 2e-6
+    again = FG.mlp_score_wgrad(x, dz1, f1, dz2, f2, g3)
+    assert all(torch.equal(a.view(torch.int32), b.view(torch.int32)) for a, b in zip((d1, d2, d3), again))
+    # the autograd node: fused weight gradients against the GEMM ones
+    w1 = torch.from_numpy((rng.standard_normal((h1, h)) / np.sqrt(h)).astype(np.float32)).to(DEV)
+    w2 = torch.from_numpy((rng.standard_normal((h2, h1)) / np.sqrt(h1)).astype(np.float32)).to(DEV)
+    w3 = torch.from_numpy((rng.standard_normal((1, h2)) / np.sqrt(h2)).astype(np.float32)).to(DEV)
+    grads = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("GGAD_MLP_WGRAD_FUSED", fused)
+        a, b, c = (t.clone().requires_grad_() for t in (w1, w2, w3))
+        FG.MlpScoreFn.apply(x.contiguous(), a, b, c).backward(g3)
+        grads.append((a.grad, b.grad, c.grad))
+    for u, v in zip(*grads):
+        assert ((u - v).abs().max() / (v.abs().max() + 1.0)).item() < 2e-6
+
+
 @pytest.mark.parametrize("r,h", [(1830, 300), (6476, 300), (37, 64), (16, 12), (5, 512), (100, 20)])
 def test_fused_scorer_mlp_forward_and_data_gradients(r, h, monkeypatch):
     """The scorer MLP of `model.py:176-180` (fc1 + relu, fc2 + relu, fc3, Linear weights without bias) as ONE launch forward and
