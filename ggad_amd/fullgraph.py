@@ -1029,9 +1029,12 @@ class GgadHeadFn(torch.autograd.Function):
         d_comb = g_comb
         if g_f3 is not None and mlp_score_supported(w1, w2, w3):           # scorer MLP: data gradients in one launch (+ g_comb)
             dz2, dz1, d_comb = mlp_score_dgrad(g_f3, f1, f2, w1, w2, w3, g_comb)
-            dw3 = gemm(g_f3.reshape(-1, 1), f2, True, False)
-            dw2 = gemm(dz2, f1, True, False)
-            dw1 = gemm(dz1, comb, True, False)
+            if os.environ.get("GGAD_MLP_WGRAD_FUSED", "1") != "0" and comb.stride(1) == 1:
+                dw1, dw2, dw3 = mlp_score_wgrad(comb, dz1, f1, dz2, f2, g_f3)       # the three weight gradients: one launch + one reduction
+            else:
+                dw3 = gemm(g_f3.reshape(-1, 1), f2, True, False)
+                dw2 = gemm(dz2, f1, True, False)
+                dw1 = gemm(dz1, comb, True, False)
         elif g_f3 is not None:                                             # ... or as LinearFn.backward three times
             dw3 = gemm(g_f3, f2, True, False)
             df2 = gemm(g_f3, w3, False, False)
