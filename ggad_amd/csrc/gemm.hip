@@ -538,6 +538,104 @@ __global__ void __launch_bounds__(256, 3) k_gemm_bres(const float *__restrict__ 
   else bres_rows<KS, 1>(A, C, bt, M, N, K, lda, ldc, bias, relu, KP, col0, rb_lo + g * 4 + wid, rb_hi, gs * 4, lane);
 }
 
+
+// ---- small products (round 5): the 239 ... 843-row products of the outlier head (fc4 forward, its two gradients: model.py:151-156) ran as
+// 20 workgroups walking ten 32-deep K tiles behind ten barriers -- 12-15 us each for 0.04 GFLOP, three per epoch.  Here a workgroup takes a
+// 32 x 32 tile, stages BOTH operand panels for the WHOLE K in LDS at once (one memory round trip instead of ten), and its four waves run
+// one 16 x 16 tile each: two interleaved accumulator chains over the k-steps, operands by ds_read_b128 (k-slot assignment as in the
+// slab kernel), bias / ReLU in the epilogue.  Any layout (strides), any M, N; K <= 512.
+constexpr int SM_T = 32;
+__host__ __device__ inline int sm_kp(int k16) {             // row stride (floats) >= k16 that is 8 or 56 mod 64: conflict-free b128 fragment reads
+  int kp = k16;
+  while ((kp & 63) != 8 && (kp & 63) != 56) kp += 4;
+  return kp;
+}
+__global__ void __launch_bounds__(256) k_gemm_small(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C, int M, int N,
+                                                    int K, int64_t sam, int64_t sak, int64_t sbk, int64_t sbn, int64_t ldc,
+                                                    const float *__restrict__ bias, int relu, int KP) {
+  extern __shared__ __attribute__((aligned(16))) float sm_lds[];      // As[32][KP], Bs[32][KP]  (row = m / n, k fastest)
+  float *As = sm_lds, *Bs = sm_lds + SM_T * KP;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int m0 = blockIdx.y * SM_T, n0 = blockIdx.x * SM_T;
+  const int k16 = (K + 15) & ~15;
+  // fill: along whichever index is fastest in memory, a batch of loads in flight before the first store (one at a time the 75 loads of
+  // a thread were 75 round trips: 21 us); rows / k beyond the matrix read a clamped element and are stored as zero
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  auto fill = [&](float *dst, const float *src, int r0, int R, int64_t sr, int64_t sk) {
+    if (sk == 1 && (K & 3) == 0 && (sr & 3) == 0 && ((uintptr_t)src & 15) == 0) {
+      // k fastest, 16-byte rows: thread = (row t / 8, float4 t % 8 + 8 q): eight threads read 128 contiguous bytes of a row
+      const int r = tid >> 3, c0 = tid & 7, k4 = K >> 2, n4 = k16 >> 2;
+      const float *rp = src + (int64_t)min(r0 + r, R - 1) * sr;
+      constexpr int NB = 8;
+      for (int q0 = 0; q0 * 8 < n4; q0 += NB) {
+        f4 v[NB];
+#pragma unroll
+        for (int q = 0; q < NB; ++q) v[q] = *reinterpret_cast<const f4 *>(rp + 4 * min(c0 + 8 * (q0 + q), k4 - 1));
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+          const int c = c0 + 8 * (q0 + q);
+          if (c < n4) *reinterpret_cast<f4 *>(dst + r * KP + 4 * c) = (r0 + r < R && c < k4) ? v[q] : f4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    } else if (sk == 1) {                                     // k fastest, unaligned: thread = (row t / 8, k t % 8 + 8 q)
+      const int r = tid >> 3, c0 = tid & 7;
+      const float *rp = src + (int64_t)min(r0 + r, R - 1) * sr;
+      constexpr int NB = 16;
+      for (int q0 = 0; q0 * 8 < k16; q0 += NB) {
+        float v[NB];
+#pragma unroll
+        for (int q = 0; q < NB; ++q) v[q] = rp[min(c0 + 8 * (q0 + q), K - 1)];
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+          const int k = c0 + 8 * (q0 + q);
+          if (k < k16) dst[r * KP + k] = (r0 + r < R && k < K) ? v[q] : 0.0f;
+        }
+      }
+    } else {                                                  // row index fastest: thread = (k t / 32 + 8 q, row t % 32): a wave reads two k of 32 rows
+      const int r = tid & 31, kq = tid >> 5;
+      const float *rp = src + (int64_t)min(r0 + r, R - 1) * sr;
+      constexpr int NB = 16;
+      for (int q0 = 0; q0 * 8 < k16; q0 += NB) {
+        float v[NB];
+#pragma unroll
+        for (int q = 0; q < NB; ++q) v[q] = rp[(int64_t)min(kq + 8 * (q0 + q), K - 1) * sk];
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+          const int k = kq + 8 * (q0 + q);
+          if (k < k16) dst[r * KP + k] = (r0 + r < R && k < K) ? v[q] : 0.0f;
+        }
+      }
+    }
+  };
+  fill(As, A, m0, M, sam, sak);
+  fill(Bs, B, n0, N, sbn, sbk);
+  __syncthreads();
+  const int li = lane & 15, ks = lane >> 4;
+  const int wr = wid >> 1, wc = wid & 1;
+  const float *ap = As + (wr * 16 + li) * KP + 4 * ks, *bp = Bs + (wc * 16 + li) * KP + 4 * ks;
+  f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  // the B fragment goes first: the tile comes out with lane (li, ks) holding C[row li][columns 4 ks .. + 3] (16-byte rows of the store)
+  for (int s = 0; s < k16; s += 16) {
+    const f4 a = *reinterpret_cast<const f4 *>(ap + s), b = *reinterpret_cast<const f4 *>(bp + s);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b.x, a.x, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b.y, a.y, acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b.z, a.z, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b.w, a.w, acc1, 0, 0, 0);
+  }
+  const f4 acc = acc0 + acc1;
+  const int row = m0 + wr * 16 + li, col = n0 + wc * 16 + 4 * ks;
+  if (row < M) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      if (col + v < N) {
+        float o = acc[v] + (bias ? bias[col + v] : 0.0f);
+        if (relu) o = fmaxf(o, 0.0f);
+        C[(int64_t)row * ldc + col + v] = o;
+      }
+    }
+  }
+}
+
 static int bres_kp(int kpad) {               // smallest row stride >= kpad that is 8 or 56 mod 64
   int kp = kpad;
   while ((kp & 63) != 8 && (kp & 63) != 56) kp += 4;
@@ -616,6 +714,21 @@ int ggad_gemm_f32(const float *A, const float *B, float *C, int32_t M, int32_t N
 #undef GGAD_BRES
     GGAD_CHECK_LAUNCH("gemm_f32 (resident operand)");
     return GGAD_OK;
+  }
+  // small products: both operand panels of a 32 x 32 tile in LDS for the whole K (one round trip), GGAD_GEMM_SMALL=0 turns it off
+  static const bool no_small = [] { const char *e = getenv("GGAD_GEMM_SMALL"); return e && e[0] == '0'; }();
+  if (!no_small && ws_elems == 0 && K >= 1 && K <= 512 && (int64_t)((M + SM_T - 1) / SM_T) * ((N + SM_T - 1) / SM_T) <= 1024 &&
+      (int64_t)M * N <= (int64_t)1024 * 512) {
+    const int KP = sm_kp((K + 15) & ~15);
+    const size_t lds = (size_t)2 * SM_T * KP * sizeof(float);
+    static const bool ok = hipFuncSetAttribute((const void *)k_gemm_small, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SM_T * 520 * 4 + 1024) == hipSuccess;
+    if (ok) {
+      k_gemm_small<<<dim3((N + SM_T - 1) / SM_T, (M + SM_T - 1) / SM_T), dim3(256), lds, st>>>(A, B, C, (int)M, (int)N, (int)K, sam, sak, sbk, sbn, ldc,
+                                                                                                  bias, (int)relu, KP);
+      GGAD_CHECK_LAUNCH("gemm_f32 (small)");
+      return GGAD_OK;
+    }
+    (void)hipGetLastError();
   }
   // LDS-DMA kernel: every 16-byte chunk an operand tile is made of must be 16-byte aligned in memory and lie inside one row
   static const bool no_dma = [] { const char *e = getenv("GGAD_GEMM_DMA"); return e && e[0] == '0'; }();
