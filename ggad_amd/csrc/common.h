@@ -96,6 +96,10 @@ int ggad_int_range_deg();      // owners above this degree are gathered by id ra
 int ggad_int_gemm_slab(const float *A, const float *B, float *C, int M, int N, int K, int64_t lda, int64_t sbk, int64_t sbn, int64_t ldc,
                        const float *bias, int relu, hipStream_t st);
 
+// ---- mlp.hip: D (m x n) = P^T Q over R rows as row-range partials + ordered reduction (the weight gradients); 1 = launched, 0 = not taken
+int64_t ggad_int_wgrad_tn_ws(int R, int m, int n);
+int ggad_int_wgrad_tn(const float *P, int64_t ldp, const float *Q, int64_t ldq, int R, int m, int n, float *D, float *ws, hipStream_t st);
+
 // ---- one-shot gradient exchange (exchange.cpp owns the handle, step.hip the kernel)
 constexpr int GGAD_XCHG_MAX_WORLD = 16;
 struct ggad_xchg_view {                          // what the kernel needs, passed by value

@@ -665,7 +665,8 @@ int64_t ggad_gemm_workspace_elems(int32_t M, int32_t N, int32_t K) {
   const int max_splits = K >= 2048 ? (K + 255) / 256 : (K + 127) / 128;
   if (splits > max_splits) splits = max_splits;
   if (splits > 128) splits = 128;
-  return splits <= 1 ? 0 : (int64_t)splits * M * N;
+  // (a "TN" product with a long K may take the row-range kernel of mlp.hip instead: its partials fit too)
+  return splits <= 1 ? 0 : std::max<int64_t>((int64_t)splits * M * N, ggad_int_wgrad_tn_ws(K, M, N));
 }
 
 int ggad_gemm_f32(const float *A, const float *B, float *C, int32_t M, int32_t N, int32_t K, int64_t sam, int64_t sak,
@@ -714,6 +715,12 @@ int ggad_gemm_f32(const float *A, const float *B, float *C, int32_t M, int32_t N
 #undef GGAD_BRES
     GGAD_CHECK_LAUNCH("gemm_f32 (resident operand)");
     return GGAD_OK;
+  }
+  // weight gradients (op(A) = A^T with A: K x M row-major, B: K x N row-major, K long): row ranges + ordered reduction (mlp.hip)
+  if (ws_elems > 0 && sam == 1 && sbn == 1 && ldc == N && !bias && !relu && ws_elems >= ggad_int_wgrad_tn_ws(K, M, N) && ggad_int_wgrad_tn_ws(K, M, N) > 0) {
+    const int r = ggad_int_wgrad_tn(A, sak, B, sbk, (int)K, (int)M, (int)N, C, workspace, st);
+    if (r < 0) { ggad_set_error(hipErrorLaunchFailure, "gemm_f32 (wgrad tn)"); return GGAD_E_LAUNCH; }
+    if (r > 0) return GGAD_OK;
   }
   // small products: both operand panels of a 32 x 32 tile in LDS for the whole K (one round trip), GGAD_GEMM_SMALL=0 turns it off
   static const bool no_small = [] { const char *e = getenv("GGAD_GEMM_SMALL"); return e && e[0] == '0'; }();

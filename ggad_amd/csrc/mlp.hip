@@ -13,6 +13,7 @@
 // so lane group q of step s of the j-th 16-k block takes k = 16 j + 4 q + s: every lane fetches its 4 values with ONE 16-byte
 // load (A from LDS, B from the weight row in L2).  Results differ from a k-ordered chain by fp32 round-off only.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -466,6 +467,42 @@ static void wg_setup(WgArgs &A, int R, int H, int H1, int H2, const float *x, in
 }
 
 }  // namespace
+
+// ---- the same kernel for ONE weight gradient of any layer: D (m x n, contiguous) = P^T Q over R rows (P: R x m, Q: R x n, row-major with
+// strides ldp / ldq).  C++ linkage, called by ggad_gemm_f32 for its "TN" products with a long K (the GCN layers' dW = dZ^T X: model.py:27
+// backwards; they ran as 64 x 64 tiles split over K + k_splitk_reduce).  Returns 1 when launched, 0 when the shape is not taken.
+int64_t ggad_int_wgrad_tn_ws(int R, int m, int n) {
+  // skinny outputs only (the first layer's dW at 10-25 features: 43.6 -> 32.5 us at T-Finance size); for 300 x 300 the wave tiles of 32 x 64
+  // re-read the operands too often (51.5 against 48.1 us for the split-K tiles, scripts/gemm_wgrad_time.py)
+  if (m < 1 || n < 1 || m > 512 || n > 512 || R < 1024 || std::min(m, n) > 32) return 0;
+  return (int64_t)std::min(std::max(1, R / 64), 64) * m * n + 16;
+}
+int ggad_int_wgrad_tn(const float *P, int64_t ldp, const float *Q, int64_t ldq, int R, int m, int n, float *D, float *ws, hipStream_t st) {
+  static const bool off = [] { const char *e = getenv("GGAD_GEMM_WGRAD_TN"); return e && e[0] == '0'; }();
+  if (off || ggad_int_wgrad_tn_ws(R, m, n) == 0 || ((uintptr_t)ws & 15) != 0) return 0;
+  WgArgs A;
+  WgProd &W = A.p[0];
+  W.P = P; W.Q = Q; W.ldp = ldp; W.ldq = ldq; W.m = m; W.n = n;
+  W.vp = std::min(2, wg_pick_vec(P, ldp, m, 2));
+  W.vq = wg_pick_vec(Q, ldq, n, 4);
+  if (!((W.vp == 2 && W.vq == 4) || (W.vp == 1 && W.vq == 2) || (W.vp == 1 && W.vq == 4) || (W.vp == 2 && W.vq == 2))) { W.vp = 1; W.vq = 1; }
+  W.tiles_m = (m + 16 * W.vp - 1) / (16 * W.vp);
+  W.tiles_n = (n + 16 * W.vq - 1) / (16 * W.vq);
+  W.splits = wg_splits(R, 0, 0);
+  W.task0 = 0; W.part0 = 0;
+  A.n_tasks = W.tiles_m * W.tiles_n * W.splits;
+  A.p[1] = W; A.p[2] = W;
+  A.p[1].task0 = A.p[2].task0 = A.n_tasks;                   // (no second / third product)
+  A.R = R; A.ws = ws;
+  k_mlp_wgrad<<<dim3((unsigned)((A.n_tasks + 3) / 4)), dim3(256), 0, st>>>(A);
+  WgRed Q3;
+  Q3.out[0] = D; Q3.out[1] = Q3.out[2] = nullptr;
+  Q3.part0[0] = 0; Q3.part0[1] = Q3.part0[2] = 0;
+  Q3.len[0] = m * n; Q3.len[1] = Q3.len[2] = 0;
+  Q3.splits[0] = W.splits; Q3.splits[1] = Q3.splits[2] = 0;
+  k_mlp_wgrad_reduce<<<dim3((unsigned)((m * n + 255) / 256)), dim3(256), 0, st>>>(Q3, ws);
+  return hipGetLastError() == hipSuccess ? 1 : -1;
+}
 
 extern "C" {
 
