@@ -688,7 +688,11 @@ def main():
                                                                       else "rccl all-reduce"))},
             "value_is": "GPU path (plans + dense steps inside the window; batch schedule prepared by the host sampler beforehand)",
             "roofline": roofline, "cpu_baseline": cpu,
+            # two ratios, named for what they divide by (measurement hygiene): the reference's own dense-mask step (a few
+            # batches) and the sparse CPU variant under BASELINE.md's protocol (whole epochs)
             "gpu_over_cpu": (value / cpu["value"]) if cpu else None,
+            "gpu_over_cpu_is": "value / cpu_baseline.value (dense-faithful port of the reference's step)" if cpu else None,
+            "gpu_over_cpu_sparse": (value / cpu["sparse_variant"]["value"]) if (cpu and cpu.get("sparse_variant")) else None,
             "first_loss": float(losses[0][0]), "last_loss": float(losses[-1][0]), "setup_s": setup_s,
         }
         out.update(extras)
