@@ -21,7 +21,7 @@ class GgadKernelError(RuntimeError):
     pass
 
 
-ABI_VERSION = 7    # what this binding was written against (include/ggad_hip.h, runtime.cpp); `load` refuses any other library
+ABI_VERSION = 8    # what this binding was written against (include/ggad_hip.h, runtime.cpp); `load` refuses any other library
 _P = c_void_p      # device (or host) pointer
 EXCHANGE_CB = ctypes.CFUNCTYPE(c_int32, c_void_p)      # int exchange(void *user): the data-parallel all-reduce hook
 _I = c_int32
@@ -53,6 +53,8 @@ SIGNATURES = {
     "ggad_mb_plan_reset": (c_int32, [_P, _P, _P, _P, _P, _P, _L, _L, _P, _P, _I, _P]),
     "ggad_mb_tile_offsets_elems": (c_int64, [_L, _I]),
     "ggad_mb_tile_offsets": (c_int32, [_P, _P, _L, _I, _P, _P]),
+    "ggad_mb_tile_major_workspace_elems": (c_int64, [_L, _I]),
+    "ggad_mb_tile_major": (c_int32, [_P, _P, _L, _I, _P, _P, _P, _P, _P]),
     "ggad_mb_ldsw_tile_shift": (c_int32, []),
     "ggad_mb_ldsw_max_owners": (c_int32, []),
     "ggad_mb_ldsw_seg_elems": (c_int64, [_L, _L]),
@@ -191,7 +193,7 @@ class MbPlan(ctypes.Structure):
                 + [(n, c_int32) for n in ("feat_dim", "feat_stride", "max_batches", "rows_cap", "ck_part_stride", "train", "hop2",
                                           "node_major")]
                 + [("mean_nbr_deg", c_float), ("xcd_skip", c_int32)]
-                + [(n, c_void_p) for n in ("ev_tile0", "ev_tile1", "node_pack_host")])
+                + [(n, c_void_p) for n in ("ev_tile0", "ev_tile1", "node_pack_host", "tile_start", "col_t")])
 
 
 class MbPlanInfo(ctypes.Structure):

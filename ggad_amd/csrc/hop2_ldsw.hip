@@ -69,6 +69,88 @@ __global__ void __launch_bounds__(256) k_tile_offsets(const int32_t *__restrict_
   while (t <= n_tiles) { o[t] = e - s; ++t; }
 }
 
+// ---- the tile-major copy of col (round 5; once per graph).  k_tile_counts reads, for every (owner, tile), the 3-4 ids of the owner's
+// sorted row that fall into the tile: 16 bytes of a 64-byte sector whose other bytes belong to other tiles, i.e. to other workgroups
+// at other times (19.7 bytes of fabric reads per 4-byte id).  col_t holds the same ids TILE-major -- all segments of tile t, in node
+// order, contiguous (n_edges / n_tiles ids: 2.6 MB on the bench graph) -- and tile_start[u][t] the position of segment (u, t) in it,
+// so the workgroups of one tile (one per batch of the chunk), placed on ONE XCD, read a region that its L2 holds.
+//   k_tm_blocksum: ids per (block of 256 nodes, tile);  k_tm_scan: exclusive prefix over the blocks per tile + the tile bases;
+//   k_tm_fill: tile_start and the copy.  Lane = tile everywhere (rows of tile_off are read as 256-byte runs).
+__global__ void __launch_bounds__(256) k_tm_blocksum(const int32_t *__restrict__ off, int64_t n_nodes, int n_tiles, int32_t *__restrict__ bsum) {
+  __shared__ int wsum[4][64];
+  const int lane = lane_id(), w = threadIdx.x >> 6;
+  const int NT1 = n_tiles + 1;
+  const int64_t u0 = (int64_t)blockIdx.x * 256 + 64 * w;
+  for (int t0 = 0; t0 < n_tiles; t0 += 64) {
+    const int t = t0 + lane;
+    int acc = 0;
+    if (t < n_tiles)
+      for (int i = 0; i < 64 && u0 + i < n_nodes; ++i) { const int32_t *o = off + (u0 + i) * NT1 + t; acc += o[1] - o[0]; }
+    wsum[w][lane] = acc;
+    __syncthreads();
+    if (w == 0 && t < n_tiles) bsum[(int64_t)blockIdx.x * n_tiles + t] = wsum[0][lane] + wsum[1][lane] + wsum[2][lane] + wsum[3][lane];
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(1024) k_tm_scan(int32_t *__restrict__ bsum, int64_t n_blocks, int n_tiles, int32_t *__restrict__ tile_base) {
+  // thread = tile: the blocks of 256 nodes in order (reads of a block's row are contiguous over the threads); then the tile bases
+  extern __shared__ int tot[];
+  for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) {
+    int run = 0;
+    int64_t b = 0;
+    for (; b + 8 <= n_blocks; b += 8) {
+      int v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = bsum[(b + q) * n_tiles + t];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { bsum[(b + q) * n_tiles + t] = run; run += v[q]; }
+    }
+    for (; b < n_blocks; ++b) { const int v = bsum[b * n_tiles + t]; bsum[b * n_tiles + t] = run; run += v; }
+    tot[t] = run;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int t = 0; t < n_tiles; ++t) { tile_base[t] = run; run += tot[t]; }
+    tile_base[n_tiles] = run;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_tm_fill(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ col,
+                                                 const int32_t *__restrict__ off, int64_t n_nodes, int n_tiles,
+                                                 const int32_t *__restrict__ bsum, const int32_t *__restrict__ tile_base,
+                                                 int32_t *__restrict__ tile_start, int32_t *__restrict__ col_t) {
+  __shared__ int wsum[4][64];
+  const int lane = lane_id(), w = threadIdx.x >> 6;
+  const int NT1 = n_tiles + 1;
+  const int64_t u0 = (int64_t)blockIdx.x * 256 + 64 * w;
+  for (int t0 = 0; t0 <= n_tiles; t0 += 64) {
+    const int t = t0 + lane;
+    int acc = 0;
+    if (t < n_tiles)
+      for (int i = 0; i < 64 && u0 + i < n_nodes; ++i) { const int32_t *o = off + (u0 + i) * NT1 + t; acc += o[1] - o[0]; }
+    wsum[w][lane] = acc;
+    __syncthreads();
+    if (t < n_tiles) {
+      int pos = tile_base[t] + bsum[(int64_t)blockIdx.x * n_tiles + t];
+      for (int ww = 0; ww < w; ++ww) pos += wsum[ww][lane];
+      for (int i = 0; i < 64 && u0 + i < n_nodes; ++i) {
+        const int64_t u = u0 + i;
+        const int32_t *o = off + u * NT1 + t;
+        const int o0 = o[0], o1 = o[1];
+        tile_start[u * NT1 + t] = pos;
+        const int32_t *src = col + rowptr[u] + o0;
+        for (int j = 0; j < o1 - o0; ++j) col_t[pos + j] = src[j];
+        pos += o1 - o0;
+      }
+    } else if (t == n_tiles) {
+      for (int i = 0; i < 64 && u0 + i < n_nodes; ++i) tile_start[(u0 + i) * NT1 + t] = 0;      // (the unused last column)
+    }
+    __syncthreads();
+  }
+}
+
 constexpr int TW_SHIFT = 15;
 constexpr int TW_TILE = 1 << TW_SHIFT;
 constexpr int TW_MAXOWN = 6144;          // owner slots (entries) per batch the LDS arrays hold; larger batches: slabs
@@ -80,9 +162,12 @@ constexpr int TW_BRK = 1536;              // bracket entries: (tile, batch) pair
 // costs one random 64-byte sector per (owner, tile).)  One workgroup = 64 entries: table rows read coalesced (one wave per
 // row), transposed through LDS, written as 256-byte runs.
 constexpr int TT_SLAB = 128;
-__global__ void __launch_bounds__(256) k_seg_transpose(const int32_t *__restrict__ tile_off, int n_tiles,
-                                                       const int32_t *__restrict__ ent_own, const int32_t *__restrict__ ent_col,
-                                                       int n_ents, int64_t seg_stride, int32_t *__restrict__ seg_t, int skip) {
+// With the tile-major copy (tile_start != null) a second plane follows seg_t's n_tiles + 1 rows: seg_s[t][e] = tile_start[ent_col[e]][t],
+// where the segment of (owner, tile) begins in col_t.
+__global__ void __launch_bounds__(256) k_seg_transpose(const int32_t *__restrict__ tile_off, const int32_t *__restrict__ tile_start,
+                                                       int n_tiles, const int32_t *__restrict__ ent_own,
+                                                       const int32_t *__restrict__ ent_col, int n_ents, int64_t seg_stride,
+                                                       int32_t *__restrict__ seg_t, int skip) {
   __shared__ int tl[TT_SLAB][65];
   unsigned vbx, vgx;
   if (!ggad_vblock(skip, vbx, vgx)) return;
@@ -95,6 +180,9 @@ __global__ void __launch_bounds__(256) k_seg_transpose(const int32_t *__restrict
   // the kernel ran at the latency of two dependent loads per entry (286 us per 150-batch plan for 0.56 GB)
   int u_l = 0, own_l = 0;
   if (p0 + lane < n_ents) { own_l = ent_own[p0 + lane] == p0 + lane ? 1 : 0; u_l = own_l ? ent_col[p0 + lane] : 0; }
+  for (int which = 0; which < (tile_start ? 2 : 1); ++which) {
+  const int32_t *table = which ? tile_start : tile_off;
+  int32_t *plane = seg_t + (which ? (int64_t)NT1 * seg_stride : 0);
   for (int t0 = 0; t0 < NT1; t0 += TT_SLAB) {
     int v0[16], v1[16];
     const int c0 = min(t0 + lane, NT1 - 1), c1 = min(t0 + 64 + lane, NT1 - 1);
@@ -102,7 +190,7 @@ __global__ void __launch_bounds__(256) k_seg_transpose(const int32_t *__restrict
     for (int jj = 0; jj < 16; ++jj) {
       const int j = wid + 4 * jj;
       const int u = __shfl(u_l, j, GGAD_WAVE);
-      const int32_t *row = tile_off + (int64_t)u * NT1;
+      const int32_t *row = table + (int64_t)u * NT1;
       v0[jj] = row[c0];
       v1[jj] = row[c1];
     }
@@ -117,9 +205,10 @@ __global__ void __launch_bounds__(256) k_seg_transpose(const int32_t *__restrict
     const int nt = min(TT_SLAB, NT1 - t0);
     for (int idx = threadIdx.x; idx < nt * 64; idx += 256) {
       const int tt = idx >> 6, j = idx & 63;
-      if (p0 + j < n_ents) seg_t[(int64_t)(t0 + tt) * seg_stride + p0 + j] = tl[tt][j];
+      if (p0 + j < n_ents) plane[(int64_t)(t0 + tt) * seg_stride + p0 + j] = tl[tt][j];
     }
     __syncthreads();
+  }
   }
 }
 
@@ -146,7 +235,10 @@ __global__ void __launch_bounds__(TW_T) k_tile_counts(const int32_t *__restrict_
                                                       int64_t n_cap, const int32_t *__restrict__ own_rp,
                                                       const int32_t *__restrict__ batch_ent_ptr,
                                                       const int32_t *__restrict__ pw_base, uint16_t *__restrict__ pc, int n_tiles,
-                                                      int n_batches, int32_t *__restrict__ counters, int skip) {
+                                                      int n_batches, int32_t *__restrict__ counters, int skip, int tile_major) {
+  // tile_major: col = the tile-major copy col_t, the plane behind seg_t's n_tiles + 1 rows = where each segment begins in it, and
+  // the workgroups of a tile -- one per batch -- are consecutive members of ONE residue class of blockIdx % 8, i.e. run on ONE XCD,
+  // whose L2 then holds the tile's region of col_t (2.6 MB on the bench graph) while its batches pass
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_u[];
   uint32_t *cnt = lds_u;                                   // TW_TILE / 2 words
   int *offs = reinterpret_cast<int *>(lds_u + TW_TILE / 2);  // TW_MAXOWN + 1
@@ -156,11 +248,25 @@ __global__ void __launch_bounds__(TW_T) k_tile_counts(const int32_t *__restrict_
   __shared__ int wbuf[16];
   unsigned vbx, vgx;
   if (!ggad_vblock(skip, vbx, vgx)) return;
-  if (vbx >= (unsigned)n_tiles * (unsigned)n_batches) return;
-  const int t = (int)(vbx % (unsigned)n_tiles), b = (int)(vbx / (unsigned)n_tiles);
+  int t, b;
+  const bool class_map = (tile_major & 2) != 0;
+  tile_major &= 1;
+  if (class_map) {
+    const int nx = skip < 0 ? 8 : 7, c = (int)(blockIdx.x & 7u);
+    const int ci = c - ((skip >= 0 && c > skip) ? 1 : 0);          // this class among the classes that work
+    const unsigned j = blockIdx.x >> 3;
+    const int nt_c = ci < n_tiles ? (n_tiles - ci + nx - 1) / nx : 0;
+    if (j >= (unsigned)nt_c * (unsigned)n_batches) return;
+    t = ci + nx * (int)(j / (unsigned)n_batches);
+    b = (int)(j % (unsigned)n_batches);
+  } else {
+    if (vbx >= (unsigned)n_tiles * (unsigned)n_batches) return;
+    t = (int)(vbx % (unsigned)n_tiles); b = (int)(vbx / (unsigned)n_tiles);
+  }
   const int o0 = batch_ent_ptr[b], o1 = batch_ent_ptr[b + 1];      // "owner slots" = the entries of batch b
   const int n_own_all = o1 - o0;
   const int32_t *seg_lo = seg_t + (int64_t)t * n_cap, *seg_hi = seg_lo + n_cap;
+  const int32_t *seg_st = tile_major ? seg_t + (int64_t)(n_tiles + 1 + t) * n_cap : own_rp;      // (plain: the row's start, + lo below)
 #ifdef GGAD_G2_PROF
   unsigned long long tcp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tct = wall_clock64();      // phase clocks of thread 0 (TC_MARK)
 #endif
@@ -184,12 +290,12 @@ __global__ void __launch_bounds__(TW_T) k_tile_counts(const int32_t *__restrict_
 #pragma unroll
           for (int q = 0; q < IPT; ++q) {
             const int i = min((int)threadIdx.x + q * TW_T, n_own - 1);
-            lo_[q] = seg_lo[ob0 + i]; hi_[q] = seg_hi[ob0 + i]; rp_[q] = own_rp[ob0 + i]; pb_[q] = pw_base[ob0 + i];
+            lo_[q] = seg_lo[ob0 + i]; hi_[q] = seg_hi[ob0 + i]; rp_[q] = seg_st[ob0 + i]; pb_[q] = pw_base[ob0 + i];
           }
 #pragma unroll
           for (int q = 0; q < IPT; ++q) {
             const int i = (int)threadIdx.x + q * TW_T;
-            if (i < n_own) { offs[i] = hi_[q] - lo_[q]; segbeg[i] = rp_[q] + lo_[q]; dst[i] = pb_[q] + lo_[q]; }
+            if (i < n_own) { offs[i] = hi_[q] - lo_[q]; segbeg[i] = rp_[q] + (tile_major ? 0 : lo_[q]); dst[i] = pb_[q] + lo_[q]; }
           }
         }
         __syncthreads();
@@ -867,8 +973,9 @@ int ggad_int_ldsw_hop2(const ggad_mb_plan *P, const ggad_plan_view &V, hipStream
   if (V.n_ents == 0 || V.n_batches == 0) return GGAD_OK;
   const int n_tiles = (int)((P->n_nodes + TW_TILE - 1) >> TW_SHIFT);
   const int skip = P->xcd_skip >= 0 && P->xcd_skip < 8 ? P->xcd_skip : -1;      // leave one XCD to the resident chunk kernel
+  const bool tile_major = P->tile_start != nullptr && P->col_t != nullptr;      // (the tile-major copy of col: ggad_mb_tile_major)
   k_seg_transpose<<<dim3(ggad_skip_grid((unsigned)((V.n_ents + 63) / 64), skip)), dim3(256), 0, st>>>(
-      P->tile_off, n_tiles, P->ent_own, P->ent_col, V.n_ents, V.seg_stride, P->seg_t, skip);
+      P->tile_off, tile_major ? P->tile_start : nullptr, n_tiles, P->ent_own, P->ent_col, V.n_ents, V.seg_stride, P->seg_t, skip);
   const size_t lds = (size_t)(TW_TILE / 2) * 4 + (size_t)(3 * TW_MAXOWN + 1) * 4 + (size_t)TW_BRK * 4;
   {  // the opt-in for 139 KB of dynamic LDS is a per-DEVICE attribute of the kernel: set (and checked) once per device of the process
     static std::mutex mu;
@@ -884,8 +991,13 @@ int ggad_int_ldsw_hop2(const ggad_mb_plan *P, const ggad_plan_view &V, hipStream
     if (state[dev] != 1) { ggad_set_error(hipErrorInvalidValue, "mb_plan_build: this device cannot give k_tile_counts its LDS"); return GGAD_E_LAUNCH; }
   }
   if (P->ev_tile0) (void)hipEventRecord(static_cast<hipEvent_t>(P->ev_tile0), st);
-  k_tile_counts<<<dim3(ggad_skip_grid((unsigned)n_tiles * (unsigned)V.n_batches, skip)), dim3(TW_T), lds, st>>>(
-      P->col, P->seg_t, V.seg_stride, P->own_rp, V.batch_ent_ptr, P->pw_base, P->pc, n_tiles, V.n_batches, P->counters, skip);
+  // (tile-major: eight residue classes of blockIdx, the tiles dealt to the classes that work, a tile's batches consecutive in its class)
+  static const int tc_map = [] { const char *e = getenv("GGAD_TC_MAP"); return e ? atoi(e) : -1; }();      // (experiment: the mapping alone)
+  const bool class_map = tc_map >= 0 ? tc_map != 0 : tile_major;
+  const unsigned tc_grid = class_map ? 8u * (unsigned)((n_tiles + (skip < 0 ? 8 : 7) - 1) / (skip < 0 ? 8 : 7)) * (unsigned)V.n_batches
+                                      : ggad_skip_grid((unsigned)n_tiles * (unsigned)V.n_batches, skip);
+  k_tile_counts<<<dim3(tc_grid), dim3(TW_T), lds, st>>>(tile_major ? P->col_t : P->col, P->seg_t, V.seg_stride, P->own_rp, V.batch_ent_ptr,
+                                                        P->pw_base, P->pc, n_tiles, V.n_batches, P->counters, skip, (tile_major ? 1 : 0) | (class_map ? 2 : 0));
   if (P->ev_tile1) (void)hipEventRecord(static_cast<hipEvent_t>(P->ev_tile1), st);
   if (ev0) (void)hipEventRecord(ev0, st);
   const int F = P->feat_dim;
@@ -957,7 +1069,7 @@ int64_t ggad_mb_tile_offsets_elems(int64_t n_nodes, int32_t tile_shift) {
   return n_nodes * (((n_nodes + (1LL << tile_shift) - 1) >> tile_shift) + 1);
 }
 int64_t ggad_mb_ldsw_seg_elems(int64_t n_nodes, int64_t n_entries_cap) {
-  return (((n_nodes + TW_TILE - 1) >> TW_SHIFT) + 1) * ((n_entries_cap + 63) / 64 * 64);
+  return 2 * (((n_nodes + TW_TILE - 1) >> TW_SHIFT) + 1) * ((n_entries_cap + 63) / 64 * 64);      // (second plane: tile-major segment starts)
 }
 
 int ggad_mb_tile_offsets(const int32_t *rowptr, const int32_t *col, int64_t n_nodes, int32_t tile_shift, int32_t *tile_off,
@@ -968,6 +1080,31 @@ int ggad_mb_tile_offsets(const int32_t *rowptr, const int32_t *col, int64_t n_no
   k_tile_offsets<<<dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0, as_stream(stream)>>>(rowptr, col, n_nodes, n_tiles,
                                                                                                tile_shift, tile_off);
   GGAD_CHECK_LAUNCH("mb_tile_offsets");
+  return GGAD_OK;
+}
+
+
+int64_t ggad_mb_tile_major_workspace_elems(int64_t n_nodes, int32_t tile_shift) {
+  if (n_nodes < 0 || tile_shift < 8 || tile_shift > 24) return 0;
+  const int64_t n_tiles = (n_nodes + (1LL << tile_shift) - 1) >> tile_shift;
+  return ((n_nodes + 255) / 256) * n_tiles + n_tiles + 1;
+}
+
+/* The tile-major copy of col and the table of its segment starts (see the kernels' header); tile_off from ggad_mb_tile_offsets,
+ * tile_start: int32 x ggad_mb_tile_offsets_elems, col_t: int32 x n_edges, workspace: int32 x ggad_mb_tile_major_workspace_elems. */
+int ggad_mb_tile_major(const int32_t *rowptr, const int32_t *col, int64_t n_nodes, int32_t tile_shift, const int32_t *tile_off,
+                       int32_t *tile_start, int32_t *col_t, int32_t *workspace, ggad_stream_t stream) {
+  GGAD_REQUIRE(rowptr && col && tile_off && tile_start && col_t && workspace && n_nodes >= 0 && tile_shift >= 8 && tile_shift <= 24);
+  if (n_nodes == 0) return GGAD_OK;
+  const int n_tiles = (int)((n_nodes + (1LL << tile_shift) - 1) >> tile_shift);
+  const int64_t n_blocks = (n_nodes + 255) / 256;
+  GGAD_REQUIRE(n_tiles <= 16384 && n_blocks < (1LL << 31));
+  hipStream_t st = as_stream(stream);
+  int32_t *bsum = workspace, *tile_base = workspace + n_blocks * n_tiles;
+  k_tm_blocksum<<<dim3((unsigned)n_blocks), dim3(256), 0, st>>>(tile_off, n_nodes, n_tiles, bsum);
+  k_tm_scan<<<dim3(1), dim3(1024), (size_t)n_tiles * sizeof(int), st>>>(bsum, n_blocks, n_tiles, tile_base);
+  k_tm_fill<<<dim3((unsigned)n_blocks), dim3(256), 0, st>>>(rowptr, col, tile_off, n_nodes, n_tiles, bsum, tile_base, tile_start, col_t);
+  GGAD_CHECK_LAUNCH("mb_tile_major");
   return GGAD_OK;
 }
 

@@ -203,5 +203,25 @@ class DeviceGraph:
             cache[shift] = t
         return t
 
+    def tile_major(self, shift: int = 16):
+        """The tile-major copy of `col` and the table of its segment starts (`ggad_mb_tile_major`, once per graph): `(tile_start,
+        col_t)`.  The pair counting of the LDS 2-hop stage reads a tile's segments from one contiguous region instead of 16-byte
+        pieces of the rows."""
+        cache = self.__dict__.setdefault("_tile_major", {})
+        t = cache.get(shift)
+        if t is None:
+            from . import _lib
+            lib = _lib.load()
+            off = self.tile_offsets(shift)
+            start = torch.empty_like(off)
+            col_t = torch.empty_like(self.col)
+            ws = torch.empty(int(lib.ggad_mb_tile_major_workspace_elems(self.n, shift)), dtype=torch.int32, device=self.device)
+            with torch.cuda.device(self.device):
+                _lib.call("ggad_mb_tile_major", self.rowptr.data_ptr(), self.col.data_ptr(), self.n, shift, off.data_ptr(),
+                          start.data_ptr(), col_t.data_ptr(), ws.data_ptr())
+                torch.cuda.synchronize(self.device)          # (the workspace goes back to the allocator)
+            t = cache[shift] = (start, col_t)
+        return t
+
     def closed_degrees(self, nodes: np.ndarray) -> np.ndarray:
         return self.closed_deg_host[np.asarray(nodes, dtype=np.int64)]

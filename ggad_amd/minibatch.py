@@ -253,6 +253,13 @@ class BatchChunk:
         ldsw = self.train and self.hop2 == "ldsw"
         P.rowptr, P.col, P.feat = ptr(g.rowptr), ptr(g.col), ptr(self.feat)
         P.tile_off = ptr(g.tile_offsets(self.lib.ggad_mb_ldsw_tile_shift())) if ldsw else None
+        if ldsw and os.environ.get("GGAD_TILE_MAJOR", "0") == "1":      # opt-in: built in round 5, measured SLOWER than the rows of col
+            # (k_tile_counts 193 -> 216 us at 20 batches with the same order of workgroups, 287 with a tile's workgroups on one XCD;
+            #  k_seg_transpose 21 -> 36 us: profiles/r05_tile_major.txt)
+            ts, ct = g.tile_major(self.lib.ggad_mb_ldsw_tile_shift())
+            P.tile_start, P.col_t = ptr(ts), ptr(ct)
+        else:
+            P.tile_start, P.col_t = None, None
         P.closed_deg_host = g.closed_deg_i32.ctypes.data
         P.pair_bound_host = g.pair_bound_host.ctypes.data if ldsw else None
         P.node_pack_host = g.node_pack_host.ctypes.data if ldsw else None

@@ -125,6 +125,9 @@ typedef struct ggad_mb_plan {
   const int64_t *node_pack_host; /* optional (ABI 6): (closed_deg_host[i] << 40) | pair_bound_host[i] per node -- the sizing pass of
                                     ggad_mb_plan_build then takes ONE cache miss per batch node instead of two (it is on the critical
                                     path of a one-chunk run).  Null: the two tables above are read. */
+  const int32_t *tile_start, *col_t; /* optional (ABI 8): the tile-major copy of col and the table of its segment starts
+                                        (ggad_mb_tile_major).  With both set the pair counting of the LDS 2-hop stage reads col_t -- a
+                                        tile's segments contiguous, its workgroups on one XCD -- instead of 16-byte pieces of rows. */
 } ggad_mb_plan;
 
 typedef struct ggad_mb_plan_info {
@@ -215,6 +218,12 @@ int64_t ggad_mb_tile_offsets_elems(int64_t n_nodes, int32_t tile_shift);
 int ggad_mb_tile_offsets(const int32_t *rowptr, const int32_t *col, int64_t n_nodes, int32_t tile_shift, int32_t *tile_off,
                          ggad_stream_t stream);
 int64_t ggad_mb_ldsw_seg_elems(int64_t n_nodes, int64_t n_entries_cap);     /* ints of seg_t */
+/* Tile-major copy of col for the pair counting (reference op: the duplicate counts of src/graphsage.py:335-348): col_t = the ids of
+ * every (node, tile) segment, all segments of a tile contiguous in node order; tile_start[u][t] (same shape as tile_off) = where
+ * segment (u, t) begins in col_t.  Built once per graph from tile_off; workspace: int32 x ggad_mb_tile_major_workspace_elems. */
+int64_t ggad_mb_tile_major_workspace_elems(int64_t n_nodes, int32_t tile_shift);
+int ggad_mb_tile_major(const int32_t *rowptr, const int32_t *col, int64_t n_nodes, int32_t tile_shift, const int32_t *tile_off,
+                       int32_t *tile_start, int32_t *col_t, int32_t *workspace, ggad_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Mini-batch path: dense step = GCNEncoder.forward + GCN.loss + backward + Adam

@@ -551,6 +551,63 @@ def test_ldsw_node_major_gather_against_per_owner_kernel(stride, mfma, ranges):
         assert torch.equal(xa.view(torch.int32), xb.view(torch.int32))
 
 
+def test_tile_major_copy_of_col_and_the_pair_counts_read_from_it(monkeypatch):
+    """Round 5 (`ggad_mb_tile_major`; reference op: the duplicate counts c' of src/graphsage.py:335-348): col_t = col reordered
+    tile-major (a stable sort of the edges by the tile of the neighbour id: node order inside a tile, id order inside a segment),
+    tile_start[u][t] = where segment (u, t) begins in it -- checked against numpy on the whole graph (10 tiles, hubs, empty
+    segments) --, and the pair counting that reads col_t (a tile's workgroups in one residue class of blockIdx, with and without an
+    XCD left out) gives x2 BIT-identical to the one that reads the rows of col."""
+    from ggad_amd import _lib
+    lib = _lib.load()
+    n = 300000
+    rowptr, col = synth.make_graph(n, 3000000, 21, kind="powerlaw", max_degree=1200)
+    feat = O.normalize_rows(synth.make_features(n, 17, 21)).astype(np.float32)
+    graph = DeviceGraph(rowptr, col, DEV)
+    shift = int(lib.ggad_mb_ldsw_tile_shift())
+    nt = (n + (1 << shift) - 1) >> shift
+    assert nt >= 9
+    off = graph.tile_offsets(shift).cpu().numpy().reshape(n, nt + 1)
+    start, col_t = graph.tile_major(shift)
+    start, col_t = start.cpu().numpy().reshape(n, nt + 1), col_t.cpu().numpy()
+    tile_of = col.astype(np.int64) >> shift
+    np.testing.assert_array_equal(col_t, col[np.argsort(tile_of, kind="stable")])
+    lens = np.diff(off, axis=1).astype(np.int64)                          # [node][tile]
+    base = np.concatenate(([0], np.cumsum(lens.sum(axis=0))))[:-1]
+    want = base[None, :] + np.cumsum(lens, axis=0) - lens
+    np.testing.assert_array_equal(start[:, :nt], want)
+    assert (start[:, nt] == 0).all()
+
+    rng = np.random.default_rng(8)
+    order = np.argsort(-np.diff(rowptr))
+    batches, labels = [], []
+    for b in range(9):
+        nodes = rng.choice(n, size=150, replace=False)
+        nodes[:3] = order[b % 2:b % 2 + 3]                                # hubs in every batch
+        lab = np.zeros(150, dtype=np.int64); lab[120:] = 1
+        batches.append(nodes); labels.append(lab)
+    ft = torch.zeros(n, 32, dtype=torch.float32, device=DEV)
+    ft[:, :17] = torch.from_numpy(feat).to(DEV)
+
+    def run(tile_major, skip):
+        monkeypatch.setenv("GGAD_TILE_MAJOR", "1" if tile_major else "0")
+        ch = BatchChunk(graph, ft, 64, max_batches=9, rows_cap=64, ent_cap=64, train=True, hop2="ldsw", feat_dim=17)
+        ch.xcd_skip = skip
+        ch.build(batches, labels)
+        torch.cuda.synchronize()
+        assert ch.last_hop2 == "ldsw" and (ch.plan.col_t is not None) == tile_major
+        own = ch.owner_entries()
+        b = torch.bucketize(own, torch.as_tensor(ch.ent_ptr_host[ch.batch_ptr_host][1:], device=DEV), right=True)
+        k = b * n + ch.ent_col[own].long()
+        o = torch.argsort(k)
+        return k[o], ch.x2.view(-1, 17)[own][o].clone()
+    k0, x0 = run(False, -1)
+    assert torch.isfinite(x0).all() and float(x0.abs().sum()) > 0
+    for skip in (-1, 0, 5):
+        k1, x1 = run(True, skip)
+        assert torch.equal(k0, k1)
+        assert torch.equal(x0.view(torch.int32), x1.view(torch.int32))
+
+
 def test_overlapped_chunks_equal_serial_execution():
     """Plan of chunk c+1 on a side stream while chunk c trains: same weights and losses as the one-stream order."""
     from ggad_amd.sampler import PyCompatRandom
