@@ -661,7 +661,12 @@ int64_t ggad_gemm_workspace_elems(int32_t M, int32_t N, int32_t K) {
   // 1,200-1,900 rows the loss reads, 1-15 tiles -- then ran as a handful of workgroups walking 58 K-tiles each: 92-99 us per
   // call, three calls per epoch, a quarter of a 1 ms epoch)
   if (K < 512 || tiles >= 256) return 0;
-  int splits = (int)((512 + tiles - 1) / tiles);
+  // tiles x splits <= 512 workgroups = two per CU, all resident at once.  (Rounded UP -- 25 tiles x 21 splits = 525 -- the last 13
+  // workgroups of a 300 x 300 weight gradient ran as a round of their own: 127 -> 106 us at K = 39,357, 46 -> 42 at 11,944;
+  // scripts/gemm_split_sweep.sh.  GGAD_GEMM_SPLIT_FLOOR=0 restores the old rounding.)
+  static const int split_target = [] { const char *e = getenv("GGAD_GEMM_SPLIT_TARGET"); return e ? atoi(e) : 512; }();
+  static const int split_floor = [] { const char *e = getenv("GGAD_GEMM_SPLIT_FLOOR"); return e ? atoi(e) : 1; }();
+  int splits = split_floor ? (int)std::max<int64_t>(split_target / tiles, 1) : (int)((split_target + tiles - 1) / tiles);
   const int max_splits = K >= 2048 ? (K + 255) / 256 : (K + 127) / 128;
   if (splits > max_splits) splits = max_splits;
   if (splits > 128) splits = 128;
