@@ -293,9 +293,18 @@ constexpr int RL_R = 4;                  // rounds of 8 entries a wave item has 
 // v_pk_fma_f32.  (The first version handed the pairs round by ds_bpermute and walked 64-bit addresses: 360 vector instructions per
 // item.  Per-workgroup clocks -- scripts/rowline_clocks.py -- then showed what actually bounds the launch: the hub rows and the
 // number of load instructions of the vector-memory path, 16 clocks each per CU.)
+// Only the loads some lane group needs are issued: n_max = the longest of the wave's 8 rows (entries of this item), wave-uniform --
+// the vector-memory path takes ~16 clocks per CU for every load instruction whatever its active lanes, and a third of the 436 K
+// instructions of a Reddit-size product were the padding of short rows to a round of 8 (profiles/r04_spmm_reddit_pmc.csv).
 __device__ __forceinline__ void rl_walk_item(const char *__restrict__ Xb, uint32_t ldx4, uint32_t voff, int e0, int step, int t,
                                              int lane, int g, const int2 (&pe)[RL_R], int2 *__restrict__ lds_w, float4 &acc) {
   rl_f2 a01 = {acc.x, acc.y}, a23 = {acc.z, acc.w};
+  int n_max = 0;                                                   // entries of the longest row of the wave (uniform)
+  {
+    const int mine = t > e0 ? (t - e0 + step - 1) / step : 0;
+#pragma unroll
+    for (int k = 0; k < RL_G; ++k) n_max = max(n_max, __builtin_amdgcn_readlane(mine, k * RL_G));
+  }
 #pragma unroll
   for (int r = 0; r < RL_R; ++r) lds_w[r * 64 + lane] = make_int2((int)__umul24((uint32_t)pe[r].x, ldx4), pe[r].y);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -303,7 +312,8 @@ __device__ __forceinline__ void rl_walk_item(const char *__restrict__ Xb, uint32
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
   for (int r = 0; r < RL_R; ++r) {
-    if (e0 + r * RL_G * step < t) {
+    const int cnt = n_max - r * RL_G;                              // loads of this round that somebody needs (uniform)
+    if (cnt > 0) {
       const int4 *rd = reinterpret_cast<const int4 *>(lds_w + r * 64 + g * RL_G);
       int4 p[RL_G / 2];
 #pragma unroll
@@ -311,8 +321,9 @@ __device__ __forceinline__ void rl_walk_item(const char *__restrict__ Xb, uint32
       float4 x[RL_G];
 #pragma unroll
       for (int k = 0; k < RL_G / 2; ++k) {
-        x[2 * k] = *reinterpret_cast<const float4 *>(Xb + ((uint32_t)p[k].x + voff));
-        x[2 * k + 1] = *reinterpret_cast<const float4 *>(Xb + ((uint32_t)p[k].z + voff));
+        x[2 * k] = x[2 * k + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (2 * k < cnt) x[2 * k] = *reinterpret_cast<const float4 *>(Xb + ((uint32_t)p[k].x + voff));
+        if (2 * k + 1 < cnt) x[2 * k + 1] = *reinterpret_cast<const float4 *>(Xb + ((uint32_t)p[k].z + voff));
       }
 #pragma unroll
       for (int k = 0; k < RL_G / 2; ++k) {
