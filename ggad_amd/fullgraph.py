@@ -815,6 +815,22 @@ def cached_aggregate(adj: "FullGraphAdj", x: torch.Tensor) -> torch.Tensor:
     return adj._ax["ax"]
 
 
+def padded_constant(adj: "FullGraphAdj", x: torch.Tensor):
+    """A constant layer input (the feature matrix) whose width is not a multiple of 4 -- Photo's 745 -- with zero columns up to the next
+    one, made once per (storage, version): the products of that layer then move 16-byte chunks (LDS-DMA tiles, split-K) instead of
+    single floats (x W^T 62 -> 56 us, dW = dZ^T x 74 -> 54 us at Photo size, scripts/gemm_k745_time.py).  None when x needs nothing."""
+    f = x.shape[1]
+    if f % 4 == 0 or f < 32 or x.requires_grad or x.dim() != 2 or os.environ.get("GGAD_PAD_FEATURES", "1") == "0":
+        return None
+    key = (x.data_ptr(), x._version, tuple(x.shape))
+    ent = adj.__dict__.get("_xpad")
+    if ent is None or ent["key"] != key:
+        xp = torch.zeros(x.shape[0], (f + 3) // 4 * 4, dtype=torch.float32, device=x.device)
+        xp[:, :f] = x
+        ent = adj.__dict__["_xpad"] = {"key": key, "x": x, "xp": xp}      # (keeps x alive: see cached_aggregate)
+    return ent["xp"]
+
+
 class GcnLayerFn(torch.autograd.Function):
     """out = PReLU(A_hat (X W^T) + b)   (reference GCN.forward, `model.py:26-35`)."""
 
@@ -828,7 +844,12 @@ class GcnLayerFn(torch.autograd.Function):
             call("ggad_prelu_fwd_f32", ptr(z), ptr(prelu_a), z.numel(), ptr(out))
             ctx.save_for_backward(ax, weight, z, prelu_a)
         else:
-            t = gemm(x, weight, False, True, out=padded_rows(x.shape[0], weight.shape[0], x.device, (adj.A, None)))      # seq_fts = fc(seq)   model.py:27
+            xq = padded_constant(adj, x)
+            if xq is not None:                                               # (zero columns behind x and W: the same sums)
+                wq = torch.nn.functional.pad(weight, (0, xq.shape[1] - x.shape[1]))
+                t = gemm(xq, wq, False, True, out=padded_rows(x.shape[0], weight.shape[0], x.device, (adj.A, None)))
+            else:
+                t = gemm(x, weight, False, True, out=padded_rows(x.shape[0], weight.shape[0], x.device, (adj.A, None)))      # seq_fts = fc(seq)   model.py:27
             out, z = spmm(adj.A, t, bias=bias, prelu_a=prelu_a, want_pre=True)   # bmm(adj, .) + bias, act  model.py:31-35
             ctx.save_for_backward(x, weight, z, prelu_a)
         ctx.adj = adj
@@ -852,7 +873,8 @@ class GcnLayerFn(torch.autograd.Function):
             dw = gemm(dz, x, True, False)                                    # (H x N)(N x F), no transposed product needed
             return None, dw, (db if ctx.has_bias else None), da.view_as(prelu_a), None
         dt = spmm(adj.At, dz)                                                # A_hat^T dZ
-        dw = gemm(dt, x, True, False)                                        # (H x N)(N x F)
+        xq = padded_constant(adj, x)
+        dw = gemm(dt, x, True, False) if xq is None else gemm(dt, xq, True, False)[:, :x.shape[1]].contiguous()      # (H x N)(N x F)
         dx = gemm(dt, weight, False, False) if ctx.needs_input_grad[0] else None
         return dx, dw, (db if ctx.has_bias else None), da.view_as(prelu_a), None
 
