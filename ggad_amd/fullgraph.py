@@ -703,7 +703,12 @@ def _use_panel(csr: Csr, p, X: torch.Tensor):
             return None
     w = X.shape[1]
     nnz = p.get("nnz", csr.nnz)
-    if force != "1" and not (w >= 64 and nnz >= 64 * p["n_out"] and nnz >= (1 << 20)):
+    # (the floors were 2^20 entries and 64 per output row: the products over Amazon's loss rows -- 1,751 rows x 368 entries, and their transpose
+    #  with 54 entries per row -- then took the sliced / segment kernels at ~80 ps per entry: epoch 0.725 against 0.694-0.698 ms with the ring,
+    #  scripts/panel_threshold_ab.sh; sparse neighbourhoods (Reddit, Photo: 16 per row) fail the per-row test and keep their kernels)
+    min_nnz = int(os.environ.get("GGAD_SPMM_PANEL_MIN_NNZ", str(1 << 18)))
+    min_row = int(os.environ.get("GGAD_SPMM_PANEL_MIN_ROW", "32"))
+    if force != "1" and not (w >= 64 and nnz >= min_row * p["n_out"] and nnz >= min_nnz):
         return None
     ring = os.environ.get("GGAD_SPMM_RING", "1") != "0" and bool(_lib.load().ggad_spmm_ring_available())
     # the LDS ring (k_spmm_ring) unless it is turned off or its plan does not qualify (fill, rounds, stream size): then the panels
