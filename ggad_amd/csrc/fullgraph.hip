@@ -737,8 +737,8 @@ __global__ void __launch_bounds__(1024) k_spmm_panel(const int32_t *__restrict__
 // accumulator -- no per-tile loop overhead, reads of quad q + 1 in flight while quad q is added.  The walk is one asm statement
 // with pinned registers (the 64 accumulators v[64:127] are its outputs); everything around it is plain HIP.
 #ifndef GGAD_RING_S
-#define GGAD_RING_S 5
-#define GGAD_RING_RS 248
+#define GGAD_RING_S 3                // (round 5: 3 x 416 instead of 5 x 248 -- the whole-matrix products are within +-2 % of each other, the products over
+#define GGAD_RING_RS 416             //  a row subset pay per PHASE: 95 instead of 159 of them at T-Finance size; epochs 1.950 -> 1.929 / 0.698 -> 0.681 ms)
 #endif
 constexpr int RING_S = GGAD_RING_S;                 // ring slots
 constexpr int RING_RS = GGAD_RING_RS;               // source rows per slot (a multiple of 8: whole 1 KB LDS-DMA pieces)
