@@ -1,4 +1,4 @@
-for so in default gpurun_variants/libggad_S3_RS416.so default gpurun_variants/libggad_S3_RS416.so default gpurun_variants/libggad_S3_RS416.so; do
+for so in default gpurun_variants/libggad_S2_RS624.so default gpurun_variants/libggad_S2_RS624.so; do
   echo "== $so"
   if [ $so = default ]; then unset GGAD_LIB_PATH; else export GGAD_LIB_PATH=$PWD/$so; fi
   timeout 600 python scripts/fullgraph_leg.py Amazon t_finance 2>/dev/null | python -c "
