@@ -669,7 +669,14 @@ def _use_rowslice(csr: Csr, p, X: torch.Tensor) -> bool:
     if force is not None:
         return force == "1"
     w = X.shape[1]
-    return w >= 160 and X.shape[0] * w * 4 >= (4 << 20)
+    # A smaller operand too when the rows are short (< 32 entries per output row: the transposed loss-row products of Reddit / Photo, a
+    # 1.4-2.2 MB operand, took the segment kernel + its combine: Photo 0.555 -> 0.542 ms, Reddit 0.496 -> 0.488); with longer rows the
+    # segment kernel stays (Amazon / T-Finance: +0.5 / +1.2 % with this kernel, scripts/rowslice_threshold_ab.sh)
+    if w < 160:
+        return False
+    nnz = p.get("nnz", csr.nnz)
+    # (short rows AND short columns: the transposed head product of T-Finance has 7 entries per output row but 540 per source row)
+    return X.shape[0] * w * 4 >= (4 << 20) or (nnz < 32 * max(int(p["n_out"]), 1) and nnz < 64 * max(int(X.shape[0]), 1))
 
 
 def _use_rowline(X: torch.Tensor) -> bool:
