@@ -303,7 +303,7 @@ int ggad_int_gemm_slab(const float *A, const float *B, float *C, int M, int N, i
   static const int min_m = [] { const char *e = getenv("GGAD_GEMM_SLAB_MIN_M"); return e ? atoi(e) : 4096; }();
   if (!enabled || M < min_m || K % 4 != 0) return 0;
   const int KSn = (K + 15) / 16;
-  if (!(KSn == 4 || (KSn >= 16 && KSn <= 20))) return 0;       // K = 49 .. 64 (a narrow first layer: Reddit's 64 features) or 241 .. 320
+  if (!(KSn == 2 || KSn == 4 || (KSn >= 16 && KSn <= 20))) return 0;       // K = 17 .. 32 / 49 .. 64 (narrow first layers) or 241 .. 320
   const int n_tiles = (N + 15) / 16, n_slabs = (n_tiles + SL_MAXTC - 1) / SL_MAXTC, n4 = SL_MAXTC * n_slabs - n_tiles;
   if (n_tiles < 8 || n4 > n_slabs) return 0;                           // (5 a + 4 b = n_tiles has no solution with a + b = n_slabs)
   if ((((uintptr_t)A | (uintptr_t)B) & 15) != 0 || lda % 4 != 0) return 0;
@@ -360,7 +360,7 @@ int ggad_int_gemm_slab(const float *A, const float *B, float *C, int M, int N, i
     k_gemm_slab<KSV><<<dim3(G), dim3(SL_THREADS), lds, st>>>(P);                                                                          \
   } break
   switch (KSn) {
-    GGAD_SLAB(4); GGAD_SLAB(16); GGAD_SLAB(17); GGAD_SLAB(18); GGAD_SLAB(19); GGAD_SLAB(20);
+    GGAD_SLAB(2); GGAD_SLAB(4); GGAD_SLAB(16); GGAD_SLAB(17); GGAD_SLAB(18); GGAD_SLAB(19); GGAD_SLAB(20);
     default: return 0;
   }
 #undef GGAD_SLAB

@@ -9,7 +9,7 @@ if len(sys.argv) > 1:
     from ggad_amd.fullgraph import gemm
     from ggad_amd.fullgraph_bench import _time_call
     torch.manual_seed(0)
-    for (m, k, n) in [(10984, 64, 300), (39357, 64, 300), (10984, 52, 300)]:
+    for (m, k, n) in [(10984, 64, 300), (39357, 20, 300), (11944, 28, 300), (10984, 52, 300)]:
         x = torch.randn(m, k, device="cuda"); w = torch.randn(n, k, device="cuda") * 0.1; b = torch.randn(n, device="cuda")
         got = gemm(x, w, False, True, bias=b)
         ref = x.double() @ w.double().T + b.double()
