@@ -21,7 +21,7 @@ class GgadKernelError(RuntimeError):
     pass
 
 
-ABI_VERSION = 8    # what this binding was written against (include/ggad_hip.h, runtime.cpp); `load` refuses any other library
+ABI_VERSION = 9    # what this binding was written against (include/ggad_hip.h, runtime.cpp); `load` refuses any other library
 _P = c_void_p      # device (or host) pointer
 EXCHANGE_CB = ctypes.CFUNCTYPE(c_int32, c_void_p)      # int exchange(void *user): the data-parallel all-reduce hook
 _I = c_int32
@@ -140,6 +140,7 @@ SIGNATURES = {
     "ggad_prelu_bwd_f32": (c_int32, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "ggad_relu_bwd_f32": (c_int32, [_P, _P, _L, _P, _P]),
     "ggad_prelu_fwd_f32": (c_int32, [_P, _P, _L, _P, _P]),
+    "ggad_linear_prelu_f32": (c_int32, [_P, _L, _P, _L, _P, _P, _I, _I, _I, _P, _L, _P, _L, _P]),
     "ggad_rownorm_f32": (c_int32, [_P, _I, _I, _P, _P, _P]),
     "ggad_rownorm_bwd_f32": (c_int32, [_P, _P, _P, _I, _I, _P, _P]),
     "ggad_rowdot_f32": (c_int32, [_P, _P, _P, _I, _I, _P, _P, _P]),

@@ -94,7 +94,7 @@ int ggad_int_range_deg();      // owners above this degree are gathered by id ra
 
 // ---- gemm_slab.hip: the slab-resident tall product; 1 = launched, 0 = not this kernel's shape, < 0 = launch error
 int ggad_int_gemm_slab(const float *A, const float *B, float *C, int M, int N, int K, int64_t lda, int64_t sbk, int64_t sbn, int64_t ldc,
-                       const float *bias, int relu, hipStream_t st);
+                       const float *bias, int relu, hipStream_t st, const float *prelu_a = nullptr, float *C2 = nullptr, int64_t ldc2 = 0);
 
 // ---- mlp.hip: D (m x n) = P^T Q over R rows as row-range partials + ordered reduction (the weight gradients); 1 = launched, 0 = not taken
 int64_t ggad_int_wgrad_tn_ws(int R, int m, int n);

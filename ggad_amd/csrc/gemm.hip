@@ -799,4 +799,18 @@ int ggad_gemm_f32(const float *A, const float *B, float *C, int32_t M, int32_t N
   return GGAD_OK;
 }
 
+
+/* z = A W^T + bias and out = PReLU(z) in ONE launch (the first GCN layer on a cached aggregate, reference model.py:27-35), when the slab
+ * kernel takes the shape (M >= 4096, K % 4 == 0 in 17 .. 32 / 49 .. 64 / 241 .. 320, N % 4 == 0, 16-byte aligned rows): returns GGAD_OK, or
+ * GGAD_E_UNSUPPORTED without launching anything -- the caller then runs ggad_gemm_f32 + ggad_prelu_fwd_f32.  A: M x K (rows lda apart),
+ * W: N x K (rows ldw apart), z / out: M x N (rows ldz / ldo apart). */
+int ggad_linear_prelu_f32(const float *A, int64_t lda, const float *W, int64_t ldw, const float *bias, const float *prelu_a, int32_t M,
+                          int32_t N, int32_t K, float *z, int64_t ldz, float *out, int64_t ldo, ggad_stream_t stream) {
+  GGAD_REQUIRE(A && W && prelu_a && z && out && M >= 0 && N >= 1 && K >= 1 && lda >= K && ldw >= K && ldz >= N && ldo >= N);
+  if (M == 0) return GGAD_OK;
+  const int r = ggad_int_gemm_slab(A, W, z, (int)M, (int)N, (int)K, lda, 1, ldw, ldz, bias, 0, as_stream(stream), prelu_a, out, ldo);
+  if (r < 0) { ggad_set_error(hipErrorLaunchFailure, "linear_prelu_f32 (slab)"); return GGAD_E_LAUNCH; }
+  return r > 0 ? GGAD_OK : GGAD_E_UNSUPPORTED;
+}
+
 }  // extern "C"

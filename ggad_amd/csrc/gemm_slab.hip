@@ -59,6 +59,9 @@ static int sl_kp(int kpad) {
 
 struct SlabArgs {
   const float *A, *B, *bias;
+  const float *prelu_a;                       // with C2: C2 = PReLU(C) stored beside C (the first GCN layer on a cached aggregate, model.py:27-35)
+  float *C2;
+  int64_t ldc2;
   float *C;
   int M, N, K, KP, relu, vec_store, bias_off; // bias_off: floats from the start of LDS to the slab's bias values;           // vec_store: 16-byte stores of C are aligned and never straddle N
   int64_t lda, sbk, sbn, ldc;
@@ -173,6 +176,11 @@ __device__ __forceinline__ void slab_rows(const SlabArgs &P, const float *__rest
       sl_f4 o = acc[t] + *reinterpret_cast<const sl_f4 *>(biasl + 16 * t);
       if (P.relu) o = sl_f4{fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f)};
       float *dst = P.C + (int64_t)row * P.ldc + col;
+      if (P.C2) {                                                  // (vec_store holds for both: checked by the host)
+        const float pa = *P.prelu_a;
+        const sl_f4 o2 = sl_f4{o.x > 0.f ? o.x : pa * o.x, o.y > 0.f ? o.y : pa * o.y, o.z > 0.f ? o.z : pa * o.z, o.w > 0.f ? o.w : pa * o.w};
+        if (row < M && col < P.N) *reinterpret_cast<sl_f4 *>(P.C2 + (int64_t)row * P.ldc2 + col) = o2;
+      }
 #ifdef GGAD_SLAB_NO_STORE    // (probe: results are dropped unless they hit an impossible value)
       if (o.x == 123456.789f) *reinterpret_cast<sl_f4 *>(dst) = o;
 #else
@@ -298,7 +306,7 @@ static unsigned long long *g_slab_prof = nullptr;
 // C++ linkage, called by ggad_gemm_f32 (gemm.hip).  Returns 1 when the product was launched here, 0 when the shape is not this kernel's
 // (the caller goes on to the tiled kernels), < 0 on a launch error.
 int ggad_int_gemm_slab(const float *A, const float *B, float *C, int M, int N, int K, int64_t lda, int64_t sbk, int64_t sbn, int64_t ldc,
-                       const float *bias, int relu, hipStream_t st) {
+                       const float *bias, int relu, hipStream_t st, const float *prelu_a, float *C2, int64_t ldc2) {
   static const int enabled = [] { const char *e = getenv("GGAD_GEMM_SLAB"); return e ? atoi(e) : 1; }();
   static const int min_m = [] { const char *e = getenv("GGAD_GEMM_SLAB_MIN_M"); return e ? atoi(e) : 4096; }();
   if (!enabled || M < min_m || K % 4 != 0) return 0;
@@ -319,6 +327,8 @@ int ggad_int_gemm_slab(const float *A, const float *B, float *C, int M, int N, i
   SlabArgs P;
   P.A = A; P.B = B; P.bias = bias; P.C = C; P.M = M; P.N = N; P.K = K; P.KP = sl_kp(KSn * 16); P.relu = relu;
   P.vec_store = (N % 4 == 0 && ldc % 4 == 0 && ((uintptr_t)C & 15) == 0) ? 1 : 0;
+  P.prelu_a = prelu_a; P.C2 = C2; P.ldc2 = ldc2;
+  if (C2 && !(prelu_a && P.vec_store && ldc2 % 4 == 0 && ldc2 >= N && ((uintptr_t)C2 & 15) == 0)) return 0;
   P.spr_magic = (uint32_t)(((1ull << 32) + (uint64_t)(P.KP / 4) - 1) / (uint64_t)(P.KP / 4));
   P.lda = lda; P.sbk = sbk; P.sbn = sbn; P.ldc = ldc; P.n_tiles = n_tiles; P.n_slabs = n_slabs; P.n_slabs5 = n_slabs - n4;
   // The CUs of an XCD are dealt to the slabs so that the busiest SIMD issues as few MFMAs as possible: slab s with n CUs gives each of its

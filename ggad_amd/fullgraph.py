@@ -859,12 +859,29 @@ class GcnLayerFn(torch.autograd.Function):
         if ctx.reordered:
             ax = cached_aggregate(adj, x)
             axp = adj._ax.get("axp")
-            if axp is not None:                                              # (zero columns behind A_hat X and W: the same sums)
-                z = gemm(axp, torch.nn.functional.pad(weight, (0, axp.shape[1] - ax.shape[1])), False, True, bias=bias)
-            else:
-                z = gemm(ax, weight, False, True, bias=bias)                 # (A_hat X) W^T + b
+            a_op = ax if axp is None else axp                                # (zero columns behind A_hat X and W: the same sums)
+            if axp is None:
+                w_op = weight.contiguous()
+            else:                                                            # the weight behind zero columns: ONE copy into a kept buffer
+                wkey = (weight.data_ptr(), tuple(weight.shape), axp.shape[1])
+                ent = adj.__dict__.get("_wpad")
+                if ent is None or ent[0] != wkey:
+                    ent = adj.__dict__["_wpad"] = (wkey, torch.zeros(weight.shape[0], axp.shape[1], dtype=torch.float32, device=weight.device))
+                w_op = ent[1]
+                w_op[:, :weight.shape[1]].copy_(weight.detach())
+            z = torch.empty(a_op.shape[0], w_op.shape[0], dtype=torch.float32, device=a_op.device)
             out = torch.empty_like(z)
-            call("ggad_prelu_fwd_f32", ptr(z), ptr(prelu_a), z.numel(), ptr(out))
+            # product, bias and activation in one launch when the slab kernel takes the shape (ggad_linear_prelu_f32), else two
+            rc = -4
+            if os.environ.get("GGAD_LINEAR_PRELU_FUSED", "1") != "0":
+                rc = int(_lib.load().ggad_linear_prelu_f32(ptr(a_op), a_op.stride(0), ptr(w_op), w_op.stride(0), ptr(bias) if bias is not None else 0,
+                                                           ptr(prelu_a), a_op.shape[0], w_op.shape[0], a_op.shape[1], ptr(z), z.stride(0),
+                                                           ptr(out), out.stride(0), _lib.current_stream()))
+            if rc == -4:                                                     # GGAD_E_UNSUPPORTED: nothing was launched
+                z = gemm(a_op, w_op, False, True, bias=bias, out=z)          # (A_hat X) W^T + b
+                call("ggad_prelu_fwd_f32", ptr(z), ptr(prelu_a), z.numel(), ptr(out))
+            else:
+                _lib.check(rc, "ggad_linear_prelu_f32")
             ctx.save_for_backward(ax, weight, z, prelu_a)
         else:
             xq = padded_constant(adj, x)

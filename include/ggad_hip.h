@@ -32,6 +32,7 @@ extern "C" {
 #define GGAD_E_INVALID (-1)   /* bad argument (null pointer, unsupported size)          */
 #define GGAD_E_LAUNCH (-2)    /* HIP launch / runtime error, see ggad_last_error()       */
 #define GGAD_E_CAPACITY (-3)  /* caller-provided workspace too small                     */
+#define GGAD_E_UNSUPPORTED (-4) /* this entry point does not take the shape; nothing was launched (the documented fallback applies) */
 
 typedef void *ggad_stream_t;  /* hipStream_t */
 
@@ -579,6 +580,12 @@ int ggad_prelu_bwd_f32(const float *g, const float *z, const float *prelu_a, int
                        float *da, float *workspace, ggad_stream_t stream);
 /* out = PReLU(z) with slope *prelu_a (model.py:35), for a GCN layer whose aggregate is taken from a cache (no SpMM epilogue) */
 int ggad_prelu_fwd_f32(const float *z, const float *prelu_a, int64_t n, float *out, ggad_stream_t stream);
+/* z = A W^T + bias and out = PReLU(z) in ONE launch (reference model.py:27-35 with A_hat X cached: nn.Linear, bias, PReLU) when the
+ * slab GEMM takes the shape (M >= 4096; K % 4 == 0 in 17..32, 49..64 or 241..320; N % 4 == 0; 16-byte aligned rows): GGAD_OK, or
+ * GGAD_E_UNSUPPORTED with nothing launched (run ggad_gemm_f32 + ggad_prelu_fwd_f32 instead).  A: M x K (rows lda floats apart),
+ * W: N x K (rows ldw apart), z / out: M x N (rows ldz / ldo apart). */
+int ggad_linear_prelu_f32(const float *A, int64_t lda, const float *W, int64_t ldw, const float *bias, const float *prelu_a, int32_t M,
+                          int32_t N, int32_t K, float *z, int64_t ldz, float *out, int64_t ldo, ggad_stream_t stream);
 /* dz = g * [y > 0] */
 int ggad_relu_bwd_f32(const float *g, const float *y, int64_t n, float *dz, ggad_stream_t stream);
 

@@ -694,3 +694,34 @@ def test_end_of_training_parity_full_graph_photo_schedule(capsys):
     assert r["eval_auc_delta_max"] <= 1e-4 and r["eval_ap_delta_max"] <= 1e-4
     assert r["final_auc_delta"] <= 1e-4 and r["final_ap_delta"] <= 1e-4
     assert r["weight_norm_rel_delta_max"] < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,n,k", [(5000, 300, 64), (4100, 300, 28), (39357, 300, 20), (6000, 300, 300), (1000, 300, 64), (5000, 300, 25)])
+def test_linear_prelu_in_one_launch_equals_gemm_then_prelu(m, n, k):
+    """`ggad_linear_prelu_f32` (round 5, ABI 9; reference model.py:27-35 on a cached aggregate): where the slab GEMM takes the shape, z and
+    out = PReLU(z) from one launch are BIT-identical to `ggad_gemm_f32` + `ggad_prelu_fwd_f32` (the same kernel computes z) and z matches an
+    fp64 product; elsewhere (M < 4,096, K not a multiple of 4) the call returns GGAD_E_UNSUPPORTED and touches nothing."""
+    from ggad_amd import _lib
+    from ggad_amd._lib import call, ptr
+    lib = _lib.load()
+    torch.manual_seed(m + k)
+    a = torch.randn(m, k, device=DEV)
+    w = torch.randn(n, k, device=DEV) * 0.2
+    b = torch.randn(n, device=DEV)
+    pa = torch.tensor([0.25], device=DEV)
+    z = torch.full((m, n), 7.0, device=DEV)
+    out = torch.full((m, n), 9.0, device=DEV)
+    rc = int(lib.ggad_linear_prelu_f32(ptr(a), a.stride(0), ptr(w), w.stride(0), ptr(b), ptr(pa), m, n, k, ptr(z), z.stride(0), ptr(out),
+                                       out.stride(0), _lib.current_stream()))
+    torch.cuda.synchronize()
+    if m < 4096 or k % 4:
+        assert rc == -4 and bool((z == 7.0).all()) and bool((out == 9.0).all())
+        return
+    assert rc == 0
+    z_ref = FG.gemm(a, w, False, True, bias=b)
+    o_ref = torch.empty_like(z_ref)
+    call("ggad_prelu_fwd_f32", ptr(z_ref), ptr(pa), z_ref.numel(), ptr(o_ref))
+    assert torch.equal(z, z_ref) and torch.equal(out, o_ref)
+    ref = a.double() @ w.double().T + b.double()
+    assert float((z.double() - ref).abs().max()) <= 3e-6 * (1.0 + float(ref.abs().max()))
