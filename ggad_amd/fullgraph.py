@@ -620,7 +620,7 @@ class FullGraphAdj:
         if s is None:
             J = np.asarray(key[0] + key[1], dtype=np.int64)
             sub = self.Rt.host[J, :]                            # |J| x N : rows of R^T
-            s = dict(J=_dev_i32(J, self.dev), n_normal=len(key[0]), n_out=len(key[1]),
+            s = dict(J=_dev_i32(J, self.dev), n_normal=len(key[0]), n_out=len(key[1]), distinct=bool(len(np.unique(J)) == len(J)),
                      r_inv_J=_dev_f32(self.r_inv_host[J], self.dev), RJ=Csr(sub.T.tocsr(), self.dev),
                      Rt_plan=self.Rt.plan(J, key=("rows", key)))
             self._loss[key] = s
@@ -1173,9 +1173,12 @@ class GgadLossFn(torch.autograd.Function):
         call("ggad_rows_scale_f32", ptr(en), ptr(J), ptr(c), L, h, 0, ptr(xc))            # c_j e_hat_j
         den = spmm(ls["RJ"], xc)                                                          # sum_j R_ij c_j e_hat_j
         # + c_j S_j on rows J; normal and abnormal segments are each duplicate-free
-        call("ggad_rows_scale_f32", ptr(s_j), ptr(J), ptr(c), nn_, h, 1, ptr(den))
-        call("ggad_rows_scale_f32", s_j.data_ptr() + 4 * nn_ * h, J.data_ptr() + 4 * nn_, c.data_ptr() + 4 * nn_, L - nn_, h, 1,
-             ptr(den))
+        if ls.get("distinct"):                                                            # no node in both lists (run.py's draws): one launch
+            call("ggad_rows_scale_f32", ptr(s_j), ptr(J), ptr(c), L, h, 1, ptr(den))
+        else:
+            call("ggad_rows_scale_f32", ptr(s_j), ptr(J), ptr(c), nn_, h, 1, ptr(den))
+            call("ggad_rows_scale_f32", s_j.data_ptr() + 4 * nn_ * h, J.data_ptr() + 4 * nn_, c.data_ptr() + 4 * nn_, L - nn_, h, 1,
+                 ptr(den))
         d_emb = torch.empty_like(en)
         call("ggad_rownorm_bwd_f32", ptr(en), ptr(inv), ptr(den), n, h, ptr(d_emb))
         return d_emb, dl, d_con, d_abn, None, None, None

@@ -111,11 +111,13 @@ def bench_one(name: str, dev, epochs: int = 30, seed: int = 0, h: int = 300) -> 
     abn, nrm = ds["abn_idx"], ds["normal_idx"]
     ls = full.loss_structs(nrm, abn)
 
+    one = torch.ones((), dtype=torch.float32, device=dev)
+
     def train_epoch():
         opt.zero_grad()
         emb, emb_combine, logits, emb_con, emb_abnormal = model(feats, full, abn, nrm, True, args)
         out = FG.ggad_loss(emb, logits, emb_con, emb_abnormal, full, ls, 0.7)
-        out[0].backward()
+        out[0].backward(gradient=one)            # (d loss / d loss = 1 from a kept tensor: autograd would fill a new one every epoch)
         opt.step()
         return out
 

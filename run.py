@@ -121,11 +121,13 @@ def fit(args, dev, full, feats, model, normal_label_idx, abnormal_label_idx, idx
     graph, static, noise_buf, pending_noise = None, None, None, None
     n_abn = len(abnormal_label_idx)
 
+    one = torch.ones((), dtype=torch.float32, device=dev)
+
     def train_epoch():
         optimiser.zero_grad()
         emb, emb_combine, logits, emb_con, emb_abnormal = model(feats, full, abnormal_label_idx, normal_label_idx, True, args)
         out = ggad_loss(emb, logits, emb_con, emb_abnormal, full, ls, 0.7)
-        out[0].backward()
+        out[0].backward(gradient=one)            # (d loss / d loss = 1 from a kept tensor: autograd would fill a new one every epoch)
         optimiser.step()
         return out
 
