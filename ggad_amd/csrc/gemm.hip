@@ -654,13 +654,15 @@ static int pick_tm(int M, int N) {
 
 extern "C" {
 
-int64_t ggad_gemm_workspace_elems(int32_t M, int32_t N, int32_t K) {
+// split-K factor of the tiled kernels for an M x N x K product (1 = no split); the ONE place that decides it -- the workspace query sizes
+// for it, the launches below use it (they used to divide the workspace size, which is the max() with the row-range kernel's: ADVICE round 5)
+static int gemm_splits(int32_t M, int32_t N, int32_t K) {
   const int tm = pick_tm(M, N);
   const int64_t tiles = (int64_t)((M + tm - 1) / tm) * ((N + BN - 1) / BN);
   // (the bar was K >= 2048 with >= 256 of K per split: the weight gradients of the scorer MLP on Reddit / Photo / Amazon -- K = the
   // 1,200-1,900 rows the loss reads, 1-15 tiles -- then ran as a handful of workgroups walking 58 K-tiles each: 92-99 us per
   // call, three calls per epoch, a quarter of a 1 ms epoch)
-  if (K < 512 || tiles >= 256) return 0;
+  if (K < 512 || tiles >= 256) return 1;
   // tiles x splits <= 512 workgroups = two per CU, all resident at once.  (Rounded UP -- 25 tiles x 21 splits = 525 -- the last 13
   // workgroups of a 300 x 300 weight gradient ran as a round of their own: 127 -> 106 us at K = 39,357, 46 -> 42 at 11,944;
   // scripts/gemm_split_sweep.sh.  GGAD_GEMM_SPLIT_FLOOR=0 restores the old rounding.)
@@ -670,6 +672,11 @@ int64_t ggad_gemm_workspace_elems(int32_t M, int32_t N, int32_t K) {
   const int max_splits = K >= 2048 ? (K + 255) / 256 : (K + 127) / 128;
   if (splits > max_splits) splits = max_splits;
   if (splits > 128) splits = 128;
+  return splits < 1 ? 1 : splits;
+}
+
+int64_t ggad_gemm_workspace_elems(int32_t M, int32_t N, int32_t K) {
+  const int splits = gemm_splits(M, N, K);
   // (a "TN" product with a long K may take the row-range kernel of mlp.hip instead: its partials fit too)
   return splits <= 1 ? 0 : std::max<int64_t>((int64_t)splits * M * N, ggad_int_wgrad_tn_ws(K, M, N));
 }
@@ -729,11 +736,25 @@ int ggad_gemm_f32(const float *A, const float *B, float *C, int32_t M, int32_t N
   }
   // small products: both operand panels of a 32 x 32 tile in LDS for the whole K (one round trip), GGAD_GEMM_SMALL=0 turns it off
   static const bool no_small = [] { const char *e = getenv("GGAD_GEMM_SMALL"); return e && e[0] == '0'; }();
-  if (!no_small && ws_elems == 0 && K >= 1 && K <= 512 && (int64_t)((M + SM_T - 1) / SM_T) * ((N + SM_T - 1) / SM_T) <= 1024 &&
+  // (gate = the measured regime, scripts/gemm_small_time.py: the 127-843-row products of the outlier head; a tall M with K = 512 would be
+  //  hundreds of 133-KB workgroups staging serially in front of the pipelined kernels -- ADVICE round 5)
+  if (!no_small && ws_elems == 0 && K >= 1 && K <= 512 && M <= 1024 && (int64_t)((M + SM_T - 1) / SM_T) * ((N + SM_T - 1) / SM_T) <= 1024 &&
       (int64_t)M * N <= (int64_t)1024 * 512) {
     const int KP = sm_kp((K + 15) & ~15);
     const size_t lds = (size_t)2 * SM_T * KP * sizeof(float);
-    static const bool ok = hipFuncSetAttribute((const void *)k_gemm_small, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SM_T * 520 * 4 + 1024) == hipSuccess;
+    // the opt-in for > 64 KB of dynamic LDS is recorded per DEVICE (0 unknown, 1 ready, -1 refused: the tiled kernels take the product)
+    static std::mutex mu;
+    static int state[64] = {};
+    int dev = 0;
+    bool ok = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
+    if (ok) {
+      std::lock_guard<std::mutex> lock(mu);
+      if (state[dev] == 0) {
+        state[dev] = hipFuncSetAttribute((const void *)k_gemm_small, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SM_T * 520 * 4 + 1024) == hipSuccess ? 1 : -1;
+        (void)hipGetLastError();
+      }
+      ok = state[dev] == 1;
+    }
     if (ok) {
       k_gemm_small<<<dim3((N + SM_T - 1) / SM_T, (M + SM_T - 1) / SM_T), dim3(256), lds, st>>>(A, B, C, (int)M, (int)N, (int)K, sam, sak, sbk, sbn, ldc,
                                                                                                   bias, (int)relu, KP);
@@ -747,7 +768,7 @@ int ggad_gemm_f32(const float *A, const float *B, float *C, int32_t M, int32_t N
   const bool a_ok = (((uintptr_t)A & 15) == 0) && (a_kfast ? (sam % 4 == 0 && K % 4 == 0) : (sak % 4 == 0 && M % 4 == 0));
   const bool b_ok = (((uintptr_t)B & 15) == 0) && (b_nfast ? (sbk % 4 == 0 && N % 4 == 0) : (sbn % 4 == 0 && K % 4 == 0));
   if (!no_dma && tm == 64 && a_ok && b_ok && K >= 32) {
-    const int splits = ws_elems ? (int)(ws_elems / ((int64_t)M * N)) : 1;
+    const int splits = ws_elems ? gemm_splits(M, N, K) : 1;
     int kps = K;
     if (splits > 1) { kps = (K + splits - 1) / splits; kps = (kps + BK - 1) / BK * BK; }
     float *out = splits > 1 ? workspace : C;
@@ -782,7 +803,7 @@ int ggad_gemm_f32(const float *A, const float *B, float *C, int32_t M, int32_t N
       launch_gemm<64>(vec, a_kfast, b_nfast, dim3(gx, gy, 1), st, A, B, C, (int)M, (int)N, (int)K, (int)sam, (int)sak, (int)sbk, (int)sbn,
                       ldc, bias, (int)relu, K > 0 ? (int)K : 1, (int64_t)0);
   } else {
-    const int splits = (int)(ws_elems / ((int64_t)M * N));
+    const int splits = gemm_splits(M, N, K);
     int kps = (K + splits - 1) / splits;
     kps = (kps + BK - 1) / BK * BK;
     if (tm == 128)

@@ -21,6 +21,7 @@
 //     three slabs by that XCD's L2.
 // Exact f32 (v_mfma_f32_16x16x4_f32 = fmaf chain); the order of the k-sum inside an output differs from the tiled kernels (lane
 // group ks of step s supplies k = 16 s + 4 ks + m to MFMA m), results agree to round-off (tests/test_fullgraph_gpu.py::test_gemm_f32_all_layouts).
+#include <mutex>
 #include <algorithm>
 #include <cstdlib>
 
@@ -302,6 +303,9 @@ __global__ void __launch_bounds__(SL_THREADS) k_gemm_slab(SlabArgs P) {
 #ifdef GGAD_SLAB_PROF
 static unsigned long long *g_slab_prof = nullptr;
 #endif
+constexpr int SL_MAXDEV = 64;
+static std::mutex g_slab_mu;
+static int g_slab_cus[SL_MAXDEV] = {};
 
 // C++ linkage, called by ggad_gemm_f32 (gemm.hip).  Returns 1 when the product was launched here, 0 when the shape is not this kernel's
 // (the caller goes on to the tiled kernels), < 0 on a launch error.
@@ -316,11 +320,19 @@ int ggad_int_gemm_slab(const float *A, const float *B, float *C, int M, int N, i
   if (n_tiles < 8 || n4 > n_slabs) return 0;                           // (5 a + 4 b = n_tiles has no solution with a + b = n_slabs)
   if ((((uintptr_t)A | (uintptr_t)B) & 15) != 0 || lda % 4 != 0) return 0;
   if (!((sbk == 1 && sbn % 4 == 0) || (sbn == 1 && sbk % 4 == 0 && N % 4 == 0))) return 0;
-  static int n_cus = 0;
-  if (n_cus == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    n_cus = v;
+  // per DEVICE, under a mutex: the CU count that sizes the grid and the slab split, and -- below -- the opt-in for
+  // more than 64 KB of dynamic LDS, which hipFuncSetAttribute records for the current device only
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SL_MAXDEV) return 0;
+  int n_cus;
+  {
+    std::lock_guard<std::mutex> lock(g_slab_mu);
+    if (g_slab_cus[dev] == 0) {
+      int v = 0;
+      if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+      g_slab_cus[dev] = v;
+    }
+    n_cus = g_slab_cus[dev];
   }
   const int G = n_cus / 8 * 8, GX = G / 8;
   if (GX < n_slabs || n_slabs > SL_MAXSLABS) return 0;
@@ -365,8 +377,16 @@ int ggad_int_gemm_slab(const float *A, const float *B, float *C, int M, int N, i
   const size_t lds = ((size_t)P.bias_off + 16 * SL_MAXTC) * sizeof(float);
 #define GGAD_SLAB(KSV)                                                                                                                   \
   case KSV: {                                                                                                                            \
-    static const bool ok = hipFuncSetAttribute((const void *)k_gemm_slab<KSV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) == hipSuccess; \
-    if (!ok) { (void)hipGetLastError(); return 0; }                                                                                      \
+    static int state[SL_MAXDEV] = {};                /* 0 unknown, 1 ready, -1 this device refuses the opt-in: shape not taken */         \
+    {                                                                                                                                    \
+      std::lock_guard<std::mutex> lock(g_slab_mu);                                                                                       \
+      if (state[dev] == 0) {                                                                                                             \
+        const bool ok = hipFuncSetAttribute((const void *)k_gemm_slab<KSV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) == hipSuccess; \
+        (void)hipGetLastError();                                                                                                         \
+        state[dev] = ok ? 1 : -1;                                                                                                        \
+      }                                                                                                                                  \
+      if (state[dev] != 1) return 0;                                                                                                     \
+    }                                                                                                                                    \
     k_gemm_slab<KSV><<<dim3(G), dim3(SL_THREADS), lds, st>>>(P);                                                                          \
   } break
   switch (KSn) {

@@ -25,6 +25,9 @@ class OneShotExchange:
         with torch.cuda.device(self.dev):
             _lib.check(self.lib.ggad_xchg_create(self.rank, self.world, self.n, ctypes.byref(self._h)), "ggad_xchg_create")
         self.ok = self.world == 1
+        # why `connect` declined (None = it did not): "export" (this rank's IPC handle), "peer_export" (another rank's), "map" (a peer's buffer
+        # could not be opened on some rank: no peer access / IPC refused), "selftest" (the known-pattern exchange timed out or disagreed)
+        self.fail_stage = None
 
     @property
     def handle(self):
@@ -51,6 +54,7 @@ class OneShotExchange:
         dist.all_gather(allh, t, group=group)
         allh = [a.cpu().numpy() for a in allh]
         if not all(int(a[-1]) for a in allh):
+            self.fail_stage = "export" if not usable else "peer_export"
             return self._agree(dist, group, False)
         blob = np.concatenate([a[:nb] for a in allh]).astype(np.uint8)
         try:
@@ -60,8 +64,12 @@ class OneShotExchange:
         except _lib.GgadKernelError:
             good = False
         if not self._agree(dist, group, good):
+            self.fail_stage = "map"
             return False
-        return self._agree(dist, group, self._selftest())
+        if not self._agree(dist, group, self._selftest()):
+            self.fail_stage = "selftest"
+            return False
+        return True
 
     @staticmethod
     def decline(dist, device, group=None) -> bool:

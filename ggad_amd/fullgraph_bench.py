@@ -29,6 +29,7 @@ EPOCHS = {"photo": 100, "elliptic": 150, "reddit": 300, "t_finance": 500, "Amazo
 NORMALISED = ("Amazon", "tf_finace", "reddit", "elliptic")            # run.py:87 (typo kept: never T-Finance)
 HBM_PEAK = 8.0e12
 F32_PEAK = 157.3e12
+LDS_PEAK = 150.0e12             # ds_read_b64 / ds_read_b128 with every CU streaming (MI355X_MICROARCH.md, LDS section: 256 B/clk/CU at ~2.4 GHz)
 
 
 def make_dataset(name: str, seed: int = 0, verbose: bool = False) -> Dict[str, object]:
@@ -188,6 +189,20 @@ def bench_one(name: str, dev, epochs: int = 30, seed: int = 0, h: int = 300) -> 
     spmm_flops = 2.0 * nnz * h
     gemm_flops = 2.0 * n * h * h
     bound = "fp32-fma" if spmm_flops / F32_PEAK > spmm_bytes / HBM_PEAK else "hbm"
+    lds = {}
+    if pp0 is not None and "wave_sb" in pp0:
+        # k_spmm_ring never reaches the FP32-FMA peak: every stored entry is one 4 H-byte row read out of LDS (ds_read_b128, 1 KB per wave
+        # instruction) and one row addition.  Its real bound is the LDS read rate (MI355X_MICROARCH: 256 B/clk/CU, ~150 TB/s over the chip):
+        # floor = 4 H bytes per walked entry / that rate; `lds_bytes` is what the schedule actually issues (padded steps, the zero columns of
+        # the last 32-float slice) -- the gap between the two is the schedule's, the gap to `us` the kernel's.
+        n_sl = (h + 31) // 32
+        walked = nnz - (n if pp0.get("diag") is not None else 0)
+        lds_alg = 4.0 * h * walked
+        lds_issued = float(pp0["quads"]) * 4 * 1024 * n_sl
+        bound = "lds"
+        lds = {"lds_alg_bytes": lds_alg, "lds_bytes": lds_issued, "lds_peak_tbs": LDS_PEAK / 1e12, "lds_floor_us": lds_alg / LDS_PEAK * 1e6,
+               "frac_of_lds_floor": lds_alg / LDS_PEAK / t_spmm, "lds_issued_floor_us": lds_issued / LDS_PEAK * 1e6,
+               "frac_of_lds_issued_floor": lds_issued / LDS_PEAK / t_spmm, "schedule_fill": float(pp0["fill"])}
     return {"nodes": n, "stored_entries_incl_identity": nnz, "directed_entries": int(ds["adj"].nnz), "feat": ds["f"], "hidden": h,
             "epoch_ms": med * 1e3, "nodes_per_s": n / med, "mode": mode, "epochs_timed": epochs, "eager_epoch_ms": eager_med * 1e3,
             "loss_after": loss,
@@ -195,7 +210,8 @@ def bench_one(name: str, dev, epochs: int = 30, seed: int = 0, h: int = 300) -> 
                            "bound": bound, "frac_of_f32_fma_peak": spmm_flops / t_spmm / F32_PEAK,
                            "frac_of_hbm_peak": spmm_bytes / t_spmm / HBM_PEAK,
                            "floor_us": max(spmm_flops / F32_PEAK, spmm_bytes / HBM_PEAK) * 1e6,
-                           "frac_of_bounding_roofline": max(spmm_flops / F32_PEAK, spmm_bytes / HBM_PEAK) / t_spmm},
+                           "frac_of_bounding_roofline": (lds["frac_of_lds_floor"] if lds else
+                                                         max(spmm_flops / F32_PEAK, spmm_bytes / HBM_PEAK) / t_spmm), **lds},
             "gemm_NxHxH": {"us": t_gemm * 1e6, "tflops": gemm_flops / t_gemm / 1e12, "frac_of_f32_mfma_peak": gemm_flops / t_gemm / F32_PEAK}}
 
 

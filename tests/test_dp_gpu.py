@@ -274,6 +274,22 @@ def test_bench_launch_line_two_ranks_one_gpu():
     assert e2e["default_mode"] == "independent"
     for mode in ("independent", "shared"):
         assert e2e[mode]["value"] > 0 and e2e[mode]["sampler_us_per_batch"] > 0 and e2e[mode]["reps"] >= 1, e2e[mode]
+    # the N > 1 line explains itself: which group was initialised, which exchange ran and why, every rank's own time,
+    # and the same window under the contracted design (RCCL all-reduce, one shared schedule) beside the default
+    mg = d["multi_gpu"]
+    assert mg["world_size"] == 2 and mg["backend"] == "gloo" and mg["rccl_ranks"] == 0           # (nccl on a node: rccl_ranks == N)
+    assert mg["allreduce_of_ones"] == 2.0 and mg["ranks_share_a_device"] is True
+    assert mg["gradient_exchange"] == d["config"]["gradient_exchange"]
+    assert (mg["gradient_exchange_fallback_reason"] is None) == mg["gradient_exchange"].startswith("oneshot")
+    pr = mg["per_rank_ms_per_step"]
+    assert len(pr["values"]) == 2 and 0 < pr["min"] <= pr["median"] <= pr["max"] <= d["ms_per_step"] * 1.05
+    alt = mg["alt_legs"]
+    assert "error" not in alt, alt
+    assert alt["dp_sampler_shared"]["value"] > 0
+    other = "exchange_rccl" if mg["gradient_exchange"].startswith("oneshot") else "exchange_oneshot"
+    assert other in alt and (alt[other].get("value", 0) > 0 or "error" in alt[other]), alt
+    vr = d["value_repeats"]
+    assert vr["reps"] == 7 and len(vr["values"]) == 7 and vr["min"] <= vr["median"] <= vr["max"]
 
 
 def test_bench_bare_line_spawns_two_ranks_one_gpu():
