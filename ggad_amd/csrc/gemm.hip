@@ -15,6 +15,7 @@
 // Long-K / few-tile shapes (weight gradients: K = number of nodes) are split along K over gridDim.z into
 // a workspace and summed by a second kernel in a fixed order (deterministic, no float atomics).
 #include <cstdlib>
+#include <mutex>
 
 #include "common.h"
 
