@@ -150,6 +150,7 @@ class ModelHandler(object):
         trainer = DGraphTrainer(graph, features.weight.data, args.emb_size, sched, chunk_batches=steps_per_epoch, rank=rank,
                                 world_size=world, allreduce=allreduce, engine=engine, exchange=exchange, own_stream=own_stream)
         self.trainer, self.model = trainer, gnn_model
+        self.sweep_ap = []                                      # AP of every sweep, validation sweeps then the test sweep (the reference prints it)
         self.epoch_losses, self.valid_history = [], []          # {total, cls, margin, rec} of every batch; (epoch, five metrics) of every sweep
         trainer.start_stream(steps_per_epoch * args.num_epochs)        # sampler thread alive across the validation pauses
         total_time = 0.0
@@ -185,6 +186,7 @@ class ModelHandler(object):
                 f1_mac_val, f1_1_val, f1_0_val, auc_val, gmean_val = test_sage(idx_valid, y_valid, gnn_model, args.batch_size,
                                                                                args.thres, dist=dist, verbose=rank == 0)
                 self.valid_history.append((epoch, (f1_mac_val, f1_1_val, f1_0_val, auc_val, gmean_val)))
+                self.sweep_ap.append(getattr(test_sage, "last_ap", None))
                 if auc_val > auc_best:
                     f1_mac_best, auc_best, ep_best = f1_mac_val, auc_val, epoch
                     if rank == 0:
@@ -206,7 +208,9 @@ class ModelHandler(object):
             if dist and world > 1:
                 dist.broadcast(engine.params, src=0)          # every rank tests the restored weights
             engine.sync_params()
-        return test_sage(idx_test, y_test, gnn_model, args.batch_size, args.thres, dist=dist, verbose=rank == 0)
+        res = test_sage(idx_test, y_test, gnn_model, args.batch_size, args.thres, dist=dist, verbose=rank == 0)
+        self.sweep_ap.append(getattr(test_sage, "last_ap", None))
+        return res
 
 
     # ---------------------------------------------------------------------------------------------------------------- SAGE

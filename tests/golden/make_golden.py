@@ -370,7 +370,7 @@ def ingest_case():
 
 
 def full_graph_long_case(tag="long_photo_schedule", n=4200, n_entries=60000, f=64, n_h=300, seed=0, mean=0.02, var=0.01,
-                         num_epoch=100, outlier_rate=0.15):
+                         num_epoch=100, outlier_rate=0.15, planted=None, normalise=True):
     """End-of-training parity (BASELINE north_star: "AUROC/AUPRC within 1e-4"): the WHOLE training schedule of the reference's
     script for `--dataset photo` (run.py:46-48: 100 epochs; README: --mean 0.02 --var 0.01; Adam lr 1e-3) on a graph the dense
     reference still runs here, restated around the imported `Model` exactly as run.py:137-240 drives it: ONE seeding at the
@@ -387,6 +387,11 @@ def full_graph_long_case(tag="long_photo_schedule", n=4200, n_entries=60000, f=6
     rowptr, col = synth.make_graph(n, n_entries, seed, kind="powerlaw", max_degree=n // 8)
     feat = synth.make_features(n, f, seed)
     ano = synth.make_labels(n, 0.06, seed)
+    if planted:
+        # round 6: labels that MEAN something -- the labelled nodes get attenuated features and a neighbourhood rewired
+        # towards each other (synth.plant_anomalies), the features stay raw as run.py keeps them for `--dataset photo` (run.py:87): the
+        # reference then ends its 100 epochs at AUROC ~0.94 instead of ~0.49
+        rowptr, col, feat = synth.plant_anomalies(rowptr, col, feat, ano, seed, **planted)
     adj_sp = synth.csr_to_scipy(rowptr, col)
     random.seed(seed)
     all_idx = list(range(n))
@@ -399,7 +404,10 @@ def full_graph_long_case(tag="long_photo_schedule", n=4200, n_entries=60000, f=6
     random.shuffle(normal_idx)
     abn_idx = normal_idx[: int(len(normal_idx) * outlier_rate)]
 
-    feats_dense, _ = rutils.preprocess_features(sp.lil_matrix(feat))
+    if normalise:
+        feats_dense, _ = rutils.preprocess_features(sp.lil_matrix(feat))
+    else:
+        feats_dense = feat                                              # run.py:87-88: photo / T-Finance features are used as loaded
     adj_norm = rutils.normalize_adj(adj_sp)
     raw_adj = torch.FloatTensor(np.asarray((adj_sp + sp.eye(n)).todense()))
     adj = torch.FloatTensor(np.asarray((adj_norm + sp.eye(n)).todense())[np.newaxis])
@@ -451,12 +459,19 @@ def full_graph_long_case(tag="long_photo_schedule", n=4200, n_entries=60000, f=6
                inputs_crc=synth.crc_of(rowptr, col, feat, ano), init_crc=init_crc,
                idx_test=np.array(idx_test), normal_idx=np.array(normal_idx), abn_idx=np.array(abn_idx),
                losses=np.array(losses, dtype=np.float64), evals=np.array(evals, dtype=np.float64),
-               final_logits=le, final_auc=auc, final_ap=ap)
+               final_logits=le, final_auc=auc, final_ap=ap, normalise=int(bool(normalise)))
+    for k, v in (planted or {}).items():
+        out["planted." + k] = np.float64(v)
     for k, v in model.state_dict().items():
         out["final_norm." + k] = np.float64(np.linalg.norm(_np(v).astype(np.float64)))
     path = os.path.join(HERE, f"fullgraph_{tag}.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, "final auc", auc, "ap", ap)
+
+
+# planted-anomaly parameters of the two round-6 fixtures (synth.plant_anomalies; chosen so that the REFERENCE separates the classes)
+PLANTED_FULL = dict(scale=0.25, rewire=0.5)
+PLANTED_MINI = dict(scale=0.5, dims=0.5, rewire=0.0, max_degree=2)
 
 
 def part_full():
@@ -675,17 +690,21 @@ def handler_case():
 
 
 
-def handler_long_case(num_epochs=5, valid_epochs=2):
+def handler_long_case(num_epochs=5, valid_epochs=2, tag="5ep", n_entries=300000, planted=None):
     """`handler_case` over FIVE epochs of 150 batches with a validation sweep at epochs 0, 2 and 4 (model_handler.py:379-392), the
     best checkpoint restored and the test sweep at the end (:405-414) -- the end-of-training parity case of the mini-batch path.
     Stored: the loss terms of all 750 batches, the five metrics of every validation sweep, the weights each sweep saw (the last one:
     the weights at the END of training), and the final test metrics."""
     import pickle
     import tempfile
-    n, n_entries, f, seed = 90000, 300000, 17, 11
+    n, f, seed = 90000, 17, 11
     rowptr, col = synth.make_graph(n, n_entries, seed, kind="powerlaw", max_degree=200)
     feat_raw = synth.make_features(n, f, seed)
     y = synth.make_labels(n, 0.02, seed)
+    if planted:
+        # round 6: planted anomalies (synth.plant_anomalies) -- sparse neighbourhoods + a feature-profile change: the reference's sweeps then
+        # end well above chance instead of at 0.46-0.49, so the AUROC / AP parity below compares rankings that separate the classes
+        rowptr, col, feat_raw = synth.plant_anomalies(rowptr, col, feat_raw, y, seed, **planted)
     adj_lists = synth.csr_to_adj_lists(rowptr, col)
     tmp = tempfile.mkdtemp(prefix="ggad_golden_")
     os.makedirs(os.path.join(tmp, "data"))
@@ -715,8 +734,16 @@ def handler_long_case(num_epochs=5, valid_epochs=2):
             rec.append([float(x) for x in r])
             return r
         gs.GCN.loss = spy
-        sweeps, seen = [], []
+        sweeps, seen, aps = [], [], []
         orig_test = mh.test_sage
+        import utils as sutils                                                # src/utils.py: test_sage computes AP but only prints it (:232)
+        orig_ap = sutils.average_precision_score
+
+        def ap_spy(*a, **k):
+            v = orig_ap(*a, **k)
+            aps.append(float(v))
+            return v
+        sutils.average_precision_score = ap_spy
 
         def test_spy(cases, labels, model, batch_size, thres=0.5):
             r = orig_test(cases, labels, model, batch_size, thres)
@@ -726,7 +753,11 @@ def handler_long_case(num_epochs=5, valid_epochs=2):
         mh.test_sage = test_spy
         res = handler.train()
         mh.test_sage = orig_test
+        sutils.average_precision_score = orig_ap
         gs.GCN.loss = orig_loss
+        out["sweep_ap"] = np.array(aps, dtype=np.float64)                     # the AP every sweep printed (src/utils.py:232), same order as `sweeps`
+        for k, v in (planted or {}).items():
+            out["planted." + k] = np.float64(v)
         out["batch_losses"] = np.array(rec, dtype=np.float64)                 # (750, 4): total, cls, margin, rec
         out["sweeps"] = np.array(sweeps, dtype=np.float64)                    # validations at epochs 0, 2, 4, then the test sweep
         out["metrics"] = np.array(res, dtype=np.float64)
@@ -736,7 +767,7 @@ def handler_long_case(num_epochs=5, valid_epochs=2):
             out["best." + k] = v
     finally:
         os.chdir(cwd)
-    path = os.path.join(HERE, "handler_dgraph_like_5ep.npz")
+    path = os.path.join(HERE, f"handler_dgraph_like_{tag}.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, "sweeps", out["sweeps"], "metrics", out["metrics"])
 
@@ -927,7 +958,7 @@ def part_mini(with_handler: bool):
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--part", choices=["all", "full", "mini", "baselines", "ocgnn", "ingest", "sage", "pcgnn", "tam", "long_full", "long_mini"], default="all")
+    ap.add_argument("--part", choices=["all", "full", "mini", "baselines", "ocgnn", "ingest", "sage", "pcgnn", "tam", "long_full", "long_mini", "planted_full", "planted_mini"], default="all")
     ap.add_argument("--no-handler", action="store_true", help="skip the slow end-to-end ModelHandler case")
     a = ap.parse_args()
     if not os.path.isdir(REF):
@@ -935,7 +966,7 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     if a.part == "all":
         env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
-        for p in ("full", "mini", "baselines", "ocgnn", "ingest", "sage", "pcgnn", "tam", "long_full", "long_mini"):
+        for p in ("full", "mini", "baselines", "ocgnn", "ingest", "sage", "pcgnn", "tam", "long_full", "long_mini", "planted_full", "planted_mini"):
             cmd = [sys.executable, os.path.abspath(__file__), "--part", p] + (["--no-handler"] if a.no_handler else [])
             subprocess.check_call(cmd, env=env)
     elif a.part == "full":
@@ -948,6 +979,14 @@ if __name__ == "__main__":
         _stub_third_party()
         sys.path.insert(0, os.path.join(REF, "src"))
         handler_long_case()
+    elif a.part == "planted_full":                 # the same two schedules on PLANTED anomalies (round 6): AUROC that means something
+        _stub_third_party()
+        sys.path.insert(0, REF)
+        full_graph_long_case(tag="long_planted", planted=PLANTED_FULL, normalise=False)
+    elif a.part == "planted_mini":
+        _stub_third_party()
+        sys.path.insert(0, os.path.join(REF, "src"))
+        handler_long_case(tag="planted", n_entries=600000, planted=PLANTED_MINI)
     elif a.part == "ingest":
         _stub_third_party()
         sys.path.insert(0, REF)

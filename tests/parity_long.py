@@ -15,7 +15,15 @@ from conftest import ROOT, load_golden
 from ggad_amd import synth
 
 
-def full_graph_long(dev="cuda:0", no_graph=False):
+def _planted(g):
+    """The synth.plant_anomalies keywords a fixture was generated with (empty: labels independent of everything, the round-5 fixtures)."""
+    out = {k[len("planted."):]: float(g[k]) for k in g.files if k.startswith("planted.")}
+    if "max_degree" in out:
+        out["max_degree"] = int(out["max_degree"])
+    return out
+
+
+def full_graph_long(dev="cuda:0", no_graph=False, fixture="fullgraph_long_photo_schedule.npz"):
     import scipy.sparse as sp
     from ggad_amd import utils as U
     from ggad_amd.fullgraph import FullGraphAdj
@@ -23,14 +31,18 @@ def full_graph_long(dev="cuda:0", no_graph=False):
     spec = importlib.util.spec_from_file_location("ggad_run_script", os.path.join(ROOT, "run.py"))
     run = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(run)
-    g = load_golden("fullgraph_long_photo_schedule.npz")
+    g = load_golden(fixture)
     n, f, h, seed = int(g["n"]), int(g["f"]), int(g["n_h"]), int(g["seed"])
     rowptr, col = synth.make_graph(n, int(g["n_entries"]), seed, kind="powerlaw", max_degree=n // 8)
     feat = synth.make_features(n, f, seed)
     ano = synth.make_labels(n, 0.06, seed)
+    planted = _planted(g)
+    if planted:
+        rowptr, col, feat = synth.plant_anomalies(rowptr, col, feat, ano, seed, **planted)
     assert synth.crc_of(rowptr, col, feat, ano) == int(g["inputs_crc"])
     adj = synth.csr_to_scipy(rowptr, col, n)
-    features = U.preprocess_features(sp.lil_matrix(feat))
+    # (run.py:87-88: features are row-normalised for Amazon / reddit / elliptic only -- the planted fixture keeps them raw like photo)
+    features = U.preprocess_features(sp.lil_matrix(feat)) if ("normalise" not in g.files or int(g["normalise"])) else feat
     dev = torch.device(dev)
     torch.cuda.set_device(dev)
     full = FullGraphAdj(U.normalize_adj(adj) + sp.eye(n), adj + sp.eye(n), dev)
@@ -61,13 +73,16 @@ def full_graph_long(dev="cuda:0", no_graph=False):
                 last_losses=(losses[-1].tolist(), ref[-1].tolist()))
 
 
-def handler_long(tmp_dir, dev_id=0):
+def handler_long(tmp_dir, dev_id=0, fixture="handler_dgraph_like_5ep.npz"):
     from ggad_amd.model_handler import ModelHandler
-    g = load_golden("handler_dgraph_like_5ep.npz")
+    g = load_golden(fixture)
     n, seed = int(g["n"]), int(g["graph_seed"])
     rowptr, col = synth.make_graph(n, int(g["n_entries"]), seed, kind="powerlaw", max_degree=200)
     feat_raw = synth.make_features(n, int(g["f"]), seed)
     y = synth.make_labels(n, 0.02, seed)
+    planted = _planted(g)
+    if planted:
+        rowptr, col, feat_raw = synth.plant_anomalies(rowptr, col, feat_raw, y, seed, **planted)
     assert synth.crc_of(rowptr, col, feat_raw, y) == int(g["inputs_crc"])
     cwd = os.getcwd()
     os.chdir(tmp_dir)
@@ -95,5 +110,8 @@ def handler_long(tmp_dir, dev_id=0):
                 sweep_delta_max={nm: float(np.abs(sweeps[:, i] - g["sweeps"][:, i]).max()) for i, nm in enumerate(names)},
                 test_metrics=(np.array(res, dtype=np.float64).tolist(), g["metrics"].tolist()),
                 test_auc_delta=abs(float(res[3]) - float(g["metrics"][3])),
+                sweep_auc=(sweeps[:, 3].tolist(), g["sweeps"][:, 3].tolist()),
+                sweep_ap=((list(h.sweep_ap), g["sweep_ap"].tolist()) if "sweep_ap" in g.files else None),
+                sweep_ap_delta_max=(float(np.abs(np.array(h.sweep_ap, dtype=np.float64) - g["sweep_ap"]).max()) if "sweep_ap" in g.files else None),
                 end_weight_delta_max=max(end.values()), best_weight_delta_max=max(best.values()),
                 valid_epochs=[e for e, _ in h.valid_history])
