@@ -21,7 +21,7 @@ class GgadKernelError(RuntimeError):
     pass
 
 
-ABI_VERSION = 9    # what this binding was written against (include/ggad_hip.h, runtime.cpp); `load` refuses any other library
+ABI_VERSION = 10   # what this binding was written against (include/ggad_hip.h, runtime.cpp); `load` refuses any other library
 _P = c_void_p      # device (or host) pointer
 EXCHANGE_CB = ctypes.CFUNCTYPE(c_int32, c_void_p)      # int exchange(void *user): the data-parallel all-reduce hook
 _I = c_int32
@@ -153,6 +153,10 @@ SIGNATURES = {
     "ggad_head_con_grad_f32": (c_int32, [_P, _P, _P, _P, _P, _I, _I, _P, _P]),
     "ggad_head_emb_grad_f32": (c_int32, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P]),
     "ggad_full_loss_workspace_elems": (c_int64, [_I, _I]),
+    "ggad_full_loss_fused_workspace_elems": (c_int64, [_I, _I]),
+    "ggad_full_loss_fused_f32": (c_int32, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "ggad_full_loss_bwd_fused_f32": (c_int32, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
+    "ggad_rownorm_bwd_add_f32": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P]),
     "ggad_full_loss_f32": (c_int32, [_P, _P, _I, _I, _P, _P, _I, _F, _P, _P, _P, _P, _P, _P]),
     "ggad_adam_f32": (c_int32, [_P, _P, _P, _P, _L, _F, _F, _P, _I, _P]),
     "ggad_adam_multi_max": (c_int32, []),

@@ -1396,6 +1396,157 @@ __global__ void __launch_bounds__(256) k_rec_apply(const float *__restrict__ emb
   }
 }
 
+// ---- round 6: the loss block in THREE launches forward (k_rownorm, the R^T product, k_loss_fwd_fused) and three backward
+// (k_loss_bwd_fused, the R[:, J] product, k_rownorm_bwd_add) instead of six + six + a torch fill (a 3-10 us launch
+// per row-local step was 67 us of a 483-us Reddit epoch).
+//
+// k_loss_fwd_fused: workgroups [0, nb_dot) form aff[p] = r_inv_J[p] <e_hat[J[p]], S[p]> for LD_ROWS rows each (what k_rowdot did),
+// workgroups [nb_dot, nb_dot + nb_rec) the partial column sums of squares of D = emb_con - emb_abn per block of REC_ROWS rows (k_rec_part).
+// Every workgroup then draws a ticket (one agent-scope atomic after an agent-scope release of its stores); the LAST one -- whichever it
+// is: it only reads what the others published and sums it in a fixed order, so the result does not depend on who it was -- does what
+// k_full_loss and the column-norm half of k_rec_apply did: BCE and d_logits, the margin and g_aff, the column norms -> rec and
+// kcol[h] = 1 / (H |D[:, h]|), the four loss values.  dD itself (A x H) is NOT formed here by one workgroup: the backward launch forms
+// d emb_con = g D kcol over all its workgroups.  The ticket counter is put back to zero by the last workgroup (graph replays).
+constexpr int LD_ROWS = 16;      // rows of the affinity per workgroup: 4 per wave (L = 1.3-6.5 K rows -> 80-400 tickets of ~7 ns each)
+__global__ void __launch_bounds__(256) k_loss_fwd_fused(const float *__restrict__ en, const int32_t *__restrict__ J,
+                                                        const float *__restrict__ S, const float *__restrict__ r_inv_j, int L, int W,
+                                                        const float *__restrict__ logits, int Nn, int A,
+                                                        const float *__restrict__ emb_con, const float *__restrict__ emb_abn,
+                                                        float margin_c, int nb_dot, int nb_rec, float *__restrict__ aff,
+                                                        float *__restrict__ ws, float *__restrict__ kcol, float *__restrict__ losses4,
+                                                        float *__restrict__ d_logits, float *__restrict__ g_aff,
+                                                        int32_t *__restrict__ ticket) {
+  __shared__ float red[4];
+  __shared__ int last;
+  const int lane = lane_id(), wid = threadIdx.x >> 6;
+  if ((int)blockIdx.x < nb_dot) {
+#pragma unroll
+    for (int k = 0; k < LD_ROWS / 4; ++k) {
+      const int p = blockIdx.x * LD_ROWS + wid * (LD_ROWS / 4) + k;
+      if (p >= L) break;
+      const float *a = en + (int64_t)J[p] * W, *b = S + (int64_t)p * W;
+      float dot = 0.f;
+      for (int c = lane; c < W; c += 64) dot = fmaf(a[c], b[c], dot);
+      dot = wave_sum(dot);
+      if (lane == 0) aff[p] = r_inv_j[p] * dot;
+    }
+  } else {
+    const int rb = blockIdx.x - nb_dot;
+    const int a0 = rb * REC_ROWS, a1 = min(A, a0 + REC_ROWS);
+    for (int h = threadIdx.x; h < W; h += 256) {
+      float ss = 0.f;
+#pragma unroll 8
+      for (int a = a0; a < a1; ++a) { const float d = emb_con[(int64_t)a * W + h] - emb_abn[(int64_t)a * W + h]; ss = fmaf(d, d, ss); }
+      ws[(int64_t)rb * W + h] = ss;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // this workgroup's aff / ws stores reach memory before its ticket
+  __syncthreads();
+  if (threadIdx.x == 0) last = (__hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) ? 1 : 0;
+  __syncthreads();
+  if (!last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // ... and everyone else's are read from memory, not from a stale line
+  if (threadIdx.x == 0) *ticket = 0;
+  auto block_sum = [&](float v) {
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+  };
+  float s_bce = 0.f, s_n = 0.f, s_a = 0.f;
+  for (int i = threadIdx.x; i < L; i += 256) {
+    const float x = logits[i];
+    const float y = i < Nn ? 0.f : 1.f;
+    s_bce += (1.0f - y) * x - (fminf(x, 0.f) - log1pf(expf(-fabsf(x))));      // BCEWithLogits, pos_weight 1
+    d_logits[i] = (1.0f / (1.0f + expf(-x)) - y) / (float)L;
+    const float av = __builtin_nontemporal_load(aff + i);
+    if (i < Nn) s_n += av; else s_a += av;
+  }
+  const float bce = block_sum(s_bce) / (float)L;
+  const float an = block_sum(s_n) / (float)Nn;
+  const float ab = block_sum(s_a) / (float)A;
+  const float m = margin_c - (an - ab);
+  const float active = m >= 0.f ? 1.f : 0.f;
+  for (int i = threadIdx.x; i < L; i += 256) g_aff[i] = active * (i < Nn ? -1.0f / (float)Nn : 1.0f / (float)A);
+  float s_rec = 0.f;
+  for (int h = threadIdx.x; h < W; h += 256) {
+    float ss = 0.f;
+#pragma unroll 8
+    for (int b = 0; b < nb_rec; ++b) ss += __builtin_nontemporal_load(ws + (int64_t)b * W + h);     // fixed order
+    const float nrm = sqrtf(ss);
+    s_rec += nrm;
+    kcol[h] = 1.0f / ((float)W * nrm);
+  }
+  const float rec = block_sum(s_rec) / (float)W;
+  if (threadIdx.x == 0) {
+    const float margin = fmaxf(m, 0.f);
+    losses4[0] = (margin + bce) + rec; losses4[1] = margin; losses4[2] = bce; losses4[3] = rec;     // total = margin + bce + rec (run.py:210)
+  }
+}
+
+// backward of the loss block, the row-local half, in one launch: with g = d total,
+//   workgroups [0, nb_l):  c[p] = g_aff[p] r_inv_J[p] g,  d logits[p] = d_logits[p] g,  xc[p][:] = c[p] e_hat[J[p]][:]    (4 rows per workgroup)
+//   the others:            d emb_con[a][h] = ((con - abn)[a][h] kcol[h]) g,  d emb_abnormal = -d emb_con                (4 rows per workgroup)
+__global__ void __launch_bounds__(256) k_loss_bwd_fused(const float *__restrict__ g_total, const float *__restrict__ g_aff,
+                                                        const float *__restrict__ r_inv_j, const float *__restrict__ d_logits,
+                                                        const float *__restrict__ en, const int32_t *__restrict__ J, int L, int W,
+                                                        const float *__restrict__ emb_con, const float *__restrict__ emb_abn,
+                                                        const float *__restrict__ kcol, int A, int nb_l, float *__restrict__ c,
+                                                        float *__restrict__ dl, float *__restrict__ xc, float *__restrict__ d_con,
+                                                        float *__restrict__ d_abn) {
+  const int lane = lane_id(), wid = threadIdx.x >> 6;
+  const float g = g_total[0];
+  if ((int)blockIdx.x < nb_l) {
+    const int p = blockIdx.x * 4 + wid;
+    if (p >= L) return;
+    const float cf = (g_aff[p] * r_inv_j[p]) * g;
+    if (lane == 0) { c[p] = cf; dl[p] = d_logits[p] * g; }
+    const float *x = en + (int64_t)J[p] * W;
+    for (int col = lane; col < W; col += 64) xc[(int64_t)p * W + col] = cf * x[col];
+  } else {
+    const int a = (blockIdx.x - nb_l) * 4 + wid;
+    if (a >= A) return;
+    const int64_t o = (int64_t)a * W;
+    for (int h = lane; h < W; h += 64) {
+      const float v = ((emb_con[o + h] - emb_abn[o + h]) * kcol[h]) * g;
+      d_con[o + h] = v;
+      d_abn[o + h] = -v;
+    }
+  }
+}
+
+// k_rownorm_bwd with the scatter-add of c_j S_j onto the rows J folded in: pos_n[r] / pos_a[r] = position of row r in the normal /
+// abnormal segment of J or -1 (each segment is duplicate-free; a node in both gets both terms, normal first -- the order of the two
+// k_rows_scale launches this replaces):  dXn_r = den_r (+ c[q] S[q]) ...;  dX_r = inv_r (dXn_r - Xn_r <Xn_r, dXn_r>)
+__global__ void __launch_bounds__(256) k_rownorm_bwd_add(const float *__restrict__ Xn, const float *__restrict__ inv,
+                                                         const float *__restrict__ den, const int32_t *__restrict__ pos_n,
+                                                         const int32_t *__restrict__ pos_a, const float *__restrict__ c,
+                                                         const float *__restrict__ S, int M, int W, float *__restrict__ dX) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= M) return;
+  const int lane = lane_id();
+  const float *xn = Xn + (int64_t)r * W, *d = den + (int64_t)r * W;
+  const int qn = pos_n[r], qa = pos_a[r];
+  const float cn = qn >= 0 ? c[qn] : 0.f, ca = qa >= 0 ? c[qa] : 0.f;
+  const float *sn = S + (int64_t)(qn >= 0 ? qn : 0) * W, *sa = S + (int64_t)(qa >= 0 ? qa : 0) * W;
+  float dot = 0.f;
+  for (int col = lane; col < W; col += 64) {
+    float v = d[col];
+    if (qn >= 0) v = fmaf(cn, sn[col], v);
+    if (qa >= 0) v = fmaf(ca, sa[col], v);
+    dot = fmaf(xn[col], v, dot);
+  }
+  dot = wave_sum(dot);
+  const float iv = inv[r];
+  for (int col = lane; col < W; col += 64) {
+    float v = d[col];
+    if (qn >= 0) v = fmaf(cn, sn[col], v);
+    if (qa >= 0) v = fmaf(ca, sa[col], v);
+    dX[(int64_t)r * W + col] = iv * (v - xn[col] * dot);
+  }
+}
+
 // torch.optim.Adam.step on a flat fp32 block (betas .9/.999, eps 1e-8, L2 weight decay), step index on device
 __global__ void __launch_bounds__(256) k_adam_flat(float *__restrict__ p, float *__restrict__ m, float *__restrict__ v,
                                                    const float *__restrict__ g, int64_t n, float lr, float wd,
@@ -1815,6 +1966,47 @@ int ggad_full_loss_bwd_scale_f32(const float *g_total, const float *g_aff, const
   k_loss_bwd_scale<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream)>>>(g_total, g_aff, r_inv_j, d_logits, dD, L, n_rec,
                                                                                          c, dl, d_con, d_abn);
   GGAD_CHECK_LAUNCH("full_loss_bwd_scale_f32");
+  return GGAD_OK;
+}
+
+/* round 6: the loss block of run.py:165-210 behind ONE forward and ONE backward launch for its row-local parts (the two products with R
+ * stay launches of their own).  ggad_full_loss_fused_workspace_elems floats of `workspace` + one zero-initialised int32 `ticket` (the
+ * kernel leaves it zero).  Outputs of the forward: aff[L], kcol[H], losses4 = {total, margin, bce, rec}, d_logits[L], g_aff[L]. */
+int64_t ggad_full_loss_fused_workspace_elems(int32_t n_out, int32_t H) { return (int64_t)((n_out + REC_ROWS - 1) / REC_ROWS) * H; }
+
+int ggad_full_loss_fused_f32(const float *e_hat, const int32_t *J, const float *S, const float *r_inv_j, int32_t n_normal, int32_t n_out,
+                             int32_t H, const float *logits, const float *emb_con, const float *emb_abn, float margin, float *aff,
+                             float *kcol, float *losses4, float *d_logits, float *g_aff, float *workspace, int32_t *ticket,
+                             ggad_stream_t stream) {
+  GGAD_REQUIRE(e_hat && J && S && r_inv_j && logits && emb_con && emb_abn && aff && kcol && losses4 && d_logits && g_aff && workspace && ticket);
+  GGAD_REQUIRE(n_normal >= 1 && n_out >= 1 && H >= 1);
+  const int L = n_normal + n_out;
+  const int nb_dot = (L + LD_ROWS - 1) / LD_ROWS, nb_rec = (n_out + REC_ROWS - 1) / REC_ROWS;
+  k_loss_fwd_fused<<<dim3(nb_dot + nb_rec), dim3(256), 0, as_stream(stream)>>>(e_hat, J, S, r_inv_j, L, H, logits, n_normal, n_out, emb_con,
+                                                                              emb_abn, margin, nb_dot, nb_rec, aff, workspace, kcol,
+                                                                              losses4, d_logits, g_aff, ticket);
+  GGAD_CHECK_LAUNCH("full_loss_fused_f32");
+  return GGAD_OK;
+}
+
+int ggad_full_loss_bwd_fused_f32(const float *g_total, const float *g_aff, const float *r_inv_j, const float *d_logits, const float *e_hat,
+                                 const int32_t *J, int32_t L, int32_t H, const float *emb_con, const float *emb_abn, const float *kcol,
+                                 int32_t n_out, float *c, float *dl, float *xc, float *d_con, float *d_abn, ggad_stream_t stream) {
+  GGAD_REQUIRE(g_total && g_aff && r_inv_j && d_logits && e_hat && J && emb_con && emb_abn && kcol && c && dl && xc && d_con && d_abn);
+  GGAD_REQUIRE(L >= 1 && H >= 1 && n_out >= 1);
+  const int nb_l = (L + 3) / 4, nb_a = (n_out + 3) / 4;
+  k_loss_bwd_fused<<<dim3(nb_l + nb_a), dim3(256), 0, as_stream(stream)>>>(g_total, g_aff, r_inv_j, d_logits, e_hat, J, L, H, emb_con, emb_abn,
+                                                                          kcol, n_out, nb_l, c, dl, xc, d_con, d_abn);
+  GGAD_CHECK_LAUNCH("full_loss_bwd_fused_f32");
+  return GGAD_OK;
+}
+
+int ggad_rownorm_bwd_add_f32(const float *Xn, const float *inv, const float *dXn, const int32_t *pos_n, const int32_t *pos_a,
+                             const float *c, const float *S, int32_t M, int32_t W, float *dX, ggad_stream_t stream) {
+  GGAD_REQUIRE(Xn && inv && dXn && pos_n && pos_a && c && S && dX && M >= 0 && W >= 1);
+  if (M == 0) return GGAD_OK;
+  k_rownorm_bwd_add<<<dim3((M + 3) / 4), dim3(256), 0, as_stream(stream)>>>(Xn, inv, dXn, pos_n, pos_a, c, S, M, W, dX);
+  GGAD_CHECK_LAUNCH("rownorm_bwd_add_f32");
   return GGAD_OK;
 }
 

@@ -41,7 +41,7 @@ extern "C" int ggad_device_cu_count(int32_t device, int32_t *out) {
 
 extern "C" {
 
-int ggad_abi_version(void) { return 9; }      // 9: ggad_linear_prelu_f32, GGAD_E_UNSUPPORTED; 8: ggad_mb_tile_major, ggad_mb_plan.tile_start / col_t; 7: ggad_mlp_score_wgrad_*; 6: ggad_spmm_rowline_*, ggad_prelu_bwd_ld_f32, ggad_mb_plan.node_pack_host  (5: ggad_spmm_ring_*; exports ggad_* only)
+int ggad_abi_version(void) { return 10; }      // 10: ggad_full_loss_fused_*, ggad_rownorm_bwd_add_f32, ggad_prelu_bwd_one_f32; 9: ggad_linear_prelu_f32, GGAD_E_UNSUPPORTED; 8: ggad_mb_tile_major, ggad_mb_plan.tile_start / col_t; 7: ggad_mlp_score_wgrad_*; 6: ggad_spmm_rowline_*, ggad_prelu_bwd_ld_f32, ggad_mb_plan.node_pack_host  (5: ggad_spmm_ring_*; exports ggad_* only)
 const char *ggad_last_error(void) { return g_last_error.c_str(); }
 
 }  // extern "C"

@@ -620,9 +620,19 @@ class FullGraphAdj:
         if s is None:
             J = np.asarray(key[0] + key[1], dtype=np.int64)
             sub = self.Rt.host[J, :]                            # |J| x N : rows of R^T
+            # position of every row in the normal / abnormal segment of J (-1: not there): the backward adds c_j S_j to the rows J inside
+            # the row-normalisation's backward launch (round 6) instead of a scatter launch per segment
+            n_rows = self.Rt.host.shape[1]
+            pos_n = np.full(n_rows, -1, dtype=np.int32)
+            pos_a = np.full(n_rows, -1, dtype=np.int32)
+            nn_ = len(key[0])
+            pos_n[J[:nn_]] = np.arange(nn_, dtype=np.int32)
+            pos_a[J[nn_:]] = np.arange(nn_, len(J), dtype=np.int32)
+            seg_unique = len(np.unique(J[:nn_])) == nn_ and len(np.unique(J[nn_:])) == len(J) - nn_
             s = dict(J=_dev_i32(J, self.dev), n_normal=len(key[0]), n_out=len(key[1]), distinct=bool(len(np.unique(J)) == len(J)),
                      r_inv_J=_dev_f32(self.r_inv_host[J], self.dev), RJ=Csr(sub.T.tocsr(), self.dev),
-                     Rt_plan=self.Rt.plan(J, key=("rows", key)))
+                     Rt_plan=self.Rt.plan(J, key=("rows", key)), pos_n=_dev_i32(pos_n, self.dev), pos_a=_dev_i32(pos_a, self.dev),
+                     seg_unique=bool(seg_unique))
             self._loss[key] = s
         return s
 
@@ -1124,6 +1134,10 @@ class GgadHeadFn(torch.autograd.Function):
         return g_emb, None, dw4, dw1, dw2, dw3, None, None
 
 
+# GGAD_LOSS_FUSED=0: the round-5 launch sequence of the loss block (A/B measurements; the tests run both)
+_LOSS_FUSED = os.environ.get("GGAD_LOSS_FUSED", "1") != "0"
+
+
 class GgadLossFn(torch.autograd.Function):
     """(total, margin, bce, rec) of `run.py:165-210`; only `total` is differentiable."""
 
@@ -1139,34 +1153,63 @@ class GgadLossFn(torch.autograd.Function):
         J, L = ls["J"], int(ls["J"].numel())
         s_j = spmm(adj.Rt, en, plan=ls["Rt_plan"])                                        # (R^T e_hat)[J]
         aff = torch.empty(L, dtype=torch.float32, device=dev)
-        call("ggad_rowdot_f32", ptr(en), ptr(J), ptr(s_j), L, h, ptr(ls["r_inv_J"]), ptr(aff))   # run.py:182-188
         losses = torch.empty(4, dtype=torch.float32, device=dev)
         d_logits = torch.empty(L, dtype=torch.float32, device=dev)
         g_aff = torch.empty(L, dtype=torch.float32, device=dev)
         emb_con, emb_abn, logits = emb_con.contiguous(), emb_abn.contiguous(), logits.contiguous()
-        dD = torch.empty_like(emb_con)
-        ws = ls.get("loss_ws")
-        if ws is None:
-            ws = ls["loss_ws"] = torch.empty(int(_lib.load().ggad_full_loss_workspace_elems(ls["n_out"], h)), dtype=torch.float32,
-                                             device=dev)
-        call("ggad_full_loss_f32", ptr(logits), ptr(aff), ls["n_normal"], ls["n_out"], ptr(emb_con), ptr(emb_abn), h,
-             float(margin), ptr(losses), ptr(d_logits), ptr(g_aff), ptr(dD), ptr(ws))
-        ctx.save_for_backward(en, inv, s_j, g_aff, d_logits, dD)
+        fused = _LOSS_FUSED and ls.get("seg_unique", False)
+        ctx.fused = fused
+        if fused:
+            # round 6: row dots, recon partials and -- in the last workgroup to finish -- BCE / margin / recon / coefficients: ONE launch
+            ws = ls.get("loss_ws_fused")
+            if ws is None:
+                ws = ls["loss_ws_fused"] = (torch.empty(int(_lib.load().ggad_full_loss_fused_workspace_elems(ls["n_out"], h)),
+                                                        dtype=torch.float32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev))
+            kcol = torch.empty(h, dtype=torch.float32, device=dev)
+            call("ggad_full_loss_fused_f32", ptr(en), ptr(J), ptr(s_j), ptr(ls["r_inv_J"]), ls["n_normal"], ls["n_out"], h, ptr(logits),
+                 ptr(emb_con), ptr(emb_abn), float(margin), ptr(aff), ptr(kcol), ptr(losses), ptr(d_logits), ptr(g_aff), ptr(ws[0]), ptr(ws[1]))
+            ctx.save_for_backward(en, inv, s_j, g_aff, d_logits, kcol, emb_con, emb_abn)
+        else:
+            call("ggad_rowdot_f32", ptr(en), ptr(J), ptr(s_j), L, h, ptr(ls["r_inv_J"]), ptr(aff))   # run.py:182-188
+            dD = torch.empty_like(emb_con)
+            ws = ls.get("loss_ws")
+            if ws is None:
+                ws = ls["loss_ws"] = torch.empty(int(_lib.load().ggad_full_loss_workspace_elems(ls["n_out"], h)), dtype=torch.float32,
+                                                 device=dev)
+            call("ggad_full_loss_f32", ptr(logits), ptr(aff), ls["n_normal"], ls["n_out"], ptr(emb_con), ptr(emb_abn), h,
+                 float(margin), ptr(losses), ptr(d_logits), ptr(g_aff), ptr(dD), ptr(ws))
+            ctx.save_for_backward(en, inv, s_j, g_aff, d_logits, dD)
         ctx.adj, ctx.ls = adj, ls
         ctx.affinity = aff
         return losses[0], losses[1], losses[2], losses[3]
 
     @staticmethod
     def backward(ctx, g_total, g_margin, g_bce, g_rec):
-        en, inv, s_j, g_aff, d_logits, dD = ctx.saved_tensors
         adj, ls = ctx.adj, ctx.ls
-        n, h = en.shape
         J, L, nn_ = ls["J"], int(ls["J"].numel()), ls["n_normal"]
         if g_total is None:
             return None, None, None, None, None, None, None
+        if g_total.dtype != torch.float32:
+            g_total = g_total.to(torch.float32)
+        g_total = g_total.reshape(1)
+        if ctx.fused:
+            en, inv, s_j, g_aff, d_logits, kcol, emb_con, emb_abn = ctx.saved_tensors
+            n, h = en.shape
+            c, dl = torch.empty_like(g_aff), torch.empty_like(d_logits)                   # c = d total / d (e_hat_j . S_j)
+            d_con, d_abn = torch.empty_like(emb_con), torch.empty_like(emb_con)
+            xc = torch.empty(L, h, dtype=torch.float32, device=en.device)                 # c_j e_hat_j
+            call("ggad_full_loss_bwd_fused_f32", ptr(g_total), ptr(g_aff), ptr(ls["r_inv_J"]), ptr(d_logits), ptr(en), ptr(J), L, h,
+                 ptr(emb_con), ptr(emb_abn), ptr(kcol), ls["n_out"], ptr(c), ptr(dl), ptr(xc), ptr(d_con), ptr(d_abn))
+            den = spmm(ls["RJ"], xc)                                                      # sum_j R_ij c_j e_hat_j
+            d_emb = torch.empty_like(en)
+            call("ggad_rownorm_bwd_add_f32", ptr(en), ptr(inv), ptr(den), ptr(ls["pos_n"]), ptr(ls["pos_a"]), ptr(c), ptr(s_j), n, h,
+                 ptr(d_emb))                                                              # + c_j S_j on the rows J, then the normalisation's VJP
+            return d_emb, dl, d_con, d_abn, None, None, None
+        en, inv, s_j, g_aff, d_logits, dD = ctx.saved_tensors
+        n, h = en.shape
         c, dl = torch.empty_like(g_aff), torch.empty_like(d_logits)                       # c = d total / d (e_hat_j . S_j)
         d_con, d_abn = torch.empty_like(dD), torch.empty_like(dD)
-        g_total = g_total.to(torch.float32).reshape(1).contiguous()
+        g_total = g_total.contiguous()
         call("ggad_full_loss_bwd_scale_f32", ptr(g_total), ptr(g_aff), ptr(ls["r_inv_J"]), ptr(d_logits), ptr(dD), L, dD.numel(),
              ptr(c), ptr(dl), ptr(d_con), ptr(d_abn))
         xc = torch.empty(L, h, dtype=torch.float32, device=en.device)

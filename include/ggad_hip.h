@@ -632,6 +632,23 @@ int ggad_full_loss_f32(const float *logits, const float *aff, int32_t n_normal, 
 int ggad_full_loss_bwd_scale_f32(const float *g_total, const float *g_aff, const float *r_inv_j, const float *d_logits, const float *dD,
                                  int32_t L, int64_t n_rec, float *c, float *dl, float *d_con, float *d_abn, ggad_stream_t stream);
 
+/* Round 6 (ABI 10): the same loss block (run.py:165-210, reference file /root/reference/run.py) with its row-local parts fused --
+ * forward: affinity row dots r_inv_J <e_hat[J], S>, the partial column sums of the recon term and, in the last workgroup to finish, BCE,
+ * margin, recon, the four loss values and the coefficients (replaces ggad_rowdot_f32 + ggad_full_loss_f32: four launches);
+ * backward: c, d logits, xc = c e_hat[J], d emb_con = g (con - abn) kcol, d emb_abnormal = -that (replaces ggad_full_loss_bwd_scale_f32 +
+ * ggad_rows_scale_f32);  ggad_rownorm_bwd_add_f32 = ggad_rownorm_bwd_f32 with dXn[r] += c[q] S[q] for r = J[q] folded in (pos_n / pos_a:
+ * position of row r in the normal / abnormal segment of J, or -1).  `ticket`: one int32, zero before the first call (left zero). */
+int64_t ggad_full_loss_fused_workspace_elems(int32_t n_out, int32_t H);
+int ggad_full_loss_fused_f32(const float *e_hat, const int32_t *J, const float *S, const float *r_inv_j, int32_t n_normal, int32_t n_out,
+                             int32_t H, const float *logits, const float *emb_con, const float *emb_abn, float margin, float *aff,
+                             float *kcol, float *losses4, float *d_logits, float *g_aff, float *workspace, int32_t *ticket,
+                             ggad_stream_t stream);
+int ggad_full_loss_bwd_fused_f32(const float *g_total, const float *g_aff, const float *r_inv_j, const float *d_logits, const float *e_hat,
+                                 const int32_t *J, int32_t L, int32_t H, const float *emb_con, const float *emb_abn, const float *kcol,
+                                 int32_t n_out, float *c, float *dl, float *xc, float *d_con, float *d_abn, ggad_stream_t stream);
+int ggad_rownorm_bwd_add_f32(const float *Xn, const float *inv, const float *dXn, const int32_t *pos_n, const int32_t *pos_a,
+                             const float *c, const float *S, int32_t M, int32_t W, float *dX, ggad_stream_t stream);
+
 /* torch.optim.Adam.step on a flat fp32 block; uses step index *step_counter + 1 and (bump_after != 0) advances it. */
 int ggad_adam_f32(float *params, float *exp_avg, float *exp_avg_sq, const float *grads, int64_t n, float lr,
                   float weight_decay, int32_t *step_counter, int32_t bump_after, ggad_stream_t stream);

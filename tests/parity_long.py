@@ -17,7 +17,7 @@ from ggad_amd import synth
 
 def _planted(g):
     """The synth.plant_anomalies keywords a fixture was generated with (empty: labels independent of everything, the round-5 fixtures)."""
-    out = {k[len("planted."):]: float(g[k]) for k in g.files if k.startswith("planted.")}
+    out = {k[len("planted."):]: float(g[k]) for k in g.keys() if k.startswith("planted.")}
     if "max_degree" in out:
         out["max_degree"] = int(out["max_degree"])
     return out
@@ -42,7 +42,7 @@ def full_graph_long(dev="cuda:0", no_graph=False, fixture="fullgraph_long_photo_
     assert synth.crc_of(rowptr, col, feat, ano) == int(g["inputs_crc"])
     adj = synth.csr_to_scipy(rowptr, col, n)
     # (run.py:87-88: features are row-normalised for Amazon / reddit / elliptic only -- the planted fixture keeps them raw like photo)
-    features = U.preprocess_features(sp.lil_matrix(feat)) if ("normalise" not in g.files or int(g["normalise"])) else feat
+    features = U.preprocess_features(sp.lil_matrix(feat)) if ("normalise" not in g or int(g["normalise"])) else feat
     dev = torch.device(dev)
     torch.cuda.set_device(dev)
     full = FullGraphAdj(U.normalize_adj(adj) + sp.eye(n), adj + sp.eye(n), dev)
@@ -111,7 +111,7 @@ def handler_long(tmp_dir, dev_id=0, fixture="handler_dgraph_like_5ep.npz"):
                 test_metrics=(np.array(res, dtype=np.float64).tolist(), g["metrics"].tolist()),
                 test_auc_delta=abs(float(res[3]) - float(g["metrics"][3])),
                 sweep_auc=(sweeps[:, 3].tolist(), g["sweeps"][:, 3].tolist()),
-                sweep_ap=((list(h.sweep_ap), g["sweep_ap"].tolist()) if "sweep_ap" in g.files else None),
-                sweep_ap_delta_max=(float(np.abs(np.array(h.sweep_ap, dtype=np.float64) - g["sweep_ap"]).max()) if "sweep_ap" in g.files else None),
+                sweep_ap=((list(h.sweep_ap), g["sweep_ap"].tolist()) if "sweep_ap" in g else None),
+                sweep_ap_delta_max=(float(np.abs(np.array(h.sweep_ap, dtype=np.float64) - g["sweep_ap"]).max()) if "sweep_ap" in g else None),
                 end_weight_delta_max=max(end.values()), best_weight_delta_max=max(best.values()),
                 valid_epochs=[e for e, _ in h.valid_history])

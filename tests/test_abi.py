@@ -22,7 +22,7 @@ def test_library_builds_and_loads():
     path = build(verbose=False)
     assert os.path.exists(path)
     lib = _lib.load()
-    assert lib.ggad_abi_version() == _lib.ABI_VERSION == 9
+    assert lib.ggad_abi_version() == _lib.ABI_VERSION == 10
 
 
 def test_only_the_c_abi_is_exported():

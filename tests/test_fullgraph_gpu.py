@@ -95,9 +95,11 @@ def test_preprocessing_matches_reference(name):
 
 @pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("name", ["fullgraph_reddit_like.npz", "fullgraph_amazon_like.npz"])
-def test_model_forward_loss_backward_trajectory(name, fused):
+def test_model_forward_loss_backward_trajectory(name, fused, monkeypatch):
     """The reference's own tensors, losses, gradients and weights (tests/golden/make_golden.py) -- with the head of the forward as
-    one autograd node (`GgadHeadFn`, the default) and op by op."""
+    one autograd node (`GgadHeadFn`, the default) and the loss block's row-local parts in one launch each way (round 6), and op by op
+    with the round-5 launch sequence of the loss block."""
+    monkeypatch.setattr(FG, "_LOSS_FUSED", bool(fused))
     g = load_golden(name)
     fa = _adj(g)
     f, h = int(g["f"]), int(g["n_h"])
@@ -151,6 +153,46 @@ def test_model_forward_loss_backward_trajectory(name, fused):
     yt = g["ano"][g["idx_test"]]
     assert abs(roc_auc_score(yt, le[g["idx_test"]]) - float(g["eval_auc"])) < 1e-4
     assert abs(average_precision_score(yt, le[g["idx_test"]]) - float(g["eval_ap"])) < 1e-4
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+@pytest.mark.parametrize("n,nn_,na,h", [(3000, 700, 90, 300), (500, 61, 7, 64), (12000, 1592, 238, 300)])
+def test_fused_loss_block_equals_the_launch_sequence(n, nn_, na, h, overlap, monkeypatch):
+    """Round 6: `ggad_full_loss_fused_f32` / `ggad_full_loss_bwd_fused_f32` / `ggad_rownorm_bwd_add_f32` (run.py:165-210 in three + three
+    launches) against the round-5 sequence of six + six on the same inputs: the four loss values (the last workgroup sums 256-wide, the
+    old kernel 1024-wide: 1e-6), the affinity and every gradient (same operations per element: 1e-6 of the scale); with `overlap` a node
+    sits in BOTH index lists (both c_j S_j terms reach its row, normal first); repeated calls are bit-identical (the ticket returns to 0)."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(n + na)
+    a = sp.random(n, n, density=8.0 / n, random_state=3, format="csr", dtype=np.float64)
+    a.data[:] = 1.0
+    a = ((a + a.T) > 0).astype(np.float64)
+    fa = FG.FullGraphAdj(U.normalize_adj(a) + sp.eye(n), a + sp.eye(n), DEV)
+    perm = rng.permutation(n)
+    nrm, abn = perm[:nn_].tolist(), perm[nn_:nn_ + na].tolist()
+    if overlap:
+        abn[0] = nrm[3]
+    ls = fa.loss_structs(nrm, abn)
+    assert ls["seg_unique"] and ls["distinct"] == (not overlap)
+    emb0 = torch.randn(n, h, device=DEV)
+    emb0[5] = 0.0                                              # a zero row: 1 / |e| = inf -> 0 (run.py:179)
+    logits0 = torch.randn(nn_ + na, device=DEV)
+    con0, abn0 = torch.randn(na, h, device=DEV), torch.randn(na, h, device=DEV)
+
+    def run(flag):
+        monkeypatch.setattr(FG, "_LOSS_FUSED", flag)
+        ins = [t.clone().requires_grad_() for t in (emb0, logits0, con0, abn0)]
+        out = FG.GgadLossFn.apply(ins[0], ins[1], ins[2], ins[3], fa, ls, 0.7)
+        out[0].backward(gradient=torch.full((), 1.7, device=DEV))
+        return [o.item() for o in out], [t.grad.clone() for t in ins]
+    l_new, g_new = run(True)
+    l_old, g_old = run(False)
+    np.testing.assert_allclose(l_new, l_old, rtol=2e-6, atol=2e-6)
+    for a_, b_ in zip(g_new, g_old):
+        scale = float(b_.abs().max())
+        assert float((a_ - b_).abs().max()) <= 2e-6 * max(scale, 1e-3)
+    l_again, g_again = run(True)
+    assert l_again == l_new and all(torch.equal(x, y) for x, y in zip(g_again, g_new))
 
 
 def test_gcn_layer_accepts_dense_adjacency_like_the_reference(g_full_reddit):
