@@ -160,7 +160,7 @@ SIGNATURES = {
     "ggad_full_loss_f32": (c_int32, [_P, _P, _I, _I, _P, _P, _I, _F, _P, _P, _P, _P, _P, _P]),
     "ggad_adam_f32": (c_int32, [_P, _P, _P, _P, _L, _F, _F, _P, _I, _P]),
     "ggad_adam_multi_max": (c_int32, []),
-    "ggad_adam_multi_f32": (c_int32, [_I, _P, _P, _P, _P, _P, _P, _F, _F, _P]),
+    "ggad_adam_multi_f32": (c_int32, [_I, _P, _P, _P, _P, _P, _P, _F, _F, _P, _P]),
     "ggad_mt_new": (c_void_p, []),
     "ggad_mt_free": (None, [c_void_p]),
     "ggad_mt_seed_u64": (c_int32, [c_void_p, c_uint64]),

@@ -344,8 +344,13 @@ __device__ __forceinline__ void rl_walk_item(const char *__restrict__ Xb, uint32
 __device__ unsigned long long g_rl_prof[4 * 8192];          // per workgroup: start, hub rows done, end (wall_clock64, 100 MHz), items walked
 #endif
 
+#ifdef GGAD_RL_WAVES                     // (occupancy experiments: -DGGAD_RL_WAVES=6 asks the compiler for <= 80 VGPRs)
+#define RL_OCC __attribute__((amdgpu_waves_per_eu(GGAD_RL_WAVES, GGAD_RL_WAVES)))
+#else
+#define RL_OCC
+#endif
 template <int NW>
-__global__ void __launch_bounds__(NW * 64) k_spmm_rowline(const int2 *__restrict__ ent, const int4 *__restrict__ unit_tab, int n_units,
+__global__ void __launch_bounds__(NW * 64) RL_OCC k_spmm_rowline(const int2 *__restrict__ ent, const int4 *__restrict__ unit_tab, int n_units,
                                                           const int4 *__restrict__ long_tab, int n_long,
                                                           const int4 *__restrict__ hub_tab, int n_hub, int n_lines,
                                                           const float *__restrict__ X, int64_t ldx, int W,
@@ -401,8 +406,12 @@ __global__ void __launch_bounds__(NW * 64) k_spmm_rowline(const int2 *__restrict
       const int4 m = hub_tab[h];
       const int vi = slice * RL_G + q, vic = vi < nv ? vi : 0;
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      const int step = NW * RL_G;
-      for (int e0 = m.x + wid * RL_G + g; e0 < m.y; e0 += step * RL_G * RL_R) {      // (the whole wave leaves together: e0 differs by < step)
+      const int step = NW * RL_G, pass = step * RL_G * RL_R;
+      // round 6: the loop runs on the WAVE's first entry (uniform: a lane group past the end walks padded pairs -- value 0 -- instead of
+      // leaving on its own, so the readlane of rl_walk_item's n_max never meets an inactive lane: ADVICE r5).  (Requesting the pairs of
+      // pass p + 1 before pass p is walked was tried here: 8 more VGPRs -> 106, four waves per SIMD instead of five, the launch 5 % slower.)
+      for (int eb = m.x + wid * RL_G; eb < m.y; eb += pass) {
+        const int e0 = eb + g;
         int2 ph[RL_R];
 #pragma unroll
         for (int rr = 0; rr < RL_R; ++rr) ph[rr] = rl_pair(ent, e0 + rr * RL_G * step, step, m.y, q);
@@ -1407,23 +1416,25 @@ __global__ void __launch_bounds__(256) k_rec_apply(const float *__restrict__ emb
 // k_full_loss and the column-norm half of k_rec_apply did: BCE and d_logits, the margin and g_aff, the column norms -> rec and
 // kcol[h] = 1 / (H |D[:, h]|), the four loss values.  dD itself (A x H) is NOT formed here by one workgroup: the backward launch forms
 // d emb_con = g D kcol over all its workgroups.  The ticket counter is put back to zero by the last workgroup (graph replays).
-constexpr int LD_ROWS = 16;      // rows of the affinity per workgroup: 4 per wave (L = 1.3-6.5 K rows -> 80-400 tickets of ~7 ns each)
-__global__ void __launch_bounds__(256) k_loss_fwd_fused(const float *__restrict__ en, const int32_t *__restrict__ J,
-                                                        const float *__restrict__ S, const float *__restrict__ r_inv_j, int L, int W,
-                                                        const float *__restrict__ logits, int Nn, int A,
-                                                        const float *__restrict__ emb_con, const float *__restrict__ emb_abn,
-                                                        float margin_c, int nb_dot, int nb_rec, float *__restrict__ aff,
-                                                        float *__restrict__ ws, float *__restrict__ kcol, float *__restrict__ losses4,
-                                                        float *__restrict__ d_logits, float *__restrict__ g_aff,
-                                                        int32_t *__restrict__ ticket) {
-  __shared__ float red[4];
+constexpr int LD_ROWS = 16;      // rows of the affinity per workgroup: one per wave (L = 1.3-6.5 K rows -> 80-400 tickets of ~7 ns each)
+constexpr int LF_T = 1024;       // threads per workgroup: the LAST workgroup's serial part is a chain of memory round trips per thread --
+                                 // the first version (256 threads, one load per loop trip) took 28 us at Reddit size, as long as the four
+                                 // launches it replaced; here every thread has all its loads in flight at once
+__global__ void __launch_bounds__(LF_T) k_loss_fwd_fused(const float *__restrict__ en, const int32_t *__restrict__ J,
+                                                         const float *__restrict__ S, const float *__restrict__ r_inv_j, int L, int W,
+                                                         const float *__restrict__ logits, int Nn, int A,
+                                                         const float *__restrict__ emb_con, const float *__restrict__ emb_abn,
+                                                         float margin_c, int nb_dot, int nb_part, float *__restrict__ aff,
+                                                         float *__restrict__ ws, float *__restrict__ kcol, float *__restrict__ losses4,
+                                                         float *__restrict__ d_logits, float *__restrict__ g_aff,
+                                                         int32_t *__restrict__ ticket) {
+  __shared__ float red[16];
+  __shared__ float qb[LF_T];
   __shared__ int last;
   const int lane = lane_id(), wid = threadIdx.x >> 6;
   if ((int)blockIdx.x < nb_dot) {
-#pragma unroll
-    for (int k = 0; k < LD_ROWS / 4; ++k) {
-      const int p = blockIdx.x * LD_ROWS + wid * (LD_ROWS / 4) + k;
-      if (p >= L) break;
+    const int p = blockIdx.x * LD_ROWS + wid;
+    if (p < L) {
       const float *a = en + (int64_t)J[p] * W, *b = S + (int64_t)p * W;
       float dot = 0.f;
       for (int c = lane; c < W; c += 64) dot = fmaf(a[c], b[c], dot);
@@ -1431,13 +1442,16 @@ __global__ void __launch_bounds__(256) k_loss_fwd_fused(const float *__restrict_
       if (lane == 0) aff[p] = r_inv_j[p] * dot;
     }
   } else {
-    const int rb = blockIdx.x - nb_dot;
-    const int a0 = rb * REC_ROWS, a1 = min(A, a0 + REC_ROWS);
-    for (int h = threadIdx.x; h < W; h += 256) {
-      float ss = 0.f;
+    // four partial rows (REC_ROWS rows of D each) per workgroup: thread group tid >> 8 takes one, its 256 threads the columns
+    const int part = ((int)blockIdx.x - nb_dot) * 4 + (threadIdx.x >> 8);
+    if (part < nb_part) {
+      const int a0 = part * REC_ROWS, a1 = min(A, a0 + REC_ROWS);
+      for (int h = threadIdx.x & 255; h < W; h += 256) {
+        float ss = 0.f;
 #pragma unroll 8
-      for (int a = a0; a < a1; ++a) { const float d = emb_con[(int64_t)a * W + h] - emb_abn[(int64_t)a * W + h]; ss = fmaf(d, d, ss); }
-      ws[(int64_t)rb * W + h] = ss;
+        for (int a = a0; a < a1; ++a) { const float d = emb_con[(int64_t)a * W + h] - emb_abn[(int64_t)a * W + h]; ss = fmaf(d, d, ss); }
+        ws[(int64_t)part * W + h] = ss;
+      }
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // this workgroup's aff / ws stores reach memory before its ticket
@@ -1447,36 +1461,69 @@ __global__ void __launch_bounds__(256) k_loss_fwd_fused(const float *__restrict_
   if (!last) return;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // ... and everyone else's are read from memory, not from a stale line
   if (threadIdx.x == 0) *ticket = 0;
-  auto block_sum = [&](float v) {
+  auto block_sum = [&](float v) {                             // 16 waves, added in wave order
     v = wave_sum(v);
     __syncthreads();
     if (lane == 0) red[wid] = v;
     __syncthreads();
-    return (red[0] + red[1]) + (red[2] + red[3]);
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k];
+    return t;
   };
+  // BCE, d_logits, the two affinity means: elements tid, tid + 1024, ...; eight of them per trip, their 16 loads issued before the first use
   float s_bce = 0.f, s_n = 0.f, s_a = 0.f;
-  for (int i = threadIdx.x; i < L; i += 256) {
-    const float x = logits[i];
-    const float y = i < Nn ? 0.f : 1.f;
-    s_bce += (1.0f - y) * x - (fminf(x, 0.f) - log1pf(expf(-fabsf(x))));      // BCEWithLogits, pos_weight 1
-    d_logits[i] = (1.0f / (1.0f + expf(-x)) - y) / (float)L;
-    const float av = __builtin_nontemporal_load(aff + i);
-    if (i < Nn) s_n += av; else s_a += av;
+  for (int i0 = threadIdx.x; i0 < L; i0 += 8 * LF_T) {
+    float xv[8], av[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = i0 + k * LF_T;
+      xv[k] = i < L ? logits[i] : 0.f;
+      av[k] = i < L ? aff[i] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = i0 + k * LF_T;
+      if (i < L) {
+        const float x = xv[k];
+        const float y = i < Nn ? 0.f : 1.f;
+        s_bce += (1.0f - y) * x - (fminf(x, 0.f) - log1pf(expf(-fabsf(x))));      // BCEWithLogits, pos_weight 1
+        d_logits[i] = (1.0f / (1.0f + expf(-x)) - y) / (float)L;
+        if (i < Nn) s_n += av[k]; else s_a += av[k];
+      }
+    }
   }
-  const float bce = block_sum(s_bce) / (float)L;
+  // column norms of D from the partial rows: G thread groups of Wp threads, group gi sums its share of the partial rows of column c
+  // (eight loads in flight), the groups are added in order
+  const int Wp = (W + 63) & ~63, G = LF_T / Wp;
+  const int gi = threadIdx.x / Wp, c = threadIdx.x - gi * Wp;
+  float part_sum = 0.f;
+  if (gi < G && c < W) {
+    const int b_lo = (int)((int64_t)nb_part * gi / G), b_hi = (int)((int64_t)nb_part * (gi + 1) / G);
+    int b = b_lo;
+    for (; b + 8 <= b_hi; b += 8) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = ws[(int64_t)(b + k) * W + c];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) part_sum += v[k];
+    }
+    for (; b < b_hi; ++b) part_sum += ws[(int64_t)b * W + c];
+  }
+  qb[threadIdx.x] = part_sum;
+  const float bce = block_sum(s_bce) / (float)L;              // (its barriers also publish qb)
   const float an = block_sum(s_n) / (float)Nn;
   const float ab = block_sum(s_a) / (float)A;
   const float m = margin_c - (an - ab);
   const float active = m >= 0.f ? 1.f : 0.f;
-  for (int i = threadIdx.x; i < L; i += 256) g_aff[i] = active * (i < Nn ? -1.0f / (float)Nn : 1.0f / (float)A);
+  for (int i = threadIdx.x; i < L; i += LF_T) g_aff[i] = active * (i < Nn ? -1.0f / (float)Nn : 1.0f / (float)A);
   float s_rec = 0.f;
-  for (int h = threadIdx.x; h < W; h += 256) {
-    float ss = 0.f;
-#pragma unroll 8
-    for (int b = 0; b < nb_rec; ++b) ss += __builtin_nontemporal_load(ws + (int64_t)b * W + h);     // fixed order
+  if (gi == 0 && c < W) {
+    float ss = qb[c];
+    for (int k = 1; k < G; ++k) ss += qb[k * Wp + c];
     const float nrm = sqrtf(ss);
-    s_rec += nrm;
-    kcol[h] = 1.0f / ((float)W * nrm);
+    s_rec = nrm;
+    kcol[c] = 1.0f / ((float)W * nrm);
   }
   const float rec = block_sum(s_rec) / (float)W;
   if (threadIdx.x == 0) {
@@ -1584,7 +1631,12 @@ struct AdamMulti {
   int blk0[ADAM_MAX_T + 1];          // first workgroup of every tensor
   int n_t;
 };
-__global__ void __launch_bounds__(256) k_adam_multi(AdamMulti A, float lr, float wd) {
+// round 6: ADAM_EPB elements per workgroup (four per thread, 256 apart: coalesced) and -- with `tickets` -- no trailing k_bump_multi
+// launch: every workgroup of tensor t draws a ticket on tickets[t] when it is done; the last one (all others have read the counter
+// by then: they read it first) advances the tensor's step counter and puts the ticket back to zero.  <= 88 tickets per address at
+// H = 300 (a ticket per 256 elements on ONE address was tried in round 5: 1,100 x ~7 ns, slower than the 4-us launch it replaced).
+constexpr int ADAM_EPB = 1024;
+__global__ void __launch_bounds__(256) k_adam_multi(AdamMulti A, float lr, float wd, int32_t *__restrict__ tickets) {
   __shared__ float sc[2];
   int t = 0;
   while (t + 1 < A.n_t && (int)blockIdx.x >= A.blk0[t + 1]) ++t;          // workgroup-uniform
@@ -1594,17 +1646,32 @@ __global__ void __launch_bounds__(256) k_adam_multi(AdamMulti A, float lr, float
     sc[1] = (float)sqrt(1.0 - pow(0.999, ts));
   }
   __syncthreads();
-  const int64_t i = (int64_t)((int)blockIdx.x - A.blk0[t]) * 256 + threadIdx.x;
-  if (i < A.n[t]) {
-    float *p = A.p[t], *m = A.m[t], *v = A.v[t];
-    float pi = p[i];
-    float gi = fmaf(wd, pi, A.g[t][i]);
-    float mi = m[i], vi = v[i];
-    mi = fmaf(gi - mi, 0.1f, mi);
-    vi = fmaf(0.001f * gi, gi, vi * 0.999f);
-    const float denom = sqrtf(vi) / sc[1] + 1e-8f;
-    pi = pi - sc[0] * (mi / denom);
-    p[i] = pi; m[i] = mi; v[i] = vi;
+  float *p = A.p[t], *m = A.m[t], *v = A.v[t];
+  const float *gr = A.g[t];
+  const int64_t i0 = (int64_t)((int)blockIdx.x - A.blk0[t]) * ADAM_EPB + threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < ADAM_EPB / 256; ++k) {
+    const int64_t i = i0 + k * 256;
+    if (i < A.n[t]) {
+      float pi = p[i];
+      float gi = fmaf(wd, pi, gr[i]);
+      float mi = m[i], vi = v[i];
+      mi = fmaf(gi - mi, 0.1f, mi);
+      vi = fmaf(0.001f * gi, gi, vi * 0.999f);
+      const float denom = sqrtf(vi) / sc[1] + 1e-8f;
+      pi = pi - sc[0] * (mi / denom);
+      p[i] = pi; m[i] = mi; v[i] = vi;
+    }
+  }
+  if (tickets) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int nb = A.blk0[t + 1] - A.blk0[t];
+      if (__hip_atomic_fetch_add(tickets + t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nb - 1) {
+        tickets[t] = 0;
+        *A.ctr[t] += 1;
+      }
+    }
   }
 }
 __global__ void k_bump_multi(AdamMulti A) { if ((int)threadIdx.x < A.n_t) *A.ctr[threadIdx.x] += 1; }
@@ -1980,11 +2047,12 @@ int ggad_full_loss_fused_f32(const float *e_hat, const int32_t *J, const float *
                              ggad_stream_t stream) {
   GGAD_REQUIRE(e_hat && J && S && r_inv_j && logits && emb_con && emb_abn && aff && kcol && losses4 && d_logits && g_aff && workspace && ticket);
   GGAD_REQUIRE(n_normal >= 1 && n_out >= 1 && H >= 1);
+  GGAD_REQUIRE(H <= LF_T);                                    /* one thread per column in the last workgroup */
   const int L = n_normal + n_out;
-  const int nb_dot = (L + LD_ROWS - 1) / LD_ROWS, nb_rec = (n_out + REC_ROWS - 1) / REC_ROWS;
-  k_loss_fwd_fused<<<dim3(nb_dot + nb_rec), dim3(256), 0, as_stream(stream)>>>(e_hat, J, S, r_inv_j, L, H, logits, n_normal, n_out, emb_con,
-                                                                              emb_abn, margin, nb_dot, nb_rec, aff, workspace, kcol,
-                                                                              losses4, d_logits, g_aff, ticket);
+  const int nb_dot = (L + LD_ROWS - 1) / LD_ROWS, nb_part = (n_out + REC_ROWS - 1) / REC_ROWS;
+  k_loss_fwd_fused<<<dim3(nb_dot + (nb_part + 3) / 4), dim3(LF_T), 0, as_stream(stream)>>>(e_hat, J, S, r_inv_j, L, H, logits, n_normal, n_out,
+                                                                                        emb_con, emb_abn, margin, nb_dot, nb_part, aff,
+                                                                                        workspace, kcol, losses4, d_logits, g_aff, ticket);
   GGAD_CHECK_LAUNCH("full_loss_fused_f32");
   return GGAD_OK;
 }
@@ -2026,11 +2094,11 @@ int ggad_adam_f32(float *params, float *exp_avg, float *exp_avg_sq, const float 
 
 int32_t ggad_adam_multi_max(void) { return ADAM_MAX_T; }
 
-/* ggad_adam_f32 (bump_after = 1) for n_tensors <= ggad_adam_multi_max() tensors in two launches; the arrays are HOST arrays of
- * device pointers / element counts; every tensor has its own step counter (torch keeps `step` per parameter). */
+/* ggad_adam_f32 (bump_after = 1) for n_tensors <= ggad_adam_multi_max() tensors in one launch (two without `tickets`); the arrays are
+ * HOST arrays of device pointers / element counts; every tensor has its own step counter (torch keeps `step` per parameter). */
 int ggad_adam_multi_f32(int32_t n_tensors, float *const *params, float *const *exp_avg, float *const *exp_avg_sq,
                         const float *const *grads, const int64_t *n_elems, int32_t *const *step_counters, float lr,
-                        float weight_decay, ggad_stream_t stream) {
+                        float weight_decay, int32_t *tickets, ggad_stream_t stream) {
   GGAD_REQUIRE(n_tensors >= 0 && n_tensors <= ADAM_MAX_T && params && exp_avg && exp_avg_sq && grads && n_elems && step_counters);
   if (n_tensors == 0) return GGAD_OK;
   AdamMulti A;
@@ -2041,15 +2109,16 @@ int ggad_adam_multi_f32(int32_t n_tensors, float *const *params, float *const *e
     A.p[k] = params[t]; A.m[k] = exp_avg[t]; A.v[k] = exp_avg_sq[t]; A.g[k] = grads[t]; A.ctr[k] = step_counters[t];
     A.n[k] = n_elems[t];
     A.blk0[k] = blocks;
-    blocks += (int)((n_elems[t] + 255) / 256);
+    blocks += (int)((n_elems[t] + ADAM_EPB - 1) / ADAM_EPB);
     ++k;
   }
   if (k == 0) return GGAD_OK;
   A.blk0[k] = blocks;
   A.n_t = k;
   hipStream_t st = as_stream(stream);
-  k_adam_multi<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(A, lr, weight_decay);
-  k_bump_multi<<<dim3(1), dim3(64), 0, st>>>(A);
+  // `tickets` (optional; ggad_adam_multi_max() int32, zero before the first call, left zero): the counters advance inside the launch
+  k_adam_multi<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(A, lr, weight_decay, tickets);
+  if (!tickets) k_bump_multi<<<dim3(1), dim3(64), 0, st>>>(A);
   GGAD_CHECK_LAUNCH("adam_multi_f32");
   return GGAD_OK;
 }

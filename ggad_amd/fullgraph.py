@@ -1157,7 +1157,7 @@ class GgadLossFn(torch.autograd.Function):
         d_logits = torch.empty(L, dtype=torch.float32, device=dev)
         g_aff = torch.empty(L, dtype=torch.float32, device=dev)
         emb_con, emb_abn, logits = emb_con.contiguous(), emb_abn.contiguous(), logits.contiguous()
-        fused = _LOSS_FUSED and ls.get("seg_unique", False)
+        fused = _LOSS_FUSED and ls.get("seg_unique", False) and h <= 1024
         ctx.fused = fused
         if fused:
             # round 6: row dots, recon partials and -- in the last workgroup to finish -- BCE / margin / recon / coefficients: ONE launch
@@ -1234,6 +1234,9 @@ def ggad_loss(emb, logits, emb_con, emb_abnormal, adj: FullGraphAdj, ls, margin:
     return GgadLossFn.apply(emb.reshape(-1, h), logits.reshape(-1), emb_con, emb_abnormal.reshape(-1, h), adj, ls, margin)
 
 
+_ADAM_TICKETS = os.environ.get("GGAD_ADAM_TICKETS", "1") != "0"      # 0: the trailing k_bump_multi launch of round 5 (A/B)
+
+
 class FlatAdam:
     """torch.optim.Adam semantics (lr, weight_decay, betas .9/.999, eps 1e-8) executed by the HIP Adam kernel on
     the parameters that received a gradient (params with ``grad is None`` are skipped, as torch does)."""
@@ -1248,7 +1251,7 @@ class FlatAdam:
             p.grad = None
 
     def step(self):
-        """One multi-tensor launch (+ one for the step counters) per <= 16 parameters with a gradient."""
+        """One multi-tensor launch per <= 16 parameters with a gradient (the step counters advance inside it)."""
         import ctypes
         todo = []
         for p in self.params:
@@ -1260,10 +1263,15 @@ class FlatAdam:
                                       torch.zeros(1, dtype=torch.int32, device=p.device))
             todo.append((p, st, p.grad.contiguous()))
         cap = int(_lib.load().ggad_adam_multi_max())
+        if todo and getattr(self, "_tickets", None) is None:
+            # one zeroed ticket word per tensor slot and launch group: the last workgroup of a tensor advances its step counter (round 6:
+            # no trailing launch); allocated once, outside any capture (the first steps of every caller are eager)
+            self._tickets = torch.zeros((len(self.params) + cap - 1) // cap * cap, dtype=torch.int32, device=todo[0][0].device)
         for i0 in range(0, len(todo), cap):
             part = todo[i0:i0 + cap]
             n = len(part)
             arr = ctypes.c_void_p * n
             call("ggad_adam_multi_f32", n, arr(*[ptr(p.data) for p, _, _ in part]), arr(*[ptr(st[0]) for _, st, _ in part]),
                  arr(*[ptr(st[1]) for _, st, _ in part]), arr(*[ptr(g) for _, _, g in part]),
-                 (ctypes.c_int64 * n)(*[p.numel() for p, _, _ in part]), arr(*[ptr(st[2]) for _, st, _ in part]), self.lr, self.wd)
+                 (ctypes.c_int64 * n)(*[p.numel() for p, _, _ in part]), arr(*[ptr(st[2]) for _, st, _ in part]), self.lr, self.wd,
+                 self._tickets.data_ptr() + 4 * i0 if _ADAM_TICKETS else 0)

@@ -652,12 +652,14 @@ int ggad_rownorm_bwd_add_f32(const float *Xn, const float *inv, const float *dXn
 /* torch.optim.Adam.step on a flat fp32 block; uses step index *step_counter + 1 and (bump_after != 0) advances it. */
 int ggad_adam_f32(float *params, float *exp_avg, float *exp_avg_sq, const float *grads, int64_t n, float lr,
                   float weight_decay, int32_t *step_counter, int32_t bump_after, ggad_stream_t stream);
-/* The same update (bump_after = 1) for up to ggad_adam_multi_max() tensors in two launches: HOST arrays of device pointers /
- * element counts; one step counter per tensor (torch keeps `step` per parameter; parameters without a gradient are left out). */
+/* The same update (bump_after = 1) for up to ggad_adam_multi_max() tensors: HOST arrays of device pointers / element counts; one step
+ * counter per tensor (torch keeps `step` per parameter; parameters without a gradient are left out).  `tickets` (ABI 10; optional):
+ * ggad_adam_multi_max() int32 in device memory, zero before the first call and left zero -- the step counters then advance inside the
+ * one launch (the last workgroup of a tensor does it); NULL: a second, trailing launch advances them. */
 int32_t ggad_adam_multi_max(void);
 int ggad_adam_multi_f32(int32_t n_tensors, float *const *params, float *const *exp_avg, float *const *exp_avg_sq,
                         const float *const *grads, const int64_t *n_elems, int32_t *const *step_counters, float lr,
-                        float weight_decay, ggad_stream_t stream);
+                        float weight_decay, int32_t *tickets, ggad_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * Host-side sampler: bit-exact CPython random.shuffle (MT19937 + getrandbits rejection),

@@ -370,7 +370,7 @@ def ingest_case():
 
 
 def full_graph_long_case(tag="long_photo_schedule", n=4200, n_entries=60000, f=64, n_h=300, seed=0, mean=0.02, var=0.01,
-                         num_epoch=100, outlier_rate=0.15, planted=None, normalise=True):
+                         num_epoch=100, outlier_rate=0.15, planted=None, normalise=True, self_sensitivity=0.0):
     """End-of-training parity (BASELINE north_star: "AUROC/AUPRC within 1e-4"): the WHOLE training schedule of the reference's
     script for `--dataset photo` (run.py:46-48: 100 epochs; README: --mean 0.02 --var 0.01; Adam lr 1e-3) on a graph the dense
     reference still runs here, restated around the imported `Model` exactly as run.py:137-240 drives it: ONE seeding at the
@@ -415,51 +415,72 @@ def full_graph_long_case(tag="long_photo_schedule", n=4200, n_entries=60000, f=6
     args = types.SimpleNamespace(mean=mean, var=var)
     bce = torch.nn.BCEWithLogitsLoss(reduction="none", pos_weight=torch.tensor([1]))
 
-    torch.manual_seed(seed)                                             # run.py:62 (the one seeding of the run)
-    model = Model(f, n_h, "prelu", 1, "avg")
-    init_crc = synth.crc_of(*[_np(v) for _, v in sorted(model.state_dict().items())])
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=0.0)
     r_inv = torch.pow(torch.sum(raw_adj, 0), -1)
     r_inv[torch.isinf(r_inv)] = 0.0
     yt = ano[np.array(idx_test)]
-    losses, evals = [], []
 
-    def evaluate():
-        model.eval()
-        with torch.no_grad():
-            _, _, lg, _, _ = model(features, adj, abn_idx, normal_idx, False, args)
-        le = _np(lg[0, :, 0])
-        return le, roc_auc_score(yt, le[np.array(idx_test)]), average_precision_score(yt, le[np.array(idx_test)], average="macro", pos_label=1)
+    def train(perturb=0.0, verbose=True):
+        torch.manual_seed(seed)                                         # run.py:62 (the one seeding of the run)
+        model = Model(f, n_h, "prelu", 1, "avg")
+        init_crc = synth.crc_of(*[_np(v) for _, v in sorted(model.state_dict().items())])
+        if perturb:
+            # conditioning probe (round 6): the SAME run from initial weights moved by a relative N(0, perturb^2) -- how far the reference's
+            # own end-of-training numbers move under a change of the size of one fp32 rounding.  Drawn from a private generator: the
+            # global stream -- the noise draws of the run -- is where the unperturbed run has it
+            gp = torch.Generator().manual_seed(999)
+            with torch.no_grad():
+                for p_ in model.parameters():
+                    p_.mul_(1.0 + perturb * torch.randn(p_.shape, generator=gp))
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=0.0)
+        losses, evals = [], []
 
-    import time as _t
-    t0 = _t.time()
-    for epoch in range(num_epoch):
-        model.train()
-        opt.zero_grad()
-        emb, emb_combine, logits, emb_con, emb_abnormal = model(features, adj, abn_idx, normal_idx, True, args)
-        lbl = torch.cat((torch.zeros(len(normal_idx)), torch.ones(len(emb_con)))).unsqueeze(1).unsqueeze(0)
-        l_bce = torch.mean(bce(logits, lbl))
-        e = torch.squeeze(emb)
-        inv = torch.pow(torch.norm(e, dim=-1, keepdim=True), -1)
-        inv[torch.isinf(inv)] = 0.0
-        en = e * inv
-        aff = torch.sum(torch.mm(en, en.T) * raw_adj, 0) * r_inv
-        l_margin = (0.7 - (torch.mean(aff[normal_idx]) - torch.mean(aff[abn_idx]))).clamp_min(min=0)
-        l_rec = torch.mean(torch.sqrt(torch.sum(torch.pow(emb_con - emb_abnormal, 2), 1)))
-        total = l_margin + l_bce + l_rec
-        total.backward()
-        opt.step()
-        losses.append([total.item(), l_margin.item(), l_bce.item(), l_rec.item()])
-        if epoch % 10 == 0:
-            _, auc, ap = evaluate()
-            evals.append([epoch, auc, ap])
-            print(f"epoch {epoch}: loss {losses[-1][0]:.6f} auc {auc:.6f} ap {ap:.6f}  ({_t.time() - t0:.0f} s)", flush=True)
-    le, auc, ap = evaluate()
+        def evaluate():
+            model.eval()
+            with torch.no_grad():
+                _, _, lg, _, _ = model(features, adj, abn_idx, normal_idx, False, args)
+            le = _np(lg[0, :, 0])
+            return le, roc_auc_score(yt, le[np.array(idx_test)]), average_precision_score(yt, le[np.array(idx_test)], average="macro", pos_label=1)
+
+        import time as _t
+        t0 = _t.time()
+        for epoch in range(num_epoch):
+            model.train()
+            opt.zero_grad()
+            emb, emb_combine, logits, emb_con, emb_abnormal = model(features, adj, abn_idx, normal_idx, True, args)
+            lbl = torch.cat((torch.zeros(len(normal_idx)), torch.ones(len(emb_con)))).unsqueeze(1).unsqueeze(0)
+            l_bce = torch.mean(bce(logits, lbl))
+            e = torch.squeeze(emb)
+            inv = torch.pow(torch.norm(e, dim=-1, keepdim=True), -1)
+            inv[torch.isinf(inv)] = 0.0
+            en = e * inv
+            aff = torch.sum(torch.mm(en, en.T) * raw_adj, 0) * r_inv
+            l_margin = (0.7 - (torch.mean(aff[normal_idx]) - torch.mean(aff[abn_idx]))).clamp_min(min=0)
+            l_rec = torch.mean(torch.sqrt(torch.sum(torch.pow(emb_con - emb_abnormal, 2), 1)))
+            total = l_margin + l_bce + l_rec
+            total.backward()
+            opt.step()
+            losses.append([total.item(), l_margin.item(), l_bce.item(), l_rec.item()])
+            if epoch % 10 == 0:
+                _, auc, ap = evaluate()
+                evals.append([epoch, auc, ap])
+                if verbose:
+                    print(f"epoch {epoch}: loss {losses[-1][0]:.6f} auc {auc:.6f} ap {ap:.6f}  ({_t.time() - t0:.0f} s)", flush=True)
+        le, auc, ap = evaluate()
+        return model, init_crc, np.array(losses, dtype=np.float64), np.array(evals, dtype=np.float64), le, auc, ap
+
+    model, init_crc, losses, evals, le, auc, ap = train()
     out = dict(n=n, n_entries=n_entries, f=f, n_h=n_h, seed=seed, mean=mean, var=var, num_epoch=num_epoch,
                inputs_crc=synth.crc_of(rowptr, col, feat, ano), init_crc=init_crc,
                idx_test=np.array(idx_test), normal_idx=np.array(normal_idx), abn_idx=np.array(abn_idx),
-               losses=np.array(losses, dtype=np.float64), evals=np.array(evals, dtype=np.float64),
-               final_logits=le, final_auc=auc, final_ap=ap, normalise=int(bool(normalise)))
+               losses=losses, evals=evals, final_logits=le, final_auc=auc, final_ap=ap, normalise=int(bool(normalise)))
+    if self_sensitivity:
+        _, _, l2, e2, le2, auc2, ap2 = train(perturb=self_sensitivity, verbose=False)
+        dl = np.abs(l2 - losses).max(axis=1)
+        out.update(self_sens_perturb=np.float64(self_sensitivity), self_sens_auc=np.float64(abs(auc2 - auc)), self_sens_ap=np.float64(abs(ap2 - ap)),
+                   self_sens_loss_by_epoch=dl, self_sens_eval_auc=np.abs(e2[:, 1] - evals[:, 1]), self_sens_eval_ap=np.abs(e2[:, 2] - evals[:, 2]),
+                   self_sens_score=np.float64(np.abs(le2 - le).max()))
+        print(f"self-sensitivity (initial weights x (1 + {self_sensitivity} N(0,1))): final auc moves {abs(auc2 - auc):.2e}, ap {abs(ap2 - ap):.2e}, "
+              f"loss curve {dl.max():.2e}")
     for k, v in (planted or {}).items():
         out["planted." + k] = np.float64(v)
     for k, v in model.state_dict().items():
@@ -982,7 +1003,12 @@ if __name__ == "__main__":
     elif a.part == "planted_full":                 # the same two schedules on PLANTED anomalies (round 6): AUROC that means something
         _stub_third_party()
         sys.path.insert(0, REF)
-        full_graph_long_case(tag="long_planted", planted=PLANTED_FULL, normalise=False)
+        # `--dataset photo --num_epoch 50`: the schedule on which the reference itself is well-conditioned (its final AUROC / AP move by
+        # 3e-6 / 2e-5 under a 1e-7 relative change of its initial weights) -> the strict 1e-4 fixture;  the default 100 epochs run through
+        # a re-activation of the margin hinge at epoch 59 after which the reference's OWN numbers move by 7e-4 / 9e-3 under that change:
+        # kept as a second fixture with that self-sensitivity stored beside it
+        full_graph_long_case(tag="long_planted", planted=PLANTED_FULL, normalise=False, num_epoch=50, self_sensitivity=1e-7)
+        full_graph_long_case(tag="long_planted_100", planted=PLANTED_FULL, normalise=False, num_epoch=100, self_sensitivity=1e-7)
     elif a.part == "planted_mini":
         _stub_third_party()
         sys.path.insert(0, os.path.join(REF, "src"))

@@ -65,6 +65,7 @@ def full_graph_long(dev="cuda:0", no_graph=False, fixture="fullgraph_long_photo_
                 loss_delta_max=float(dl.max()), loss_delta_at=[float(dl[i]) for i in (0, 9, 49, len(ref) - 1)],
                 first_epoch_loss_delta_above=first,
                 eval_auc_delta_max=float(np.abs(evals[:, 1] - ref_e[:, 1]).max()), eval_ap_delta_max=float(np.abs(evals[:, 2] - ref_e[:, 2]).max()),
+                eval_auc_delta_by_eval=np.abs(evals[:, 1] - ref_e[:, 1]).tolist(), eval_ap_delta_by_eval=np.abs(evals[:, 2] - ref_e[:, 2]).tolist(),
                 final_auc=(float(hist["final_auc"]), float(g["final_auc"])), final_ap=(float(hist["final_ap"]), float(g["final_ap"])),
                 final_auc_delta=abs(float(hist["final_auc"]) - float(g["final_auc"])), final_ap_delta=abs(float(hist["final_ap"]) - float(g["final_ap"])),
                 final_score_delta_max=float(np.abs(hist["final_logits"] - g["final_logits"]).max()),

@@ -195,6 +195,30 @@ def test_fused_loss_block_equals_the_launch_sequence(n, nn_, na, h, overlap, mon
     assert l_again == l_new and all(torch.equal(x, y) for x, y in zip(g_again, g_new))
 
 
+@pytest.mark.parametrize("tickets", [True, False])
+def test_flat_adam_against_torch_adam_with_and_without_ticket_bump(tickets, monkeypatch):
+    """`ggad_adam_multi_f32` (torch.optim.Adam.step of run.py:118,213): 1,024 elements per workgroup; with `tickets` (round 6) the last
+    workgroup of every tensor advances its step counter inside the launch, without them a trailing launch does.  Six steps on tensors of
+    awkward sizes (1 element, 1,023, 1,025, 300 x 300, a tensor that never gets a gradient) against torch's own Adam; counters = steps."""
+    monkeypatch.setattr(FG, "_ADAM_TICKETS", tickets)
+    torch.manual_seed(3)
+    shapes = [(1,), (1023,), (1025,), (300, 300), (7, 64), (300,), (2048,)]
+    ps = [torch.nn.Parameter(torch.randn(*s_, device=DEV)) for s_ in shapes] + [torch.nn.Parameter(torch.randn(5, device=DEV))]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    opt, topt = FG.FlatAdam(ps, lr=1e-3, weight_decay=0.007), torch.optim.Adam(ref, lr=1e-3, weight_decay=0.007)
+    for step in range(6):
+        opt.zero_grad(); topt.zero_grad()
+        for p, r in zip(ps[:-1], ref[:-1]):
+            gval = torch.randn_like(p)
+            p.grad, r.grad = gval.clone(), gval.clone()
+        opt.step(); topt.step()
+    for p, r in zip(ps, ref):
+        np.testing.assert_allclose(p.detach().cpu().numpy(), r.detach().cpu().numpy(), rtol=2e-6, atol=2e-7)
+    assert all(int(opt.state[p][2].item()) == 6 for p in ps[:-1]) and ps[-1] not in opt.state
+    if tickets:
+        assert int(opt._tickets.abs().sum().item()) == 0          # every ticket word is back at zero
+
+
 def test_gcn_layer_accepts_dense_adjacency_like_the_reference(g_full_reddit):
     g = g_full_reddit
     import scipy.sparse as sp
@@ -740,20 +764,43 @@ def test_end_of_training_parity_full_graph_photo_schedule(capsys):
 
 @pytest.mark.gpu
 def test_end_of_training_parity_full_graph_planted_anomalies(capsys):
-    """The same 100-epoch schedule on PLANTED anomalies (round 6; tests/golden/make_golden.py --part planted_full,
+    """End-of-training parity where AUROC MEANS something (round 6; tests/golden/make_golden.py --part planted_full,
     `synth.plant_anomalies`: attenuated features + neighbourhoods rewired towards each other, raw features as run.py keeps them for
-    photo): the imported reference ends at AUROC 0.938 / AP 0.769 -- a ranking that separates the classes, not the 0.49 of labels drawn
-    independently of the inputs -- and the HIP path must reproduce every AUROC / AP of the run to 1e-4 (north_star)."""
+    photo): `run.py --dataset photo --num_epoch 50` of the imported reference ends at AUROC 0.923 / AP 0.654 -- a ranking that separates
+    the classes, not the 0.46 of labels drawn independently of the inputs -- and is well-conditioned there (ITS final AUROC / AP move
+    by 3e-6 / 2e-5 under a 1e-7 relative change of its initial weights, stored in the fixture).  The HIP path must reproduce every
+    AUROC / AP of the run to 1e-4 (north_star)."""
     import parity_long
     r = parity_long.full_graph_long(fixture="fullgraph_long_planted.npz")
     with capsys.disabled():
-        print("\n[end-of-training parity, full graph, planted anomalies]", r)
-    assert r["epochs"] == 100 and r["captured"]
+        print("\n[end-of-training parity, full graph, planted anomalies, 50 epochs]", r)
+    assert r["epochs"] == 50 and r["captured"]
     assert r["final_auc"][1] >= 0.8 and r["final_ap"][1] >= 0.5          # the REFERENCE separates the classes on this fixture
     assert r["loss_delta_max"] < 2e-4
     assert r["eval_auc_delta_max"] <= 1e-4 and r["eval_ap_delta_max"] <= 1e-4
     assert r["final_auc_delta"] <= 1e-4 and r["final_ap_delta"] <= 1e-4
     assert r["weight_norm_rel_delta_max"] < 1e-4
+
+
+@pytest.mark.gpu
+def test_end_of_training_planted_anomalies_100_epochs_within_the_reference_own_sensitivity(capsys):
+    """The same planted problem over the script's default 100 epochs: at epoch 59 the margin hinge of run.py:195 re-activates for one
+    step and the trajectory becomes ILL-conditioned -- the reference's own final AUROC / AP move by 6e-4 / 3e-3 when its initial weights
+    change by 1e-7 relative (measured by the generator, stored as self_sens_*).  No implementation that is not bit-identical can hold
+    1e-4 there; asserted: every evaluation up to epoch 50 to 1e-4 (the well-conditioned stretch), the final AUROC / AP within 3 x the
+    reference's own sensitivity, and that the reference still separates the classes (0.938 / 0.769)."""
+    import parity_long
+    from conftest import load_golden
+    g = load_golden("fullgraph_long_planted_100.npz")
+    r = parity_long.full_graph_long(fixture="fullgraph_long_planted_100.npz")
+    with capsys.disabled():
+        print("\n[end-of-training parity, full graph, planted anomalies, 100 epochs]", r,
+              {"reference_self_sensitivity": {"auc": float(g["self_sens_auc"]), "ap": float(g["self_sens_ap"]), "perturbation": float(g["self_sens_perturb"])}})
+    assert r["epochs"] == 100 and r["captured"] and r["final_auc"][1] >= 0.9 and r["final_ap"][1] >= 0.7
+    assert float(g["self_sens_auc"]) > 1e-4 and float(g["self_sens_ap"]) > 1e-4          # (the reason this fixture is not held to 1e-4)
+    assert max(r["eval_auc_delta_by_eval"][:6]) <= 1e-4 and max(r["eval_ap_delta_by_eval"][:6]) <= 1e-4      # evaluations of epochs 0 .. 50
+    assert r["first_epoch_loss_delta_above"][1e-4] == -1 or r["first_epoch_loss_delta_above"][1e-4] >= 59
+    assert r["final_auc_delta"] <= 3 * float(g["self_sens_auc"]) and r["final_ap_delta"] <= 3 * float(g["self_sens_ap"])
 
 
 @pytest.mark.gpu
