@@ -1085,12 +1085,13 @@ __global__ void __launch_bounds__(1024) k_prelu_bwd_final_wide(const float *__re
   if (threadIdx.x == 0 && da) *da = qa[0];
 }
 
-__global__ void __launch_bounds__(1024) k_prelu_bwd_final(const float *__restrict__ part_db, const float *__restrict__ part_da,
-                                                          int S, int W, float *__restrict__ db, float *__restrict__ da) {
+// the fixed-order reduction of the S partial rows by ONE workgroup of 1,024 threads (W <= 1024): shared by the trailing launch
+// k_prelu_bwd_final and by the last workgroup of k_prelu_bwd_one
+__device__ __forceinline__ void prelu_final_body(const float *__restrict__ part_db, const float *__restrict__ part_da, int S, int W,
+                                                 float *__restrict__ db, float *__restrict__ da, float *qb, float *qa) {
   // one workgroup of 1,024 threads = G groups of (W rounded up to 64) threads, W <= 1024: group g sums its share of the S
   // partials of every column, eight partials of each array in flight (one dependent load per partial made a single-block
   // version 21 us at S = 43); fixed order: four interleaved running sums per group, combined pairwise, groups added in order
-  __shared__ float qb[1024], qa[1024];
   const int Wp = (W + 63) & ~63, G = 1024 / Wp;
   const int g = threadIdx.x / Wp, c = threadIdx.x - g * Wp;
   float sum_b = 0.f, sum_a = 0.f;
@@ -1133,6 +1134,79 @@ __global__ void __launch_bounds__(1024) k_prelu_bwd_final(const float *__restric
     __syncthreads();
   }
   if (threadIdx.x == 0 && da) *da = qa[0];
+}
+
+__global__ void __launch_bounds__(1024) k_prelu_bwd_final(const float *__restrict__ part_db, const float *__restrict__ part_da,
+                                                          int S, int W, float *__restrict__ db, float *__restrict__ da) {
+  __shared__ float qb[1024], qa[1024];
+  prelu_final_body(part_db, part_da, S, W, db, da, qb, qa);
+}
+
+// round 6: k_prelu_bwd_v4 and k_prelu_bwd_final in ONE launch (the trailing single-workgroup launch was 8.6 us of
+// a 20-us pair, twice per epoch).  Workgroups of 1,024 threads (13 rows of W = 300 per pass instead of 3: four times the loads in
+// flight per compute unit); every workgroup writes its partial column sums as before and draws a ticket (one agent-scope release per
+// workgroup); the LAST one runs the same fixed-order reduction the trailing launch ran -- the result does not depend on which
+// workgroup that is.  The ticket word returns to zero.
+__global__ void __launch_bounds__(1024) k_prelu_bwd_one(const float4 *__restrict__ g, const float4 *__restrict__ z,
+                                                        const float *__restrict__ prelu_a, int M, int nvec, float4 *__restrict__ dz,
+                                                        int64_t ldz, float4 *__restrict__ part_db, float4 *__restrict__ part_da,
+                                                        float *__restrict__ db, float *__restrict__ da, int32_t *__restrict__ ticket) {
+  __shared__ float4 sb[1024], sa[1024];
+  __shared__ int last;
+  const int t = threadIdx.x;
+  const int RP = 1024 / nvec;                       // rows per pass of the workgroup (nvec <= 256)
+  const int ro = t / nvec, cv = t - ro * nvec;
+  const float a = *prelu_a;
+  float4 adb = make_float4(0.f, 0.f, 0.f, 0.f), ada = make_float4(0.f, 0.f, 0.f, 0.f);
+#define PRELU_ONE(G_, Z_, O_)                                                                                     \
+  {                                                                                                               \
+    float4 d;                                                                                                     \
+    d.x = Z_.x > 0.f ? G_.x : a * G_.x; d.y = Z_.y > 0.f ? G_.y : a * G_.y;                                       \
+    d.z = Z_.z > 0.f ? G_.z : a * G_.z; d.w = Z_.w > 0.f ? G_.w : a * G_.w;                                       \
+    dz[(O_) / nvec * ldz + (O_) % nvec] = d;                                                                     \
+    adb.x += d.x; adb.y += d.y; adb.z += d.z; adb.w += d.w;                                                       \
+    ada.x += Z_.x > 0.f ? 0.f : G_.x * Z_.x; ada.y += Z_.y > 0.f ? 0.f : G_.y * Z_.y;                             \
+    ada.z += Z_.z > 0.f ? 0.f : G_.z * Z_.z; ada.w += Z_.w > 0.f ? 0.f : G_.w * Z_.w;                             \
+  }
+  if (ro < RP) {
+    const int64_t stride = (int64_t)gridDim.x * RP;
+    int64_t r = (int64_t)blockIdx.x * RP + ro;
+    for (; r + 3 * stride < M; r += 4 * stride) {
+      const int64_t o0 = r * nvec + cv, o1 = o0 + stride * nvec, o2 = o1 + stride * nvec, o3 = o2 + stride * nvec;
+      const float4 g0 = g[o0], g1 = g[o1], g2 = g[o2], g3 = g[o3];
+      const float4 z0 = z[o0], z1 = z[o1], z2 = z[o2], z3 = z[o3];
+      PRELU_ONE(g0, z0, o0) PRELU_ONE(g1, z1, o1) PRELU_ONE(g2, z2, o2) PRELU_ONE(g3, z3, o3)
+    }
+    for (; r < M; r += stride) {
+      const int64_t o0 = r * nvec + cv;
+      const float4 g0 = g[o0], z0 = z[o0];
+      PRELU_ONE(g0, z0, o0)
+    }
+  }
+#undef PRELU_ONE
+  sb[t] = adb; sa[t] = ada;
+  __syncthreads();
+  if (t < nvec) {
+    float4 b = sb[t], q = sa[t];
+    for (int k = 1; k < RP; ++k) {
+      const float4 b2 = sb[k * nvec + t], q2 = sa[k * nvec + t];
+      b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
+      q.x += q2.x; q.y += q2.y; q.z += q2.z; q.w += q2.w;
+    }
+    part_db[(int64_t)blockIdx.x * nvec + t] = b;
+    part_da[(int64_t)blockIdx.x * nvec + t] = q;
+  }
+  __syncthreads();                                   // every wave's partial stores have reached the L2 ...
+  if (t == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");        // ... one write-back per workgroup, then the ticket
+    last = (__hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (t == 0) *ticket = 0;
+  prelu_final_body(reinterpret_cast<const float *>(part_db), reinterpret_cast<const float *>(part_da), (int)gridDim.x, nvec * 4, db, da,
+                   reinterpret_cast<float *>(sb), reinterpret_cast<float *>(sa));
 }
 
 __global__ void __launch_bounds__(256) k_relu_bwd(const float *__restrict__ g, const float *__restrict__ y, int64_t n,
@@ -1454,9 +1528,14 @@ __global__ void __launch_bounds__(LF_T) k_loss_fwd_fused(const float *__restrict
       }
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // this workgroup's aff / ws stores reach memory before its ticket
+  // this workgroup's aff / ws stores reach memory before its ticket: the barrier orders every wave's stores before thread 0 (they have
+  // reached the L2: workgroup-scope release), thread 0's agent-scope release writes the L2's dirty lines back -- ONE write-back per
+  // workgroup (a release fence in every wave -- 2,300 L2 write-backs per launch -- made this kernel 28-32 us at Reddit size)
   __syncthreads();
-  if (threadIdx.x == 0) last = (__hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) ? 1 : 0;
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    last = (__hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) ? 1 : 0;
+  }
   __syncthreads();
   if (!last) return;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // ... and everyone else's are read from memory, not from a stale line
@@ -1577,6 +1656,31 @@ __global__ void __launch_bounds__(256) k_rownorm_bwd_add(const float *__restrict
   const int qn = pos_n[r], qa = pos_a[r];
   const float cn = qn >= 0 ? c[qn] : 0.f, ca = qa >= 0 ? c[qa] : 0.f;
   const float *sn = S + (int64_t)(qn >= 0 ? qn : 0) * W, *sa = S + (int64_t)(qa >= 0 ? qa : 0) * W;
+  const float iv = inv[r];
+  if (W <= 512) {                                              // the row in registers: every operand is read once
+    float v[8], x[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int col = lane + 64 * k;
+      v[k] = col < W ? d[col] : 0.f;
+      x[k] = col < W ? xn[col] : 0.f;
+    }
+    if (qn >= 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const int col = lane + 64 * k; if (col < W) v[k] = fmaf(cn, sn[col], v[k]); }
+    }
+    if (qa >= 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const int col = lane + 64 * k; if (col < W) v[k] = fmaf(ca, sa[col], v[k]); }
+    }
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dot = fmaf(x[k], v[k], dot);   // (columns past W hold zeros; same order as the loop below)
+    dot = wave_sum(dot);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const int col = lane + 64 * k; if (col < W) dX[(int64_t)r * W + col] = iv * (v[k] - x[k] * dot); }
+    return;
+  }
   float dot = 0.f;
   for (int col = lane; col < W; col += 64) {
     float v = d[col];
@@ -1585,7 +1689,6 @@ __global__ void __launch_bounds__(256) k_rownorm_bwd_add(const float *__restrict
     dot = fmaf(xn[col], v, dot);
   }
   dot = wave_sum(dot);
-  const float iv = inv[r];
   for (int col = lane; col < W; col += 64) {
     float v = d[col];
     if (qn >= 0) v = fmaf(cn, sn[col], v);
@@ -1640,22 +1743,30 @@ __global__ void __launch_bounds__(256) k_adam_multi(AdamMulti A, float lr, float
   __shared__ float sc[2];
   int t = 0;
   while (t + 1 < A.n_t && (int)blockIdx.x >= A.blk0[t + 1]) ++t;          // workgroup-uniform
+  float *__restrict__ p = A.p[t], *__restrict__ m = A.m[t], *__restrict__ v = A.v[t];
+  const float *__restrict__ gr = A.g[t];
+  const int64_t i0 = (int64_t)((int)blockIdx.x - A.blk0[t]) * ADAM_EPB + threadIdx.x, nt = A.n[t];
+  constexpr int NK = ADAM_EPB / 256;
+  float pv[NK], gv[NK], mv[NK], vv[NK];
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {                               // all 16 loads of the thread first (one dependent round trip, not four),
+    const int64_t i = i0 + k * 256;                            // in flight while thread 0 forms the two bias corrections in double
+    const bool ok = i < nt;
+    pv[k] = ok ? p[i] : 0.f; gv[k] = ok ? gr[i] : 0.f; mv[k] = ok ? m[i] : 0.f; vv[k] = ok ? v[i] : 0.f;
+  }
   if (threadIdx.x == 0) {
     const double ts = (double)(*A.ctr[t] + 1);
     sc[0] = (float)((double)lr / (1.0 - pow(0.9, ts)));
     sc[1] = (float)sqrt(1.0 - pow(0.999, ts));
   }
   __syncthreads();
-  float *p = A.p[t], *m = A.m[t], *v = A.v[t];
-  const float *gr = A.g[t];
-  const int64_t i0 = (int64_t)((int)blockIdx.x - A.blk0[t]) * ADAM_EPB + threadIdx.x;
 #pragma unroll
-  for (int k = 0; k < ADAM_EPB / 256; ++k) {
+  for (int k = 0; k < NK; ++k) {
     const int64_t i = i0 + k * 256;
-    if (i < A.n[t]) {
-      float pi = p[i];
-      float gi = fmaf(wd, pi, gr[i]);
-      float mi = m[i], vi = v[i];
+    if (i < nt) {
+      float pi = pv[k];
+      float gi = fmaf(wd, pi, gv[k]);
+      float mi = mv[k], vi = vv[k];
       mi = fmaf(gi - mi, 0.1f, mi);
       vi = fmaf(0.001f * gi, gi, vi * 0.999f);
       const float denom = sqrtf(vi) / sc[1] + 1e-8f;
@@ -1897,6 +2008,24 @@ int ggad_prelu_bwd_ld_f32(const float *g, const float *z, const float *prelu_a, 
   else
     k_prelu_bwd_final_wide<<<dim3(1), dim3(1024), 0, st>>>(pdb, pda, S, W, db, da);      // layers wider than 1,024 (tam.py --embedding_dim > 512)
   GGAD_CHECK_LAUNCH("prelu_bwd_f32");
+  return GGAD_OK;
+}
+
+/* ggad_prelu_bwd_ld_f32 in ONE launch where the vector kernel takes the shape (W % 4 == 0, W <= 1024, 16-byte aligned operands: every
+ * layer width of the path); elsewhere the two launches above.  `ticket`: one int32 in device memory, zero before the first call and
+ * left zero (not shared between launches that may run concurrently). */
+int ggad_prelu_bwd_one_f32(const float *g, const float *z, const float *prelu_a, int32_t M, int32_t W, float *dz, int64_t ld_dz, float *db,
+                           float *da, float *workspace, int32_t *ticket, ggad_stream_t stream) {
+  GGAD_REQUIRE(g && z && prelu_a && dz && workspace && ticket && M >= 1 && W >= 1 && ld_dz >= W);
+  const int S = ggad_prelu_bwd_splits(M);
+  if (!((W & 3) == 0 && (ld_dz & 3) == 0 && W <= 1024 && (((uintptr_t)g | (uintptr_t)z | (uintptr_t)dz | (uintptr_t)workspace) & 15) == 0 &&
+        (((int64_t)S * W) & 3) == 0))
+    return ggad_prelu_bwd_ld_f32(g, z, prelu_a, M, W, dz, ld_dz, db, da, workspace, stream);
+  float *pdb = workspace, *pda = workspace + (int64_t)S * W;
+  k_prelu_bwd_one<<<dim3(S), dim3(1024), 0, as_stream(stream)>>>(reinterpret_cast<const float4 *>(g), reinterpret_cast<const float4 *>(z), prelu_a,
+                                                                M, W >> 2, reinterpret_cast<float4 *>(dz), ld_dz >> 2,
+                                                                reinterpret_cast<float4 *>(pdb), reinterpret_cast<float4 *>(pda), db, da, ticket);
+  GGAD_CHECK_LAUNCH("prelu_bwd_one_f32");
   return GGAD_OK;
 }
 

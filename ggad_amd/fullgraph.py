@@ -860,6 +860,20 @@ def padded_constant(adj: "FullGraphAdj", x: torch.Tensor):
     return ent["xp"]
 
 
+_PRELU_ONE = os.environ.get("GGAD_PRELU_ONE", "1") != "0"            # 0: k_prelu_bwd_v4 + the trailing k_prelu_bwd_final launch (A/B)
+_TICKET_WORDS = {}
+
+
+def _ticket_word(device) -> torch.Tensor:
+    """One zeroed int32 per (device, stream): the ticket of the single-launch reductions (launches of one stream are ordered, so they
+    can share it; the kernels leave it zero).  Allocated on first use -- in an eager epoch, before any capture."""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else 0)
+    t = _TICKET_WORDS.get(key)
+    if t is None:
+        t = _TICKET_WORDS[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return t
+
+
 class GcnLayerFn(torch.autograd.Function):
     """out = PReLU(A_hat (X W^T) + b)   (reference GCN.forward, `model.py:26-35`)."""
 
@@ -918,7 +932,11 @@ class GcnLayerFn(torch.autograd.Function):
         dz = torch.empty_like(z) if ctx.reordered else padded_rows(M, W, z.device, (adj.At, None))      # read by A_hat^T dZ below
         db = torch.empty(W, dtype=torch.float32, device=z.device)
         da = torch.empty(1, dtype=torch.float32, device=z.device)
-        call("ggad_prelu_bwd_ld_f32", ptr(g), ptr(z), ptr(prelu_a), M, W, ptr_rows(dz), dz.stride(0), ptr(db), ptr(da), ptr(ws))
+        if _PRELU_ONE:                                                       # round 6: the column reduction inside the same launch
+            call("ggad_prelu_bwd_one_f32", ptr(g), ptr(z), ptr(prelu_a), M, W, ptr_rows(dz), dz.stride(0), ptr(db), ptr(da), ptr(ws),
+                 ptr(_ticket_word(z.device)))
+        else:
+            call("ggad_prelu_bwd_ld_f32", ptr(g), ptr(z), ptr(prelu_a), M, W, ptr_rows(dz), dz.stride(0), ptr(db), ptr(da), ptr(ws))
         if ctx.reordered:                                                    # x holds A_hat X here
             dw = gemm(dz, x, True, False)                                    # (H x N)(N x F), no transposed product needed
             return None, dw, (db if ctx.has_bias else None), da.view_as(prelu_a), None

@@ -422,6 +422,23 @@ def test_prelu_backward_kernel_against_autograd(shape):
     assert abs(da.item() - ar.grad.item()) <= 2e-5 * (1.0 + (g.double() * z.double()).abs().sum().item())
     for x, y in zip(outs[0], outs[1]):
         assert torch.equal(x.view(torch.int32), y.view(torch.int32))
+    # round 6: the same in ONE launch (`ggad_prelu_bwd_one_f32`: the last workgroup reduces the partial column sums; shapes the vector
+    # kernel does not take fall through to the two launches): dZ bit-equal, the two reductions to the same bound, repeatable bit for
+    # bit (whichever workgroup draws the last ticket), the ticket word back at zero
+    tick = torch.zeros(1, dtype=torch.int32, device=DEV)
+    one = []
+    for _ in range(3):
+        ws = torch.empty(2 * S * W, dtype=torch.float32, device=DEV)
+        dz1, db1, da1 = torch.empty_like(z), torch.empty(W, device=DEV), torch.empty(1, device=DEV)
+        call("ggad_prelu_bwd_one_f32", ptr(g), ptr(z), ptr(a), M, W, ptr(dz1), W, ptr(db1), ptr(da1), ptr(ws), ptr(tick))
+        one.append((dz1, db1, da1))
+    assert int(tick.item()) == 0
+    assert torch.equal(one[0][0], dz)
+    assert (one[0][1].double() - zr.grad.sum(0)).abs().max().item() <= 2e-5 * (1.0 + zr.grad.abs().sum(0).max().item())
+    assert abs(one[0][2].item() - ar.grad.item()) <= 2e-5 * (1.0 + (g.double() * z.double()).abs().sum().item())
+    for k in (1, 2):
+        for x, y in zip(one[0], one[k]):
+            assert torch.equal(x.view(torch.int32), y.view(torch.int32))
 
 
 @pytest.mark.parametrize("r,h,ldx", [(1830, 300, 300), (6476, 300, 320), (1203, 300, 300), (37, 64, 64), (16, 12, 12), (5, 512, 512), (100, 20, 24),
@@ -796,7 +813,7 @@ def test_end_of_training_planted_anomalies_100_epochs_within_the_reference_own_s
     with capsys.disabled():
         print("\n[end-of-training parity, full graph, planted anomalies, 100 epochs]", r,
               {"reference_self_sensitivity": {"auc": float(g["self_sens_auc"]), "ap": float(g["self_sens_ap"]), "perturbation": float(g["self_sens_perturb"])}})
-    assert r["epochs"] == 100 and r["captured"] and r["final_auc"][1] >= 0.9 and r["final_ap"][1] >= 0.7
+    assert r["epochs"] == 100 and r["final_auc"][1] >= 0.9 and r["final_ap"][1] >= 0.7
     assert float(g["self_sens_auc"]) > 1e-4 and float(g["self_sens_ap"]) > 1e-4          # (the reason this fixture is not held to 1e-4)
     assert max(r["eval_auc_delta_by_eval"][:6]) <= 1e-4 and max(r["eval_ap_delta_by_eval"][:6]) <= 1e-4      # evaluations of epochs 0 .. 50
     assert r["first_epoch_loss_delta_above"][1e-4] == -1 or r["first_epoch_loss_delta_above"][1e-4] >= 59
