@@ -150,6 +150,8 @@ SIGNATURES = {
     "ggad_full_loss_bwd_scale_f32": (c_int32, [_P, _P, _P, _P, _P, _I, _L, _P, _P, _P, _P, _P]),
     "ggad_head_gather_f32": (c_int32, [_P, _P, _P, _I, _I, _P, _P]),
     "ggad_head_combine_f32": (c_int32, [_P, _P, _I, _P, _I, _I, _P, _P]),
+    "ggad_head_rows_f32": (c_int32, [_P, _P, _P, _I, _P, _I, _I, _P, _P, _P]),
+    "ggad_head_emb_put_f32": (c_int32, [_P, _P, _I, _I, _P, _P]),
     "ggad_head_emb_out_f32": (c_int32, [_P, _P, _P, _I, _I, _P, _P]),
     "ggad_head_con_grad_f32": (c_int32, [_P, _P, _P, _P, _P, _I, _I, _P, _P]),
     "ggad_head_emb_grad_f32": (c_int32, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P]),

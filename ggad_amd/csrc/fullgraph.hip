@@ -1343,6 +1343,33 @@ __global__ void __launch_bounds__(256) k_head_emb_out(const float *__restrict__ 
   const float *x = q >= 0 ? con + (int64_t)q * W : X + (int64_t)i * W;
   for (int c = lane; c < W; c += 64) out[(int64_t)i * W + c] = x[c];
 }
+// round 6: k_head_gather and the emb[normal] half of k_head_combine in ONE launch (both read rows of emb before anything else of the head
+// runs; the emb_con half of emb_combine is written in place by the product that forms it):
+//   p < n_abn:  out_abn[p] = X[abn[p]] + add[p]          otherwise:  out_comb[p - n_abn] = X[nrm[p - n_abn]]
+__global__ void __launch_bounds__(256) k_head_rows(const float *__restrict__ X, const int32_t *__restrict__ abn,
+                                                   const float *__restrict__ add, int n_abn, const int32_t *__restrict__ nrm, int n_nrm,
+                                                   int W, float *__restrict__ out_abn, float *__restrict__ out_comb) {
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= n_abn + n_nrm) return;
+  const int lane = lane_id();
+  if (p < n_abn) {
+    const float *x = X + (int64_t)abn[p] * W;
+    for (int c = lane; c < W; c += 64) out_abn[(int64_t)p * W + c] = x[c] + (add ? add[(int64_t)p * W + c] : 0.0f);
+  } else {
+    const int q = p - n_abn;
+    const float *x = X + (int64_t)nrm[q] * W;
+    for (int c = lane; c < W; c += 64) out_comb[(int64_t)q * W + c] = x[c];
+  }
+}
+// X[abn[p]] = con[p]  (abn duplicate-free)                                               emb[:, abn, :] = emb_con IN PLACE   model.py:182
+__global__ void __launch_bounds__(256) k_head_emb_put(const float *__restrict__ con, const int32_t *__restrict__ abn, int n_abn, int W,
+                                                      float *__restrict__ X) {
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= n_abn) return;
+  const int lane = lane_id();
+  float *x = X + (int64_t)abn[p] * W;
+  for (int c = lane; c < W; c += 64) x[c] = con[(int64_t)p * W + c];
+}
 // dz[p] = [y[p] > 0] * (g_con[p] + g_out[abn[p]] + g_tail[p]): the three gradients that reach emb_con = relu(fc4(.)) (the loss, the
 // rows written back into emb, the tail of emb_combine) and the relu in one pass; absent terms are null
 __global__ void __launch_bounds__(256) k_head_con_grad(const float *__restrict__ g_con, const float *__restrict__ g_out,
@@ -1754,11 +1781,8 @@ __global__ void __launch_bounds__(256) k_adam_multi(AdamMulti A, float lr, float
     const bool ok = i < nt;
     pv[k] = ok ? p[i] : 0.f; gv[k] = ok ? gr[i] : 0.f; mv[k] = ok ? m[i] : 0.f; vv[k] = ok ? v[i] : 0.f;
   }
-  if (threadIdx.x == 0) {
-    const double ts = (double)(*A.ctr[t] + 1);
-    sc[0] = (float)((double)lr / (1.0 - pow(0.9, ts)));
-    sc[1] = (float)sqrt(1.0 - pow(0.999, ts));
-  }
+  if (threadIdx.x == 0) sc[0] = (float)((double)lr / (1.0 - pow(0.9, (double)(*A.ctr[t] + 1))));       // (two waves: the two double pow()
+  if (threadIdx.x == 64) sc[1] = (float)sqrt(1.0 - pow(0.999, (double)(*A.ctr[t] + 1)));               //  side by side, not one after the other)
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < NK; ++k) {
@@ -2017,10 +2041,13 @@ int ggad_prelu_bwd_ld_f32(const float *g, const float *z, const float *prelu_a, 
 int ggad_prelu_bwd_one_f32(const float *g, const float *z, const float *prelu_a, int32_t M, int32_t W, float *dz, int64_t ld_dz, float *db,
                            float *da, float *workspace, int32_t *ticket, ggad_stream_t stream) {
   GGAD_REQUIRE(g && z && prelu_a && dz && workspace && ticket && M >= 1 && W >= 1 && ld_dz >= W);
-  const int S = ggad_prelu_bwd_splits(M);
+  const int S0 = ggad_prelu_bwd_splits(M);
   if (!((W & 3) == 0 && (ld_dz & 3) == 0 && W <= 1024 && (((uintptr_t)g | (uintptr_t)z | (uintptr_t)dz | (uintptr_t)workspace) & 15) == 0 &&
-        (((int64_t)S * W) & 3) == 0))
+        (((int64_t)S0 * W) & 3) == 0))
     return ggad_prelu_bwd_ld_f32(g, z, prelu_a, M, W, dz, ld_dz, db, da, workspace, stream);
+  // workgroups of 1,024 threads: half as many of them as the 256-thread kernel has (twice the waves all the same), so the last one
+  // reduces half as many partial rows -- with S0 = 172 partials that reduction alone took the 8.6 us of the launch it replaces
+  const int S = std::max(1, std::min(S0, std::min(128, (M + 127) / 128)));
   float *pdb = workspace, *pda = workspace + (int64_t)S * W;
   k_prelu_bwd_one<<<dim3(S), dim3(1024), 0, as_stream(stream)>>>(reinterpret_cast<const float4 *>(g), reinterpret_cast<const float4 *>(z), prelu_a,
                                                                 M, W >> 2, reinterpret_cast<float4 *>(dz), ld_dz >> 2,
@@ -2047,6 +2074,21 @@ int ggad_head_gather_f32(const float *X, const int32_t *idx, const float *add, i
   if (n == 0) return GGAD_OK;
   k_head_gather<<<dim3((n + 3) / 4), dim3(256), 0, as_stream(stream)>>>(X, idx, add, n, W, out);
   GGAD_CHECK_LAUNCH("head_gather_f32");
+  return GGAD_OK;
+}
+int ggad_head_rows_f32(const float *X, const int32_t *abn, const float *add, int32_t n_abn, const int32_t *nrm, int32_t n_nrm, int32_t W,
+                       float *out_abn, float *out_comb, ggad_stream_t stream) {
+  GGAD_REQUIRE(X && n_abn >= 0 && n_nrm >= 0 && W >= 1 && (n_abn == 0 || (abn && out_abn)) && (n_nrm == 0 || (nrm && out_comb)));
+  if (n_abn + n_nrm == 0) return GGAD_OK;
+  k_head_rows<<<dim3((n_abn + n_nrm + 3) / 4), dim3(256), 0, as_stream(stream)>>>(X, abn, add, n_abn, nrm, n_nrm, W, out_abn, out_comb);
+  GGAD_CHECK_LAUNCH("head_rows_f32");
+  return GGAD_OK;
+}
+int ggad_head_emb_put_f32(const float *con, const int32_t *abn, int32_t n_abn, int32_t W, float *X, ggad_stream_t stream) {
+  GGAD_REQUIRE(con && abn && X && n_abn >= 0 && W >= 1);
+  if (n_abn == 0) return GGAD_OK;
+  k_head_emb_put<<<dim3((n_abn + 3) / 4), dim3(256), 0, as_stream(stream)>>>(con, abn, n_abn, W, X);
+  GGAD_CHECK_LAUNCH("head_emb_put_f32");
   return GGAD_OK;
 }
 int ggad_head_combine_f32(const float *X, const int32_t *nrm, int32_t n_nrm, const float *con, int32_t n_con, int32_t W, float *out,

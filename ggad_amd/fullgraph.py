@@ -1065,6 +1065,9 @@ class SpmmRowsFn(torch.autograd.Function):
         return spmm(ctx.sub_t, g.contiguous()), None, None, None
 
 
+_HEAD_LEAN = os.environ.get("GGAD_HEAD_LEAN", "1") != "0"            # 0: the round-5 glue (separate gathers, emb_out as a second N x H tensor)
+
+
 class GgadHeadFn(torch.autograd.Function):
     """The training forward from `emb` on (`model.py:140-182`) as ONE autograd node:
 
@@ -1082,25 +1085,40 @@ class GgadHeadFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, emb, noise, w4, w1, w2, w3, adj: FullGraphAdj, hs):
+        emb_in = emb
         emb = emb.contiguous()
         n, h = emb.shape
         dev = emb.device
         na, nn_ = hs["n_abn"], hs["n_nrm"]
         noise = noise.reshape(na, h).contiguous() if noise is not None else None
         emb_abn = torch.empty(na, h, dtype=torch.float32, device=dev)
-        call("ggad_head_gather_f32", ptr(emb), ptr(hs["abn"]), ptr(noise), na, h, ptr(emb_abn))
-        con_pre = spmm(adj.A, emb, plan=hs["rows_plan"])
-        emb_con = gemm(con_pre, w4, False, True, relu=True)
         comb = torch.empty(nn_ + na, h, dtype=torch.float32, device=dev)
-        call("ggad_head_combine_f32", ptr(emb), ptr(hs["nrm"]), nn_, ptr(emb_con), na, h, ptr(comb))
+        lean = _HEAD_LEAN and emb_in.is_contiguous()
+        if lean:
+            # round 6: both row gathers from emb in one launch; emb_con is written by its product straight into the tail of emb_combine
+            call("ggad_head_rows_f32", ptr(emb), ptr(hs["abn"]), ptr(noise), na, ptr(hs["nrm"]), nn_, h, ptr(emb_abn), ptr(comb))
+            con_pre = spmm(adj.A, emb, plan=hs["rows_plan"])
+            emb_con = gemm(con_pre, w4, False, True, relu=True, out=comb[nn_:])
+        else:
+            call("ggad_head_gather_f32", ptr(emb), ptr(hs["abn"]), ptr(noise), na, h, ptr(emb_abn))
+            con_pre = spmm(adj.A, emb, plan=hs["rows_plan"])
+            emb_con = gemm(con_pre, w4, False, True, relu=True)
+            call("ggad_head_combine_f32", ptr(emb), ptr(hs["nrm"]), nn_, ptr(emb_con), na, h, ptr(comb))
         if mlp_score_supported(w1, w2, w3):
             f1, f2, f3 = mlp_score_fwd(comb, w1, w2, w3)                   # one launch (csrc/mlp.hip)
         else:
             f1 = gemm(comb, w1, False, True, relu=True)
             f2 = gemm(f1, w2, False, True, relu=True)
             f3 = gemm(f2, w3, False, True)
-        emb_out = torch.empty_like(emb)
-        call("ggad_head_emb_out_f32", ptr(emb), ptr(hs["abn_pos"]), ptr(emb_con), n, h, ptr(emb_out))
+        if lean:
+            # emb[:, abn, :] = emb_con in place, as the reference writes it (model.py:182): A rows instead of a second N x H tensor.  Every
+            # read of the old rows (emb[abn] + noise, A_hat[abn, :] emb, emb[normal]) is behind us; GcnLayerFn keeps z, not its output
+            call("ggad_head_emb_put_f32", ptr(emb_con), ptr(hs["abn"]), na, h, ptr(emb))
+            ctx.mark_dirty(emb_in)
+            emb_out = emb_in
+        else:
+            emb_out = torch.empty_like(emb)
+            call("ggad_head_emb_out_f32", ptr(emb), ptr(hs["abn_pos"]), ptr(emb_con), n, h, ptr(emb_out))
         ctx.save_for_backward(con_pre, emb_con, comb, f1, f2, w4, w1, w2, w3)
         ctx.hs, ctx.shape = hs, (n, h)
         ctx.set_materialize_grads(False)

@@ -604,6 +604,12 @@ int ggad_relu_bwd_f32(const float *g, const float *y, int64_t n, float *dz, ggad
 int ggad_head_gather_f32(const float *X, const int32_t *idx, const float *add, int32_t n, int32_t W, float *out, ggad_stream_t stream);
 int ggad_head_combine_f32(const float *X, const int32_t *nrm, int32_t n_nrm, const float *con, int32_t n_con, int32_t W, float *out,
                           ggad_stream_t stream);
+/* ABI 10: ggad_head_gather_f32 and the emb[normal] rows of ggad_head_combine_f32 in one launch (model.py:141-145,159: both read rows of
+ * emb before anything else of the head runs); and emb[:, abn, :] = emb_con IN PLACE as the reference writes it (model.py:182; abn
+ * duplicate-free) instead of a second N x H tensor. */
+int ggad_head_rows_f32(const float *X, const int32_t *abn, const float *add, int32_t n_abn, const int32_t *nrm, int32_t n_nrm, int32_t W,
+                       float *out_abn, float *out_comb, ggad_stream_t stream);
+int ggad_head_emb_put_f32(const float *con, const int32_t *abn, int32_t n_abn, int32_t W, float *X, ggad_stream_t stream);
 int ggad_head_emb_out_f32(const float *X, const int32_t *abn_pos, const float *con, int32_t n, int32_t W, float *out,
                           ggad_stream_t stream);
 int ggad_head_con_grad_f32(const float *g_con, const float *g_out, const int32_t *abn, const float *g_tail, const float *y, int32_t n,
