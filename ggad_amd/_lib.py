@@ -112,6 +112,8 @@ SIGNATURES = {
     "ggad_spmm_rowline_f32": (c_int32, [_P, _P, _I, _P, _I, _P, _I, _P, _L, _I, _L, _P, _P, _P, _L, _P, _P]),
     "ggad_prelu_bwd_ld_f32": (c_int32, [_P, _P, _P, _I, _I, _P, _L, _P, _P, _P, _P]),
     "ggad_prelu_bwd_one_f32": (c_int32, [_P, _P, _P, _I, _I, _P, _L, _P, _P, _P, _P, _P]),
+    "ggad_prelu_bwd_one_workspace_elems": (c_int64, [_I, _I]),
+    "ggad_prelu_bwd_one_tickets": (c_int32, []),
     "ggad_spmm_sliced_workspace_elems": (c_int64, [_L, _I]),
     "ggad_spmm_sliced_seg_len": (c_int32, []),
     "ggad_spmm_panel_available": (c_int32, []),

@@ -1147,9 +1147,12 @@ __global__ void __launch_bounds__(1024) k_prelu_bwd_final(const float *__restric
 // flight per compute unit); every workgroup writes its partial column sums as before and draws a ticket (one agent-scope release per
 // workgroup); the LAST one runs the same fixed-order reduction the trailing launch ran -- the result does not depend on which
 // workgroup that is.  The ticket word returns to zero.
+constexpr int PB_GRP = 4;          // workgroups per first-level group
+constexpr int PB_MAXS = 320;       // workgroups of a launch at most (80 groups: the last group's reduction reads 27 rows per thread group)
 __global__ void __launch_bounds__(1024) k_prelu_bwd_one(const float4 *__restrict__ g, const float4 *__restrict__ z,
                                                         const float *__restrict__ prelu_a, int M, int nvec, float4 *__restrict__ dz,
                                                         int64_t ldz, float4 *__restrict__ part_db, float4 *__restrict__ part_da,
+                                                        float4 *__restrict__ gpart_db, float4 *__restrict__ gpart_da,
                                                         float *__restrict__ db, float *__restrict__ da, int32_t *__restrict__ ticket) {
   __shared__ float4 sb[1024], sa[1024];
   __shared__ int last;
@@ -1196,16 +1199,42 @@ __global__ void __launch_bounds__(1024) k_prelu_bwd_one(const float4 *__restrict
     part_db[(int64_t)blockIdx.x * nvec + t] = b;
     part_da[(int64_t)blockIdx.x * nvec + t] = q;
   }
+  // two levels of tickets (the elementwise pass wants >= one workgroup per compute unit, the final reduction few partial rows):
+  //   groups of PB_GRP consecutive workgroups -- the last of a group to finish adds the group's partial rows (block order) into ONE row
+  //   of gpart;  the last GROUP to finish runs the fixed-order reduction over the group rows.  Every sum has a fixed order; which
+  //   workgroup performs it does not matter.  ticket[0]: groups done, ticket[1 + g]: workgroups of group g done; all left at zero.
+  const int gid = blockIdx.x / PB_GRP, n_groups = (gridDim.x + PB_GRP - 1) / PB_GRP;
+  const int gsize = min(PB_GRP, (int)gridDim.x - gid * PB_GRP);
   __syncthreads();                                   // every wave's partial stores have reached the L2 ...
   if (t == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");        // ... one write-back per workgroup, then the ticket
-    last = (__hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) ? 1 : 0;
+    last = (__hip_atomic_fetch_add(ticket + 1 + gid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (t == 0) ticket[1 + gid] = 0;
+  if (t < 2 * nvec) {                                // float4 column t of [db | da] of the group row
+    const float4 *src = (t < nvec ? part_db : part_da) + (int64_t)gid * PB_GRP * nvec + (t < nvec ? t : t - nvec);
+    float4 v[PB_GRP];
+#pragma unroll
+    for (int k = 0; k < PB_GRP; ++k) v[k] = src[(int64_t)min(k, gsize - 1) * nvec];
+    float4 acc = v[0];
+#pragma unroll
+    for (int k = 1; k < PB_GRP; ++k)
+      if (k < gsize) { acc.x += v[k].x; acc.y += v[k].y; acc.z += v[k].z; acc.w += v[k].w; }
+    (t < nvec ? gpart_db : gpart_da)[(int64_t)gid * nvec + (t < nvec ? t : t - nvec)] = acc;
+  }
+  __syncthreads();
+  if (t == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    last = (__hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_groups - 1) ? 1 : 0;
   }
   __syncthreads();
   if (!last) return;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   if (t == 0) *ticket = 0;
-  prelu_final_body(reinterpret_cast<const float *>(part_db), reinterpret_cast<const float *>(part_da), (int)gridDim.x, nvec * 4, db, da,
+  prelu_final_body(reinterpret_cast<const float *>(gpart_db), reinterpret_cast<const float *>(gpart_da), n_groups, nvec * 4, db, da,
                    reinterpret_cast<float *>(sb), reinterpret_cast<float *>(sa));
 }
 
@@ -2035,9 +2064,21 @@ int ggad_prelu_bwd_ld_f32(const float *g, const float *z, const float *prelu_a, 
   return GGAD_OK;
 }
 
+// workgroups of the one-launch kernel: one per pass of 1024 / (W / 4) rows up to PB_MAXS (>= one per compute unit on every layer here)
+static int prelu_one_blocks(int32_t M, int32_t W) {
+  const int rp = std::max(1, 1024 / std::max(1, W >> 2));
+  return std::max(1, std::min(PB_MAXS, (M + rp - 1) / rp));
+}
+/* floats of `workspace` and int32 of `ticket` ggad_prelu_bwd_one_f32 needs (>= what ggad_prelu_bwd_ld_f32 needs: its fallback) */
+int64_t ggad_prelu_bwd_one_workspace_elems(int32_t M, int32_t W) {
+  const int64_t S = prelu_one_blocks(M, W), NG = (S + PB_GRP - 1) / PB_GRP;
+  return std::max<int64_t>(2 * (S + NG) * (int64_t)W, 2 * (int64_t)ggad_prelu_bwd_splits(M) * W);
+}
+int32_t ggad_prelu_bwd_one_tickets(void) { return 1 + (PB_MAXS + PB_GRP - 1) / PB_GRP; }
+
 /* ggad_prelu_bwd_ld_f32 in ONE launch where the vector kernel takes the shape (W % 4 == 0, W <= 1024, 16-byte aligned operands: every
- * layer width of the path); elsewhere the two launches above.  `ticket`: one int32 in device memory, zero before the first call and
- * left zero (not shared between launches that may run concurrently). */
+ * layer width of the path); elsewhere the two launches above.  `ticket`: ggad_prelu_bwd_one_tickets() int32 in device memory, zero before
+ * the first call and left zero (not shared between launches that may run concurrently); `workspace`: ggad_prelu_bwd_one_workspace_elems. */
 int ggad_prelu_bwd_one_f32(const float *g, const float *z, const float *prelu_a, int32_t M, int32_t W, float *dz, int64_t ld_dz, float *db,
                            float *da, float *workspace, int32_t *ticket, ggad_stream_t stream) {
   GGAD_REQUIRE(g && z && prelu_a && dz && workspace && ticket && M >= 1 && W >= 1 && ld_dz >= W);
@@ -2045,13 +2086,12 @@ int ggad_prelu_bwd_one_f32(const float *g, const float *z, const float *prelu_a,
   if (!((W & 3) == 0 && (ld_dz & 3) == 0 && W <= 1024 && (((uintptr_t)g | (uintptr_t)z | (uintptr_t)dz | (uintptr_t)workspace) & 15) == 0 &&
         (((int64_t)S0 * W) & 3) == 0))
     return ggad_prelu_bwd_ld_f32(g, z, prelu_a, M, W, dz, ld_dz, db, da, workspace, stream);
-  // workgroups of 1,024 threads: half as many of them as the 256-thread kernel has (twice the waves all the same), so the last one
-  // reduces half as many partial rows -- with S0 = 172 partials that reduction alone took the 8.6 us of the launch it replaces
-  const int S = std::max(1, std::min(S0, std::min(128, (M + 127) / 128)));
-  float *pdb = workspace, *pda = workspace + (int64_t)S * W;
+  const int S = prelu_one_blocks(M, W), NG = (S + PB_GRP - 1) / PB_GRP;
+  float *pdb = workspace, *pda = pdb + (int64_t)S * W, *gdb = pda + (int64_t)S * W, *gda = gdb + (int64_t)NG * W;
   k_prelu_bwd_one<<<dim3(S), dim3(1024), 0, as_stream(stream)>>>(reinterpret_cast<const float4 *>(g), reinterpret_cast<const float4 *>(z), prelu_a,
                                                                 M, W >> 2, reinterpret_cast<float4 *>(dz), ld_dz >> 2,
-                                                                reinterpret_cast<float4 *>(pdb), reinterpret_cast<float4 *>(pda), db, da, ticket);
+                                                                reinterpret_cast<float4 *>(pdb), reinterpret_cast<float4 *>(pda),
+                                                                reinterpret_cast<float4 *>(gdb), reinterpret_cast<float4 *>(gda), db, da, ticket);
   GGAD_CHECK_LAUNCH("prelu_bwd_one_f32");
   return GGAD_OK;
 }

@@ -870,7 +870,7 @@ def _ticket_word(device) -> torch.Tensor:
     key = (str(device), torch.cuda.current_stream(device).cuda_stream if torch.device(device).type == "cuda" else 0)
     t = _TICKET_WORDS.get(key)
     if t is None:
-        t = _TICKET_WORDS[key] = torch.zeros(1, dtype=torch.int32, device=device)
+        t = _TICKET_WORDS[key] = torch.zeros(max(1, int(_lib.load().ggad_prelu_bwd_one_tickets())), dtype=torch.int32, device=device)
     return t
 
 
@@ -928,7 +928,7 @@ class GcnLayerFn(torch.autograd.Function):
         M, W = z.shape
         lib = _lib.load()
         S = int(lib.ggad_prelu_bwd_splits(M))
-        ws = torch.empty(2 * S * W, dtype=torch.float32, device=z.device)
+        ws = torch.empty(int(lib.ggad_prelu_bwd_one_workspace_elems(M, W)) if _PRELU_ONE else 2 * S * W, dtype=torch.float32, device=z.device)
         dz = torch.empty_like(z) if ctx.reordered else padded_rows(M, W, z.device, (adj.At, None))      # read by A_hat^T dZ below
         db = torch.empty(W, dtype=torch.float32, device=z.device)
         da = torch.empty(1, dtype=torch.float32, device=z.device)

@@ -465,9 +465,13 @@ int ggad_spmm_rowline_f32(const int32_t *ent, const int32_t *unit_tab, int32_t n
 /* ggad_prelu_bwd_f32 with a row stride for dz (ld_dz >= W, multiple of 4): the gradient a following line-granular product reads. */
 int ggad_prelu_bwd_ld_f32(const float *g, const float *z, const float *prelu_a, int32_t M, int32_t W, float *dz, int64_t ld_dz, float *db,
                           float *da, float *workspace, ggad_stream_t stream);
-/* The same in ONE launch (ABI 10; autograd of `self.act(out)`, /root/reference/model.py:35): the last workgroup to finish reduces the
- * partial column sums in the fixed order of the two-launch form.  `ticket`: one int32 in device memory, zero before the first call,
- * left zero, not shared between launches that may run concurrently.  Shapes the vector kernel does not take run the two launches. */
+/* The same in ONE launch (ABI 10; autograd of `self.act(out)`, /root/reference/model.py:35): two levels of tickets -- the last workgroup
+ * of every group of four adds the group's partial column sums, the last group reduces the group rows -- every sum in a fixed order.
+ * `workspace`: ggad_prelu_bwd_one_workspace_elems(M, W) floats; `ticket`: ggad_prelu_bwd_one_tickets() int32 in device memory, zero
+ * before the first call, left zero, not shared between launches that may run concurrently.  Shapes the vector kernel does not take run
+ * the two launches. */
+int64_t ggad_prelu_bwd_one_workspace_elems(int32_t M, int32_t W);
+int32_t ggad_prelu_bwd_one_tickets(void);
 int ggad_prelu_bwd_one_f32(const float *g, const float *z, const float *prelu_a, int32_t M, int32_t W, float *dz, int64_t ld_dz, float *db,
                            float *da, float *workspace, int32_t *ticket, ggad_stream_t stream);
 

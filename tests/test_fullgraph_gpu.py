@@ -425,14 +425,15 @@ def test_prelu_backward_kernel_against_autograd(shape):
     # round 6: the same in ONE launch (`ggad_prelu_bwd_one_f32`: the last workgroup reduces the partial column sums; shapes the vector
     # kernel does not take fall through to the two launches): dZ bit-equal, the two reductions to the same bound, repeatable bit for
     # bit (whichever workgroup draws the last ticket), the ticket word back at zero
-    tick = torch.zeros(1, dtype=torch.int32, device=DEV)
+    lib = _lib.load()
+    tick = torch.zeros(int(lib.ggad_prelu_bwd_one_tickets()), dtype=torch.int32, device=DEV)
     one = []
     for _ in range(3):
-        ws = torch.empty(2 * S * W, dtype=torch.float32, device=DEV)
+        ws = torch.empty(int(lib.ggad_prelu_bwd_one_workspace_elems(M, W)), dtype=torch.float32, device=DEV)
         dz1, db1, da1 = torch.empty_like(z), torch.empty(W, device=DEV), torch.empty(1, device=DEV)
         call("ggad_prelu_bwd_one_f32", ptr(g), ptr(z), ptr(a), M, W, ptr(dz1), W, ptr(db1), ptr(da1), ptr(ws), ptr(tick))
         one.append((dz1, db1, da1))
-    assert int(tick.item()) == 0
+    assert int(tick.abs().sum().item()) == 0
     assert torch.equal(one[0][0], dz)
     assert (one[0][1].double() - zr.grad.sum(0)).abs().max().item() <= 2e-5 * (1.0 + zr.grad.abs().sum(0).max().item())
     assert abs(one[0][2].item() - ar.grad.item()) <= 2e-5 * (1.0 + (g.double() * z.double()).abs().sum().item())
