@@ -1085,10 +1085,32 @@ __global__ void __launch_bounds__(1024) k_prelu_bwd_final_wide(const float *__re
   if (threadIdx.x == 0 && da) *da = qa[0];
 }
 
+// Hand-offs between workgroups of ONE launch without an agent-scope release FENCE: that fence writes back every dirty line of the
+// XCD's L2 -- in a kernel that is itself streaming out N x H floats (dz) each of its 320 fences flushed that stream: 50 us instead of
+// 20.  The partial sums are instead STORED with agent-scope relaxed atomics (sc1: written through to memory), the wave drains its
+// store counter (s_waitcnt vmcnt(0)) before the workgroup barrier, one thread draws the ticket (agent-scope RMW), and the reader uses
+// agent-scope relaxed atomic LOADS (sc1: not served from a stale L2 line of an earlier launch).  Same hardware reasoning as the
+// tagged-slot barrier of step_xcd.hip and the granules of exchange.cpp; tests/test_fullgraph_gpu.py re-runs the kernel on the same
+// workspace with different data and checks every sum.
+__device__ __forceinline__ void st_agent16(float4 *p, float4 v) {
+  unsigned long long *q = reinterpret_cast<unsigned long long *>(p);
+  __hip_atomic_store(q, ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(q + 1, ((unsigned long long)__float_as_uint(v.w) << 32) | __float_as_uint(v.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float4 ld_agent16(const float4 *p) {
+  const unsigned long long *q = reinterpret_cast<const unsigned long long *>(p);
+  const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return make_float4(__uint_as_float((unsigned)a), __uint_as_float((unsigned)(a >> 32)), __uint_as_float((unsigned)b), __uint_as_float((unsigned)(b >> 32)));
+}
+__device__ __forceinline__ float ld_agent(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // the fixed-order reduction of the S partial rows by ONE workgroup of 1,024 threads (W <= 1024): shared by the trailing launch
 // k_prelu_bwd_final and by the last workgroup of k_prelu_bwd_one
+template <bool AGENT = false>
 __device__ __forceinline__ void prelu_final_body(const float *__restrict__ part_db, const float *__restrict__ part_da, int S, int W,
                                                  float *__restrict__ db, float *__restrict__ da, float *qb, float *qa) {
+  auto ldp = [](const float *p) -> float { if constexpr (AGENT) return ld_agent(p); else return *p; };
   // one workgroup of 1,024 threads = G groups of (W rounded up to 64) threads, W <= 1024: group g sums its share of the S
   // partials of every column, eight partials of each array in flight (one dependent load per partial made a single-block
   // version 21 us at S = 43); fixed order: four interleaved running sums per group, combined pairwise, groups added in order
@@ -1102,18 +1124,18 @@ __device__ __forceinline__ void prelu_final_body(const float *__restrict__ part_
     for (; s0 + 16 <= s_hi; s0 += 16) {                    // (16 partials of each array in flight: S = 172 at Reddit size is 57 per group --
       float vb[16], va[16];                                //  four round trips instead of seven; the same additions in the same order)
 #pragma unroll
-      for (int k = 0; k < 16; ++k) { vb[k] = part_db[(int64_t)(s0 + k) * W + c]; va[k] = part_da[(int64_t)(s0 + k) * W + c]; }
+      for (int k = 0; k < 16; ++k) { vb[k] = ldp(part_db + (int64_t)(s0 + k) * W + c); va[k] = ldp(part_da + (int64_t)(s0 + k) * W + c); }
 #pragma unroll
       for (int k = 0; k < 16; ++k) { b4[k & 3] += vb[k]; a4[k & 3] += va[k]; }
     }
     for (; s0 + 8 <= s_hi; s0 += 8) {
       float vb[8], va[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) { vb[k] = part_db[(int64_t)(s0 + k) * W + c]; va[k] = part_da[(int64_t)(s0 + k) * W + c]; }
+      for (int k = 0; k < 8; ++k) { vb[k] = ldp(part_db + (int64_t)(s0 + k) * W + c); va[k] = ldp(part_da + (int64_t)(s0 + k) * W + c); }
 #pragma unroll
       for (int k = 0; k < 8; ++k) { b4[k & 3] += vb[k]; a4[k & 3] += va[k]; }
     }
-    for (; s0 < s_hi; ++s0) { b4[(s0 - s_lo) & 3] += part_db[(int64_t)s0 * W + c]; a4[(s0 - s_lo) & 3] += part_da[(int64_t)s0 * W + c]; }
+    for (; s0 < s_hi; ++s0) { b4[(s0 - s_lo) & 3] += ldp(part_db + (int64_t)s0 * W + c); a4[(s0 - s_lo) & 3] += ldp(part_da + (int64_t)s0 * W + c); }
     sum_b = (b4[0] + b4[1]) + (b4[2] + b4[3]);
     sum_a = (a4[0] + a4[1]) + (a4[2] + a4[3]);
   }
@@ -1196,8 +1218,8 @@ __global__ void __launch_bounds__(1024) k_prelu_bwd_one(const float4 *__restrict
       b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
       q.x += q2.x; q.y += q2.y; q.z += q2.z; q.w += q2.w;
     }
-    part_db[(int64_t)blockIdx.x * nvec + t] = b;
-    part_da[(int64_t)blockIdx.x * nvec + t] = q;
+    st_agent16(part_db + (int64_t)blockIdx.x * nvec + t, b);
+    st_agent16(part_da + (int64_t)blockIdx.x * nvec + t, q);
   }
   // two levels of tickets (the elementwise pass wants >= one workgroup per compute unit, the final reduction few partial rows):
   //   groups of PB_GRP consecutive workgroups -- the last of a group to finish adds the group's partial rows (block order) into ONE row
@@ -1205,37 +1227,31 @@ __global__ void __launch_bounds__(1024) k_prelu_bwd_one(const float4 *__restrict
   //   workgroup performs it does not matter.  ticket[0]: groups done, ticket[1 + g]: workgroups of group g done; all left at zero.
   const int gid = blockIdx.x / PB_GRP, n_groups = (gridDim.x + PB_GRP - 1) / PB_GRP;
   const int gsize = min(PB_GRP, (int)gridDim.x - gid * PB_GRP);
-  __syncthreads();                                   // every wave's partial stores have reached the L2 ...
-  if (t == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");        // ... one write-back per workgroup, then the ticket
-    last = (__hip_atomic_fetch_add(ticket + 1 + gid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1) ? 1 : 0;
-  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through stores are acknowledged ...
+  __syncthreads();                                   // ... every wave's are: the ticket may be drawn
+  if (t == 0) last = (__hip_atomic_fetch_add(ticket + 1 + gid, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1) ? 1 : 0;
   __syncthreads();
   if (!last) return;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   if (t == 0) ticket[1 + gid] = 0;
   if (t < 2 * nvec) {                                // float4 column t of [db | da] of the group row
     const float4 *src = (t < nvec ? part_db : part_da) + (int64_t)gid * PB_GRP * nvec + (t < nvec ? t : t - nvec);
     float4 v[PB_GRP];
 #pragma unroll
-    for (int k = 0; k < PB_GRP; ++k) v[k] = src[(int64_t)min(k, gsize - 1) * nvec];
+    for (int k = 0; k < PB_GRP; ++k) v[k] = ld_agent16(src + (int64_t)min(k, gsize - 1) * nvec);
     float4 acc = v[0];
 #pragma unroll
     for (int k = 1; k < PB_GRP; ++k)
       if (k < gsize) { acc.x += v[k].x; acc.y += v[k].y; acc.z += v[k].z; acc.w += v[k].w; }
-    (t < nvec ? gpart_db : gpart_da)[(int64_t)gid * nvec + (t < nvec ? t : t - nvec)] = acc;
+    st_agent16((t < nvec ? gpart_db : gpart_da) + (int64_t)gid * nvec + (t < nvec ? t : t - nvec), acc);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (t == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    last = (__hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_groups - 1) ? 1 : 0;
-  }
+  if (t == 0) last = (__hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_groups - 1) ? 1 : 0;
   __syncthreads();
   if (!last) return;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   if (t == 0) *ticket = 0;
-  prelu_final_body(reinterpret_cast<const float *>(gpart_db), reinterpret_cast<const float *>(gpart_da), n_groups, nvec * 4, db, da,
-                   reinterpret_cast<float *>(sb), reinterpret_cast<float *>(sa));
+  prelu_final_body<true>(reinterpret_cast<const float *>(gpart_db), reinterpret_cast<const float *>(gpart_da), n_groups, nvec * 4, db, da,
+                         reinterpret_cast<float *>(sb), reinterpret_cast<float *>(sa));
 }
 
 __global__ void __launch_bounds__(256) k_relu_bwd(const float *__restrict__ g, const float *__restrict__ y, int64_t n,

@@ -145,7 +145,9 @@ int ggad_mb_plan_build(const ggad_mb_plan *P, const int64_t *nodes_host, const i
     // slots of feat_dim floats: ceil(deg / SL) <= 2 deg / SL per occurrence of an owner with > SL neighbours, GGAD_RANGES per
     // occurrence of one with > GGAD_RANGE_DEG
     info->need_part2 = (2 + (ggad_int_range_deg() == INT32_MAX ? 0 : (int64_t)GGAD_RANGES * SL / GGAD_RANGE_DEG)) * (bound / SL) + 8;
-    info->need_seg = 2 * n_tiles1 * seg_stride;      // (second plane: where the segments begin in the tile-major copy of col)
+    // (a second plane -- where the segments begin in the tile-major copy of col -- only when that opt-in copy is handed in: it was
+    //  allocated unconditionally, hundreds of MB at DGraph size for a plane nobody wrote: ADVICE round 5)
+    info->need_seg = ((P->tile_start && P->col_t) ? 2 : 1) * n_tiles1 * seg_stride;
   }
   info->need_cnt2 = (mode == 2 && P->cnt2 == nullptr) ? 1 : 0;
   if (rows > P->rows_cap || n_ents > P->ent_cap || n_chunks > P->ck_cap || stage_need > P->stage_cap || info->need_cnt2 ||
