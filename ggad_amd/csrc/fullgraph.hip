@@ -394,11 +394,7 @@ __global__ void __launch_bounds__(NW * 64) RL_OCC k_spmm_rowline(const int2 *__r
     return m;
   };
   const int i0 = b * NW + wid;
-  int4 m0 = fetch_tab(i0), m1 = fetch_tab(i0 + stride);
-  int2 pe[RL_R];
-#pragma unroll
-  for (int rr = 0; rr < RL_R; ++rr) pe[rr] = rl_pair(ent, m0.x + rr * RL_G * m0.w, m0.w, m0.y, q);
-  {                                                                // hub rows (behind the first prefetches): the 8 x NW lane groups of the
+  {                                                                // hub rows (BEFORE the item pipeline is primed, round 6): the 8 x NW lane groups of the
     const int hshare = extra > 0 ? (n_hub + servers - 1) / servers : 0;      // workgroup take every (8 NW)-th entry, 8 NW x 8 RL_R entries per pass
     for (int i = b; i < n_hub + hshare; i += B) {
       int slice = x, h = i;
@@ -407,15 +403,24 @@ __global__ void __launch_bounds__(NW * 64) RL_OCC k_spmm_rowline(const int2 *__r
       const int vi = slice * RL_G + q, vic = vi < nv ? vi : 0;
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
       const int step = NW * RL_G, pass = step * RL_G * RL_R;
-      // round 6: the loop runs on the WAVE's first entry (uniform: a lane group past the end walks padded pairs -- value 0 -- instead of
-      // leaving on its own, so the readlane of rl_walk_item's n_max never meets an inactive lane: ADVICE r5).  (Requesting the pairs of
-      // pass p + 1 before pass p is walked was tried here: 8 more VGPRs -> 106, four waves per SIMD instead of five, the launch 5 % slower.)
-      for (int eb = m.x + wid * RL_G; eb < m.y; eb += pass) {
-        const int e0 = eb + g;
-        int2 ph[RL_R];
+      // round 6: (1) the loop runs on the WAVE's first entry (uniform: a lane group past the end walks padded pairs -- value 0 -- instead
+      // of leaving on its own, so the readlane of rl_walk_item's n_max never meets an inactive lane: ADVICE r5);  (2) the pairs of pass
+      // p + 1 are requested before pass p is walked -- a pass was pairs -> LDS -> rows of X -> adds, two dependent round trips, and the
+      // longest hub row (1,373 entries at Reddit size = six passes of one workgroup) is the launch's critical path.  The 8 registers of
+      // that prefetch come from priming the item pipeline AFTER the hub rows (on top of it they made 106 VGPRs: four waves per SIMD
+      // instead of five, the launch 5 % slower).
+      const int eb0 = m.x + wid * RL_G;
+      int2 ph[RL_R];
 #pragma unroll
-        for (int rr = 0; rr < RL_R; ++rr) ph[rr] = rl_pair(ent, e0 + rr * RL_G * step, step, m.y, q);
+      for (int rr = 0; rr < RL_R; ++rr) ph[rr] = rl_pair(ent, eb0 + g + rr * RL_G * step, step, m.y, q);
+      for (int eb = eb0; eb < m.y; eb += pass) {
+        const int e0 = eb + g;
+        int2 pn[RL_R];
+#pragma unroll
+        for (int rr = 0; rr < RL_R; ++rr) pn[rr] = rl_pair(ent, e0 + pass + rr * RL_G * step, step, m.y, q);
         rl_walk_item(Xb, ldx4, (uint32_t)vic * 16u, e0, step, m.y, lane, g, ph, lds_w, acc);
+#pragma unroll
+        for (int rr = 0; rr < RL_R; ++rr) ph[rr] = pn[rr];
       }
       const float4 tot = rl_group_sum(acc, q);
       if (g == 0) hub_part[wid][q] = tot;
@@ -433,6 +438,10 @@ __global__ void __launch_bounds__(NW * 64) RL_OCC k_spmm_rowline(const int2 *__r
   if (threadIdx.x == 0 && blockIdx.x < 8192) g_rl_prof[4 * blockIdx.x + 1] = wall_clock64();
   int n_walked = 0;
 #endif
+  int4 m0 = fetch_tab(i0), m1 = fetch_tab(i0 + stride);
+  int2 pe[RL_R];
+#pragma unroll
+  for (int rr = 0; rr < RL_R; ++rr) pe[rr] = rl_pair(ent, m0.x + rr * RL_G * m0.w, m0.w, m0.y, q);
   for (int i = i0; i < n_items; i += stride) {
 #ifdef GGAD_RL_PROF
     ++n_walked;
