@@ -1,5 +1,5 @@
 """The committed counter files that bench.py's `roofline.traffic` / `hbm_frac` are read from belong to the build that is benched:
-`profiles/r05_pmc_gather2_items.json` carries the commit in which the sources of the 2-hop gather last changed when its PMC passes ran
+`profiles/r06_pmc_gather2_items.json` carries the commit in which the sources of the 2-hop gather last changed when its PMC passes ran
 (scripts/pmc_gather2.sh); if those sources change again, the file must be regenerated (measurement 4b)."""
 import json
 import os
@@ -13,7 +13,7 @@ SOURCES = ["ggad_amd/csrc/hop2_ldsw.hip", "ggad_amd/csrc/plan_build.cpp", "ggad_
 
 
 def test_gather_pmc_file_is_stamped_with_the_last_change_of_the_gather_sources():
-    path = os.path.join(ROOT, "profiles", "r05_pmc_gather2_items.json")
+    path = os.path.join(ROOT, "profiles", "r06_pmc_gather2_items.json")
     assert os.path.exists(path), "run scripts/pmc_gather2.sh on a GPU box and commit its JSON under profiles/"
     doc = json.load(open(path))
     for key in ("20", "150"):
@@ -30,7 +30,7 @@ def test_gather_pmc_file_is_stamped_with_the_last_change_of_the_gather_sources()
     head = out.stdout.strip()
     assert not dirty.stdout.strip(), "uncommitted changes in the gather sources: commit them, then regenerate the PMC file"
     assert head and (doc["commit"].startswith(head) or head.startswith(doc["commit"])), \
-        f"profiles/r05_pmc_gather2_items.json was measured on {doc['commit']}, the gather sources last changed in {head}: regenerate it"
+        f"profiles/r06_pmc_gather2_items.json was measured on {doc['commit']}, the gather sources last changed in {head}: regenerate it"
 
 
 def test_chunk_kernel_pmc_file_is_stamped_with_the_last_change_of_its_sources():
