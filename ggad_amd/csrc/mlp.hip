@@ -47,6 +47,25 @@ __device__ __forceinline__ mlp_f4 mlp_ldw_kfast(const float *__restrict__ W, int
   }
 }
 
+// round 6: inside a training epoch the weights were rewritten by Adam a moment ago -- no XCD's L2 holds them -- and a layer's k loop
+// requests them three 16-k blocks at a time: six to seven DEPENDENT first-touch round trips per layer (the stand-alone timings of
+// round 4, back to back on warm L2s, never saw them: 17 us there, 22.9 us inside the Reddit-size epoch).  Every thread therefore
+// touches the 128-byte lines of both weight matrices once at the top of the kernel: one round trip, behind which the k loops hit.
+// GGAD_MLP_TOUCH=0 at build time (-DGGAD_MLP_TOUCH=0) takes it out (A/B).
+#ifndef GGAD_MLP_TOUCH
+#define GGAD_MLP_TOUCH 1
+#endif
+// The touches are LDS-DMA loads (global_load_lds_dword: no destination register to clobber, counted by vmcnt like any load) into a
+// 1-KB scratch piece of LDS nobody reads; the first workgroup barrier of the kernel waits for them together with the row loads.
+__device__ __forceinline__ void mlp_touch(const float *__restrict__ W, int n_floats, int tid, float *junk) {
+#if GGAD_MLP_TOUCH
+  const int wave = tid >> 6;
+  for (int i = tid * 32; i < n_floats; i += 256 * 32)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(W + i),
+                                     (__attribute__((address_space(3))) void *)(junk + wave * 64), 4, 0, 0);
+#endif
+}
+
 // out (16 x n_out, LDS tile `dst` with stride ld_dst, and global `gdst` rows row0.., ld = n_out) = act(src (16 x K in LDS) x W^T),
 // W = [n_out][K].  Every wave takes the column tiles t = wave, wave + 4, ...
 template <int MAXT, bool RELU, int VEC>
@@ -138,6 +157,9 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(const float *__restrict__ X, in
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row0 = blockIdx.x * MLP_R;
   const int n_rows = min(MLP_R, R - row0);
+  __shared__ float touch_junk[256];
+  mlp_touch(W1, H1 * H, tid, touch_junk);
+  mlp_touch(W2, H2 * H1, tid, touch_junk);
   // rows of x -> LDS (float4 along the row; zero behind the row end and for rows past R)
   for (int i = tid; i < MLP_R * (ldx_s / 4); i += 256) {
     const int r = i / (ldx_s / 4), c4 = i - r * (ldx_s / 4);
@@ -273,6 +295,9 @@ __global__ void __launch_bounds__(256) k_mlp_dgrad(const float *__restrict__ g3,
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row0 = blockIdx.x * MLP_R;
   const int n_rows = min(MLP_R, R - row0);
+  __shared__ float touch_junk[256];
+  mlp_touch(W2, H2 * H1, tid, touch_junk);
+  mlp_touch(W1, H1 * H, tid, touch_junk);
   // dz_2 = g_3 w3^T masked by f_2 > 0 (model.py:178-180 backwards); zero-padded to the next 16 k
   for (int i = tid; i < MLP_R * ld2; i += 256) {
     const int r = i / ld2, n = i - r * ld2;
