@@ -17,6 +17,10 @@ class GgadLibraryError(RuntimeError):
     pass
 
 
+# status codes of include/ggad_hip.h
+GGAD_OK, GGAD_E_INVALID, GGAD_E_LAUNCH, GGAD_E_CAPACITY, GGAD_E_UNSUPPORTED = 0, -1, -2, -3, -4
+
+
 class GgadKernelError(RuntimeError):
     pass
 

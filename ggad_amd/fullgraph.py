@@ -896,12 +896,12 @@ class GcnLayerFn(torch.autograd.Function):
             z = torch.empty(a_op.shape[0], w_op.shape[0], dtype=torch.float32, device=a_op.device)
             out = torch.empty_like(z)
             # product, bias and activation in one launch when the slab kernel takes the shape (ggad_linear_prelu_f32), else two
-            rc = -4
+            rc = _lib.GGAD_E_UNSUPPORTED
             if os.environ.get("GGAD_LINEAR_PRELU_FUSED", "1") != "0":
                 rc = int(_lib.load().ggad_linear_prelu_f32(ptr(a_op), a_op.stride(0), ptr(w_op), w_op.stride(0), ptr(bias) if bias is not None else 0,
                                                            ptr(prelu_a), a_op.shape[0], w_op.shape[0], a_op.shape[1], ptr(z), z.stride(0),
                                                            ptr(out), out.stride(0), _lib.current_stream()))
-            if rc == -4:                                                     # GGAD_E_UNSUPPORTED: nothing was launched
+            if rc == _lib.GGAD_E_UNSUPPORTED:                                # nothing was launched: the documented fallback
                 z = gemm(a_op, w_op, False, True, bias=bias, out=z)          # (A_hat X) W^T + b
                 call("ggad_prelu_fwd_f32", ptr(z), ptr(prelu_a), z.numel(), ptr(out))
             else:
