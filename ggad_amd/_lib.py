@@ -137,7 +137,8 @@ SIGNATURES = {
     "ggad_spmm_ring_rounds": (c_int32, []),
     "ggad_spmm_ring_count": (c_int32, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _I]),
     "ggad_spmm_ring_fill": (c_int32, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _L, _I]),
-    "ggad_spmm_ring_f32": (c_int32, [_P, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _L, _I, _L, _P, _P, _P, _P, _L, _P, _P]),
+    "ggad_spmm_ring_walkers_subset": (c_int32, []),
+    "ggad_spmm_ring_f32": (c_int32, [_P, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _L, _I, _L, _P, _P, _P, _P, _L, _P, _P]),
     "ggad_mlp_score_supported": (c_int32, [_I, _I, _I]),
     "ggad_mlp_score_fwd_f32": (c_int32, [_P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "ggad_mlp_score_wgrad_workspace_elems": (c_int64, [_I, _I, _I, _I]),

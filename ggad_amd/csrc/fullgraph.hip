@@ -762,6 +762,10 @@ constexpr int RING_S = GGAD_RING_S;                 // ring slots
 constexpr int RING_RS = GGAD_RING_RS;               // source rows per slot (a multiple of 8: whole 1 KB LDS-DMA pieces)
 constexpr int RING_V = RING_S - 1;                  // slots readable during a phase
 constexpr int RING_WALK = 15;                       // walker waves (wave 15 loads)
+#ifndef GGAD_RING_WALK_SUBSET
+#define GGAD_RING_WALK_SUBSET 13
+#endif
+constexpr int RING_WALK_SUBSET = GGAD_RING_WALK_SUBSET;    // ... of the loader-bound products (round 6): waves 13..15 load
 constexpr int RING_KR = 16;                         // rounds (of 8 lane rows) per walker: 64 accumulator registers
 constexpr int RING_LDS = (RING_S * RING_RS + 2) * SPMM_SL * 16;   // ring + two zero rows
 static_assert(RING_LDS <= 160 * 1024 && RING_RS % 8 == 0, "ring must fit the 160 KB of a CU; slots are whole 1 KB pieces");
@@ -844,6 +848,12 @@ typedef float ring_v32f __attribute__((ext_vector_type(32)));
   "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61",      \
   "v62", "v63"
 
+// round 6: NWALK walker waves + (16 - NWALK) LOADER waves.  A loader wave is ISSUE-bound -- ~100 clocks per 1-KB LDS-DMA instruction
+// inside a busy phase, 52 of them per 416-row slot = ~2 us per slot -- which the whole-matrix products hide (a phase of theirs walks
+// 3-4 us) but the products over a row SUBSET (the loss rows, their transpose) do not: their walkers have 10-20 steps per phase and the
+// timing variant without any load ran 187 -> 103 us (T-Finance loss rows) and 65.5 -> 27.8 us (Amazon): profiles/r06_ring_noload.log.
+// Those products run with three loader waves (pieces dealt round-robin) and 13 walkers.
+template <int NWALK>
 __global__ void __launch_bounds__(1024) k_spmm_ring(const int32_t *__restrict__ wg_tab, const int32_t *__restrict__ wave_sb,
                                                     const uint16_t *__restrict__ idx, const uint32_t *__restrict__ ctl,
                                                     const int32_t *__restrict__ row_tab, int n_phases,
@@ -859,15 +869,18 @@ __global__ void __launch_bounds__(1024) k_spmm_ring(const int32_t *__restrict__ 
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const float4 *__restrict__ xs = XS + (int64_t)slice * n_src * SPMM_SL;
-  if (wave == RING_WALK) {
-    // ---- loader: slot s = source rows [s * RS, (s + 1) * RS) -> buffer s % S, 1 KB (8 rows) per instruction, lanes past the operand off
+  if (wave >= NWALK) {
+    // ---- loaders: slot s = source rows [s * RS, (s + 1) * RS) -> buffer s % S, 1 KB (8 rows) per instruction, lanes past the operand off;
+    // loader li of NL takes the pieces li, li + NL, ...
+    constexpr int NL = 16 - NWALK;
+    const int li = wave - NWALK;
     auto issue = [&](int slot) {
       const int r0 = slot * RING_RS;
       const int nf4 = (n_src - r0 < RING_RS ? n_src - r0 : RING_RS) * SPMM_SL;
       const float4 *__restrict__ src = xs + (int64_t)r0 * SPMM_SL;
       float4 *dst = panel + (slot % RING_S) * RING_RS * SPMM_SL;
 #pragma unroll
-      for (int p = 0; p < RING_RS * SPMM_SL / 64; ++p) {
+      for (int p = li; p < RING_RS * SPMM_SL / 64; p += NL) {
         const int i = p * 64 + lane;
         if (i < nf4)
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + i),
@@ -891,7 +904,7 @@ __global__ void __launch_bounds__(1024) k_spmm_ring(const int32_t *__restrict__ 
   }
   const int g = lane >> 3, j = lane & 7;
   if (tid < 2 * SPMM_SL) panel[RING_S * RING_RS * SPMM_SL + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
-  const int gw = block * RING_WALK + wave;
+  const int gw = block * NWALK + wave;
   const int sb0 = __builtin_amdgcn_readfirstlane(wave_sb[2 * gw]), nsb = __builtin_amdgcn_readfirstlane(wave_sb[2 * gw + 1]);
   const uint16_t *ip = idx + (int64_t)sb0 * 128;
   const uint32_t *cp = ctl + sb0;
@@ -2031,7 +2044,8 @@ static bool ring_lds_ready() {
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
   std::lock_guard<std::mutex> lock(mu);
   if (state[dev] == 0) {
-    const bool ok = hipFuncSetAttribute((const void *)k_spmm_ring, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS) == hipSuccess;
+    const bool ok = hipFuncSetAttribute((const void *)k_spmm_ring<RING_WALK>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS) == hipSuccess &&
+                    hipFuncSetAttribute((const void *)k_spmm_ring<RING_WALK_SUBSET>, hipFuncAttributeMaxDynamicSharedMemorySize, RING_LDS) == hipSuccess;
     (void)hipGetLastError();
     state[dev] = ok ? 1 : -1;
   }
@@ -2042,12 +2056,14 @@ int32_t ggad_spmm_ring_slot_rows(void) { return RING_RS; }
 int32_t ggad_spmm_ring_slots(void) { return RING_S; }
 int32_t ggad_spmm_ring_window(void) { return RING_V; }
 int32_t ggad_spmm_ring_walkers(void) { return RING_WALK; }
+int32_t ggad_spmm_ring_walkers_subset(void) { return RING_WALK_SUBSET; }
 int32_t ggad_spmm_ring_rounds(void) { return RING_KR; }
 
 int ggad_spmm_ring_f32(const int32_t *wg_tab, int32_t n_wg, const int32_t *wave_sb, const uint16_t *idx, const uint32_t *ctl,
-                       const int32_t *row_tab, int32_t n_phases, const float *col_scale, const float *row_scale, const float *diag,
-                       const float *X, int64_t ldx, int32_t W, int64_t n_src_rows, float *xs_workspace, const float *bias,
-                       const float *prelu_a, float *out, int64_t ldo, float *out_pre, ggad_stream_t stream_) {
+                       const int32_t *row_tab, int32_t n_phases, int32_t n_walkers, const float *col_scale, const float *row_scale,
+                       const float *diag, const float *X, int64_t ldx, int32_t W, int64_t n_src_rows, float *xs_workspace,
+                       const float *bias, const float *prelu_a, float *out, int64_t ldo, float *out_pre, ggad_stream_t stream_) {
+  GGAD_REQUIRE(n_walkers == RING_WALK || n_walkers == RING_WALK_SUBSET);      /* the plan was dealt to that many walkers per workgroup */
   GGAD_REQUIRE(wg_tab && wave_sb && idx && ctl && row_tab && X && out && xs_workspace && W >= 4 && (W & 3) == 0 && n_wg >= 0);
   GGAD_REQUIRE((ldx & 3) == 0 && (ldo & 3) == 0 && ldx >= W && ldo >= W && n_src_rows >= 1);
   const int S = spmm_n_slices(W);
@@ -2059,9 +2075,14 @@ int ggad_spmm_ring_f32(const int32_t *wg_tab, int32_t n_wg, const int32_t *wave_
   const int64_t nt = n_src_rows * S * SPMM_SL;
   k_slice_major<<<dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st>>>(X, ldx, (int)n_src_rows, W, S, col_scale,
                                                                         reinterpret_cast<float4 *>(xs_workspace));
-  k_spmm_ring<<<dim3((unsigned)n_wg), dim3(1024), RING_LDS, st>>>(wg_tab, wave_sb, idx, ctl, row_tab, n_phases,
-                                                                reinterpret_cast<const float4 *>(xs_workspace), (int)n_src_rows, W,
-                                                                row_scale, diag, X, ldx, bias, prelu_a, out, ldo, out_pre);
+  if (n_walkers == RING_WALK)
+    k_spmm_ring<RING_WALK><<<dim3((unsigned)n_wg), dim3(1024), RING_LDS, st>>>(wg_tab, wave_sb, idx, ctl, row_tab, n_phases,
+                                                                            reinterpret_cast<const float4 *>(xs_workspace), (int)n_src_rows, W,
+                                                                            row_scale, diag, X, ldx, bias, prelu_a, out, ldo, out_pre);
+  else
+    k_spmm_ring<RING_WALK_SUBSET><<<dim3((unsigned)n_wg), dim3(1024), RING_LDS, st>>>(wg_tab, wave_sb, idx, ctl, row_tab, n_phases,
+                                                                                   reinterpret_cast<const float4 *>(xs_workspace), (int)n_src_rows,
+                                                                                   W, row_scale, diag, X, ldx, bias, prelu_a, out, ldo, out_pre);
   GGAD_CHECK_LAUNCH("spmm_ring_f32");
   return GGAD_OK;
 }

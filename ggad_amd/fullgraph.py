@@ -368,15 +368,25 @@ class Csr:
         fac = self.value_factors()
         plan = None
         if fac is not False and (rows_sel is None or fac[2] is None):
-            plan = self._build_ring(int(n_slices), fac, rows_sel)
+            lib = _lib.load()
+            plan = self._build_ring(int(n_slices), fac, rows_sel, int(lib.ggad_spmm_ring_walkers()))
+            # round 6: a product whose walkers have only a handful of steps per phase waits for its ONE loader wave (~2 us per 416-row slot:
+            # ~100 clocks per LDS-DMA instruction) -- the products over a row subset and their transposes: the kernel variant with three
+            # loader waves and 13 walkers takes them (GGAD_RING_SUBSET_STEPS: steps per walker and phase below which it does; 0 = never)
+            lim = float(os.environ.get("GGAD_RING_SUBSET_STEPS", "40"))
+            if plan is not None and plan["steps_per_phase"] < lim and int(lib.ggad_spmm_ring_walkers_subset()) != plan["walkers"]:
+                alt = self._build_ring(int(n_slices), fac, rows_sel, int(lib.ggad_spmm_ring_walkers_subset()))
+                if alt is not None:
+                    plan = alt
         store[key] = plan
         return plan
 
-    def _build_ring(self, n_slices, fac, rows_sel=None):
+    def _build_ring(self, n_slices, fac, rows_sel=None, NW=None):
         import heapq
         lib = _lib.load()
         RS, S, V = int(lib.ggad_spmm_ring_slot_rows()), int(lib.ggad_spmm_ring_slots()), int(lib.ggad_spmm_ring_window())
-        NW, KR = int(lib.ggad_spmm_ring_walkers()), int(lib.ggad_spmm_ring_rounds())
+        KR = int(lib.ggad_spmm_ring_rounds())
+        NW = int(lib.ggad_spmm_ring_walkers()) if NW is None else int(NW)
         m = self.host
         n_rows, n_src = m.shape
         rs, cs, diag = fac
@@ -522,7 +532,8 @@ class Csr:
                     ctl=torch.from_numpy(ctl.view(np.int32)).to(dev), row_tab=_dev_i32(row_tab, dev), n_phases=int(NP),
                     rs=None if rs is None else _dev_f32(rs, dev), cs=None if cs is None else _dev_f32(cs, dev),
                     diag=None if diag is None else _dev_f32(diag, dev), fill=fill, blocks=int(nb), rounds=int(kr),
-                    quads=int(tq.sum()), phase_skew=float(per_phase.reshape(nb, NW, NP).max(1).sum() / max(1.0, per_phase.sum() / NW)))
+                    quads=int(tq.sum()), phase_skew=float(per_phase.reshape(nb, NW, NP).max(1).sum() / max(1.0, per_phase.sum() / NW)),
+                    walkers=int(NW), steps_per_phase=float(4.0 * tq.sum() / max(1, n_gw * NP)))
 
 
 class FullGraphAdj:
@@ -782,7 +793,7 @@ def spmm(csr: Csr, X: torch.Tensor, plan=None, bias=None, prelu_a=None, want_pre
         opt_p = lambda t: ptr(t) if t is not None else 0
         if "wave_sb" in pp:
             call("ggad_spmm_ring_f32", ptr(pp["wg"]), pp["n_wg"], ptr(pp["wave_sb"]), ptr(pp["idx"]), ptr(pp["ctl"]), ptr(pp["row_tab"]),
-                 pp["n_phases"], opt_p(pp["cs"]), opt_p(pp["rs"]), opt_p(pp["diag"]), ptr(X), W, W, X.shape[0], ptr(xs), *opt)
+                 pp["n_phases"], pp["walkers"], opt_p(pp["cs"]), opt_p(pp["rs"]), opt_p(pp["diag"]), ptr(X), W, W, X.shape[0], ptr(xs), *opt)
         else:
             call("ggad_spmm_panel_f32", ptr(pp["wg"]), pp["n_wg"], ptr(pp["dir"]), ptr(pp["stream"]), ptr(pp["row_tab"]), pp["n_chunks"],
                  opt_p(pp["cs"]), opt_p(pp["rs"]), opt_p(pp["diag"]), ptr(X), W, W, X.shape[0], ptr(xs), *opt)

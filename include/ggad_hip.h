@@ -554,10 +554,14 @@ int32_t ggad_spmm_ring_slots(void);
 int32_t ggad_spmm_ring_window(void);
 int32_t ggad_spmm_ring_walkers(void);
 int32_t ggad_spmm_ring_rounds(void);
+/* n_walkers (ABI 10): the walker waves per workgroup the plan was dealt to -- ggad_spmm_ring_walkers() (one loader wave: the whole-matrix
+ * products) or ggad_spmm_ring_walkers_subset() (three loader waves: products whose walkers have a handful of steps per phase and would wait
+ * for a single, issue-bound loader -- the loss-row products of run.py:182-188 and their transposes). */
+int32_t ggad_spmm_ring_walkers_subset(void);
 int ggad_spmm_ring_f32(const int32_t *wg_tab, int32_t n_wg, const int32_t *wave_sb, const uint16_t *idx, const uint32_t *ctl,
-                       const int32_t *row_tab, int32_t n_phases, const float *col_scale, const float *row_scale, const float *diag,
-                       const float *X, int64_t ldx, int32_t W, int64_t n_src_rows, float *xs_workspace, const float *bias,
-                       const float *prelu_a, float *out, int64_t ldo, float *out_pre, ggad_stream_t stream_);
+                       const int32_t *row_tab, int32_t n_phases, int32_t n_walkers, const float *col_scale, const float *row_scale,
+                       const float *diag, const float *X, int64_t ldx, int32_t W, int64_t n_src_rows, float *xs_workspace,
+                       const float *bias, const float *prelu_a, float *out, int64_t ldo, float *out_pre, ggad_stream_t stream_);
 
 /* Fused scorer MLP (model.py:176-180: f_1 = relu(fc1 x), f_2 = relu(fc2 f_1), f_3 = fc3 f_2; Linear weights [out][in], no bias) on
  * the exact-f32 matrix cores, one launch each way instead of three GEMMs forward and five launches for the data gradients backward

@@ -12,7 +12,8 @@ from test_fullgraph_panel_cpu import WIDE, _normalized
 def _replay(plan, x, n_rows, n_src):
     lib = _lib.load()
     RS, S, V = int(lib.ggad_spmm_ring_slot_rows()), int(lib.ggad_spmm_ring_slots()), int(lib.ggad_spmm_ring_window())
-    NW, KR = int(lib.ggad_spmm_ring_walkers()), int(lib.ggad_spmm_ring_rounds())
+    NW, KR = int(plan["walkers"]), int(lib.ggad_spmm_ring_rounds())          # 15, or 13 with three loader waves (round 6)
+    assert NW in (int(lib.ggad_spmm_ring_walkers()), int(lib.ggad_spmm_ring_walkers_subset()))
     wave_sb = plan["wave_sb"].numpy().reshape(-1, 2)
     idx = plan["idx"].numpy().view(np.uint16).reshape(-1, 2, 8, 2, 4)         # [super-block][half][lane group][quad in half][step]
     ctl = plan["ctl"].numpy().view(np.uint8)
@@ -58,7 +59,14 @@ def _replay(plan, x, n_rows, n_src):
     return out, seen, pad
 
 
-def test_ring_plan_replays_to_the_sparse_product():
+import pytest
+
+
+@pytest.mark.parametrize("subset_steps", ["0", "1000000"])
+def test_ring_plan_replays_to_the_sparse_product(subset_steps, monkeypatch):
+    """Both dealings of the plan: 15 walkers + one loader wave (GGAD_RING_SUBSET_STEPS=0: never the other) and 13 walkers + three
+    loader waves (every plan whose walkers have fewer steps per phase than the limit: here all)."""
+    monkeypatch.setenv("GGAD_RING_SUBSET_STEPS", subset_steps)
     lib = _lib.load()
     RS, S = int(lib.ggad_spmm_ring_slot_rows()), int(lib.ggad_spmm_ring_slots())
     n = 9 * RS + 101                                                       # 10 phases (two trips round the ring), the last slot partial
@@ -67,6 +75,7 @@ def test_ring_plan_replays_to_the_sparse_product():
         csr = Csr(m, "cpu")
         plan = csr.ring_plan(3)
         assert plan is not None and plan["n_phases"] == 10
+        assert plan["walkers"] == (int(lib.ggad_spmm_ring_walkers()) if subset_steps == "0" else int(lib.ggad_spmm_ring_walkers_subset()))
         x = np.random.default_rng(0).standard_normal((n, 5))
         out, seen, pad = _replay(plan, x, n, n)
         assert seen == m.nnz - n                                           # every off-diagonal entry exactly once
