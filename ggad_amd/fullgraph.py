@@ -370,10 +370,13 @@ class Csr:
         if fac is not False and (rows_sel is None or fac[2] is None):
             lib = _lib.load()
             plan = self._build_ring(int(n_slices), fac, rows_sel, int(lib.ggad_spmm_ring_walkers()))
-            # round 6: a product whose walkers have only a handful of steps per phase waits for its ONE loader wave (~2 us per 416-row slot:
-            # ~100 clocks per LDS-DMA instruction) -- the products over a row subset and their transposes: the kernel variant with three
-            # loader waves and 13 walkers takes them (GGAD_RING_SUBSET_STEPS: steps per walker and phase below which it does; 0 = never)
-            lim = float(os.environ.get("GGAD_RING_SUBSET_STEPS", "40"))
+            # round 6: ONE loader wave is issue-bound (~100 clocks per 1-KB LDS-DMA instruction: ~2 us per 416-row slot).  The products over
+            # a row subset and their transposes (10-20 steps per walker and phase) waited for it outright -- 276 -> 153 us (T-Finance loss
+            # rows), 92 -> 52 us (Amazon) with three loader waves and 13 walkers -- and so did the whole-matrix product at Amazon size
+            # (56 steps per phase: 112.6 -> 93.8 us); at T-Finance size (91 steps) 13 walkers are 2 % faster than 15.  Same-box sweep,
+            # profiles/r06_ring_loaders_ab.log: epochs 2.013 -> 1.868 ms (T-Finance), 0.730 -> 0.639 (Amazon).  So every plan takes the
+            # three-loader variant; GGAD_RING_SUBSET_STEPS = the steps per walker and phase below which a plan does (0: never = round 5).
+            lim = float(os.environ.get("GGAD_RING_SUBSET_STEPS", "1e9"))
             if plan is not None and plan["steps_per_phase"] < lim and int(lib.ggad_spmm_ring_walkers_subset()) != plan["walkers"]:
                 alt = self._build_ring(int(n_slices), fac, rows_sel, int(lib.ggad_spmm_ring_walkers_subset()))
                 if alt is not None:

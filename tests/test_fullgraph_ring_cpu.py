@@ -62,10 +62,10 @@ def _replay(plan, x, n_rows, n_src):
 import pytest
 
 
-@pytest.mark.parametrize("subset_steps", ["0", "1000000"])
+@pytest.mark.parametrize("subset_steps", ["0", "1e9"])
 def test_ring_plan_replays_to_the_sparse_product(subset_steps, monkeypatch):
     """Both dealings of the plan: 15 walkers + one loader wave (GGAD_RING_SUBSET_STEPS=0: never the other) and 13 walkers + three
-    loader waves (every plan whose walkers have fewer steps per phase than the limit: here all)."""
+    loader waves (every plan whose walkers have fewer steps per phase than the limit: the default takes all)."""
     monkeypatch.setenv("GGAD_RING_SUBSET_STEPS", subset_steps)
     lib = _lib.load()
     RS, S = int(lib.ggad_spmm_ring_slot_rows()), int(lib.ggad_spmm_ring_slots())
