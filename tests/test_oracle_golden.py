@@ -275,3 +275,43 @@ def test_aegis_mlp_restatement_equals_torch_layers():
     ref = lin1(torch.sigmoid(bn(lin0(x))))
     got = O.aegis_mlp(P, "d", x, torch.sigmoid)
     np.testing.assert_allclose(got.detach().numpy(), ref.detach().numpy(), atol=2e-6, rtol=0)
+
+
+def test_planted_anomaly_generator_keeps_the_graph_simple_and_pins_the_fixtures():
+    """`synth.plant_anomalies` (round 6: end-of-training parity on labels that mean something): the planted graph stays symmetric and
+    simple with every node keeping a neighbour, only the labelled rows of the feature table change, the same seed gives the same
+    arrays -- and the inputs the three planted fixtures were generated on are exactly what the generator produces today (the GPU tests
+    assert the same CRC before they run; a drift of the generator shows here, without a GPU)."""
+    import numpy as np
+    from conftest import load_golden
+    from ggad_amd import synth
+    n, f = 3000, 24
+    rp, col = synth.make_graph(n, 40000, 5, kind="powerlaw", max_degree=n // 8)
+    feat = synth.make_features(n, f, 5)
+    y = synth.make_labels(n, 0.05, 5)
+    for kw in (dict(scale=0.25, rewire=0.5), dict(scale=0.5, dims=0.5, rewire=0.0, max_degree=2), dict(scale=1.0, rewire=1.0, shift=0.3)):
+        rp2, col2, f2 = synth.plant_anomalies(rp, col, feat, y, 5, **kw)
+        a = synth.csr_to_scipy(rp2, col2, n)
+        assert (a != a.T).nnz == 0 and a.diagonal().sum() == 0 and int(a.data.max()) == 1          # symmetric, no self loops, no duplicates
+        assert int(np.diff(rp2).min()) >= 1
+        assert np.array_equal(f2[y == 0], feat[y == 0]) and not np.array_equal(f2[y == 1], feat[y == 1])
+        if kw.get("max_degree"):
+            deg = np.diff(rp2)
+            assert int(deg[y == 1].max()) <= kw["max_degree"] + 1                                   # (+1: the edge a node without any is given)
+        again = synth.plant_anomalies(rp, col, feat, y, 5, **kw)
+        assert all(np.array_equal(u, v) for u, v in zip((rp2, col2, f2), again))
+    # the fixtures' inputs
+    for name, rate, maxdeg_of in (("fullgraph_long_planted.npz", 0.06, None), ("fullgraph_long_planted_100.npz", 0.06, None),
+                                  ("handler_dgraph_like_planted.npz", 0.02, 200)):
+        g = load_golden(name)
+        seed = int(g["seed"]) if "seed" in g else int(g["graph_seed"])
+        nn = int(g["n"])
+        rp0, c0 = synth.make_graph(nn, int(g["n_entries"]), seed, kind="powerlaw", max_degree=(maxdeg_of or nn // 8))
+        ft = synth.make_features(nn, int(g["f"]), seed)
+        lab = synth.make_labels(nn, rate, seed)
+        kw = {k[len("planted."):]: float(g[k]) for k in g if k.startswith("planted.")}
+        if "max_degree" in kw:
+            kw["max_degree"] = int(kw["max_degree"])
+        assert kw, name
+        rp1, c1, ft1 = synth.plant_anomalies(rp0, c0, ft, lab, seed, **kw)
+        assert synth.crc_of(rp1, c1, ft1, lab) == int(g["inputs_crc"]), name
